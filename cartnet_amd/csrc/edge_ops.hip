@@ -1,0 +1,276 @@
+// Per-edge kernels of the CartNet layer (HBM-bound): Cartesian edge features, the neighbour-equalised gate with
+// its CSR segmented reduction (forward and backward) and row-segment sums.
+//
+// Layout: edge rows of width D (fp32) are walked one row per wavefront-instruction: lane l owns channels
+// 4l..4l+3 of a 256-channel chunk, so a D=256 row is one coalesced 1 KiB dwordx4 access.  One wavefront owns one
+// target node and visits its edges in edge order (edges are sorted by target), so sums reproduce the sequential
+// CPU scatter_add_ order and need no atomics.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int NODES_PER_BLOCK = 4;   // one wave per node
+constexpr int MAX_PARTS = 1024;
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// Sum the four waves' float4 partials of a block and let wave 0 write them: parts[blockIdx.x][c .. c+3].
+__device__ __forceinline__ void block_store_parts(f32x4 v, float* lds /* [4][256] */, float* parts, int D, int c,
+                                                  bool active, int wid, int lane) {
+  __syncthreads();
+  st4(lds + wid * 256 + lane * 4, v);
+  __syncthreads();
+  if (wid == 0 && active) {
+    f32x4 t = ld4(lds + lane * 4);
+#pragma unroll
+    for (int w = 1; w < NODES_PER_BLOCK; ++w) t += ld4(lds + w * 256 + lane * 4);
+    st4(parts + (size_t)blockIdx.x * D + c, t);
+  }
+}
+
+__global__ void cn_edge_features_kernel(const float* __restrict__ dist, const float* __restrict__ dir,
+                                        const float* __restrict__ means, const float* __restrict__ betas,
+                                        long long E, int R, int invariant, float radius, float env_radius,
+                                        float* __restrict__ feat, int ldf, float* __restrict__ env) {
+  const long long total = E * ldf;
+  const float alpha = 5.0f / radius;
+  const float kPi = 3.14159265358979323846f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i / ldf;
+    const int c = (int)(i - e * ldf);
+    const float d = dist[e];
+    float v = 0.f;
+    if (c < R) {
+      const float cut = (d < radius) ? 0.5f * (cosf(d * kPi / radius) + 1.0f) : 0.f;
+      const float t = expf(alpha * (-d)) - means[c];
+      v = cut * expf(-betas[c] * t * t);
+    } else if (!invariant && c < R + 3) {
+      v = dir[e * 3 + (c - R)];
+    }
+    feat[i] = v;
+    if (c == 0 && env) env[e] = (d < env_radius) ? 0.5f * (cosf(d * kPi / env_radius) + 1.0f) : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ gate forward
+__global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
+    const float* __restrict__ gs, const float* __restrict__ e_in, const float* __restrict__ env,
+    const int* __restrict__ rowptr, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int N, int D, float* __restrict__ e_out, float* __restrict__ aggr,
+    float* __restrict__ parts_sum, float* __restrict__ parts_sq) {
+  __shared__ __attribute__((aligned(16))) float red[NODES_PER_BLOCK * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int ld = 2 * D;
+  for (int c0 = 0; c0 < D; c0 += 256) {
+    const int c = c0 + lane * 4;
+    const bool active = c < D;
+    f32x4 mean = {0, 0, 0, 0}, scale = {0, 0, 0, 0}, shift = {0, 0, 0, 0};
+    if (active) {
+      mean = ld4(mean_rstd + c);
+      scale = ld4(mean_rstd + D + c) * ld4(gamma + c);
+      shift = ld4(beta + c);
+    }
+    f32x4 ps = {0, 0, 0, 0}, pq = {0, 0, 0, 0};
+    for (int t = blockIdx.x * NODES_PER_BLOCK + wid; t < N; t += gridDim.x * NODES_PER_BLOCK) {
+      const int k0 = rowptr[t], k1 = rowptr[t + 1];
+      f32x4 acc = {0, 0, 0, 0};
+      if (active) {
+#pragma unroll 2
+        for (int k = k0; k < k1; ++k) {
+          const f32x4 g = ld4(gs + (size_t)k * ld + c);
+          const f32x4 s = ld4(gs + (size_t)k * ld + D + c);
+          const f32x4 ei = ld4(e_in + (size_t)k * D + c);
+          const float ev = env ? env[k] : 1.0f;
+          f32x4 sig;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sig[q] = ev * cn_sigmoid((g[q] - mean[q]) * scale[q] + shift[q]);
+          st4(e_out + (size_t)k * D + c, ei + sig);
+          acc += sig * s;
+        }
+        st4(aggr + (size_t)t * D + c, acc);
+      }
+      ps += acc;
+      pq += acc * acc;
+    }
+    block_store_parts(ps, red, parts_sum, D, c, active, wid, lane);
+    block_store_parts(pq, red, parts_sq, D, c, active, wid, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ gate backward
+// MODE 0: statistics (sum dbn, sum dbn*ghat).  MODE 1: apply in place (g <- dg, s <- ds) + sums of dg, ds.
+template <int MODE>
+__global__ __launch_bounds__(256) void cn_gate_scatter_bwd_kernel(
+    float* gs, const float* __restrict__ de_out, const float* __restrict__ daggr, const float* __restrict__ env,
+    const int* __restrict__ rowptr, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ sums, float inv_count, int N, int D,
+    float* __restrict__ parts_a, float* __restrict__ parts_b) {
+  __shared__ __attribute__((aligned(16))) float red[NODES_PER_BLOCK * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int ld = 2 * D;
+  for (int c0 = 0; c0 < D; c0 += 256) {
+    const int c = c0 + lane * 4;
+    const bool active = c < D;
+    f32x4 mean = {0, 0, 0, 0}, rstd = {0, 0, 0, 0}, gam = {0, 0, 0, 0}, shift = {0, 0, 0, 0};
+    f32x4 m_a = {0, 0, 0, 0}, m_b = {0, 0, 0, 0};
+    if (active) {
+      mean = ld4(mean_rstd + c);
+      rstd = ld4(mean_rstd + D + c);
+      gam = ld4(gamma + c);
+      shift = ld4(beta + c);
+      if (MODE == 1) {
+        m_a = ld4(sums + c) * inv_count;
+        m_b = ld4(sums + D + c) * inv_count;
+      }
+    }
+    f32x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+    for (int t = blockIdx.x * NODES_PER_BLOCK + wid; t < N; t += gridDim.x * NODES_PER_BLOCK) {
+      const int k0 = rowptr[t], k1 = rowptr[t + 1];
+      if (!active) continue;
+      const f32x4 dm = ld4(daggr + (size_t)t * D + c);
+#pragma unroll 2
+      for (int k = k0; k < k1; ++k) {
+        const f32x4 g = ld4(gs + (size_t)k * ld + c);
+        const f32x4 s = ld4(gs + (size_t)k * ld + D + c);
+        const f32x4 de = ld4(de_out + (size_t)k * D + c);
+        const float ev = env ? env[k] : 1.0f;
+        f32x4 dgv, dsv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float ghat = (g[q] - mean[q]) * rstd[q];
+          const float z = cn_sigmoid(ghat * gam[q] + shift[q]);
+          const float dsig = dm[q] * s[q] + de[q];
+          const float dbn = dsig * ev * z * (1.0f - z);
+          if (MODE == 0) {
+            pa[q] += dbn;
+            pb[q] += dbn * ghat;
+          } else {
+            dgv[q] = gam[q] * rstd[q] * (dbn - m_a[q] - ghat * m_b[q]);
+            dsv[q] = dm[q] * ev * z;
+            pa[q] += dgv[q];
+            pb[q] += dsv[q];
+          }
+        }
+        if (MODE == 1) {
+          st4(gs + (size_t)k * ld + c, dgv);
+          st4(gs + (size_t)k * ld + D + c, dsv);
+        }
+      }
+    }
+    block_store_parts(pa, red, parts_a, D, c, active, wid, lane);
+    block_store_parts(pb, red, parts_b, D, c, active, wid, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ segment sums
+__global__ __launch_bounds__(256) void cn_segment_sum_kernel(const float* __restrict__ rows, int ld,
+                                                             const int* __restrict__ ptr,
+                                                             const int* __restrict__ perm, int N, int W,
+                                                             float* __restrict__ out, int ldo) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int chunks = (W + 255) / 256;
+  const long long items = (long long)N * chunks;
+  for (long long it = (long long)blockIdx.x * NODES_PER_BLOCK + wid; it < items;
+       it += (long long)gridDim.x * NODES_PER_BLOCK) {
+    const int t = (int)(it / chunks);
+    const int c = (int)(it % chunks) * 256 + lane * 4;
+    if (c >= W) continue;
+    const int k0 = ptr[t], k1 = ptr[t + 1];
+    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) {
+      const int r = perm ? perm[k] : k;
+      acc += ld4(rows + (size_t)r * ld + c);
+    }
+    st4(out + (size_t)t * ldo + c, acc);
+  }
+}
+
+inline int gate_parts(int N) {
+  int b = cn_ceil_div(N, NODES_PER_BLOCK);
+  if (b > MAX_PARTS) b = MAX_PARTS;
+  if (b < 1) b = 1;
+  return b;
+}
+
+}  // namespace
+
+extern "C" int cartnet_edge_features(const float* cart_dist, const float* cart_dir, const float* means,
+                                     const float* betas, int64_t E, int32_t R, int32_t invariant, float radius,
+                                     float env_radius, float* feat, int32_t ldf, float* env, void* stream) {
+  CN_CHECK(E >= 0 && R >= 1, "cartnet_edge_features: bad sizes");
+  CN_CHECK(ldf >= R + (invariant ? 0 : 3), "cartnet_edge_features: ldf=%d too small", ldf);
+  CN_CHECK(radius > 0.f && env_radius > 0.f, "cartnet_edge_features: radius must be positive");
+  if (E == 0) return 0;
+  CN_CHECK(cart_dist && means && betas && feat && (invariant || cart_dir), "cartnet_edge_features: null pointer");
+  long long blocks = (E * ldf + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(cn_edge_features_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     cart_dist, cart_dir, means, betas, (long long)E, R, invariant, radius, env_radius, feat, ldf,
+                     env);
+  CN_LAUNCH_CHECK("cartnet_edge_features");
+  return 0;
+}
+
+extern "C" int cartnet_gate_scatter_nparts(int32_t N) { return gate_parts(N); }
+
+extern "C" int cartnet_gate_scatter_fwd(const float* gs, const float* e_in, const float* env, const int32_t* rowptr,
+                                        const float* mean_rstd, const float* gamma, const float* beta, int32_t N,
+                                        int32_t D, float* e_out, float* aggr, float* parts_sum, float* parts_sq,
+                                        void* stream) {
+  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_fwd: D=%d must be a positive multiple of 4", D);
+  CN_CHECK(gs && e_in && rowptr && mean_rstd && gamma && beta && e_out && aggr && parts_sum && parts_sq,
+           "cartnet_gate_scatter_fwd: null pointer");
+  hipLaunchKernelGGL(cn_gate_scatter_fwd_kernel, dim3(gate_parts(N)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), gs, e_in, env, rowptr, mean_rstd, gamma, beta, N, D,
+                     e_out, aggr, parts_sum, parts_sq);
+  CN_LAUNCH_CHECK("cartnet_gate_scatter_fwd");
+  return 0;
+}
+
+extern "C" int cartnet_gate_scatter_bwd_stats(const float* gs, const float* de_out, const float* daggr,
+                                              const float* env, const int32_t* rowptr, const float* mean_rstd,
+                                              const float* gamma, const float* beta, int32_t N, int32_t D,
+                                              float* parts_a, float* parts_b, void* stream) {
+  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_bwd_stats: D=%d must be a multiple of 4", D);
+  CN_CHECK(gs && de_out && daggr && rowptr && mean_rstd && gamma && beta && parts_a && parts_b,
+           "cartnet_gate_scatter_bwd_stats: null pointer");
+  hipLaunchKernelGGL(cn_gate_scatter_bwd_kernel<0>, dim3(gate_parts(N)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), const_cast<float*>(gs), de_out, daggr, env, rowptr,
+                     mean_rstd, gamma, beta, (const float*)nullptr, 0.f, N, D, parts_a, parts_b);
+  CN_LAUNCH_CHECK("cartnet_gate_scatter_bwd_stats");
+  return 0;
+}
+
+extern "C" int cartnet_gate_scatter_bwd_apply(float* gs, const float* de_out, const float* daggr, const float* env,
+                                              const int32_t* rowptr, const float* mean_rstd, const float* gamma,
+                                              const float* beta, const float* sums, int64_t E, int32_t training,
+                                              int32_t N, int32_t D, float* parts_dg, float* parts_ds, void* stream) {
+  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_bwd_apply: D=%d must be a multiple of 4", D);
+  CN_CHECK(gs && de_out && daggr && rowptr && mean_rstd && gamma && beta && sums && parts_dg && parts_ds,
+           "cartnet_gate_scatter_bwd_apply: null pointer");
+  const float inv = (training && E > 0) ? (float)(1.0 / (double)E) : 0.f;
+  hipLaunchKernelGGL(cn_gate_scatter_bwd_kernel<1>, dim3(gate_parts(N)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), gs, de_out, daggr, env, rowptr, mean_rstd, gamma, beta,
+                     sums, inv, N, D, parts_dg, parts_ds);
+  CN_LAUNCH_CHECK("cartnet_gate_scatter_bwd_apply");
+  return 0;
+}
+
+extern "C" int cartnet_segment_sum(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t N,
+                                   int32_t W, float* out, int32_t ldo, void* stream) {
+  CN_CHECK(N >= 0 && W >= 4 && W % 4 == 0 && ld % 4 == 0 && ldo % 4 == 0 && ld >= W && ldo >= W,
+           "cartnet_segment_sum: W=%d ld=%d ldo=%d must be multiples of 4", W, ld, ldo);
+  if (N == 0) return 0;
+  CN_CHECK(rows && ptr && out, "cartnet_segment_sum: null pointer");
+  long long items = (long long)N * ((W + 255) / 256);
+  long long blocks = (items + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cn_segment_sum_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     rows, ld, ptr, perm, N, W, out, ldo);
+  CN_LAUNCH_CHECK("cartnet_segment_sum");
+  return 0;
+}

@@ -1,0 +1,547 @@
+// Per-node kernels: atom embedding, BatchNorm statistics, node update, Cholesky / scalar heads.
+// All are tiny next to the per-edge work (N ~ E/14); they favour determinism (fixed-order sums, fp64 finalise)
+// over the last few percent of bandwidth.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int NODES_PER_BLOCK = 4;
+constexpr int MAX_NODE_PARTS = 256;
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+inline int node_parts(int N) {
+  int b = cn_ceil_div(N, NODES_PER_BLOCK);
+  if (b > MAX_NODE_PARTS) b = MAX_NODE_PARTS;
+  if (b < 1) b = 1;
+  return b;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ void block_store_parts(f32x4 v, float* lds, float* parts, int D, int c, bool active,
+                                                  int wid, int lane) {
+  __syncthreads();
+  st4(lds + wid * 256 + lane * 4, v);
+  __syncthreads();
+  if (wid == 0 && active) {
+    f32x4 t = ld4(lds + lane * 4);
+#pragma unroll
+    for (int w = 1; w < NODES_PER_BLOCK; ++w) t += ld4(lds + w * 256 + lane * 4);
+    st4(parts + (size_t)blockIdx.x * D + c, t);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ embedding
+__global__ void cn_node_embed_kernel(const int64_t* __restrict__ z, const int64_t* __restrict__ batch,
+                                     const float* __restrict__ temperature, const float* __restrict__ emb,
+                                     const float* __restrict__ wt, const float* __restrict__ bt,
+                                     const float* __restrict__ bias, int N, int C, float* __restrict__ x0) {
+  const long long total = (long long)N * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / C), c = (int)(i % C);
+    float v = 0.f;
+    if (emb) v = emb[(size_t)z[n] * C + c];
+    if (wt) {
+      // Linear(1 -> C) on the crystal's temperature, then broadcast to its atoms (cartnet.py:145)
+      const float t = temperature[batch[n]] * wt[c] + bt[c];
+      v = emb ? v + t : t;
+    }
+    if (bias) v += bias[c];
+    x0[i] = v;
+  }
+}
+
+// One wave per (atom type a, 256-channel chunk): fixed node order -> reproducible embedding gradient.
+__global__ __launch_bounds__(64) void cn_embed_bwd_types_kernel(const int64_t* __restrict__ z,
+                                                                const float* __restrict__ dx0, int N, int C,
+                                                                float* __restrict__ demb) {
+  const int a = blockIdx.x, lane = threadIdx.x;
+  const int c = blockIdx.y * 256 + lane * 4;
+  f32x4 acc = {0, 0, 0, 0};
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    const int n = n0 + lane;
+    const bool hit = (n < N) && (z[n] == a);
+    unsigned long long m = __ballot(hit);
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      if (c < C) acc += ld4(dx0 + (size_t)(n0 + b) * C + c);
+    }
+  }
+  if (c < C) st4(demb + (size_t)a * C + c, acc);
+}
+
+// Column sums of dx0 and of T[batch[n]] * dx0 (temperature projection gradients), per-block partials.
+__global__ __launch_bounds__(256) void cn_embed_bwd_cols_kernel(const int64_t* __restrict__ batch,
+                                                                const float* __restrict__ temperature,
+                                                                const float* __restrict__ dx0, int N, int C,
+                                                                float* __restrict__ parts_w,
+                                                                float* __restrict__ parts_b) {
+  __shared__ __attribute__((aligned(16))) float red[NODES_PER_BLOCK * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + lane * 4;
+    const bool active = c < C;
+    f32x4 pw = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+    for (int n = blockIdx.x * NODES_PER_BLOCK + wid; n < N; n += gridDim.x * NODES_PER_BLOCK) {
+      if (!active) continue;
+      const f32x4 d = ld4(dx0 + (size_t)n * C + c);
+      const float t = temperature ? temperature[batch[n]] : 0.f;
+      pw += d * t;
+      pb += d;
+    }
+    block_store_parts(pw, red, parts_w, C, c, active, wid, lane);
+    block_store_parts(pb, red, parts_b, C, c, active, wid, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm stats
+__global__ void cn_bn_finalize_kernel(const float* __restrict__ parts_sum, const float* __restrict__ parts_sq,
+                                      int nparts, long long count, int C, float eps, float momentum, int training,
+                                      float* __restrict__ running_mean, float* __restrict__ running_var,
+                                      int64_t* __restrict__ nbt, float* __restrict__ mean_rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && training && nbt) nbt[0] += 1;
+  if (c >= C) return;
+  if (training) {
+    double s = 0.0, q = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+      s += (double)parts_sum[(size_t)p * C + c];
+      q += (double)parts_sq[(size_t)p * C + c];
+    }
+    const double n = (double)count;
+    const double mean = n > 0 ? s / n : 0.0;
+    double var = n > 0 ? q / n - mean * mean : 0.0;
+    if (var < 0.0) var = 0.0;
+    mean_rstd[c] = (float)mean;
+    mean_rstd[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+      const double unb = count > 1 ? var * (n / (n - 1.0)) : var;
+      running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+      running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+    }
+  } else {
+    mean_rstd[c] = running_mean[c];
+    mean_rstd[C + c] = (float)(1.0 / sqrt((double)running_var[c] + (double)eps));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ node update
+__global__ void cn_node_update_fwd_kernel(const float* __restrict__ aggr, const float* __restrict__ x_in,
+                                          const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                          const float* __restrict__ beta, int N, int D, float* __restrict__ x_out) {
+  const long long total4 = (long long)N * D / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % D);
+    const f32x4 a = ld4(aggr + i * 4), xi = ld4(x_in + i * 4);
+    const f32x4 mean = ld4(mean_rstd + c), rstd = ld4(mean_rstd + D + c), gam = ld4(gamma + c), bet = ld4(beta + c);
+    f32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = cn_silu((a[q] - mean[q]) * rstd[q] * gam[q] + bet[q]) + xi[q];
+    st4(x_out + i * 4, o);
+  }
+}
+
+// MODE 0: partial sums of dxn and dxn*ahat.  MODE 1: daggr.
+template <int MODE>
+__global__ __launch_bounds__(256) void cn_node_update_bwd_kernel(
+    const float* __restrict__ aggr, const float* __restrict__ dx_out, const float* __restrict__ mean_rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums, float inv_count,
+    int N, int D, float* __restrict__ parts_a, float* __restrict__ parts_b, float* __restrict__ daggr) {
+  __shared__ __attribute__((aligned(16))) float red[NODES_PER_BLOCK * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < D; c0 += 256) {
+    const int c = c0 + lane * 4;
+    const bool active = c < D;
+    f32x4 mean = {0, 0, 0, 0}, rstd = {0, 0, 0, 0}, gam = {0, 0, 0, 0}, bet = {0, 0, 0, 0};
+    f32x4 m_a = {0, 0, 0, 0}, m_b = {0, 0, 0, 0};
+    if (active) {
+      mean = ld4(mean_rstd + c);
+      rstd = ld4(mean_rstd + D + c);
+      gam = ld4(gamma + c);
+      bet = ld4(beta + c);
+      if (MODE == 1) {
+        m_a = ld4(sums + c) * inv_count;
+        m_b = ld4(sums + D + c) * inv_count;
+      }
+    }
+    f32x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+    for (int n = blockIdx.x * NODES_PER_BLOCK + wid; n < N; n += gridDim.x * NODES_PER_BLOCK) {
+      if (!active) continue;
+      const f32x4 a = ld4(aggr + (size_t)n * D + c), dy = ld4(dx_out + (size_t)n * D + c);
+      f32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float ahat = (a[q] - mean[q]) * rstd[q];
+        const float dxn = dy[q] * cn_dsilu(ahat * gam[q] + bet[q]);
+        if (MODE == 0) {
+          pa[q] += dxn;
+          pb[q] += dxn * ahat;
+        } else {
+          o[q] = gam[q] * rstd[q] * (dxn - m_a[q] - ahat * m_b[q]);
+        }
+      }
+      if (MODE == 1) st4(daggr + (size_t)n * D + c, o);
+    }
+    if (MODE == 0) {
+      block_store_parts(pa, red, parts_a, D, c, active, wid, lane);
+      block_store_parts(pb, red, parts_b, D, c, active, wid, lane);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ heads
+// Single workgroup: out_index[n] = rank of atom n among masked atoms (or -1), count[0] = number of masked atoms.
+__global__ __launch_bounds__(1024) void cn_mask_index_kernel(const uint8_t* __restrict__ mask, int N,
+                                                             int* __restrict__ out_index, int* __restrict__ count) {
+  __shared__ int wave_cnt[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int n0 = 0; n0 < N; n0 += 1024) {
+    const int n = n0 + tid;
+    const bool f = (n < N) && mask[n] != 0;
+    const unsigned long long b = __ballot(f);
+    const int rank_in_wave = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wid] = __popcll(b);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wid; ++w) off += wave_cnt[w];
+    if (n < N) out_index[n] = f ? off + rank_in_wave : -1;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += wave_cnt[w];
+      base_s += t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && count) count[0] = base_s;
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float dsoftplus_f(float x) { return x > 20.f ? 1.f : cn_sigmoid(x); }
+
+constexpr int HEAD_MAX_H = 512;   // hidden width handled by one wave: up to 8 values per lane
+
+__global__ __launch_bounds__(256) void cn_cholesky_head_fwd_kernel(const float* __restrict__ hid,
+                                                                   const int* __restrict__ out_index,
+                                                                   const float* __restrict__ W2,
+                                                                   const float* __restrict__ b2, int N, int H,
+                                                                   float* __restrict__ p6, float* __restrict__ pred) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int n = blockIdx.x * NODES_PER_BLOCK + wid; n < N; n += gridDim.x * NODES_PER_BLOCK) {
+    const int m = out_index[n];
+    if (m < 0) continue;
+    float p[6] = {0, 0, 0, 0, 0, 0};
+    for (int c = lane; c < H; c += 64) {
+      const float hv = cn_silu(hid[(size_t)n * H + c]);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) p[r] += hv * W2[r * H + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) p[r] = wave_sum(p[r]) + b2[r];
+    if (lane == 0) {
+      const float d0 = softplus_f(p[0]), d1 = softplus_f(p[1]), d2 = softplus_f(p[2]);
+      const float a = p[3], b = p[4], c = p[5];
+      // L = [[d0,a,b],[0,d1,c],[0,0,d2]] ; U = L^T L
+      float* u = pred + (size_t)m * 9;
+      u[0] = d0 * d0;  u[1] = d0 * a;           u[2] = d0 * b;
+      u[3] = d0 * a;   u[4] = a * a + d1 * d1;  u[5] = a * b + d1 * c;
+      u[6] = d0 * b;   u[7] = a * b + d1 * c;   u[8] = b * b + c * c + d2 * d2;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) p6[(size_t)m * 6 + r] = p[r];
+    }
+  }
+}
+
+// dhid + per-block partials of dW2 [6,H] and db2 [6] (parts row layout: 6*H weights, then 6 biases, 2 pad).
+__global__ __launch_bounds__(256) void cn_cholesky_head_bwd_kernel(const float* __restrict__ hid,
+                                                                   const int* __restrict__ out_index,
+                                                                   const float* __restrict__ W2,
+                                                                   const float* __restrict__ p6,
+                                                                   const float* __restrict__ dpred, int N, int H,
+                                                                   float* __restrict__ dhid,
+                                                                   float* __restrict__ parts) {
+  __shared__ float red[NODES_PER_BLOCK][6 * HEAD_MAX_H + 8];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int per_lane = (H + 63) / 64;  // <= 8
+  float wacc[6][8];
+  float bacc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wacc[r][j] = 0.f;
+  for (int n = blockIdx.x * NODES_PER_BLOCK + wid; n < N; n += gridDim.x * NODES_PER_BLOCK) {
+    const int m = out_index[n];
+    if (m < 0) {
+      for (int c = lane; c < H; c += 64) dhid[(size_t)n * H + c] = 0.f;
+      continue;
+    }
+    const float* G = dpred + (size_t)m * 9;
+    const float* p = p6 + (size_t)m * 6;
+    const float d0 = softplus_f(p[0]), d1 = softplus_f(p[1]), d2 = softplus_f(p[2]);
+    const float a = p[3], b = p[4], c5 = p[5];
+    // S = G + G^T ; dL = L S ; keep the upper-triangular entries
+    const float S00 = 2.f * G[0], S01 = G[1] + G[3], S02 = G[2] + G[6];
+    const float S11 = 2.f * G[4], S12 = G[5] + G[7], S22 = 2.f * G[8];
+    float dp[6];
+    dp[0] = (d0 * S00 + a * S01 + b * S02) * dsoftplus_f(p[0]);   // dL00
+    dp[3] = d0 * S01 + a * S11 + b * S12;                          // dL01
+    dp[4] = d0 * S02 + a * S12 + b * S22;                          // dL02
+    dp[1] = (d1 * S11 + c5 * S12) * dsoftplus_f(p[1]);            // dL11
+    dp[5] = d1 * S12 + c5 * S22;                                   // dL12
+    dp[2] = (d2 * S22) * dsoftplus_f(p[2]);                        // dL22
+#pragma unroll
+    for (int r = 0; r < 6; ++r) bacc[r] += dp[r];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = lane + j * 64;
+      if (j < per_lane && c < H) {
+        const float hp = hid[(size_t)n * H + c];
+        const float hv = cn_silu(hp);
+        float dh = 0.f;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          dh += dp[r] * W2[r * H + c];
+          wacc[r][j] += dp[r] * hv;
+        }
+        dhid[(size_t)n * H + c] = dh * cn_dsilu(hp);
+      }
+    }
+  }
+  // block partials
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = lane + j * 64;
+      if (c < H) red[wid][r * H + c] = wacc[r][j];
+    }
+    if (lane == 0) red[wid][6 * H + r] = bacc[r];
+  }
+  __syncthreads();
+  const int row = 6 * H + 8;
+  for (int i = threadIdx.x; i < 6 * H + 6; i += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NODES_PER_BLOCK; ++w) t += red[w][i];
+    parts[(size_t)blockIdx.x * row + i] = t;
+  }
+}
+
+// Scalar head: one wave per crystal, atoms in order.
+__global__ __launch_bounds__(64) void cn_scalar_head_fwd_kernel(const float* __restrict__ hid,
+                                                                const float* __restrict__ w2,
+                                                                const float* __restrict__ b2,
+                                                                const int64_t* __restrict__ graph_ptr, int Bg, int H,
+                                                                float* __restrict__ out) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const int n0 = (int)graph_ptr[g], n1 = (int)graph_ptr[g + 1];
+  float tot = 0.f;
+  for (int n = n0; n < n1; ++n) {
+    float v = 0.f;
+    for (int c = lane; c < H; c += 64) v += cn_silu(hid[(size_t)n * H + c]) * w2[c];
+    tot += wave_sum(v) + b2[0];
+  }
+  const int cnt = n1 - n0;
+  if (lane == 0) out[g] = tot / (float)(cnt > 0 ? cnt : 1);
+}
+
+__global__ __launch_bounds__(256) void cn_scalar_head_bwd_kernel(const float* __restrict__ hid,
+                                                                 const float* __restrict__ w2,
+                                                                 const int64_t* __restrict__ graph_ptr,
+                                                                 const int64_t* __restrict__ batch,
+                                                                 const float* __restrict__ dout, int N, int H,
+                                                                 float* __restrict__ dhid,
+                                                                 float* __restrict__ parts) {
+  __shared__ float red[NODES_PER_BLOCK][HEAD_MAX_H + 8];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float wacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float bacc = 0.f;
+  for (int n = blockIdx.x * NODES_PER_BLOCK + wid; n < N; n += gridDim.x * NODES_PER_BLOCK) {
+    const int g = (int)batch[n];
+    const int cnt = (int)(graph_ptr[g + 1] - graph_ptr[g]);
+    const float dv = dout[g] / (float)(cnt > 0 ? cnt : 1);
+    bacc += dv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = lane + j * 64;
+      if (c < H) {
+        const float hp = hid[(size_t)n * H + c];
+        wacc[j] += dv * cn_silu(hp);
+        dhid[(size_t)n * H + c] = dv * w2[c] * cn_dsilu(hp);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = lane + j * 64;
+    if (c < H) red[wid][c] = wacc[j];
+  }
+  if (lane == 0) red[wid][H] = bacc;
+  __syncthreads();
+  const int row = H + 8;
+  for (int i = threadIdx.x; i < H + 1; i += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NODES_PER_BLOCK; ++w) t += red[w][i];
+    parts[(size_t)blockIdx.x * row + i] = t;
+  }
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int cartnet_node_embed(const int64_t* z, const int64_t* batch, const float* temperature, const float* emb,
+                                  const float* wt, const float* bt, const float* bias, int32_t N, int32_t C,
+                                  float* x0, void* stream) {
+  CN_CHECK(N >= 0 && C >= 1, "cartnet_node_embed: bad sizes");
+  if (N == 0) return 0;
+  CN_CHECK(x0 && (emb || wt), "cartnet_node_embed: need an embedding table or a temperature projection");
+  CN_CHECK(!emb || z, "cartnet_node_embed: embedding needs atomic numbers");
+  CN_CHECK(!wt || (bt && temperature && batch), "cartnet_node_embed: temperature projection needs wt, bt, T, batch");
+  long long blocks = ((long long)N * C + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cn_node_embed_kernel, dim3((int)blocks), dim3(256), 0, ST(stream), z, batch, temperature, emb,
+                     wt, bt, bias, N, C, x0);
+  CN_LAUNCH_CHECK("cartnet_node_embed");
+  return 0;
+}
+
+extern "C" int cartnet_node_nparts(int32_t N) { return node_parts(N); }
+
+extern "C" int cartnet_node_embed_bwd(const int64_t* z, const int64_t* batch, const float* temperature,
+                                      const float* dx0, int32_t N, int32_t C, int32_t n_types, float* demb,
+                                      float* parts_w, float* parts_b, void* stream) {
+  CN_CHECK(N >= 0 && C >= 4 && C % 4 == 0, "cartnet_node_embed_bwd: C=%d must be a multiple of 4", C);
+  CN_CHECK(dx0 || N == 0, "cartnet_node_embed_bwd: null dx0");
+  if (demb) {
+    CN_CHECK(z && n_types >= 1, "cartnet_node_embed_bwd: embedding gradient needs z");
+    hipLaunchKernelGGL(cn_embed_bwd_types_kernel, dim3(n_types, cn_ceil_div(C, 256)), dim3(64), 0, ST(stream), z, dx0,
+                       N, C, demb);
+    CN_LAUNCH_CHECK("cartnet_node_embed_bwd/types");
+  }
+  if (parts_b) {
+    CN_CHECK(parts_w, "cartnet_node_embed_bwd: parts_w and parts_b must pair");
+    CN_CHECK(!temperature || batch, "cartnet_node_embed_bwd: temperature needs batch");
+    hipLaunchKernelGGL(cn_embed_bwd_cols_kernel, dim3(node_parts(N)), dim3(256), 0, ST(stream), batch, temperature,
+                       dx0, N, C, parts_w, parts_b);
+    CN_LAUNCH_CHECK("cartnet_node_embed_bwd/cols");
+  }
+  return 0;
+}
+
+extern "C" int cartnet_bn_finalize(const float* parts_sum, const float* parts_sq, int32_t nparts, int64_t count,
+                                   int32_t C, float eps, float momentum, int32_t training, float* running_mean,
+                                   float* running_var, int64_t* num_batches_tracked, float* mean_rstd, void* stream) {
+  CN_CHECK(C >= 1 && mean_rstd, "cartnet_bn_finalize: bad arguments");
+  if (training) CN_CHECK(parts_sum && parts_sq && nparts >= 0 && count >= 0, "cartnet_bn_finalize: missing partial sums");
+  else CN_CHECK(running_mean && running_var, "cartnet_bn_finalize: eval mode needs running statistics");
+  CN_CHECK((running_mean == nullptr) == (running_var == nullptr), "cartnet_bn_finalize: running stats must pair");
+  hipLaunchKernelGGL(cn_bn_finalize_kernel, dim3(cn_ceil_div(C, 64)), dim3(64), 0, ST(stream), parts_sum, parts_sq,
+                     nparts, (long long)count, C, eps, momentum, training, running_mean, running_var,
+                     num_batches_tracked, mean_rstd);
+  CN_LAUNCH_CHECK("cartnet_bn_finalize");
+  return 0;
+}
+
+extern "C" int cartnet_node_update_fwd(const float* aggr, const float* x_in, const float* mean_rstd,
+                                       const float* gamma, const float* beta, int32_t N, int32_t D, float* x_out,
+                                       void* stream) {
+  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_node_update_fwd: D=%d must be a multiple of 4", D);
+  if (N == 0) return 0;
+  CN_CHECK(aggr && x_in && mean_rstd && gamma && beta && x_out, "cartnet_node_update_fwd: null pointer");
+  long long blocks = ((long long)N * D / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(cn_node_update_fwd_kernel, dim3((int)blocks), dim3(256), 0, ST(stream), aggr, x_in, mean_rstd,
+                     gamma, beta, N, D, x_out);
+  CN_LAUNCH_CHECK("cartnet_node_update_fwd");
+  return 0;
+}
+
+extern "C" int cartnet_node_update_bwd_stats(const float* aggr, const float* dx_out, const float* mean_rstd,
+                                             const float* gamma, const float* beta, int32_t N, int32_t D,
+                                             float* parts_a, float* parts_b, void* stream) {
+  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_node_update_bwd_stats: D=%d must be a multiple of 4", D);
+  CN_CHECK(aggr && dx_out && mean_rstd && gamma && beta && parts_a && parts_b,
+           "cartnet_node_update_bwd_stats: null pointer");
+  hipLaunchKernelGGL(cn_node_update_bwd_kernel<0>, dim3(node_parts(N)), dim3(256), 0, ST(stream), aggr, dx_out,
+                     mean_rstd, gamma, beta, (const float*)nullptr, 0.f, N, D, parts_a, parts_b, (float*)nullptr);
+  CN_LAUNCH_CHECK("cartnet_node_update_bwd_stats");
+  return 0;
+}
+
+extern "C" int cartnet_node_update_bwd_apply(const float* aggr, const float* dx_out, const float* mean_rstd,
+                                             const float* gamma, const float* beta, const float* sums,
+                                             int32_t training, int32_t N, int32_t D, float* daggr, void* stream) {
+  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_node_update_bwd_apply: D=%d must be a multiple of 4", D);
+  if (N == 0) return 0;
+  CN_CHECK(aggr && dx_out && mean_rstd && gamma && beta && sums && daggr, "cartnet_node_update_bwd_apply: null pointer");
+  const float inv = (training && N > 0) ? (float)(1.0 / (double)N) : 0.f;
+  hipLaunchKernelGGL(cn_node_update_bwd_kernel<1>, dim3(node_parts(N)), dim3(256), 0, ST(stream), aggr, dx_out,
+                     mean_rstd, gamma, beta, sums, inv, N, D, (float*)nullptr, (float*)nullptr, daggr);
+  CN_LAUNCH_CHECK("cartnet_node_update_bwd_apply");
+  return 0;
+}
+
+extern "C" int cartnet_mask_index(const uint8_t* mask, int32_t N, int32_t* out_index, int32_t* count, void* stream) {
+  CN_CHECK(N >= 0 && (N == 0 || (mask && out_index)), "cartnet_mask_index: bad arguments");
+  hipLaunchKernelGGL(cn_mask_index_kernel, dim3(1), dim3(1024), 0, ST(stream), mask, N, out_index, count);
+  CN_LAUNCH_CHECK("cartnet_mask_index");
+  return 0;
+}
+
+extern "C" int cartnet_cholesky_head_fwd(const float* hid, const int32_t* out_index, const float* W2, const float* b2,
+                                         int32_t N, int32_t H, float* p6, float* pred, void* stream) {
+  CN_CHECK(N >= 0 && H >= 1 && H <= HEAD_MAX_H, "cartnet_cholesky_head_fwd: H=%d out of range (max %d)", H, HEAD_MAX_H);
+  if (N == 0) return 0;
+  CN_CHECK(hid && out_index && W2 && b2 && p6 && pred, "cartnet_cholesky_head_fwd: null pointer");
+  hipLaunchKernelGGL(cn_cholesky_head_fwd_kernel, dim3(cn_ceil_div(N, 4) > 2048 ? 2048 : cn_ceil_div(N, 4)), dim3(256),
+                     0, ST(stream), hid, out_index, W2, b2, N, H, p6, pred);
+  CN_LAUNCH_CHECK("cartnet_cholesky_head_fwd");
+  return 0;
+}
+
+extern "C" int cartnet_cholesky_head_bwd(const float* hid, const int32_t* out_index, const float* W2, const float* p6,
+                                         const float* dpred, int32_t N, int32_t H, float* dhid, float* parts,
+                                         void* stream) {
+  CN_CHECK(N >= 0 && H >= 1 && H <= HEAD_MAX_H, "cartnet_cholesky_head_bwd: H=%d out of range (max %d)", H, HEAD_MAX_H);
+  CN_CHECK(hid && out_index && W2 && p6 && dpred && dhid && parts, "cartnet_cholesky_head_bwd: null pointer");
+  hipLaunchKernelGGL(cn_cholesky_head_bwd_kernel, dim3(node_parts(N)), dim3(256), 0, ST(stream), hid, out_index, W2,
+                     p6, dpred, N, H, dhid, parts);
+  CN_LAUNCH_CHECK("cartnet_cholesky_head_bwd");
+  return 0;
+}
+
+extern "C" int cartnet_scalar_head_fwd(const float* hid, const float* w2, const float* b2, const int64_t* graph_ptr,
+                                       int32_t Bg, int32_t H, float* out, void* stream) {
+  CN_CHECK(Bg >= 0 && H >= 1, "cartnet_scalar_head_fwd: bad sizes");
+  if (Bg == 0) return 0;
+  CN_CHECK(hid && w2 && b2 && graph_ptr && out, "cartnet_scalar_head_fwd: null pointer");
+  hipLaunchKernelGGL(cn_scalar_head_fwd_kernel, dim3(Bg), dim3(64), 0, ST(stream), hid, w2, b2, graph_ptr, Bg, H, out);
+  CN_LAUNCH_CHECK("cartnet_scalar_head_fwd");
+  return 0;
+}
+
+extern "C" int cartnet_scalar_head_bwd(const float* hid, const float* w2, const int64_t* graph_ptr,
+                                       const int64_t* batch, const float* dout, int32_t N, int32_t Bg, int32_t H,
+                                       float* dhid, float* parts, void* stream) {
+  CN_CHECK(N >= 0 && Bg >= 0 && H >= 1 && H <= HEAD_MAX_H, "cartnet_scalar_head_bwd: H=%d out of range", H);
+  CN_CHECK(hid && w2 && graph_ptr && batch && dout && dhid && parts, "cartnet_scalar_head_bwd: null pointer");
+  hipLaunchKernelGGL(cn_scalar_head_bwd_kernel, dim3(node_parts(N)), dim3(256), 0, ST(stream), hid, w2, graph_ptr,
+                     batch, dout, N, H, dhid, parts);
+  CN_LAUNCH_CHECK("cartnet_scalar_head_bwd");
+  return 0;
+}

@@ -1,0 +1,127 @@
+"""ctypes binding of libcartnet_hip.so (the C ABI declared in include/cartnet_hip.h).
+
+The product path has no CPU or PyTorch fallback: if the shared library is missing or a call fails, this module
+raises.  Tensors cross the boundary as raw device pointers + sizes; the HIP stream is torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcartnet_hip.so")
+MAX_GROUPS = 4
+
+_lib: Optional[C.CDLL] = None
+
+c_f32p = C.c_void_p
+c_i32p = C.c_void_p
+c_i64p = C.c_void_p
+c_u8p = C.c_void_p
+c_stream = C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p * MAX_GROUPS), ("B", C.c_void_p * MAX_GROUPS), ("C", C.c_void_p * MAX_GROUPS),
+        ("cpre", C.c_void_p * MAX_GROUPS), ("bias", C.c_void_p * MAX_GROUPS),
+        ("gather_i", C.c_void_p * MAX_GROUPS), ("gather_j", C.c_void_p * MAX_GROUPS),
+        ("resid", C.c_void_p * MAX_GROUPS), ("dact", C.c_void_p * MAX_GROUPS),
+        ("colsum", C.c_void_p * MAX_GROUPS), ("colsq", C.c_void_p * MAX_GROUPS),
+        ("tgt", C.c_void_p), ("src", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldg", C.c_int32), ("ldr", C.c_int32),
+        ("ldd", C.c_int32),
+        ("ngroups", C.c_int32), ("nsegs", C.c_int32), ("splitk", C.c_int32),
+        ("a_kstrided", C.c_int32), ("b_kstrided", C.c_int32), ("a_act", C.c_int32), ("b_act", C.c_int32),
+        ("out_act", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/cartnet_hip.h declares
+PROTOTYPES = {
+    "cartnet_last_error": (C.c_char_p, []),
+    "cartnet_abi_version": (C.c_int, []),
+    "cartnet_gemm": (C.c_int, [C.POINTER(GemmArgs), c_stream]),
+    "cartnet_splitk_reduce": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_stream]),
+    "cartnet_colsum_finalize": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_stream]),
+    "cartnet_csr_build": (C.c_int, [c_i64p, C.c_int64, C.c_int32, c_i64p, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p,
+                                    c_i32p, c_i32p, c_stream]),
+    "cartnet_edge_features": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float,
+                                        C.c_float, c_f32p, C.c_int32, c_f32p, c_stream]),
+    "cartnet_node_embed": (C.c_int, [c_i64p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32,
+                                     c_f32p, c_stream]),
+    "cartnet_node_nparts": (C.c_int, [C.c_int32]),
+    "cartnet_node_embed_bwd": (C.c_int, [c_i64p, c_i64p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
+                                         c_f32p, c_f32p, c_stream]),
+    "cartnet_bn_finalize": (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float,
+                                      C.c_int32, c_f32p, c_f32p, c_i64p, c_f32p, c_stream]),
+    "cartnet_gate_scatter_nparts": (C.c_int, [C.c_int32]),
+    "cartnet_gate_scatter_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, C.c_int32,
+                                           C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "cartnet_gate_scatter_bwd_stats": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p,
+                                                 C.c_int32, C.c_int32, c_f32p, c_f32p, c_stream]),
+    "cartnet_gate_scatter_bwd_apply": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p,
+                                                 c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p,
+                                                 c_stream]),
+    "cartnet_segment_sum": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int32,
+                                      c_stream]),
+    "cartnet_node_update_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p,
+                                          c_stream]),
+    "cartnet_node_update_bwd_stats": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p,
+                                                c_f32p, c_stream]),
+    "cartnet_node_update_bwd_apply": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32,
+                                                C.c_int32, c_f32p, c_stream]),
+    "cartnet_mask_index": (C.c_int, [c_u8p, C.c_int32, c_i32p, c_i32p, c_stream]),
+    "cartnet_cholesky_head_fwd": (C.c_int, [c_f32p, c_i32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p,
+                                            c_stream]),
+    "cartnet_cholesky_head_bwd": (C.c_int, [c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p,
+                                            c_f32p, c_stream]),
+    "cartnet_scalar_head_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, C.c_int32, C.c_int32, c_f32p, c_stream]),
+    "cartnet_scalar_head_bwd": (C.c_int, [c_f32p, c_f32p, c_i64p, c_i64p, c_f32p, C.c_int32, C.c_int32, C.c_int32,
+                                          c_f32p, c_f32p, c_stream]),
+    "cartnet_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                    C.c_float, C.c_int32, C.c_float, c_stream]),
+}
+
+
+class CartnetHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once) and attach prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CartnetHipError(
+            f"{LIB_PATH} not found: build it with `python -m cartnet_amd.build` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the CartNet hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing -> loud
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().cartnet_last_error()
+        raise CartnetHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Raw device pointer of a tensor (None stays NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()

@@ -1,0 +1,510 @@
+"""Host-side wrappers over the C ABI: each function validates shapes / dtypes / devices on the host (a bad
+operand must never reach a hand-written kernel), then passes raw device pointers and torch's current stream.
+
+Operands are given as 2-D torch *views* (unit stride in the last dim); the leading dimension handed to the kernel
+is the view's row stride, so column blocks of a reference-shaped weight such as ``MLP_gate.0.weight[:, D:2D]`` are
+used in place, without packing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import lib as _l
+
+Tensor = torch.Tensor
+
+
+def _f32_2d(t: Tensor, name: str) -> None:
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2):
+        raise ValueError(f"{name}: expected a 2-D fp32 CUDA tensor, got {type(t).__name__} "
+                         f"{getattr(t, 'dtype', None)} {tuple(getattr(t, 'shape', ()))} cuda={getattr(t, 'is_cuda', None)}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise ValueError(f"{name}: last dimension must have unit stride (strides {t.stride()})")
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        raise ValueError(f"{name}: overlapping rows (strides {t.stride()}, shape {tuple(t.shape)})")
+
+
+def _ld(t: Tensor) -> int:
+    return int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))
+
+
+def _vec(t: Optional[Tensor], n: int, name: str, dtype=torch.float32) -> None:
+    if t is None:
+        return
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous() and t.numel() >= n):
+        raise ValueError(f"{name}: expected contiguous {dtype} CUDA tensor with >= {n} elements, "
+                         f"got {t.dtype} {tuple(t.shape)}")
+
+
+def _aslist(x, n):
+    if x is None:
+        return [None] * n
+    if torch.is_tensor(x):
+        return [x]
+    return list(x)
+
+
+def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequence[Tensor] | Tensor, *,
+         a_kstrided: bool = False, b_kstrided: bool = False, a_act: bool = False, b_act: bool = False,
+         out_act: bool = False, segments: bool = False, bias=None, gather_i=None, gather_j=None, tgt=None, src=None,
+         resid=None, dact=None, cpre=None, colsum=None, colsq=None, splitk: int = 1) -> None:
+    """C[g] = epilogue(sum_s opA(A[s]) @ opB(B[s])) on the fp32 matrix cores (see include/cartnet_hip.h).
+
+    A / B / C_out: one tensor or a list.  With ``segments=False`` the lists are independent problems (groups) of
+    identical shape; with ``segments=True`` A and B list K-segments that are summed into the single output.
+    Shapes: A [M,K] (or [K,M] if a_kstrided), B [N,K] (or [K,N] if b_kstrided), C [M,N]
+    (for splitk > 1: C is [splitk*M, N] contiguous slabs).
+    """
+    lib = _l.load()
+    A, B, C_out = _aslist(A, 1), _aslist(B, 1), _aslist(C_out, 1)
+    if len(A) != len(B) or not (1 <= len(A) <= _l.MAX_GROUPS):
+        raise ValueError(f"gemm: {len(A)} A operands vs {len(B)} B operands (max {_l.MAX_GROUPS})")
+    nptr = len(A)
+    ngroups, nsegs = (1, nptr) if segments else (nptr, 1)
+    if len(C_out) != ngroups:
+        raise ValueError(f"gemm: expected {ngroups} outputs, got {len(C_out)}")
+    for i, (a, b) in enumerate(zip(A, B)):
+        _f32_2d(a, f"gemm A[{i}]")
+        _f32_2d(b, f"gemm B[{i}]")
+    M, K = (A[0].shape[1], A[0].shape[0]) if a_kstrided else (A[0].shape[0], A[0].shape[1])
+    N, Kb = (B[0].shape[1], B[0].shape[0]) if b_kstrided else (B[0].shape[0], B[0].shape[1])
+    if K != Kb:
+        raise ValueError(f"gemm: inner dimensions differ: A gives K={K}, B gives K={Kb}")
+    lda, ldb = _ld(A[0]), _ld(B[0])
+    for i in range(nptr):
+        if tuple(A[i].shape) != tuple(A[0].shape) or tuple(B[i].shape) != tuple(B[0].shape) or \
+                _ld(A[i]) != lda or _ld(B[i]) != ldb:
+            raise ValueError("gemm: all groups / segments must share shapes and leading dimensions")
+    rows_c = M * splitk
+    for i, c in enumerate(C_out):
+        _f32_2d(c, f"gemm C[{i}]")
+        if tuple(c.shape) != (rows_c, N):
+            raise ValueError(f"gemm C[{i}]: expected shape {(rows_c, N)}, got {tuple(c.shape)}")
+    ldc = _ld(C_out[0])
+    if splitk > 1 and ldc != N:
+        raise ValueError("gemm: split-K slabs must be contiguous [splitk*M, N]")
+    args = _l.GemmArgs()
+    args.M, args.N, args.K = int(M), int(N), int(K)
+    args.lda, args.ldb, args.ldc = lda, ldb, ldc
+    args.ngroups, args.nsegs, args.splitk = ngroups, nsegs, int(splitk)
+    args.a_kstrided, args.b_kstrided = int(a_kstrided), int(b_kstrided)
+    args.a_act, args.b_act, args.out_act = int(a_act), int(b_act), int(out_act)
+    for i in range(nptr):
+        args.A[i] = A[i].data_ptr()
+        args.B[i] = B[i].data_ptr()
+    for g in range(ngroups):
+        if _ld(C_out[g]) != ldc:
+            raise ValueError("gemm: outputs must share a leading dimension")
+        args.C[g] = C_out[g].data_ptr()
+
+    def per_group(name, val, shape, field, ldfield=None, vector=False):
+        vals = _aslist(val, ngroups)
+        if len(vals) != ngroups:
+            raise ValueError(f"gemm {name}: expected {ngroups} entries")
+        ld = None
+        for g, t in enumerate(vals):
+            if t is None:
+                continue
+            if vector:
+                _vec(t, shape, f"gemm {name}[{g}]")
+            else:
+                _f32_2d(t, f"gemm {name}[{g}]")
+                if shape is not None and tuple(t.shape) != shape:
+                    raise ValueError(f"gemm {name}[{g}]: expected shape {shape}, got {tuple(t.shape)}")
+                if ld is None:
+                    ld = _ld(t)
+                elif _ld(t) != ld:
+                    raise ValueError(f"gemm {name}: entries must share a leading dimension")
+            getattr(args, field)[g] = t.data_ptr()
+        if ldfield is not None and ld is not None:
+            setattr(args, ldfield, ld)
+        return vals
+
+    per_group("bias", bias, N, "bias", vector=True)
+    gi = per_group("gather_i", gather_i, None, "gather_i", "ldg")
+    gj = per_group("gather_j", gather_j, None, "gather_j", "ldg")
+    if any(t is not None for t in gi):
+        _vec(tgt, M, "gemm tgt", torch.int32)
+        _vec(src, M, "gemm src", torch.int32)
+        if tgt is None or src is None:
+            raise ValueError("gemm: gather epilogue needs tgt and src")
+        for a, b in zip(gi, gj):
+            if (a is None) != (b is None) or (a is not None and (a.shape[1] != N or b.shape[1] != N or
+                                                                  _ld(a) != _ld(b))):
+                raise ValueError("gemm: gather_i / gather_j must pair up with N columns and equal row stride")
+        args.tgt, args.src = tgt.data_ptr(), src.data_ptr()
+    per_group("resid", resid, (M, N), "resid", "ldr")
+    per_group("dact", dact, (M, N), "dact", "ldd")
+    cp = per_group("cpre", cpre, (M, N), "cpre")
+    for t in cp:
+        if t is not None and _ld(t) != ldc:
+            raise ValueError("gemm: cpre must share the output's leading dimension")
+    tiles_m = (M + 127) // 128
+    cs = _aslist(colsum, ngroups)
+    cq = _aslist(colsq, ngroups)
+    for g in range(ngroups):
+        for name, t, field in (("colsum", cs[g], "colsum"), ("colsq", cq[g], "colsq")):
+            if t is None:
+                continue
+            _vec(t, tiles_m * N, f"gemm {name}[{g}]")
+            getattr(args, field)[g] = t.data_ptr()
+    _l.check(lib.cartnet_gemm(C.byref(args), _l.stream_ptr()), "cartnet_gemm")
+
+
+def gemm_tiles_m(M: int) -> int:
+    """Number of row tiles (= partial-sum rows written by the colsum epilogue)."""
+    return (int(M) + 127) // 128
+
+
+def splitk_reduce(slabs: Tensor, splitk: int, out: Tensor) -> None:
+    _f32_2d(out, "splitk_reduce out")
+    M, N = out.shape
+    _vec(slabs, splitk * M * N, "splitk_reduce slabs")
+    _l.check(_l.load().cartnet_splitk_reduce(slabs.data_ptr(), splitk, M, N, out.data_ptr(), _ld(out),
+                                             _l.stream_ptr()), "cartnet_splitk_reduce")
+
+
+def colsum_finalize(parts: Tensor, nparts: int, out: Tensor) -> None:
+    n = out.numel()
+    _vec(out, n, "colsum_finalize out")
+    _vec(parts, nparts * n, "colsum_finalize parts")
+    _l.check(_l.load().cartnet_colsum_finalize(parts.data_ptr(), nparts, n, out.data_ptr(), _l.stream_ptr()),
+             "cartnet_colsum_finalize")
+
+
+class GraphLayout:
+    """Device-side CSR (by target) / CSC (by source) layout of one batch; built once per batch."""
+
+    def __init__(self, edge_index: Tensor, num_nodes: int, graph_ptr: Optional[Tensor], need_csc: bool = True):
+        if not (edge_index.is_cuda and edge_index.dtype == torch.int64 and edge_index.dim() == 2 and
+                edge_index.shape[0] == 2):
+            raise ValueError("edge_index must be a CUDA int64 tensor of shape [2, E]")
+        edge_index = edge_index.contiguous()
+        dev = edge_index.device
+        E, N = int(edge_index.shape[1]), int(num_nodes)
+        self.E, self.N = E, N
+        self.src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        self.tgt = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        self.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        self.colptr = torch.empty(N + 1, dtype=torch.int32, device=dev) if need_csc else None
+        self.perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if need_csc else None
+        self.status = torch.empty(1, dtype=torch.int32, device=dev)
+        Bg = 1
+        gp = None
+        if graph_ptr is not None:
+            if not (graph_ptr.is_cuda and graph_ptr.dtype == torch.int64 and graph_ptr.is_contiguous()):
+                raise ValueError("graph_ptr must be a contiguous CUDA int64 tensor")
+            Bg = int(graph_ptr.numel()) - 1
+            gp = graph_ptr.data_ptr()
+        _l.check(_l.load().cartnet_csr_build(
+            edge_index.data_ptr(), E, N, gp, Bg, self.src.data_ptr(), self.tgt.data_ptr(), self.rowptr.data_ptr(),
+            _l.ptr(self.colptr), _l.ptr(self.perm), self.status.data_ptr(), _l.stream_ptr()), "cartnet_csr_build")
+
+    def validate(self) -> None:
+        """Host check of the device status word (one sync; call once per batch in debug / tests)."""
+        s = int(self.status.item())
+        if s:
+            why = []
+            if s & 1:
+                why.append("edge_index[1] is not sorted ascending")
+            if s & 2:
+                why.append("an index is outside [0, N)")
+            if s & 4:
+                why.append("an edge connects two different crystals")
+            if s & 8:
+                why.append("a crystal has more than 8192 atoms")
+            raise ValueError("invalid graph: " + "; ".join(why))
+
+
+def edge_features(cart_dist: Tensor, cart_dir: Optional[Tensor], means: Tensor, betas: Tensor, invariant: bool,
+                  radius: float, env_radius: float, feat: Tensor, env: Optional[Tensor]) -> None:
+    E = int(cart_dist.numel())
+    R = int(means.numel())
+    _vec(cart_dist, E, "edge_features cart_dist")
+    _vec(means, R, "edge_features means")
+    _vec(betas, R, "edge_features betas")
+    if not invariant:
+        if cart_dir is None or not (cart_dir.is_cuda and cart_dir.dtype == torch.float32 and
+                                    cart_dir.is_contiguous() and tuple(cart_dir.shape) == (E, 3)):
+            raise ValueError("edge_features: cart_dir must be a contiguous fp32 CUDA tensor [E,3]")
+    _f32_2d(feat, "edge_features feat")
+    if feat.shape[0] != E or not feat.is_contiguous():
+        raise ValueError("edge_features: feat must be contiguous [E, ldf]")
+    _vec(env, E, "edge_features env")
+    _l.check(_l.load().cartnet_edge_features(
+        cart_dist.data_ptr(), _l.ptr(cart_dir), means.data_ptr(), betas.data_ptr(), E, R, int(invariant),
+        float(radius), float(env_radius), feat.data_ptr(), int(feat.shape[1]), _l.ptr(env), _l.stream_ptr()),
+        "cartnet_edge_features")
+
+
+def node_embed(z, batch, temperature, emb, wt, bt, bias, x0: Tensor) -> None:
+    _f32_2d(x0, "node_embed x0")
+    N, Cc = x0.shape
+    if not x0.is_contiguous():
+        raise ValueError("node_embed: x0 must be contiguous")
+    if z is not None:
+        _vec(z, N, "node_embed z", torch.int64)
+    if batch is not None:
+        _vec(batch, N, "node_embed batch", torch.int64)
+    if emb is not None:
+        _f32_2d(emb, "node_embed emb")
+        if emb.shape[1] != Cc or not emb.is_contiguous():
+            raise ValueError("node_embed: embedding table must be contiguous [n_types, C]")
+    _vec(wt, Cc, "node_embed wt")
+    _vec(bt, Cc, "node_embed bt")
+    _vec(bias, Cc, "node_embed bias")
+    if temperature is not None:
+        _vec(temperature, 1, "node_embed temperature")
+    _l.check(_l.load().cartnet_node_embed(_l.ptr(z), _l.ptr(batch), _l.ptr(temperature), _l.ptr(emb), _l.ptr(wt),
+                                          _l.ptr(bt), _l.ptr(bias), N, Cc, x0.data_ptr(), _l.stream_ptr()),
+             "cartnet_node_embed")
+
+
+def node_nparts(N: int) -> int:
+    return int(_l.load().cartnet_node_nparts(int(N)))
+
+
+def gate_nparts(N: int) -> int:
+    return int(_l.load().cartnet_gate_scatter_nparts(int(N)))
+
+
+def node_embed_bwd(z, batch, temperature, dx0: Tensor, n_types: int, demb, parts_w, parts_b) -> None:
+    _f32_2d(dx0, "node_embed_bwd dx0")
+    N, Cc = dx0.shape
+    if not dx0.is_contiguous():
+        raise ValueError("node_embed_bwd: dx0 must be contiguous")
+    if demb is not None:
+        _vec(z, N, "node_embed_bwd z", torch.int64)
+        _vec(demb, n_types * Cc, "node_embed_bwd demb")
+    npart = node_nparts(N)
+    _vec(parts_w, npart * Cc, "node_embed_bwd parts_w")
+    _vec(parts_b, npart * Cc, "node_embed_bwd parts_b")
+    if batch is not None:
+        _vec(batch, N, "node_embed_bwd batch", torch.int64)
+    _l.check(_l.load().cartnet_node_embed_bwd(_l.ptr(z), _l.ptr(batch), _l.ptr(temperature), dx0.data_ptr(), N, Cc,
+                                              int(n_types), _l.ptr(demb), _l.ptr(parts_w), _l.ptr(parts_b),
+                                              _l.stream_ptr()), "cartnet_node_embed_bwd")
+
+
+def bn_finalize(parts_sum, parts_sq, nparts: int, count: int, Cc: int, eps: float, momentum: float, training: bool,
+                running_mean, running_var, nbt, mean_rstd: Tensor) -> None:
+    _vec(mean_rstd, 2 * Cc, "bn_finalize mean_rstd")
+    if training:
+        _vec(parts_sum, nparts * Cc, "bn_finalize parts_sum")
+        _vec(parts_sq, nparts * Cc, "bn_finalize parts_sq")
+    _vec(running_mean, Cc, "bn_finalize running_mean")
+    _vec(running_var, Cc, "bn_finalize running_var")
+    if nbt is not None:
+        _vec(nbt, 1, "bn_finalize num_batches_tracked", torch.int64)
+    _l.check(_l.load().cartnet_bn_finalize(_l.ptr(parts_sum), _l.ptr(parts_sq), int(nparts), int(count), int(Cc),
+                                           float(eps), float(momentum), int(training), _l.ptr(running_mean),
+                                           _l.ptr(running_var), _l.ptr(nbt), mean_rstd.data_ptr(), _l.stream_ptr()),
+             "cartnet_bn_finalize")
+
+
+def _edge_rows(t: Tensor, E: int, W: int, name: str) -> None:
+    _f32_2d(t, name)
+    if tuple(t.shape) != (E, W) or not t.is_contiguous():
+        raise ValueError(f"{name}: expected contiguous [{E},{W}], got {tuple(t.shape)}")
+
+
+def gate_scatter_fwd(gs, e_in, env, layout: GraphLayout, mean_rstd, gamma, beta, e_out, aggr, parts_sum,
+                     parts_sq) -> None:
+    E, N = layout.E, layout.N
+    D = int(aggr.shape[1])
+    _edge_rows(gs, E, 2 * D, "gate_scatter_fwd gs")
+    _edge_rows(e_in, E, D, "gate_scatter_fwd e_in")
+    _edge_rows(e_out, E, D, "gate_scatter_fwd e_out")
+    _edge_rows(aggr, N, D, "gate_scatter_fwd aggr")
+    _vec(env, E, "gate_scatter_fwd env")
+    _vec(mean_rstd, 2 * D, "gate_scatter_fwd mean_rstd")
+    _vec(gamma, D, "gate_scatter_fwd gamma")
+    _vec(beta, D, "gate_scatter_fwd beta")
+    npart = gate_nparts(N)
+    _vec(parts_sum, npart * D, "gate_scatter_fwd parts_sum")
+    _vec(parts_sq, npart * D, "gate_scatter_fwd parts_sq")
+    _l.check(_l.load().cartnet_gate_scatter_fwd(gs.data_ptr(), e_in.data_ptr(), _l.ptr(env), layout.rowptr.data_ptr(),
+                                                mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, D,
+                                                e_out.data_ptr(), aggr.data_ptr(), parts_sum.data_ptr(),
+                                                parts_sq.data_ptr(), _l.stream_ptr()), "cartnet_gate_scatter_fwd")
+
+
+def gate_scatter_bwd_stats(gs, de_out, daggr, env, layout: GraphLayout, mean_rstd, gamma, beta, parts_a,
+                           parts_b) -> None:
+    E, N = layout.E, layout.N
+    D = int(daggr.shape[1])
+    _edge_rows(gs, E, 2 * D, "gate_scatter_bwd_stats gs")
+    _edge_rows(de_out, E, D, "gate_scatter_bwd_stats de_out")
+    _edge_rows(daggr, N, D, "gate_scatter_bwd_stats daggr")
+    _vec(env, E, "gate_scatter_bwd_stats env")
+    _vec(mean_rstd, 2 * D, "mean_rstd")
+    _vec(gamma, D, "gamma")
+    _vec(beta, D, "beta")
+    npart = gate_nparts(N)
+    _vec(parts_a, npart * D, "parts_a")
+    _vec(parts_b, npart * D, "parts_b")
+    _l.check(_l.load().cartnet_gate_scatter_bwd_stats(
+        gs.data_ptr(), de_out.data_ptr(), daggr.data_ptr(), _l.ptr(env), layout.rowptr.data_ptr(),
+        mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, D, parts_a.data_ptr(), parts_b.data_ptr(),
+        _l.stream_ptr()), "cartnet_gate_scatter_bwd_stats")
+
+
+def gate_scatter_bwd_apply(gs, de_out, daggr, env, layout: GraphLayout, mean_rstd, gamma, beta, sums, training: bool,
+                           parts_dg, parts_ds) -> None:
+    E, N = layout.E, layout.N
+    D = int(daggr.shape[1])
+    _edge_rows(gs, E, 2 * D, "gate_scatter_bwd_apply gs")
+    _edge_rows(de_out, E, D, "gate_scatter_bwd_apply de_out")
+    _edge_rows(daggr, N, D, "gate_scatter_bwd_apply daggr")
+    _vec(env, E, "env")
+    _vec(mean_rstd, 2 * D, "mean_rstd")
+    _vec(gamma, D, "gamma")
+    _vec(beta, D, "beta")
+    _vec(sums, 2 * D, "sums")
+    npart = gate_nparts(N)
+    _vec(parts_dg, npart * D, "parts_dg")
+    _vec(parts_ds, npart * D, "parts_ds")
+    _l.check(_l.load().cartnet_gate_scatter_bwd_apply(
+        gs.data_ptr(), de_out.data_ptr(), daggr.data_ptr(), _l.ptr(env), layout.rowptr.data_ptr(),
+        mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), E, int(training), N, D,
+        parts_dg.data_ptr(), parts_ds.data_ptr(), _l.stream_ptr()), "cartnet_gate_scatter_bwd_apply")
+
+
+def segment_sum(rows: Tensor, ptr_: Tensor, perm: Optional[Tensor], out: Tensor) -> None:
+    _f32_2d(rows, "segment_sum rows")
+    _f32_2d(out, "segment_sum out")
+    N, W = out.shape
+    if rows.shape[1] != W:
+        raise ValueError("segment_sum: width mismatch")
+    _vec(ptr_, N + 1, "segment_sum ptr", torch.int32)
+    if perm is not None:
+        _vec(perm, rows.shape[0], "segment_sum perm", torch.int32)
+    _l.check(_l.load().cartnet_segment_sum(rows.data_ptr(), _ld(rows), ptr_.data_ptr(), _l.ptr(perm), N, W,
+                                           out.data_ptr(), _ld(out), _l.stream_ptr()), "cartnet_segment_sum")
+
+
+def node_update_fwd(aggr, x_in, mean_rstd, gamma, beta, x_out) -> None:
+    _f32_2d(aggr, "node_update_fwd aggr")
+    N, D = aggr.shape
+    for name, t in (("aggr", aggr), ("x_in", x_in), ("x_out", x_out)):
+        _edge_rows(t, N, D, f"node_update_fwd {name}")
+    _vec(mean_rstd, 2 * D, "mean_rstd")
+    _vec(gamma, D, "gamma")
+    _vec(beta, D, "beta")
+    _l.check(_l.load().cartnet_node_update_fwd(aggr.data_ptr(), x_in.data_ptr(), mean_rstd.data_ptr(),
+                                               gamma.data_ptr(), beta.data_ptr(), N, D, x_out.data_ptr(),
+                                               _l.stream_ptr()), "cartnet_node_update_fwd")
+
+
+def node_update_bwd_stats(aggr, dx_out, mean_rstd, gamma, beta, parts_a, parts_b) -> None:
+    _f32_2d(aggr, "node_update_bwd_stats aggr")
+    N, D = aggr.shape
+    _edge_rows(aggr, N, D, "aggr")
+    _edge_rows(dx_out, N, D, "dx_out")
+    _vec(mean_rstd, 2 * D, "mean_rstd")
+    _vec(gamma, D, "gamma")
+    _vec(beta, D, "beta")
+    npart = node_nparts(N)
+    _vec(parts_a, npart * D, "parts_a")
+    _vec(parts_b, npart * D, "parts_b")
+    _l.check(_l.load().cartnet_node_update_bwd_stats(aggr.data_ptr(), dx_out.data_ptr(), mean_rstd.data_ptr(),
+                                                     gamma.data_ptr(), beta.data_ptr(), N, D, parts_a.data_ptr(),
+                                                     parts_b.data_ptr(), _l.stream_ptr()),
+             "cartnet_node_update_bwd_stats")
+
+
+def node_update_bwd_apply(aggr, dx_out, mean_rstd, gamma, beta, sums, training: bool, daggr) -> None:
+    _f32_2d(aggr, "node_update_bwd_apply aggr")
+    N, D = aggr.shape
+    _edge_rows(aggr, N, D, "aggr")
+    _edge_rows(dx_out, N, D, "dx_out")
+    _edge_rows(daggr, N, D, "daggr")
+    _vec(mean_rstd, 2 * D, "mean_rstd")
+    _vec(gamma, D, "gamma")
+    _vec(beta, D, "beta")
+    _vec(sums, 2 * D, "sums")
+    _l.check(_l.load().cartnet_node_update_bwd_apply(aggr.data_ptr(), dx_out.data_ptr(), mean_rstd.data_ptr(),
+                                                     gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(),
+                                                     int(training), N, D, daggr.data_ptr(), _l.stream_ptr()),
+             "cartnet_node_update_bwd_apply")
+
+
+def mask_index(mask: Tensor, out_index: Tensor, count: Optional[Tensor]) -> None:
+    N = int(mask.numel())
+    if not (mask.is_cuda and mask.dtype in (torch.bool, torch.uint8) and mask.is_contiguous()):
+        raise ValueError("mask_index: mask must be a contiguous bool/uint8 CUDA tensor")
+    _vec(out_index, N, "mask_index out_index", torch.int32)
+    if count is not None:
+        _vec(count, 1, "mask_index count", torch.int32)
+    _l.check(_l.load().cartnet_mask_index(mask.data_ptr(), N, out_index.data_ptr(), _l.ptr(count), _l.stream_ptr()),
+             "cartnet_mask_index")
+
+
+def cholesky_head_fwd(hid, out_index, W2, b2, p6, pred) -> None:
+    _f32_2d(hid, "cholesky_head_fwd hid")
+    N, H = hid.shape
+    if not hid.is_contiguous():
+        raise ValueError("cholesky_head_fwd: hid must be contiguous")
+    _vec(out_index, N, "out_index", torch.int32)
+    _vec(W2, 6 * H, "W2")
+    _vec(b2, 6, "b2")
+    M = int(pred.shape[0])
+    _vec(pred, M * 9, "pred")
+    _vec(p6, M * 6, "p6")
+    _l.check(_l.load().cartnet_cholesky_head_fwd(hid.data_ptr(), out_index.data_ptr(), W2.data_ptr(), b2.data_ptr(),
+                                                 N, H, p6.data_ptr(), pred.data_ptr(), _l.stream_ptr()),
+             "cartnet_cholesky_head_fwd")
+
+
+def cholesky_head_bwd(hid, out_index, W2, p6, dpred, dhid, parts) -> None:
+    _f32_2d(hid, "cholesky_head_bwd hid")
+    N, H = hid.shape
+    _edge_rows(dhid, N, H, "cholesky_head_bwd dhid")
+    _vec(out_index, N, "out_index", torch.int32)
+    _vec(W2, 6 * H, "W2")
+    M = int(dpred.shape[0])
+    _vec(dpred, M * 9, "dpred")
+    _vec(p6, M * 6, "p6")
+    _vec(parts, node_nparts(N) * (6 * H + 8), "parts")
+    _l.check(_l.load().cartnet_cholesky_head_bwd(hid.data_ptr(), out_index.data_ptr(), W2.data_ptr(), p6.data_ptr(),
+                                                 dpred.data_ptr(), N, H, dhid.data_ptr(), parts.data_ptr(),
+                                                 _l.stream_ptr()), "cartnet_cholesky_head_bwd")
+
+
+def scalar_head_fwd(hid, w2, b2, graph_ptr, out) -> None:
+    _f32_2d(hid, "scalar_head_fwd hid")
+    N, H = hid.shape
+    Bg = int(out.numel())
+    _vec(w2, H, "w2")
+    _vec(b2, 1, "b2")
+    _vec(graph_ptr, Bg + 1, "graph_ptr", torch.int64)
+    _vec(out, Bg, "out")
+    _l.check(_l.load().cartnet_scalar_head_fwd(hid.data_ptr(), w2.data_ptr(), b2.data_ptr(), graph_ptr.data_ptr(), Bg,
+                                               H, out.data_ptr(), _l.stream_ptr()), "cartnet_scalar_head_fwd")
+
+
+def scalar_head_bwd(hid, w2, graph_ptr, batch, dout, dhid, parts) -> None:
+    _f32_2d(hid, "scalar_head_bwd hid")
+    N, H = hid.shape
+    Bg = int(dout.numel())
+    _edge_rows(dhid, N, H, "dhid")
+    _vec(w2, H, "w2")
+    _vec(graph_ptr, Bg + 1, "graph_ptr", torch.int64)
+    _vec(batch, N, "batch", torch.int64)
+    _vec(dout, Bg, "dout")
+    _vec(parts, node_nparts(N) * (H + 8), "parts")
+    _l.check(_l.load().cartnet_scalar_head_bwd(hid.data_ptr(), w2.data_ptr(), graph_ptr.data_ptr(), batch.data_ptr(),
+                                               dout.data_ptr(), N, Bg, H, dhid.data_ptr(), parts.data_ptr(),
+                                               _l.stream_ptr()), "cartnet_scalar_head_bwd")
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0) -> None:
+    n = int(param.numel())
+    for name, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        _vec(t, n, f"adam_step {name}")
+    _l.check(_l.load().cartnet_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                         n, float(lr), float(beta1), float(beta2), float(eps), int(step),
+                                         float(grad_scale), _l.stream_ptr()), "cartnet_adam_step")

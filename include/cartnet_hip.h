@@ -1,0 +1,214 @@
+/*
+ * cartnet_hip.h -- C ABI of libcartnet_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the CartNet
+ * message-passing hot path (reference: models/cartnet.py:65-73 CartNet.forward and its autograd backward).
+ *
+ * The reference has no native boundary of its own (pure Python on PyG / pytorch-scatter / ATen); each entry
+ * point below names the reference call site whose ATen/PyG kernels it replaces.  Conventions:
+ *   - every pointer is a borrowed DEVICE pointer (the caller, e.g. torch, owns all memory); float = fp32
+ *     row-major with an explicit leading dimension in elements; indices are int32 on the device
+ *     (cartnet_csr_build converts the int64 edge_index of the PyG API once per batch);
+ *   - `stream` is a hipStream_t passed as void*; kernels are only enqueued, no host synchronisation, no
+ *     allocation, no global state -> safe to capture in a hipGraph;
+ *   - return value 0 = ok, non-zero = error; cartnet_last_error() returns a thread-local message.
+ *   - shapes are validated on the host before launch (a bad shape returns an error, it never launches).
+ */
+#ifndef CARTNET_HIP_H
+#define CARTNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CARTNET_MAX_GROUPS 4
+
+const char* cartnet_last_error(void);
+int cartnet_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Dense per-row GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 accumulate).
+ * Replaces every pyg_nn.Linear on the path (models/cartnet.py:119,126,133,135,188-195,289-291,319-321) and the
+ * matching autograd mm/addmm backward kernels.  One launch computes `ngroups` independent problems of the
+ * same shape (e.g. the gate and sender MLPs of a layer) or one problem summed over `nsegs` K-segments
+ * (e.g. dX = sum_s dY_s @ W_s).  Index the pointer arrays by group when ngroups > 1, by segment otherwise.
+ *
+ *   C[g][m, n] = epilogue( sum_s sum_k opA(A[s])[m, k] * opB(B[s])[k, n] )
+ *
+ * a_kstrided = 0: A[m,k] at A + m*lda + k      (activations, k contiguous)
+ * a_kstrided = 1: A[m,k] at A + k*lda + m      (transposed use: weight gradients, reduction over rows)
+ * b_kstrided = 0: B[k,n] at B + n*ldb + k      (weights stored [out,in]: Y = X W^T)
+ * b_kstrided = 1: B[k,n] at B + k*ldb + n      (dX = dY W ; weight gradients)
+ * a_act / b_act = 1 applies SiLU to the operand as it is staged (fuses the activation between two Linears).
+ *
+ * Epilogue, applied in this order to v = accumulator:
+ *   v += bias[g][n]; v += gather_i[g][tgt[m]*ldg + n] + gather_j[g][src[m]*ldg + n]; v += resid[g][m*ldr+n];
+ *   v *= silu'(dact[g][m*ldd + n]);
+ *   if colsum[g]: per-column partial sums of v (and v*v into colsq[g]) over this block's rows are written to
+ *                 colsum[g][tile_m * N + n]  (tile_m in [0, ceil(M/128)); reduce with cartnet_colsum_finalize
+ *                 or cartnet_bn_finalize -- deterministic, no atomics);
+ *   if cpre[g]:   cpre[g][m*ldc + n] = v;      (pre-activation kept for backward)
+ *   if out_act:   v = silu(v);
+ *   C[g][m*ldc + n] = v.
+ * splitk > 1 (only with a_kstrided = b_kstrided = 1, no epilogue): the K range is cut into `splitk` chunks and
+ *   chunk s writes its raw partial tile to C[g] + s*M*ldc; reduce with cartnet_splitk_reduce.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct CartnetGemmArgs {
+  const float* A[CARTNET_MAX_GROUPS];
+  const float* B[CARTNET_MAX_GROUPS];
+  float* C[CARTNET_MAX_GROUPS];
+  float* cpre[CARTNET_MAX_GROUPS];
+  const float* bias[CARTNET_MAX_GROUPS];
+  const float* gather_i[CARTNET_MAX_GROUPS];
+  const float* gather_j[CARTNET_MAX_GROUPS];
+  const float* resid[CARTNET_MAX_GROUPS];
+  const float* dact[CARTNET_MAX_GROUPS];
+  float* colsum[CARTNET_MAX_GROUPS];
+  float* colsq[CARTNET_MAX_GROUPS];
+  const int32_t* tgt;
+  const int32_t* src;
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc, ldg, ldr, ldd;
+  int32_t ngroups, nsegs, splitk;
+  int32_t a_kstrided, b_kstrided, a_act, b_act, out_act;
+} CartnetGemmArgs;
+
+int cartnet_gemm(const CartnetGemmArgs* args, void* stream);
+
+/* out[m*ldo + n] = sum_{s<splitk} slabs[s*M*N + m*N + n]  (fixed order s = 0..splitk-1). */
+int cartnet_splitk_reduce(const float* slabs, int32_t splitk, int32_t M, int32_t N, float* out, int32_t ldo,
+                          void* stream);
+
+/* out[n] = sum_{p<nparts} parts[p*N + n], accumulated in fp64 in fixed order (bias gradients). */
+int cartnet_colsum_finalize(const float* parts, int32_t nparts, int32_t N, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Graph layout.  Replaces PyG MessagePassing's per-layer index_select bookkeeping (called at
+ * models/cartnet.py:218) with a once-per-batch CSR/CSC build.  edge_index is the PyG tensor [2,E] int64,
+ * row 0 = source j, row 1 = target i, row 1 sorted ascending (dataset/utils.py:235).
+ *   src32/tgt32 [E]  int32 copies;   rowptr [N+1]: edges of target t are [rowptr[t], rowptr[t+1]);
+ *   colptr [N+1] / perm [E]: edges with source j are perm[colptr[j] .. colptr[j+1]), in ascending edge order
+ *   (stable), so by-source reductions are bitwise reproducible;
+ *   status[0] is set non-zero on the device if row 1 is not sorted or an index is outside [0,N).
+ * graph_ptr [Bg+1] int64 node offsets of each crystal (Batch.ptr); crystals never share edges, which the
+ * CSC build uses to work one crystal per workgroup.
+ * ---------------------------------------------------------------------------------------------------- */
+int cartnet_csr_build(const int64_t* edge_index, int64_t E, int32_t N, const int64_t* graph_ptr, int32_t Bg,
+                      int32_t* src32, int32_t* tgt32, int32_t* rowptr, int32_t* colptr, int32_t* perm,
+                      int32_t* status, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Cartesian edge encoding (models/cartnet.py:159 + models/utils.py:56-61,87-91):
+ *   feat[e, 0:R]   = cutoff(d_e; radius) * exp(-betas[k] * (exp(-(5/radius) d_e) - means[k])^2)
+ *   feat[e, R:R+3] = cart_dir[e]   (omitted when invariant != 0);   columns up to ldf are zero-filled
+ *   env[e]         = 0.5 (cos(pi d_e / env_radius) + 1) (d_e < env_radius)    (layer envelope, cartnet.py:201,241)
+ * ---------------------------------------------------------------------------------------------------- */
+int cartnet_edge_features(const float* cart_dist, const float* cart_dir, const float* means, const float* betas,
+                          int64_t E, int32_t R, int32_t invariant, float radius, float env_radius,
+                          float* feat, int32_t ldf, float* env, void* stream);
+
+/* Node embedding (models/cartnet.py:145-149):
+ *   x0[n, c] = emb[z[n], c] (if emb) + (temperature[batch[n]] * wt[c] + bt[c]) (if wt) + bias[c] (if bias). */
+int cartnet_node_embed(const int64_t* z, const int64_t* batch, const float* temperature, const float* emb,
+                       const float* wt, const float* bt, const float* bias, int32_t N, int32_t C, float* x0,
+                       void* stream);
+/* Backward of the above: demb[a, c] = sum_{n: z[n]=a} dx0[n,c] for a < n_types (fixed node order, no atomics);
+ * parts_w[p][c] / parts_b[p][c]: per-block partial sums over atoms of T[batch[n]]*dx0[n,c] and dx0[n,c]
+ * (p < cartnet_node_nparts(N)); reduce with cartnet_colsum_finalize into the gradients of
+ * temperature_proj_atom.weight and .bias (or encoder.bias).  demb, or the parts pair, may be NULL. */
+int cartnet_node_nparts(int32_t N);
+int cartnet_node_embed_bwd(const int64_t* z, const int64_t* batch, const float* temperature, const float* dx0,
+                           int32_t N, int32_t C, int32_t n_types, float* demb, float* parts_w, float* parts_b,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * BatchNorm statistics (nn.BatchNorm1d at models/cartnet.py:198-199, used at :238 over E rows and :269 over
+ * N rows).  parts_sum / parts_sq hold `nparts` per-column partial sums.  training != 0: batch mean and biased
+ * variance -> mean_rstd[0:C] = mean, mean_rstd[C:2C] = 1/sqrt(var + eps); running stats updated in place with
+ * `momentum` and the unbiased variance; num_batches_tracked += 1.  training == 0: mean_rstd from running stats.
+ * ---------------------------------------------------------------------------------------------------- */
+int cartnet_bn_finalize(const float* parts_sum, const float* parts_sq, int32_t nparts, int64_t count, int32_t C,
+                        float eps, float momentum, int32_t training, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, float* mean_rstd, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Neighbour-equalised gate + aggregation (models/cartnet.py:238-243 message, :259 scatter-sum, :225 edge
+ * residual).  gs [E, 2D]: columns 0:D = pre-BatchNorm gate g, D:2D = sender s.  One wavefront walks the edges of
+ * one target node in edge order (CSR), so the sum order equals the CPU scatter_add_ order:
+ *   sigma = env[e] * sigmoid((g - mean) * rstd * gamma + beta);  e_out = e_in + sigma;
+ *   aggr[t] = sum_{e in row t} sigma * s[e].
+ * Also writes per-block column partial sums of aggr / aggr^2 (BatchNorm over nodes) to parts_sum / parts_sq
+ * [nparts = cartnet_gate_scatter_nparts(N)][D].
+ * ---------------------------------------------------------------------------------------------------- */
+int cartnet_gate_scatter_nparts(int32_t N);
+int cartnet_gate_scatter_fwd(const float* gs, const float* e_in, const float* env, const int32_t* rowptr,
+                             const float* mean_rstd, const float* gamma, const float* beta, int32_t N, int32_t D,
+                             float* e_out, float* aggr, float* parts_sum, float* parts_sq, void* stream);
+
+/* Backward, pass 1 (statistics): with dm = daggr[tgt], z = sigmoid(bn(g)), dbn = (dm*s + de_out) * env * z(1-z):
+ * column partial sums of dbn and dbn * ghat (ghat = (g-mean)*rstd) -> parts_a, parts_b [nparts][D]. */
+int cartnet_gate_scatter_bwd_stats(const float* gs, const float* de_out, const float* daggr, const float* env,
+                                   const int32_t* rowptr, const float* mean_rstd, const float* gamma,
+                                   const float* beta, int32_t N, int32_t D, float* parts_a, float* parts_b,
+                                   void* stream);
+/* Backward, pass 2 (apply), in place on gs: g <- dg = gamma*rstd*(dbn - sum_dbn/E - ghat*sum_dbn_ghat/E)
+ * (the two mean terms are dropped when training == 0), s <- ds = dm * sigma.  sums[0:D] = sum dbn,
+ * sums[D:2D] = sum dbn*ghat (from cartnet_colsum_finalize).  Column partial sums of dg and ds (bias gradients
+ * of the second Linears) -> parts_dg, parts_ds [nparts][D]. */
+int cartnet_gate_scatter_bwd_apply(float* gs, const float* de_out, const float* daggr, const float* env,
+                                   const int32_t* rowptr, const float* mean_rstd, const float* gamma,
+                                   const float* beta, const float* sums, int64_t E, int32_t training, int32_t N,
+                                   int32_t D, float* parts_dg, float* parts_ds, void* stream);
+
+/* Row-segment sums: out[t, :] = sum_{k in [ptr[t], ptr[t+1])} rows[(perm ? perm[k] : k), :]  (fixed order).
+ * Backward of the two index_selects PyG performs per layer (x_i by target: perm = NULL; x_j by source: CSC). */
+int cartnet_segment_sum(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t N,
+                        int32_t W, float* out, int32_t ldo, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Node update (models/cartnet.py:269 norm2, :223 SiLU + residual):  x_out = silu(bn(aggr)) + x_in.
+ * ---------------------------------------------------------------------------------------------------- */
+int cartnet_node_update_fwd(const float* aggr, const float* x_in, const float* mean_rstd, const float* gamma,
+                            const float* beta, int32_t N, int32_t D, float* x_out, void* stream);
+/* Backward pass 1: dxn = dx_out * silu'(xn); column partial sums of dxn and dxn*ahat -> parts_a/parts_b
+ * [cartnet_node_nparts(N)][D]. */
+int cartnet_node_update_bwd_stats(const float* aggr, const float* dx_out, const float* mean_rstd,
+                                  const float* gamma, const float* beta, int32_t N, int32_t D, float* parts_a,
+                                  float* parts_b, void* stream);
+/* Backward pass 2: daggr = gamma*rstd*(dxn - sum_a/N - ahat*sum_b/N) (mean terms dropped when training == 0). */
+int cartnet_node_update_bwd_apply(const float* aggr, const float* dx_out, const float* mean_rstd,
+                                  const float* gamma, const float* beta, const float* sums, int32_t training,
+                                  int32_t N, int32_t D, float* daggr, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Cholesky ADP head (models/cartnet.py:293-305).  hid [N, H] = pre-activation of head.MLP.0 for every atom;
+ * atoms with mask != 0 get an output row (in atom order): p = W2 silu(hid) + b2 (6 values),
+ * diag = softplus(p[0:3]), L upper-triangular (L01 = p3, L02 = p4, L12 = p5), pred = L^T L  [M,3,3].
+ * out_index [N] receives the output row of each masked atom (-1 otherwise).
+ * ---------------------------------------------------------------------------------------------------- */
+int cartnet_mask_index(const uint8_t* mask, int32_t N, int32_t* out_index, int32_t* count, void* stream);
+int cartnet_cholesky_head_fwd(const float* hid, const int32_t* out_index, const float* W2, const float* b2,
+                              int32_t N, int32_t H, float* p6, float* pred, void* stream);
+/* Backward: dhid [N,H] (zero rows for unmasked atoms), partial sums for dW2 [6,H] and db2 [6] ->
+ * parts [cartnet_node_nparts(N)][6*H + 8]. */
+int cartnet_cholesky_head_bwd(const float* hid, const int32_t* out_index, const float* W2, const float* p6,
+                              const float* dpred, int32_t N, int32_t H, float* dhid, float* parts, void* stream);
+
+/* Scalar head (models/cartnet.py:323-327): v[n] = w2 . silu(hid[n]) + b2 ; out[g] = mean of v over the atoms of
+ * crystal g (graph_ptr int64 [Bg+1]). */
+int cartnet_scalar_head_fwd(const float* hid, const float* w2, const float* b2, const int64_t* graph_ptr,
+                            int32_t Bg, int32_t H, float* out, void* stream);
+int cartnet_scalar_head_bwd(const float* hid, const float* w2, const int64_t* graph_ptr, const int64_t* batch,
+                            const float* dout, int32_t N, int32_t Bg, int32_t H, float* dhid, float* parts,
+                            void* stream);
+
+/* Fused Adam step over a flat fp32 parameter buffer (torch.optim.Adam semantics, reference main.py:208):
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr * (m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps).
+ * grad_scale multiplies g first (1/world_size after the RCCL gradient all-reduce). */
+int cartnet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                      float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CARTNET_HIP_H */

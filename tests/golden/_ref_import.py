@@ -1,0 +1,134 @@
+"""Import the reference's model code read-only from /root/reference (BUILD CONTAINER ONLY).
+
+The reference is pure Python but depends on packages that are not installed here (torch_geometric 2.5.2,
+torch_scatter 2.1.1, yacs via GraphGym, e3nn).  To execute its own ``models/cartnet.py`` / ``dataset/utils.py``
+unmodified we register small stand-in modules for those *third-party* imports before importing it.  The stand-ins
+restate the published semantics the reference relies on:
+
+  * ``torch_geometric.nn.Linear``                -> ``torch.nn.Linear`` (same affine map and default init law)
+  * ``torch_geometric.nn.conv.MessagePassing``   -> ``propagate`` with flow='source_to_target', node_dim=-2:
+        ``<name>_i`` = ``<name>.index_select(0, edge_index[1])``, ``<name>_j`` = ``...(0, edge_index[0])``,
+        ``index`` = ``edge_index[1]``; message -> aggregate -> update, arguments matched by parameter name
+  * ``torch_scatter.scatter(src, index, dim, out, dim_size, reduce)`` -> ``zeros.scatter_add_`` (sum / mean)
+  * ``torch_geometric.graphgym.config.cfg``      -> attribute bag (only ``invariant`` and ``radius`` are read)
+
+Nothing from /root/reference is copied; this file never travels as anything but test tooling and is not used on
+the GPU box (tests that need it are skipped when /root/reference is absent).
+"""
+from __future__ import annotations
+
+import inspect
+import sys
+import types
+
+import torch
+
+REFERENCE_ROOT = "/root/reference"
+
+
+class _Cfg:
+    invariant = False
+    radius = 5.0
+
+
+def _scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
+    assert dim == 0 and out is None
+    if dim_size is None:
+        dim_size = int(index.max()) + 1
+    idx = index
+    while idx.dim() < src.dim():
+        idx = idx.unsqueeze(-1)
+    idx = idx.expand_as(src)
+    res = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device).scatter_add_(0, idx, src)
+    if reduce in ("sum", "add"):
+        return res
+    if reduce == "mean":
+        cnt = torch.zeros(dim_size, dtype=src.dtype, device=src.device).scatter_add_(
+            0, index, torch.ones(index.shape[0], dtype=src.dtype, device=src.device)).clamp_(min=1)
+        while cnt.dim() < res.dim():
+            cnt = cnt.unsqueeze(-1)
+        return res / cnt
+    raise NotImplementedError(reduce)
+
+
+class _MessagePassing(torch.nn.Module):
+    def __init__(self, aggr="add", flow="source_to_target", node_dim=-2, **kw):
+        super().__init__()
+        self.node_dim = node_dim
+
+    def _collect(self, fn, edge_index, size_n, kw, extra):
+        params = [p for p in inspect.signature(fn).parameters]
+        args = {}
+        for name in params:
+            if name in extra:
+                args[name] = extra[name]
+            elif name.endswith("_i") and name[:-2] in kw:
+                args[name] = kw[name[:-2]].index_select(0, edge_index[1])
+            elif name.endswith("_j") and name[:-2] in kw:
+                args[name] = kw[name[:-2]].index_select(0, edge_index[0])
+            elif name in kw:
+                args[name] = kw[name]
+            elif name == "index":
+                args[name] = edge_index[1]
+            elif name in ("dim_size", "size_i"):
+                args[name] = size_n
+            elif name == "ptr":
+                args[name] = None
+            else:
+                raise TypeError(f"cannot resolve propagate argument {name}")
+        return args
+
+    def propagate(self, edge_index, size=None, **kw):
+        first = next(v for v in kw.values() if torch.is_tensor(v) and v.dim() >= 2)
+        n = first.shape[0]
+        msg = self.message(**self._collect(self.message, edge_index, n, kw, {}))
+        agg = self.aggregate(**self._collect(self.aggregate, edge_index, n, kw,
+                                             {next(iter(inspect.signature(self.aggregate).parameters)): msg}))
+        return self.update(**self._collect(self.update, edge_index, n, kw,
+                                           {next(iter(inspect.signature(self.update).parameters)): agg}))
+
+
+def install_standins():
+    sys.dont_write_bytecode = True   # never drop __pycache__ into the read-only reference tree
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+    tg = mod("torch_geometric")
+    tg_nn = mod("torch_geometric.nn")
+    tg_conv = mod("torch_geometric.nn.conv")
+    tg_gg = mod("torch_geometric.graphgym")
+    tg_cfg = mod("torch_geometric.graphgym.config")
+    tg_typing = mod("torch_geometric.typing")
+    tg_data = mod("torch_geometric.data")
+    ts = mod("torch_scatter")
+    tg.nn, tg.graphgym, tg.typing, tg.data = tg_nn, tg_gg, tg_typing, tg_data
+    tg_nn.Linear = torch.nn.Linear
+    tg_nn.conv = tg_conv
+    tg_nn.MessagePassing = _MessagePassing
+    tg_conv.MessagePassing = _MessagePassing
+    tg_gg.config = tg_cfg
+    tg_cfg.cfg = _Cfg
+    tg_typing.Adj = tg_typing.OptTensor = tg_typing.PairTensor = object
+    tg_data.Data = type("Data", (), {})
+    tg_data.Batch = type("Batch", (), {})
+    ts.scatter = _scatter
+
+    def _segment_unavailable(*a, **k):
+        raise NotImplementedError("segment_coo/csr are only reached with a neighbour cap, which CartNet disables")
+    ts.segment_coo = ts.segment_csr = _segment_unavailable
+    return _Cfg
+
+
+def import_reference():
+    """Returns (cfg stand-in, reference models.cartnet module, reference dataset.utils module)."""
+    cfg = install_standins()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    import importlib
+    ref_cartnet = importlib.import_module("models.cartnet")
+    try:
+        ref_dutils = importlib.import_module("dataset.utils")
+    except Exception:  # tqdm etc. are present here, but keep the model import usable on its own
+        ref_dutils = None
+    return cfg, ref_cartnet, ref_dutils

@@ -1,0 +1,468 @@
+"""Per-kernel parity on the GPU, through the C ABI (cartnet_amd.ops -> libcartnet_hip.so).
+
+Each hand-written kernel is compared with an fp64 torch evaluation of the same arithmetic (the oracle functions in
+oracle/cartnet_ref.py where one exists).  Tolerance: max|delta| <= 1e-5 * max|ref| (north_star's fp32 bar),
+integers bit-exact.
+"""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from cartnet_amd import ops as _ops
+    from cartnet_amd import lib
+    lib.load()
+    return _ops
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev())
+
+
+def silu64(x):
+    return x * torch.sigmoid(x)
+
+
+def dsilu64(x):
+    s = torch.sigmoid(x)
+    return s * (1 + x * (1 - s))
+
+
+# --------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (129, 64, 67), (1000, 128, 512), (5, 200, 40), (128, 256, 16),
+                                   (257, 512, 100)])
+def test_gemm_nt_plain(ops, M, N, K):
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    C = torch.empty(M, N, device=dev())
+    ops.gemm(A, B, C)
+    ref = A.double() @ B.double().t()
+    assert rel_err(C, ref) < TOL
+
+
+def test_gemm_layout_asymmetric(ops):
+    # A = I (padded) against an asymmetric B catches swapped row/col maps in the MFMA epilogue.
+    M = N = K = 256
+    A = torch.eye(M, device=dev())
+    B = (torch.arange(N * K, device=dev(), dtype=torch.float32).reshape(N, K) % 1021) / 7.0
+    C = torch.empty(M, N, device=dev())
+    ops.gemm(A, B, C)
+    assert torch.equal(C, B.t().contiguous())
+
+
+def test_gemm_nt_strided_views_and_epilogue(ops):
+    M, D = 700, 64
+    W = rnd(D, 3 * D, seed=3)              # reference-shaped [D, 3D] weight, use the last column block in place
+    A = rnd(M, D, seed=4)
+    bias = rnd(D, seed=5)
+    Nn = 90
+    Pi, Pj = rnd(Nn, 2 * D, seed=6), rnd(Nn, 2 * D, seed=7)
+    g = torch.Generator().manual_seed(8)
+    tgt = torch.sort(torch.randint(0, Nn, (M,), generator=g)).values.to(torch.int32).to(dev())
+    src = torch.randint(0, Nn, (M,), generator=g).to(torch.int32).to(dev())
+    out = torch.empty(M, 2 * D, device=dev())
+    tiles = ops.gemm_tiles_m(M)
+    cs = torch.zeros(tiles * D, device=dev())
+    cq = torch.zeros(tiles * D, device=dev())
+    ops.gemm(A, W[:, 2 * D:], out[:, D:], bias=bias, gather_i=Pi[:, D:], gather_j=Pj[:, D:], tgt=tgt, src=src,
+             colsum=cs, colsq=cq)
+    ref = A.double() @ W[:, 2 * D:].double().t() + bias.double() + Pi[:, D:].double()[tgt.long()] + \
+        Pj[:, D:].double()[src.long()]
+    assert rel_err(out[:, D:], ref) < TOL
+    assert rel_err(cs.view(tiles, D).sum(0), ref.sum(0)) < 1e-5
+    assert rel_err(cq.view(tiles, D).sum(0), (ref ** 2).sum(0)) < 1e-5
+
+
+def test_gemm_act_prologue_epilogue(ops):
+    M, N, K = 333, 128, 256
+    A, B, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    C = torch.empty(M, N, device=dev())
+    Cpre = torch.empty(M, N, device=dev())
+    ops.gemm(A, B, C, a_act=True, out_act=True, bias=bias, cpre=Cpre)
+    pre = silu64(A.double()) @ B.double().t() + bias.double()
+    assert rel_err(Cpre, pre) < TOL
+    assert rel_err(C, silu64(pre)) < TOL
+
+
+def test_gemm_nn_segments_resid_dact(ops):
+    # dX = resid + sum_s dY_s @ W_s, then * silu'(pre) -- the shape of the layer's backward data GEMMs
+    M, D = 450, 64
+    dY = rnd(M, 2 * D, seed=1)
+    W1, W2 = rnd(D, 3 * D, seed=2, scale=0.2), rnd(D, 3 * D, seed=3, scale=0.2)
+    resid, pre = rnd(M, D, seed=4), rnd(M, D, seed=5)
+    out = torch.empty(M, D, device=dev())
+    ops.gemm([dY[:, :D], dY[:, D:]], [W1[:, 2 * D:], W2[:, 2 * D:]], out, b_kstrided=True, segments=True,
+             resid=resid, dact=pre)
+    ref = (resid.double() + dY[:, :D].double() @ W1[:, 2 * D:].double() + dY[:, D:].double() @ W2[:, 2 * D:].double()) \
+        * dsilu64(pre.double())
+    assert rel_err(out, ref) < TOL
+    # in place: output aliases dact
+    pre2 = pre.clone()
+    ops.gemm([dY[:, :D], dY[:, D:]], [W1[:, 2 * D:], W2[:, 2 * D:]], pre2, b_kstrided=True, segments=True,
+             resid=resid, dact=pre2)
+    assert rel_err(pre2, ref) < TOL
+
+
+@pytest.mark.parametrize("E,Dout,Din,splitk", [(5000, 64, 64, 7), (3000, 256, 256, 4), (777, 128, 67, 3),
+                                              (100, 64, 256, 1)])
+def test_gemm_tn_splitk_groups(ops, E, Dout, Din, splitk):
+    # dW[g] = dY[g]^T @ silu(X[g]) with the reduction over E rows split across workgroups
+    dY = [rnd(E, Dout, seed=1), rnd(E, Dout, seed=2)]
+    X = [rnd(E, Din, seed=3), rnd(E, Din, seed=4)]
+    if splitk > 1:
+        slabs = [torch.empty(splitk * Dout, Din, device=dev()) for _ in range(2)]
+        ops.gemm(dY, X, slabs, a_kstrided=True, b_kstrided=True, b_act=True, splitk=splitk)
+        outs = [torch.empty(Dout, 3 * Din, device=dev()) for _ in range(2)]
+        for s, o in zip(slabs, outs):
+            ops.splitk_reduce(s, splitk, o[:, Din:2 * Din])
+        got = [o[:, Din:2 * Din] for o in outs]
+    else:
+        got = [torch.empty(Dout, Din, device=dev()) for _ in range(2)]
+        ops.gemm(dY, X, got, a_kstrided=True, b_kstrided=True, b_act=True)
+    for gI in range(2):
+        ref = dY[gI].double().t() @ silu64(X[gI].double())
+        assert rel_err(got[gI], ref) < TOL
+
+
+def test_gemm_four_groups(ops):
+    N, D = 200, 64
+    x = rnd(N, D, seed=1)
+    Wg, Wa = rnd(D, 3 * D, seed=2), rnd(D, 3 * D, seed=3)
+    bg, ba = rnd(D, seed=4), rnd(D, seed=5)
+    P = torch.empty(N, 4 * D, device=dev())
+    ops.gemm([x, x, x, x], [Wg[:, :D], Wa[:, :D], Wg[:, D:2 * D], Wa[:, D:2 * D]],
+             [P[:, 0:D], P[:, D:2 * D], P[:, 2 * D:3 * D], P[:, 3 * D:]], bias=[bg, ba, None, None])
+    xd = x.double()
+    ref = torch.cat([xd @ Wg[:, :D].double().t() + bg.double(), xd @ Wa[:, :D].double().t() + ba.double(),
+                     xd @ Wg[:, D:2 * D].double().t(), xd @ Wa[:, D:2 * D].double().t()], dim=1)
+    assert rel_err(P, ref) < TOL
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    A, B = rnd(10, 16), rnd(12, 20)
+    with pytest.raises(ValueError):
+        ops.gemm(A, B, torch.empty(10, 12, device=dev()))
+    with pytest.raises(ValueError):
+        ops.gemm(A, rnd(12, 16), torch.empty(10, 13, device=dev()))
+    with pytest.raises(ValueError):
+        ops.gemm(A.cpu(), rnd(12, 16), torch.empty(10, 12, device=dev()))
+
+
+def test_colsum_finalize(ops):
+    parts = rnd(37, 100, seed=1)
+    out = torch.empty(100, device=dev())
+    ops.colsum_finalize(parts, 37, out)
+    assert rel_err(out, parts.double().sum(0)) < 1e-6
+
+
+# --------------------------------------------------------------------------------------------------- graph layout
+def _random_graph_batch(n_graphs, n_lo, n_hi, deg, seed):
+    g = torch.Generator().manual_seed(seed)
+    srcs, tgts, ptr = [], [], [0]
+    for _ in range(n_graphs):
+        n = int(torch.randint(n_lo, n_hi + 1, (1,), generator=g))
+        d = torch.randint(0, deg + 1, (n,), generator=g)
+        t = torch.repeat_interleave(torch.arange(n), d)
+        s = torch.randint(0, n, (int(d.sum()),), generator=g)
+        srcs.append(s + ptr[-1])
+        tgts.append(t + ptr[-1])
+        ptr.append(ptr[-1] + n)
+    ei = torch.stack([torch.cat(srcs), torch.cat(tgts)]).to(torch.int64)
+    return ei, torch.tensor(ptr, dtype=torch.int64)
+
+
+@pytest.mark.parametrize("n_graphs,n_lo,n_hi,deg", [(1, 5, 5, 3), (7, 1, 60, 20), (3, 300, 700, 30), (4, 1, 3, 0)])
+def test_csr_csc_build_exact(ops, n_graphs, n_lo, n_hi, deg):
+    ei, ptr = _random_graph_batch(n_graphs, n_lo, n_hi, deg, seed=n_graphs)
+    N, E = int(ptr[-1]), ei.shape[1]
+    lay = ops.GraphLayout(ei.to(dev()), N, ptr.to(dev()))
+    lay.validate()
+    assert torch.equal(lay.src[:E].cpu().long(), ei[0])
+    assert torch.equal(lay.tgt[:E].cpu().long(), ei[1])
+    rowptr = torch.zeros(N + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(ei[1], minlength=N), 0)
+    assert torch.equal(lay.rowptr.cpu().long(), rowptr)
+    colptr = torch.zeros(N + 1, dtype=torch.int64)
+    colptr[1:] = torch.cumsum(torch.bincount(ei[0], minlength=N), 0)
+    assert torch.equal(lay.colptr.cpu().long(), colptr)
+    perm = torch.argsort(ei[0], stable=True)
+    assert torch.equal(lay.perm[:E].cpu().long(), perm)
+
+
+def test_csr_build_flags_unsorted_and_out_of_range(ops):
+    ei = torch.tensor([[0, 1, 2], [2, 1, 0]], dtype=torch.int64)
+    lay = ops.GraphLayout(ei.to(dev()), 3, None)
+    with pytest.raises(ValueError, match="sorted"):
+        lay.validate()
+    ei = torch.tensor([[0, 5], [0, 1]], dtype=torch.int64)
+    lay = ops.GraphLayout(ei.to(dev()), 3, None)
+    with pytest.raises(ValueError, match="outside"):
+        lay.validate()
+
+
+def test_csr_empty_graph(ops):
+    ei = torch.zeros(2, 0, dtype=torch.int64)
+    lay = ops.GraphLayout(ei.to(dev()), 4, torch.tensor([0, 4]).to(dev()))
+    lay.validate()
+    assert lay.rowptr.cpu().tolist() == [0, 0, 0, 0, 0]
+    assert lay.colptr.cpu().tolist() == [0, 0, 0, 0, 0]
+
+
+# --------------------------------------------------------------------------------------------------- edge ops
+@pytest.mark.parametrize("invariant", [False, True])
+def test_edge_features_vs_oracle(ops, invariant):
+    from oracle import cartnet_ref as orc
+    E, R, radius = 1000, 64, 5.0
+    g = torch.Generator().manual_seed(0)
+    dist = (0.01 + 5.2 * torch.rand(E, generator=g))
+    dist[:3] = torch.tensor([5.0, 4.9999995, 0.0101])
+    dirv = torch.nn.functional.normalize(torch.randn(E, 3, generator=g), dim=-1)
+    means, betas = orc.rbf_constants(radius, R)
+    ldf = 72
+    feat = torch.full((E, ldf), 7.0, device=dev())
+    env = torch.empty(E, device=dev())
+    ops.edge_features(dist.to(dev()), dirv.to(dev()), means.to(dev()), betas.to(dev()), invariant, radius, 4.0, feat,
+                      env)
+    rbf = orc.exp_normal_smearing(dist.double(), means.double(), betas.double(), radius)
+    assert rel_err(feat[:, :R], rbf) < TOL
+    if invariant:
+        assert torch.count_nonzero(feat[:, R:]) == 0
+    else:
+        assert torch.equal(feat[:, R:R + 3].cpu(), dirv)
+        assert torch.count_nonzero(feat[:, R + 3:]) == 0
+    assert rel_err(env, orc.cosine_cutoff(dist.double(), 4.0)) < TOL
+
+
+def _gate_reference(gs, e_in, env, tgt, N, mean, rstd, gamma, beta):
+    D = e_in.shape[1]
+    g, s = gs[:, :D], gs[:, D:]
+    sig = env[:, None] * torch.sigmoid((g - mean) * rstd * gamma + beta)
+    aggr = torch.zeros(N, D, dtype=gs.dtype).index_add_(0, tgt, sig * s)
+    return e_in + sig, aggr
+
+
+@pytest.mark.parametrize("D", [16, 64, 256, 320])
+def test_gate_scatter_fwd_bwd(ops, D):
+    ei, ptr = _random_graph_batch(5, 10, 60, 25, seed=D)
+    N, E = int(ptr[-1]), ei.shape[1]
+    lay = ops.GraphLayout(ei.to(dev()), N, ptr.to(dev()))
+    gs, e_in = rnd(E, 2 * D, seed=1), rnd(E, D, seed=2)
+    env = torch.rand(E, generator=torch.Generator().manual_seed(3)).to(dev())
+    mean, var = rnd(D, seed=4, scale=0.3), (0.5 + torch.rand(D, generator=torch.Generator().manual_seed(5))).to(dev())
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    mean_rstd = torch.cat([mean, rstd]).contiguous()
+    gamma, beta = rnd(D, seed=6), rnd(D, seed=7)
+    e_out, aggr = torch.empty(E, D, device=dev()), torch.empty(N, D, device=dev())
+    nparts = ops.gate_nparts(N)
+    ps, pq = torch.zeros(nparts * D, device=dev()), torch.zeros(nparts * D, device=dev())
+    ops.gate_scatter_fwd(gs, e_in, env, lay, mean_rstd, gamma, beta, e_out, aggr, ps, pq)
+
+    c = lambda t: t.detach().double().cpu()
+    gs64 = c(gs).requires_grad_(True)
+    eo_ref, ag_ref = _gate_reference(gs64, c(e_in), c(env), ei[1], N, c(mean), c(rstd), c(gamma), c(beta))
+    assert rel_err(e_out, eo_ref) < TOL
+    assert rel_err(aggr, ag_ref) < TOL
+    assert rel_err(ps.view(nparts, D).sum(0), ag_ref.sum(0)) < 1e-5
+    assert rel_err(pq.view(nparts, D).sum(0), (ag_ref ** 2).sum(0)) < 1e-5
+
+    # backward with "training" BatchNorm: mean/rstd are functions of g -> use batch statistics for the reference
+    g64 = gs64[:, :D]
+    bmean = g64.mean(0)
+    bvar = g64.var(0, unbiased=False)
+    brstd = torch.rsqrt(bvar + 1e-5)
+    mean_rstd_b = torch.cat([bmean, brstd]).detach().float().to(dev()).contiguous()
+    eo_ref, ag_ref = _gate_reference(gs64, c(e_in), c(env), ei[1], N, bmean, brstd, c(gamma), c(beta))
+    de_out, daggr = rnd(E, D, seed=8), rnd(N, D, seed=9)
+    (eo_ref * c(de_out)).sum().add((ag_ref * c(daggr)).sum()).backward()
+    pa, pb = torch.zeros(nparts * D, device=dev()), torch.zeros(nparts * D, device=dev())
+    ops.gate_scatter_bwd_stats(gs, de_out, daggr, env, lay, mean_rstd_b, gamma, beta, pa, pb)
+    sums = torch.empty(2 * D, device=dev())
+    ops.colsum_finalize(pa, nparts, sums[:D])
+    ops.colsum_finalize(pb, nparts, sums[D:])
+    gs_work = gs.clone()
+    pdg, pds = torch.zeros(nparts * D, device=dev()), torch.zeros(nparts * D, device=dev())
+    ops.gate_scatter_bwd_apply(gs_work, de_out, daggr, env, lay, mean_rstd_b, gamma, beta, sums, True, pdg, pds)
+    assert rel_err(gs_work, gs64.grad) < 2e-5
+    assert rel_err(pds.view(nparts, D).sum(0), gs64.grad[:, D:].sum(0)) < 1e-4
+
+
+def test_segment_sum(ops):
+    ei, ptr = _random_graph_batch(6, 5, 80, 18, seed=11)
+    N, E = int(ptr[-1]), ei.shape[1]
+    lay = ops.GraphLayout(ei.to(dev()), N, ptr.to(dev()))
+    W = 128
+    rows = rnd(E, W, seed=1)
+    out_t, out_s = torch.empty(N, W, device=dev()), torch.empty(N, 2 * W, device=dev())
+    ops.segment_sum(rows, lay.rowptr, None, out_t)
+    ops.segment_sum(rows, lay.colptr, lay.perm, out_s[:, W:])
+    ref_t = torch.zeros(N, W, dtype=torch.float64).index_add_(0, ei[1], rows.double().cpu())
+    ref_s = torch.zeros(N, W, dtype=torch.float64).index_add_(0, ei[0], rows.double().cpu())
+    assert rel_err(out_t, ref_t) < TOL
+    assert rel_err(out_s[:, W:], ref_s) < TOL
+
+
+# --------------------------------------------------------------------------------------------------- node ops
+def test_bn_finalize_and_node_update(ops):
+    N, D = 777, 64
+    aggr, x_in = rnd(N, D, seed=1, scale=2.0) + 0.5, rnd(N, D, seed=2)
+    gamma, beta = rnd(D, seed=3), rnd(D, seed=4)
+    # statistics from 5 partial blocks
+    chunks = torch.chunk(aggr, 5, dim=0)
+    ps = torch.stack([ch.sum(0) for ch in chunks]).contiguous().view(-1)
+    pq = torch.stack([(ch * ch).sum(0) for ch in chunks]).contiguous().view(-1)
+    rm, rv = torch.zeros(D, device=dev()), torch.ones(D, device=dev())
+    nbt = torch.zeros(1, dtype=torch.int64, device=dev())
+    mean_rstd = torch.empty(2 * D, device=dev())
+    ops.bn_finalize(ps, pq, 5, N, D, 1e-5, 0.1, True, rm, rv, nbt, mean_rstd)
+    a64 = aggr.double().cpu().requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(D).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma.double().cpu())
+        bn.bias.copy_(beta.double().cpu())
+    xn = bn(a64)
+    assert rel_err(mean_rstd[:D], a64.mean(0)) < 1e-5
+    assert rel_err(mean_rstd[D:], torch.rsqrt(a64.var(0, unbiased=False) + 1e-5)) < 1e-5
+    assert rel_err(rm, bn.running_mean) < 1e-5 and rel_err(rv, bn.running_var) < 1e-5
+    assert int(nbt.item()) == 1
+    x_out = torch.empty(N, D, device=dev())
+    ops.node_update_fwd(aggr, x_in, mean_rstd, gamma, beta, x_out)
+    ref = torch.nn.functional.silu(xn) + x_in.double().cpu()
+    assert rel_err(x_out, ref) < TOL
+    # backward
+    dx = rnd(N, D, seed=5)
+    (ref * dx.double().cpu()).sum().backward()
+    nparts = ops.node_nparts(N)
+    pa, pb = torch.zeros(nparts * D, device=dev()), torch.zeros(nparts * D, device=dev())
+    ops.node_update_bwd_stats(aggr, dx, mean_rstd, gamma, beta, pa, pb)
+    sums = torch.empty(2 * D, device=dev())
+    ops.colsum_finalize(pa, nparts, sums[:D])
+    ops.colsum_finalize(pb, nparts, sums[D:])
+    daggr = torch.empty(N, D, device=dev())
+    ops.node_update_bwd_apply(aggr, dx, mean_rstd, gamma, beta, sums, True, daggr)
+    assert rel_err(daggr, a64.grad) < 2e-5
+    assert rel_err(sums[:D], bn.bias.grad) < 2e-5
+    assert rel_err(sums[D:], bn.weight.grad) < 2e-5
+    # eval mode uses running statistics
+    ops.bn_finalize(None, None, 0, 0, D, 1e-5, 0.1, False, rm, rv, None, mean_rstd)
+    assert rel_err(mean_rstd[:D], rm) == 0
+    assert rel_err(mean_rstd[D:], torch.rsqrt(rv.double() + 1e-5)) < 1e-6
+
+
+def test_node_embed_fwd_bwd(ops):
+    N, Cc, Bg = 500, 128, 6
+    g = torch.Generator().manual_seed(0)
+    z = torch.randint(1, 119, (N,), generator=g)
+    batch = torch.sort(torch.randint(0, Bg, (N,), generator=g)).values
+    T = torch.randn(Bg, generator=g)
+    emb, wt, bt = rnd(119, Cc, seed=1), rnd(Cc, 1, seed=2), rnd(Cc, seed=3)
+    x0 = torch.empty(N, Cc, device=dev())
+    ops.node_embed(z.to(dev()), batch.to(dev()), T.to(dev()), emb, wt, bt, None, x0)
+    e64, w64, b64 = (t.double().cpu().requires_grad_(True) for t in (emb, wt, bt))
+    ref = e64[z] + (T.double()[:, None] @ w64.t() + b64)[batch]
+    assert rel_err(x0, ref) < 1e-6
+    dx0 = rnd(N, Cc, seed=4)
+    (ref * dx0.double().cpu()).sum().backward()
+    demb = torch.empty(119, Cc, device=dev())
+    nparts = ops.node_nparts(N)
+    pw, pb = torch.zeros(nparts * Cc, device=dev()), torch.zeros(nparts * Cc, device=dev())
+    ops.node_embed_bwd(z.to(dev()), batch.to(dev()), T.to(dev()), dx0, 119, demb, pw, pb)
+    dwt, dbt = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
+    ops.colsum_finalize(pw, nparts, dwt)
+    ops.colsum_finalize(pb, nparts, dbt)
+    assert rel_err(demb, e64.grad) < TOL
+    assert rel_err(dwt, w64.grad.view(-1)) < TOL
+    assert rel_err(dbt, b64.grad) < TOL
+
+
+@pytest.mark.parametrize("H", [8, 32, 128])
+def test_cholesky_head_fwd_bwd(ops, H):
+    from oracle import cartnet_ref as orc
+    N = 301
+    g = torch.Generator().manual_seed(H)
+    mask = torch.rand(N, generator=g) < 0.55
+    hid = rnd(N, H, seed=1)
+    W2, b2 = rnd(6, H, seed=2, scale=0.3), rnd(6, seed=3)
+    idx = torch.empty(N, dtype=torch.int32, device=dev())
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev())
+    ops.mask_index(mask.to(dev()), idx, cnt)
+    M = int(mask.sum())
+    assert int(cnt.item()) == M
+    exp_idx = torch.full((N,), -1, dtype=torch.int64)
+    exp_idx[mask] = torch.arange(M)
+    assert torch.equal(idx.cpu().long(), exp_idx)
+    p6, pred = torch.empty(M, 6, device=dev()), torch.empty(M, 3, 3, device=dev())
+    ops.cholesky_head_fwd(hid, idx, W2, b2, p6, pred)
+    h64 = hid.double().cpu().requires_grad_(True)
+    w64, bb64 = W2.double().cpu().requires_grad_(True), b2.double().cpu().requires_grad_(True)
+    # oracle head = Linear(D->H) [identity here] -> SiLU -> Linear(H->6) -> softplus / L^T L
+    sd = {"head.MLP.0.weight": torch.eye(H, dtype=torch.float64), "head.MLP.0.bias": torch.zeros(H, dtype=torch.float64),
+          "head.MLP.2.weight": w64, "head.MLP.2.bias": bb64}
+    ref = orc.cholesky_head(sd, h64, mask)
+    assert rel_err(pred, ref) < TOL
+    dpred = rnd(M, 3, 3, seed=4)
+    (ref * dpred.double().cpu()).sum().backward()
+    dhid = torch.empty(N, H, device=dev())
+    nparts = ops.node_nparts(N)
+    parts = torch.zeros(nparts * (6 * H + 8), device=dev())
+    ops.cholesky_head_bwd(hid, idx, W2, p6, dpred.contiguous(), dhid, parts)
+    assert rel_err(dhid, h64.grad) < TOL
+    tot = parts.view(nparts, 6 * H + 8).double().sum(0)
+    assert rel_err(tot[:6 * H].view(6, H), w64.grad) < TOL
+    assert rel_err(tot[6 * H:6 * H + 6], bb64.grad) < TOL
+
+
+def test_scalar_head_fwd_bwd(ops):
+    from oracle import cartnet_ref as orc
+    H, Bg = 32, 9
+    g = torch.Generator().manual_seed(1)
+    sizes = torch.randint(1, 12, (Bg,), generator=g)
+    ptr = torch.zeros(Bg + 1, dtype=torch.int64)
+    ptr[1:] = torch.cumsum(sizes, 0)
+    N = int(ptr[-1])
+    batch = torch.repeat_interleave(torch.arange(Bg), sizes)
+    hid, w2, b2 = rnd(N, H, seed=2), rnd(1, H, seed=3), rnd(1, seed=4)
+    out = torch.empty(Bg, device=dev())
+    ops.scalar_head_fwd(hid, w2, b2, ptr.to(dev()), out)
+    h64 = hid.double().cpu().requires_grad_(True)
+    w64, bb64 = w2.double().cpu().requires_grad_(True), b2.double().cpu().requires_grad_(True)
+    sd = {"head.MLP.0.weight": torch.eye(H, dtype=torch.float64), "head.MLP.0.bias": torch.zeros(H, dtype=torch.float64),
+          "head.MLP.2.weight": w64, "head.MLP.2.bias": bb64}
+    ref = orc.scalar_head(sd, h64, batch, Bg)
+    assert rel_err(out, ref) < TOL
+    dout = rnd(Bg, seed=5)
+    (ref * dout.double().cpu()).sum().backward()
+    dhid = torch.empty(N, H, device=dev())
+    nparts = ops.node_nparts(N)
+    parts = torch.zeros(nparts * (H + 8), device=dev())
+    ops.scalar_head_bwd(hid, w2, ptr.to(dev()), batch.to(dev()), dout, dhid, parts)
+    assert rel_err(dhid, h64.grad) < TOL
+    tot = parts.view(nparts, H + 8).double().sum(0)
+    assert rel_err(tot[:H], w64.grad.view(-1)) < TOL
+    assert rel_err(tot[H:H + 1], bb64.grad) < TOL
+
+
+def test_adam_matches_torch(ops):
+    n = 10007
+    p0, g0 = rnd(n, seed=1), rnd(n, seed=2)
+    p_ref = torch.nn.Parameter(p0.clone().cpu())
+    opt = torch.optim.Adam([p_ref], lr=1e-3)
+    p, m, v = p0.clone(), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    for step in range(1, 4):
+        gstep = g0 * step
+        p_ref.grad = gstep.clone().cpu()
+        opt.step()
+        ops.adam_step(p, gstep, m, v, 1e-3, 0.9, 0.999, 1e-8, step, 1.0)
+    assert rel_err(p, p_ref.data) < 1e-6
