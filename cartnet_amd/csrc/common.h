@@ -38,4 +38,31 @@ __device__ __forceinline__ float cn_dsilu(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// Per-block partial column sums, kept in fp64 (see cartnet_hip.h "partial sums").  Four waves each hold the sums
+// of channels c..c+3 (lane l -> c = c0 + 4l); wave 0 adds them in wave order and writes parts[blockIdx.x][c..c+3].
+// lds: 4 * 256 doubles.
+__device__ __forceinline__ void cn_block_store_parts(f64x4 v, double* lds, double* parts, int D, int c, bool active,
+                                                     int wid, int lane) {
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) lds[wid * 256 + lane * 4 + q] = v[q];
+  __syncthreads();
+  if (wid == 0 && active) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double t = lds[lane * 4 + q];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) t += lds[w * 256 + lane * 4 + q];
+      parts[(size_t)blockIdx.x * D + c + q] = t;
+    }
+  }
+}
+
+__device__ __forceinline__ void cn_acc4(f64x4& a, f32x4 v) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a[q] += (double)v[q];
+}
+
 static inline int cn_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -16,20 +16,6 @@ constexpr int MAX_PARTS = 1024;
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-// Sum the four waves' float4 partials of a block and let wave 0 write them: parts[blockIdx.x][c .. c+3].
-__device__ __forceinline__ void block_store_parts(f32x4 v, float* lds /* [4][256] */, float* parts, int D, int c,
-                                                  bool active, int wid, int lane) {
-  __syncthreads();
-  st4(lds + wid * 256 + lane * 4, v);
-  __syncthreads();
-  if (wid == 0 && active) {
-    f32x4 t = ld4(lds + lane * 4);
-#pragma unroll
-    for (int w = 1; w < NODES_PER_BLOCK; ++w) t += ld4(lds + w * 256 + lane * 4);
-    st4(parts + (size_t)blockIdx.x * D + c, t);
-  }
-}
-
 __global__ void cn_edge_features_kernel(const float* __restrict__ dist, const float* __restrict__ dir,
                                         const float* __restrict__ means, const float* __restrict__ betas,
                                         long long E, int R, int invariant, float radius, float env_radius,
@@ -60,8 +46,8 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
     const float* __restrict__ gs, const float* __restrict__ e_in, const float* __restrict__ env,
     const int* __restrict__ rowptr, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, int N, int D, float* __restrict__ e_out, float* __restrict__ aggr,
-    float* __restrict__ parts_sum, float* __restrict__ parts_sq) {
-  __shared__ __attribute__((aligned(16))) float red[NODES_PER_BLOCK * 256];
+    double* __restrict__ parts_sum, double* __restrict__ parts_sq) {
+  __shared__ double red[NODES_PER_BLOCK * 256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int ld = 2 * D;
   for (int c0 = 0; c0 < D; c0 += 256) {
@@ -73,7 +59,7 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
       scale = ld4(mean_rstd + D + c) * ld4(gamma + c);
       shift = ld4(beta + c);
     }
-    f32x4 ps = {0, 0, 0, 0}, pq = {0, 0, 0, 0};
+    f64x4 ps = {0, 0, 0, 0}, pq = {0, 0, 0, 0};
     for (int t = blockIdx.x * NODES_PER_BLOCK + wid; t < N; t += gridDim.x * NODES_PER_BLOCK) {
       const int k0 = rowptr[t], k1 = rowptr[t + 1];
       f32x4 acc = {0, 0, 0, 0};
@@ -92,11 +78,14 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
         }
         st4(aggr + (size_t)t * D + c, acc);
       }
-      ps += acc;
-      pq += acc * acc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ps[q] += (double)acc[q];
+        pq[q] += (double)acc[q] * (double)acc[q];
+      }
     }
-    block_store_parts(ps, red, parts_sum, D, c, active, wid, lane);
-    block_store_parts(pq, red, parts_sq, D, c, active, wid, lane);
+    cn_block_store_parts(ps, red, parts_sum, D, c, active, wid, lane);
+    cn_block_store_parts(pq, red, parts_sq, D, c, active, wid, lane);
   }
 }
 
@@ -107,8 +96,8 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_bwd_kernel(
     float* gs, const float* __restrict__ de_out, const float* __restrict__ daggr, const float* __restrict__ env,
     const int* __restrict__ rowptr, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ sums, float inv_count, int N, int D,
-    float* __restrict__ parts_a, float* __restrict__ parts_b) {
-  __shared__ __attribute__((aligned(16))) float red[NODES_PER_BLOCK * 256];
+    double* __restrict__ parts_a, double* __restrict__ parts_b) {
+  __shared__ double red[NODES_PER_BLOCK * 256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int ld = 2 * D;
   for (int c0 = 0; c0 < D; c0 += 256) {
@@ -126,16 +115,18 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_bwd_kernel(
         m_b = ld4(sums + D + c) * inv_count;
       }
     }
-    f32x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+    f64x4 ta = {0, 0, 0, 0}, tb = {0, 0, 0, 0};
     for (int t = blockIdx.x * NODES_PER_BLOCK + wid; t < N; t += gridDim.x * NODES_PER_BLOCK) {
       const int k0 = rowptr[t], k1 = rowptr[t + 1];
       if (!active) continue;
       const f32x4 dm = ld4(daggr + (size_t)t * D + c);
+      f32x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};   // fp32 over one node's edges, fp64 across nodes
 #pragma unroll 2
       for (int k = k0; k < k1; ++k) {
         const f32x4 g = ld4(gs + (size_t)k * ld + c);
         const f32x4 s = ld4(gs + (size_t)k * ld + D + c);
-        const f32x4 de = ld4(de_out + (size_t)k * D + c);
+        f32x4 de = {0, 0, 0, 0};
+        if (de_out) de = ld4(de_out + (size_t)k * D + c);
         const float ev = env ? env[k] : 1.0f;
         f32x4 dgv, dsv;
 #pragma unroll
@@ -159,9 +150,11 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_bwd_kernel(
           st4(gs + (size_t)k * ld + D + c, dsv);
         }
       }
+      cn_acc4(ta, pa);
+      cn_acc4(tb, pb);
     }
-    block_store_parts(pa, red, parts_a, D, c, active, wid, lane);
-    block_store_parts(pb, red, parts_b, D, c, active, wid, lane);
+    cn_block_store_parts(ta, red, parts_a, D, c, active, wid, lane);
+    cn_block_store_parts(tb, red, parts_b, D, c, active, wid, lane);
   }
 }
 
@@ -219,7 +212,7 @@ extern "C" int cartnet_gate_scatter_nparts(int32_t N) { return gate_parts(N); }
 
 extern "C" int cartnet_gate_scatter_fwd(const float* gs, const float* e_in, const float* env, const int32_t* rowptr,
                                         const float* mean_rstd, const float* gamma, const float* beta, int32_t N,
-                                        int32_t D, float* e_out, float* aggr, float* parts_sum, float* parts_sq,
+                                        int32_t D, float* e_out, float* aggr, double* parts_sum, double* parts_sq,
                                         void* stream) {
   CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_fwd: D=%d must be a positive multiple of 4", D);
   CN_CHECK(gs && e_in && rowptr && mean_rstd && gamma && beta && e_out && aggr && parts_sum && parts_sq,
@@ -234,9 +227,9 @@ extern "C" int cartnet_gate_scatter_fwd(const float* gs, const float* e_in, cons
 extern "C" int cartnet_gate_scatter_bwd_stats(const float* gs, const float* de_out, const float* daggr,
                                               const float* env, const int32_t* rowptr, const float* mean_rstd,
                                               const float* gamma, const float* beta, int32_t N, int32_t D,
-                                              float* parts_a, float* parts_b, void* stream) {
+                                              double* parts_a, double* parts_b, void* stream) {
   CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_bwd_stats: D=%d must be a multiple of 4", D);
-  CN_CHECK(gs && de_out && daggr && rowptr && mean_rstd && gamma && beta && parts_a && parts_b,
+  CN_CHECK(gs && daggr && rowptr && mean_rstd && gamma && beta && parts_a && parts_b,
            "cartnet_gate_scatter_bwd_stats: null pointer");
   hipLaunchKernelGGL(cn_gate_scatter_bwd_kernel<0>, dim3(gate_parts(N)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), const_cast<float*>(gs), de_out, daggr, env, rowptr,
@@ -248,9 +241,9 @@ extern "C" int cartnet_gate_scatter_bwd_stats(const float* gs, const float* de_o
 extern "C" int cartnet_gate_scatter_bwd_apply(float* gs, const float* de_out, const float* daggr, const float* env,
                                               const int32_t* rowptr, const float* mean_rstd, const float* gamma,
                                               const float* beta, const float* sums, int64_t E, int32_t training,
-                                              int32_t N, int32_t D, float* parts_dg, float* parts_ds, void* stream) {
+                                              int32_t N, int32_t D, double* parts_dg, double* parts_ds, void* stream) {
   CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_bwd_apply: D=%d must be a multiple of 4", D);
-  CN_CHECK(gs && de_out && daggr && rowptr && mean_rstd && gamma && beta && sums && parts_dg && parts_ds,
+  CN_CHECK(gs && daggr && rowptr && mean_rstd && gamma && beta && sums && parts_dg && parts_ds,
            "cartnet_gate_scatter_bwd_apply: null pointer");
   const float inv = (training && E > 0) ? (float)(1.0 / (double)E) : 0.f;
   hipLaunchKernelGGL(cn_gate_scatter_bwd_kernel<1>, dim3(gate_parts(N)), dim3(256), 0,

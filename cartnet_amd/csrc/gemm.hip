@@ -194,18 +194,18 @@ __global__ __launch_bounds__(256, 2) void cn_gemm_kernel(const CartnetGemmArgs p
   const float* resid = p.resid[g];
   const float* dact = p.dact[g];
   float* cpre = p.cpre[g];
-  float* __restrict__ colsum = p.colsum[g];
-  float* __restrict__ colsq = p.colsq[g];
+  double* __restrict__ colsum = p.colsum[g];
+  double* __restrict__ colsq = p.colsq[g];
   const bool out_act = p.out_act != 0;
 
   float biasv[TN];
-  float cs[TN], cq[TN];
+  double cs[TN], cq[TN];   // fp64: BatchNorm variance = E[v^2] - mean^2 must not lose digits to cancellation
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int gcol = col0 + wn * WN + b * 32 + li;
     biasv[b] = (bias && gcol < p.N) ? bias[gcol] : 0.f;
-    cs[b] = 0.f;
-    cq[b] = 0.f;
+    cs[b] = 0.0;
+    cq[b] = 0.0;
   }
 
 #pragma unroll
@@ -227,8 +227,10 @@ __global__ __launch_bounds__(256, 2) void cn_gemm_kernel(const CartnetGemmArgs p
         if (gi) v += gi[(size_t)ti * p.ldg + gcol] + gj[(size_t)sj * p.ldg + gcol];
         if (resid) v += resid[(size_t)grow * p.ldr + gcol];
         if (dact) v *= cn_dsilu(dact[(size_t)grow * p.ldd + gcol]);
-        cs[b] += v;
-        cq[b] += v * v;
+        if (colsum) {
+          cs[b] += (double)v;
+          cq[b] += (double)v * (double)v;
+        }
         if (cpre) cpre[(size_t)grow * p.ldc + gcol] = v;
         if (out_act) v = cn_silu(v);
         C[(size_t)grow * p.ldc + gcol] = v;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void cn_gemm_kernel(const CartnetGemmArgs p
 
   if (colsum) {
     // rows of this block -> one partial per column: lane halves, then the two waves stacked in M.
-    float* red = sA;  // [2 (sum,sq)][2 (wm)][BN]; the K loop ended with a barrier, sA is free
+    double* red = reinterpret_cast<double*>(sA);  // [2 (sum,sq)][2 (wm)][BN] doubles <= sizeof(sA); K loop ended with a barrier
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       cs[b] += __shfl_xor(cs[b], 32);
@@ -269,8 +271,8 @@ __global__ void cn_splitk_reduce_kernel(const float* __restrict__ slabs, int spl
   }
 }
 
-__global__ void cn_colsum_finalize_kernel(const float* __restrict__ parts, int nparts, int N,
-                                          float* __restrict__ out) {
+template <typename T>
+__global__ void cn_colsum_finalize_kernel(const T* __restrict__ parts, int nparts, int N, float* __restrict__ out) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   double acc = 0.0;
@@ -359,12 +361,22 @@ extern "C" int cartnet_splitk_reduce(const float* slabs, int32_t splitk, int32_t
   return 0;
 }
 
-extern "C" int cartnet_colsum_finalize(const float* parts, int32_t nparts, int32_t N, float* out, void* stream) {
+extern "C" int cartnet_colsum_finalize(const double* parts, int32_t nparts, int32_t N, float* out, void* stream) {
   CN_CHECK(parts && out, "cartnet_colsum_finalize: null pointer");
   CN_CHECK(nparts >= 0 && N >= 0, "cartnet_colsum_finalize: bad shape");
   if (N == 0) return 0;
-  hipLaunchKernelGGL(cn_colsum_finalize_kernel, dim3(cn_ceil_div(N, 128)), dim3(128), 0,
+  hipLaunchKernelGGL(cn_colsum_finalize_kernel<double>, dim3(cn_ceil_div(N, 128)), dim3(128), 0,
                      reinterpret_cast<hipStream_t>(stream), parts, nparts, N, out);
   CN_LAUNCH_CHECK("cartnet_colsum_finalize");
+  return 0;
+}
+
+extern "C" int cartnet_colsum_finalize_f32(const float* parts, int32_t nparts, int32_t N, float* out, void* stream) {
+  CN_CHECK(parts && out, "cartnet_colsum_finalize_f32: null pointer");
+  CN_CHECK(nparts >= 0 && N >= 0, "cartnet_colsum_finalize_f32: bad shape");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(cn_colsum_finalize_kernel<float>, dim3(cn_ceil_div(N, 128)), dim3(128), 0,
+                     reinterpret_cast<hipStream_t>(stream), parts, nparts, N, out);
+  CN_LAUNCH_CHECK("cartnet_colsum_finalize_f32");
   return 0;
 }

@@ -25,19 +25,6 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ void block_store_parts(f32x4 v, float* lds, float* parts, int D, int c, bool active,
-                                                  int wid, int lane) {
-  __syncthreads();
-  st4(lds + wid * 256 + lane * 4, v);
-  __syncthreads();
-  if (wid == 0 && active) {
-    f32x4 t = ld4(lds + lane * 4);
-#pragma unroll
-    for (int w = 1; w < NODES_PER_BLOCK; ++w) t += ld4(lds + w * 256 + lane * 4);
-    st4(parts + (size_t)blockIdx.x * D + c, t);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ embedding
 __global__ void cn_node_embed_kernel(const int64_t* __restrict__ z, const int64_t* __restrict__ batch,
                                      const float* __restrict__ temperature, const float* __restrict__ emb,
@@ -83,28 +70,28 @@ __global__ __launch_bounds__(64) void cn_embed_bwd_types_kernel(const int64_t* _
 __global__ __launch_bounds__(256) void cn_embed_bwd_cols_kernel(const int64_t* __restrict__ batch,
                                                                 const float* __restrict__ temperature,
                                                                 const float* __restrict__ dx0, int N, int C,
-                                                                float* __restrict__ parts_w,
-                                                                float* __restrict__ parts_b) {
-  __shared__ __attribute__((aligned(16))) float red[NODES_PER_BLOCK * 256];
+                                                                double* __restrict__ parts_w,
+                                                                double* __restrict__ parts_b) {
+  __shared__ double red[NODES_PER_BLOCK * 256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   for (int c0 = 0; c0 < C; c0 += 256) {
     const int c = c0 + lane * 4;
     const bool active = c < C;
-    f32x4 pw = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+    f64x4 pw = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
     for (int n = blockIdx.x * NODES_PER_BLOCK + wid; n < N; n += gridDim.x * NODES_PER_BLOCK) {
       if (!active) continue;
       const f32x4 d = ld4(dx0 + (size_t)n * C + c);
       const float t = temperature ? temperature[batch[n]] : 0.f;
-      pw += d * t;
-      pb += d;
+      cn_acc4(pw, d * t);
+      cn_acc4(pb, d);
     }
-    block_store_parts(pw, red, parts_w, C, c, active, wid, lane);
-    block_store_parts(pb, red, parts_b, C, c, active, wid, lane);
+    cn_block_store_parts(pw, red, parts_w, C, c, active, wid, lane);
+    cn_block_store_parts(pb, red, parts_b, C, c, active, wid, lane);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm stats
-__global__ void cn_bn_finalize_kernel(const float* __restrict__ parts_sum, const float* __restrict__ parts_sq,
+__global__ void cn_bn_finalize_kernel(const double* __restrict__ parts_sum, const double* __restrict__ parts_sq,
                                       int nparts, long long count, int C, float eps, float momentum, int training,
                                       float* __restrict__ running_mean, float* __restrict__ running_var,
                                       int64_t* __restrict__ nbt, float* __restrict__ mean_rstd) {
@@ -114,8 +101,8 @@ __global__ void cn_bn_finalize_kernel(const float* __restrict__ parts_sum, const
   if (training) {
     double s = 0.0, q = 0.0;
     for (int p = 0; p < nparts; ++p) {
-      s += (double)parts_sum[(size_t)p * C + c];
-      q += (double)parts_sq[(size_t)p * C + c];
+      s += parts_sum[(size_t)p * C + c];
+      q += parts_sq[(size_t)p * C + c];
     }
     const double n = (double)count;
     const double mean = n > 0 ? s / n : 0.0;
@@ -156,8 +143,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void cn_node_update_bwd_kernel(
     const float* __restrict__ aggr, const float* __restrict__ dx_out, const float* __restrict__ mean_rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums, float inv_count,
-    int N, int D, float* __restrict__ parts_a, float* __restrict__ parts_b, float* __restrict__ daggr) {
-  __shared__ __attribute__((aligned(16))) float red[NODES_PER_BLOCK * 256];
+    int N, int D, double* __restrict__ parts_a, double* __restrict__ parts_b, float* __restrict__ daggr) {
+  __shared__ double red[NODES_PER_BLOCK * 256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   for (int c0 = 0; c0 < D; c0 += 256) {
     const int c = c0 + lane * 4;
@@ -174,7 +161,7 @@ __global__ __launch_bounds__(256) void cn_node_update_bwd_kernel(
         m_b = ld4(sums + D + c) * inv_count;
       }
     }
-    f32x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+    f64x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
     for (int n = blockIdx.x * NODES_PER_BLOCK + wid; n < N; n += gridDim.x * NODES_PER_BLOCK) {
       if (!active) continue;
       const f32x4 a = ld4(aggr + (size_t)n * D + c), dy = ld4(dx_out + (size_t)n * D + c);
@@ -184,8 +171,8 @@ __global__ __launch_bounds__(256) void cn_node_update_bwd_kernel(
         const float ahat = (a[q] - mean[q]) * rstd[q];
         const float dxn = dy[q] * cn_dsilu(ahat * gam[q] + bet[q]);
         if (MODE == 0) {
-          pa[q] += dxn;
-          pb[q] += dxn * ahat;
+          pa[q] += (double)dxn;
+          pb[q] += (double)dxn * (double)ahat;
         } else {
           o[q] = gam[q] * rstd[q] * (dxn - m_a[q] - ahat * m_b[q]);
         }
@@ -193,8 +180,8 @@ __global__ __launch_bounds__(256) void cn_node_update_bwd_kernel(
       if (MODE == 1) st4(daggr + (size_t)n * D + c, o);
     }
     if (MODE == 0) {
-      block_store_parts(pa, red, parts_a, D, c, active, wid, lane);
-      block_store_parts(pb, red, parts_b, D, c, active, wid, lane);
+      cn_block_store_parts(pa, red, parts_a, D, c, active, wid, lane);
+      cn_block_store_parts(pb, red, parts_b, D, c, active, wid, lane);
     }
   }
 }
@@ -265,7 +252,7 @@ __global__ __launch_bounds__(256) void cn_cholesky_head_fwd_kernel(const float* 
   }
 }
 
-// dhid + per-block partials of dW2 [6,H] and db2 [6] (parts row layout: 6*H weights, then 6 biases, 2 pad).
+// dhid + per-block partials (parts row layout: 6*H dW2, 6 db2, 2 pad, H column sums of dhid = grad of head.MLP.0.bias).
 __global__ __launch_bounds__(256) void cn_cholesky_head_bwd_kernel(const float* __restrict__ hid,
                                                                    const int* __restrict__ out_index,
                                                                    const float* __restrict__ W2,
@@ -273,10 +260,11 @@ __global__ __launch_bounds__(256) void cn_cholesky_head_bwd_kernel(const float* 
                                                                    const float* __restrict__ dpred, int N, int H,
                                                                    float* __restrict__ dhid,
                                                                    float* __restrict__ parts) {
-  __shared__ float red[NODES_PER_BLOCK][6 * HEAD_MAX_H + 8];
+  __shared__ float red[NODES_PER_BLOCK][7 * HEAD_MAX_H + 8];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int per_lane = (H + 63) / 64;  // <= 8
   float wacc[6][8];
+  float hacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float bacc[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int r = 0; r < 6; ++r)
@@ -316,7 +304,9 @@ __global__ __launch_bounds__(256) void cn_cholesky_head_bwd_kernel(const float* 
           dh += dp[r] * W2[r * H + c];
           wacc[r][j] += dp[r] * hv;
         }
-        dhid[(size_t)n * H + c] = dh * cn_dsilu(hp);
+        dh *= cn_dsilu(hp);
+        hacc[j] += dh;
+        dhid[(size_t)n * H + c] = dh;
       }
     }
   }
@@ -330,9 +320,15 @@ __global__ __launch_bounds__(256) void cn_cholesky_head_bwd_kernel(const float* 
     }
     if (lane == 0) red[wid][6 * H + r] = bacc[r];
   }
+  if (lane < 2) red[wid][6 * H + 6 + lane] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = lane + j * 64;
+    if (c < H) red[wid][6 * H + 8 + c] = hacc[j];
+  }
   __syncthreads();
-  const int row = 6 * H + 8;
-  for (int i = threadIdx.x; i < 6 * H + 6; i += 256) {
+  const int row = 7 * H + 8;
+  for (int i = threadIdx.x; i < row; i += 256) {
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < NODES_PER_BLOCK; ++w) t += red[w][i];
@@ -365,9 +361,10 @@ __global__ __launch_bounds__(256) void cn_scalar_head_bwd_kernel(const float* __
                                                                  const float* __restrict__ dout, int N, int H,
                                                                  float* __restrict__ dhid,
                                                                  float* __restrict__ parts) {
-  __shared__ float red[NODES_PER_BLOCK][HEAD_MAX_H + 8];
+  __shared__ float red[NODES_PER_BLOCK][2 * HEAD_MAX_H + 8];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float wacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float hacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float bacc = 0.f;
   for (int n = blockIdx.x * NODES_PER_BLOCK + wid; n < N; n += gridDim.x * NODES_PER_BLOCK) {
     const int g = (int)batch[n];
@@ -380,19 +377,24 @@ __global__ __launch_bounds__(256) void cn_scalar_head_bwd_kernel(const float* __
       if (c < H) {
         const float hp = hid[(size_t)n * H + c];
         wacc[j] += dv * cn_silu(hp);
-        dhid[(size_t)n * H + c] = dv * w2[c] * cn_dsilu(hp);
+        const float dh = dv * w2[c] * cn_dsilu(hp);
+        hacc[j] += dh;
+        dhid[(size_t)n * H + c] = dh;
       }
     }
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = lane + j * 64;
-    if (c < H) red[wid][c] = wacc[j];
+    if (c < H) {
+      red[wid][c] = wacc[j];
+      red[wid][H + 8 + c] = hacc[j];
+    }
   }
-  if (lane == 0) red[wid][H] = bacc;
+  if (lane < 8) red[wid][H + lane] = (lane == 0) ? bacc : 0.f;
   __syncthreads();
-  const int row = H + 8;
-  for (int i = threadIdx.x; i < H + 1; i += 256) {
+  const int row = 2 * H + 8;
+  for (int i = threadIdx.x; i < row; i += 256) {
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < NODES_PER_BLOCK; ++w) t += red[w][i];
@@ -424,7 +426,7 @@ extern "C" int cartnet_node_nparts(int32_t N) { return node_parts(N); }
 
 extern "C" int cartnet_node_embed_bwd(const int64_t* z, const int64_t* batch, const float* temperature,
                                       const float* dx0, int32_t N, int32_t C, int32_t n_types, float* demb,
-                                      float* parts_w, float* parts_b, void* stream) {
+                                      double* parts_w, double* parts_b, void* stream) {
   CN_CHECK(N >= 0 && C >= 4 && C % 4 == 0, "cartnet_node_embed_bwd: C=%d must be a multiple of 4", C);
   CN_CHECK(dx0 || N == 0, "cartnet_node_embed_bwd: null dx0");
   if (demb) {
@@ -443,7 +445,7 @@ extern "C" int cartnet_node_embed_bwd(const int64_t* z, const int64_t* batch, co
   return 0;
 }
 
-extern "C" int cartnet_bn_finalize(const float* parts_sum, const float* parts_sq, int32_t nparts, int64_t count,
+extern "C" int cartnet_bn_finalize(const double* parts_sum, const double* parts_sq, int32_t nparts, int64_t count,
                                    int32_t C, float eps, float momentum, int32_t training, float* running_mean,
                                    float* running_var, int64_t* num_batches_tracked, float* mean_rstd, void* stream) {
   CN_CHECK(C >= 1 && mean_rstd, "cartnet_bn_finalize: bad arguments");
@@ -473,7 +475,7 @@ extern "C" int cartnet_node_update_fwd(const float* aggr, const float* x_in, con
 
 extern "C" int cartnet_node_update_bwd_stats(const float* aggr, const float* dx_out, const float* mean_rstd,
                                              const float* gamma, const float* beta, int32_t N, int32_t D,
-                                             float* parts_a, float* parts_b, void* stream) {
+                                             double* parts_a, double* parts_b, void* stream) {
   CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_node_update_bwd_stats: D=%d must be a multiple of 4", D);
   CN_CHECK(aggr && dx_out && mean_rstd && gamma && beta && parts_a && parts_b,
            "cartnet_node_update_bwd_stats: null pointer");
@@ -491,7 +493,7 @@ extern "C" int cartnet_node_update_bwd_apply(const float* aggr, const float* dx_
   CN_CHECK(aggr && dx_out && mean_rstd && gamma && beta && sums && daggr, "cartnet_node_update_bwd_apply: null pointer");
   const float inv = (training && N > 0) ? (float)(1.0 / (double)N) : 0.f;
   hipLaunchKernelGGL(cn_node_update_bwd_kernel<1>, dim3(node_parts(N)), dim3(256), 0, ST(stream), aggr, dx_out,
-                     mean_rstd, gamma, beta, sums, inv, N, D, (float*)nullptr, (float*)nullptr, daggr);
+                     mean_rstd, gamma, beta, sums, inv, N, D, (double*)nullptr, (double*)nullptr, daggr);
   CN_LAUNCH_CHECK("cartnet_node_update_bwd_apply");
   return 0;
 }

@@ -149,7 +149,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
         for name, t, field in (("colsum", cs[g], "colsum"), ("colsq", cq[g], "colsq")):
             if t is None:
                 continue
-            _vec(t, tiles_m * N, f"gemm {name}[{g}]")
+            _vec(t, tiles_m * N, f"gemm {name}[{g}]", torch.float64)
             getattr(args, field)[g] = t.data_ptr()
     _l.check(lib.cartnet_gemm(C.byref(args), _l.stream_ptr()), "cartnet_gemm")
 
@@ -168,11 +168,16 @@ def splitk_reduce(slabs: Tensor, splitk: int, out: Tensor) -> None:
 
 
 def colsum_finalize(parts: Tensor, nparts: int, out: Tensor) -> None:
+    """out[n] = sum_p parts[p, n] in fixed order; parts are the fp64 (or, for the head kernels, fp32) partial rows."""
     n = out.numel()
     _vec(out, n, "colsum_finalize out")
-    _vec(parts, nparts * n, "colsum_finalize parts")
-    _l.check(_l.load().cartnet_colsum_finalize(parts.data_ptr(), nparts, n, out.data_ptr(), _l.stream_ptr()),
-             "cartnet_colsum_finalize")
+    if parts.dtype == torch.float64:
+        _vec(parts, nparts * n, "colsum_finalize parts", torch.float64)
+        fn = _l.load().cartnet_colsum_finalize
+    else:
+        _vec(parts, nparts * n, "colsum_finalize parts", torch.float32)
+        fn = _l.load().cartnet_colsum_finalize_f32
+    _l.check(fn(parts.data_ptr(), nparts, n, out.data_ptr(), _l.stream_ptr()), "cartnet_colsum_finalize")
 
 
 class GraphLayout:
@@ -280,8 +285,8 @@ def node_embed_bwd(z, batch, temperature, dx0: Tensor, n_types: int, demb, parts
         _vec(z, N, "node_embed_bwd z", torch.int64)
         _vec(demb, n_types * Cc, "node_embed_bwd demb")
     npart = node_nparts(N)
-    _vec(parts_w, npart * Cc, "node_embed_bwd parts_w")
-    _vec(parts_b, npart * Cc, "node_embed_bwd parts_b")
+    _vec(parts_w, npart * Cc, "node_embed_bwd parts_w", torch.float64)
+    _vec(parts_b, npart * Cc, "node_embed_bwd parts_b", torch.float64)
     if batch is not None:
         _vec(batch, N, "node_embed_bwd batch", torch.int64)
     _l.check(_l.load().cartnet_node_embed_bwd(_l.ptr(z), _l.ptr(batch), _l.ptr(temperature), dx0.data_ptr(), N, Cc,
@@ -293,8 +298,8 @@ def bn_finalize(parts_sum, parts_sq, nparts: int, count: int, Cc: int, eps: floa
                 running_mean, running_var, nbt, mean_rstd: Tensor) -> None:
     _vec(mean_rstd, 2 * Cc, "bn_finalize mean_rstd")
     if training:
-        _vec(parts_sum, nparts * Cc, "bn_finalize parts_sum")
-        _vec(parts_sq, nparts * Cc, "bn_finalize parts_sq")
+        _vec(parts_sum, nparts * Cc, "bn_finalize parts_sum", torch.float64)
+        _vec(parts_sq, nparts * Cc, "bn_finalize parts_sq", torch.float64)
     _vec(running_mean, Cc, "bn_finalize running_mean")
     _vec(running_var, Cc, "bn_finalize running_var")
     if nbt is not None:
@@ -324,8 +329,8 @@ def gate_scatter_fwd(gs, e_in, env, layout: GraphLayout, mean_rstd, gamma, beta,
     _vec(gamma, D, "gate_scatter_fwd gamma")
     _vec(beta, D, "gate_scatter_fwd beta")
     npart = gate_nparts(N)
-    _vec(parts_sum, npart * D, "gate_scatter_fwd parts_sum")
-    _vec(parts_sq, npart * D, "gate_scatter_fwd parts_sq")
+    _vec(parts_sum, npart * D, "gate_scatter_fwd parts_sum", torch.float64)
+    _vec(parts_sq, npart * D, "gate_scatter_fwd parts_sq", torch.float64)
     _l.check(_l.load().cartnet_gate_scatter_fwd(gs.data_ptr(), e_in.data_ptr(), _l.ptr(env), layout.rowptr.data_ptr(),
                                                 mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, D,
                                                 e_out.data_ptr(), aggr.data_ptr(), parts_sum.data_ptr(),
@@ -337,17 +342,18 @@ def gate_scatter_bwd_stats(gs, de_out, daggr, env, layout: GraphLayout, mean_rst
     E, N = layout.E, layout.N
     D = int(daggr.shape[1])
     _edge_rows(gs, E, 2 * D, "gate_scatter_bwd_stats gs")
-    _edge_rows(de_out, E, D, "gate_scatter_bwd_stats de_out")
+    if de_out is not None:
+        _edge_rows(de_out, E, D, "gate_scatter_bwd_stats de_out")
     _edge_rows(daggr, N, D, "gate_scatter_bwd_stats daggr")
     _vec(env, E, "gate_scatter_bwd_stats env")
     _vec(mean_rstd, 2 * D, "mean_rstd")
     _vec(gamma, D, "gamma")
     _vec(beta, D, "beta")
     npart = gate_nparts(N)
-    _vec(parts_a, npart * D, "parts_a")
-    _vec(parts_b, npart * D, "parts_b")
+    _vec(parts_a, npart * D, "parts_a", torch.float64)
+    _vec(parts_b, npart * D, "parts_b", torch.float64)
     _l.check(_l.load().cartnet_gate_scatter_bwd_stats(
-        gs.data_ptr(), de_out.data_ptr(), daggr.data_ptr(), _l.ptr(env), layout.rowptr.data_ptr(),
+        gs.data_ptr(), _l.ptr(de_out), daggr.data_ptr(), _l.ptr(env), layout.rowptr.data_ptr(),
         mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, D, parts_a.data_ptr(), parts_b.data_ptr(),
         _l.stream_ptr()), "cartnet_gate_scatter_bwd_stats")
 
@@ -357,7 +363,8 @@ def gate_scatter_bwd_apply(gs, de_out, daggr, env, layout: GraphLayout, mean_rst
     E, N = layout.E, layout.N
     D = int(daggr.shape[1])
     _edge_rows(gs, E, 2 * D, "gate_scatter_bwd_apply gs")
-    _edge_rows(de_out, E, D, "gate_scatter_bwd_apply de_out")
+    if de_out is not None:
+        _edge_rows(de_out, E, D, "gate_scatter_bwd_apply de_out")
     _edge_rows(daggr, N, D, "gate_scatter_bwd_apply daggr")
     _vec(env, E, "env")
     _vec(mean_rstd, 2 * D, "mean_rstd")
@@ -365,10 +372,10 @@ def gate_scatter_bwd_apply(gs, de_out, daggr, env, layout: GraphLayout, mean_rst
     _vec(beta, D, "beta")
     _vec(sums, 2 * D, "sums")
     npart = gate_nparts(N)
-    _vec(parts_dg, npart * D, "parts_dg")
-    _vec(parts_ds, npart * D, "parts_ds")
+    _vec(parts_dg, npart * D, "parts_dg", torch.float64)
+    _vec(parts_ds, npart * D, "parts_ds", torch.float64)
     _l.check(_l.load().cartnet_gate_scatter_bwd_apply(
-        gs.data_ptr(), de_out.data_ptr(), daggr.data_ptr(), _l.ptr(env), layout.rowptr.data_ptr(),
+        gs.data_ptr(), _l.ptr(de_out), daggr.data_ptr(), _l.ptr(env), layout.rowptr.data_ptr(),
         mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), E, int(training), N, D,
         parts_dg.data_ptr(), parts_ds.data_ptr(), _l.stream_ptr()), "cartnet_gate_scatter_bwd_apply")
 
@@ -408,8 +415,8 @@ def node_update_bwd_stats(aggr, dx_out, mean_rstd, gamma, beta, parts_a, parts_b
     _vec(gamma, D, "gamma")
     _vec(beta, D, "beta")
     npart = node_nparts(N)
-    _vec(parts_a, npart * D, "parts_a")
-    _vec(parts_b, npart * D, "parts_b")
+    _vec(parts_a, npart * D, "parts_a", torch.float64)
+    _vec(parts_b, npart * D, "parts_b", torch.float64)
     _l.check(_l.load().cartnet_node_update_bwd_stats(aggr.data_ptr(), dx_out.data_ptr(), mean_rstd.data_ptr(),
                                                      gamma.data_ptr(), beta.data_ptr(), N, D, parts_a.data_ptr(),
                                                      parts_b.data_ptr(), _l.stream_ptr()),
@@ -468,7 +475,7 @@ def cholesky_head_bwd(hid, out_index, W2, p6, dpred, dhid, parts) -> None:
     M = int(dpred.shape[0])
     _vec(dpred, M * 9, "dpred")
     _vec(p6, M * 6, "p6")
-    _vec(parts, node_nparts(N) * (6 * H + 8), "parts")
+    _vec(parts, node_nparts(N) * (7 * H + 8), "parts")
     _l.check(_l.load().cartnet_cholesky_head_bwd(hid.data_ptr(), out_index.data_ptr(), W2.data_ptr(), p6.data_ptr(),
                                                  dpred.data_ptr(), N, H, dhid.data_ptr(), parts.data_ptr(),
                                                  _l.stream_ptr()), "cartnet_cholesky_head_bwd")
@@ -495,7 +502,7 @@ def scalar_head_bwd(hid, w2, graph_ptr, batch, dout, dhid, parts) -> None:
     _vec(graph_ptr, Bg + 1, "graph_ptr", torch.int64)
     _vec(batch, N, "batch", torch.int64)
     _vec(dout, Bg, "dout")
-    _vec(parts, node_nparts(N) * (H + 8), "parts")
+    _vec(parts, node_nparts(N) * (2 * H + 8), "parts")
     _l.check(_l.load().cartnet_scalar_head_bwd(hid.data_ptr(), w2.data_ptr(), graph_ptr.data_ptr(), batch.data_ptr(),
                                                dout.data_ptr(), N, Bg, H, dhid.data_ptr(), parts.data_ptr(),
                                                _l.stream_ptr()), "cartnet_scalar_head_bwd")

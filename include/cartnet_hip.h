@@ -63,8 +63,8 @@ typedef struct CartnetGemmArgs {
   const float* gather_j[CARTNET_MAX_GROUPS];
   const float* resid[CARTNET_MAX_GROUPS];
   const float* dact[CARTNET_MAX_GROUPS];
-  float* colsum[CARTNET_MAX_GROUPS];
-  float* colsq[CARTNET_MAX_GROUPS];
+  double* colsum[CARTNET_MAX_GROUPS];
+  double* colsq[CARTNET_MAX_GROUPS];
   const int32_t* tgt;
   const int32_t* src;
   int32_t M, N, K;
@@ -79,8 +79,12 @@ int cartnet_gemm(const CartnetGemmArgs* args, void* stream);
 int cartnet_splitk_reduce(const float* slabs, int32_t splitk, int32_t M, int32_t N, float* out, int32_t ldo,
                           void* stream);
 
-/* out[n] = sum_{p<nparts} parts[p*N + n], accumulated in fp64 in fixed order (bias gradients). */
-int cartnet_colsum_finalize(const float* parts, int32_t nparts, int32_t N, float* out, void* stream);
+/* Partial sums.  Kernels that reduce over rows (BatchNorm statistics, bias / affine gradients) never use atomics:
+ * every workgroup writes one fp64 row of per-column partial sums (fp64 so that var = E[v^2] - mean^2 keeps its
+ * digits), and a finalise kernel adds the rows in fixed order.
+ * out[n] = (float) sum_{p<nparts} parts[p*N + n].  The _f32 form reads the fp32 partial rows of the head kernels. */
+int cartnet_colsum_finalize(const double* parts, int32_t nparts, int32_t N, float* out, void* stream);
+int cartnet_colsum_finalize_f32(const float* parts, int32_t nparts, int32_t N, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Graph layout.  Replaces PyG MessagePassing's per-layer index_select bookkeeping (called at
@@ -118,7 +122,7 @@ int cartnet_node_embed(const int64_t* z, const int64_t* batch, const float* temp
  * temperature_proj_atom.weight and .bias (or encoder.bias).  demb, or the parts pair, may be NULL. */
 int cartnet_node_nparts(int32_t N);
 int cartnet_node_embed_bwd(const int64_t* z, const int64_t* batch, const float* temperature, const float* dx0,
-                           int32_t N, int32_t C, int32_t n_types, float* demb, float* parts_w, float* parts_b,
+                           int32_t N, int32_t C, int32_t n_types, float* demb, double* parts_w, double* parts_b,
                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -127,7 +131,7 @@ int cartnet_node_embed_bwd(const int64_t* z, const int64_t* batch, const float* 
  * variance -> mean_rstd[0:C] = mean, mean_rstd[C:2C] = 1/sqrt(var + eps); running stats updated in place with
  * `momentum` and the unbiased variance; num_batches_tracked += 1.  training == 0: mean_rstd from running stats.
  * ---------------------------------------------------------------------------------------------------- */
-int cartnet_bn_finalize(const float* parts_sum, const float* parts_sq, int32_t nparts, int64_t count, int32_t C,
+int cartnet_bn_finalize(const double* parts_sum, const double* parts_sq, int32_t nparts, int64_t count, int32_t C,
                         float eps, float momentum, int32_t training, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, float* mean_rstd, void* stream);
 
@@ -143,13 +147,14 @@ int cartnet_bn_finalize(const float* parts_sum, const float* parts_sq, int32_t n
 int cartnet_gate_scatter_nparts(int32_t N);
 int cartnet_gate_scatter_fwd(const float* gs, const float* e_in, const float* env, const int32_t* rowptr,
                              const float* mean_rstd, const float* gamma, const float* beta, int32_t N, int32_t D,
-                             float* e_out, float* aggr, float* parts_sum, float* parts_sq, void* stream);
+                             float* e_out, float* aggr, double* parts_sum, double* parts_sq, void* stream);
 
-/* Backward, pass 1 (statistics): with dm = daggr[tgt], z = sigmoid(bn(g)), dbn = (dm*s + de_out) * env * z(1-z):
+/* de_out may be NULL in both backward passes (last layer: the head does not read the edge features).
+ * Backward, pass 1 (statistics): with dm = daggr[tgt], z = sigmoid(bn(g)), dbn = (dm*s + de_out) * env * z(1-z):
  * column partial sums of dbn and dbn * ghat (ghat = (g-mean)*rstd) -> parts_a, parts_b [nparts][D]. */
 int cartnet_gate_scatter_bwd_stats(const float* gs, const float* de_out, const float* daggr, const float* env,
                                    const int32_t* rowptr, const float* mean_rstd, const float* gamma,
-                                   const float* beta, int32_t N, int32_t D, float* parts_a, float* parts_b,
+                                   const float* beta, int32_t N, int32_t D, double* parts_a, double* parts_b,
                                    void* stream);
 /* Backward, pass 2 (apply), in place on gs: g <- dg = gamma*rstd*(dbn - sum_dbn/E - ghat*sum_dbn_ghat/E)
  * (the two mean terms are dropped when training == 0), s <- ds = dm * sigma.  sums[0:D] = sum dbn,
@@ -158,7 +163,7 @@ int cartnet_gate_scatter_bwd_stats(const float* gs, const float* de_out, const f
 int cartnet_gate_scatter_bwd_apply(float* gs, const float* de_out, const float* daggr, const float* env,
                                    const int32_t* rowptr, const float* mean_rstd, const float* gamma,
                                    const float* beta, const float* sums, int64_t E, int32_t training, int32_t N,
-                                   int32_t D, float* parts_dg, float* parts_ds, void* stream);
+                                   int32_t D, double* parts_dg, double* parts_ds, void* stream);
 
 /* Row-segment sums: out[t, :] = sum_{k in [ptr[t], ptr[t+1])} rows[(perm ? perm[k] : k), :]  (fixed order).
  * Backward of the two index_selects PyG performs per layer (x_i by target: perm = NULL; x_j by source: CSC). */
@@ -173,8 +178,8 @@ int cartnet_node_update_fwd(const float* aggr, const float* x_in, const float* m
 /* Backward pass 1: dxn = dx_out * silu'(xn); column partial sums of dxn and dxn*ahat -> parts_a/parts_b
  * [cartnet_node_nparts(N)][D]. */
 int cartnet_node_update_bwd_stats(const float* aggr, const float* dx_out, const float* mean_rstd,
-                                  const float* gamma, const float* beta, int32_t N, int32_t D, float* parts_a,
-                                  float* parts_b, void* stream);
+                                  const float* gamma, const float* beta, int32_t N, int32_t D, double* parts_a,
+                                  double* parts_b, void* stream);
 /* Backward pass 2: daggr = gamma*rstd*(dxn - sum_a/N - ahat*sum_b/N) (mean terms dropped when training == 0). */
 int cartnet_node_update_bwd_apply(const float* aggr, const float* dx_out, const float* mean_rstd,
                                   const float* gamma, const float* beta, const float* sums, int32_t training,
@@ -189,8 +194,8 @@ int cartnet_node_update_bwd_apply(const float* aggr, const float* dx_out, const 
 int cartnet_mask_index(const uint8_t* mask, int32_t N, int32_t* out_index, int32_t* count, void* stream);
 int cartnet_cholesky_head_fwd(const float* hid, const int32_t* out_index, const float* W2, const float* b2,
                               int32_t N, int32_t H, float* p6, float* pred, void* stream);
-/* Backward: dhid [N,H] (zero rows for unmasked atoms), partial sums for dW2 [6,H] and db2 [6] ->
- * parts [cartnet_node_nparts(N)][6*H + 8]. */
+/* Backward: dhid [N,H] (zero rows for unmasked atoms); per-block partial sums -> parts [cartnet_node_nparts(N)][7*H+8],
+ * row layout: 6*H of dW2, 6 of db2, 2 pad, H column sums of dhid (= gradient of head.MLP.0.bias). */
 int cartnet_cholesky_head_bwd(const float* hid, const int32_t* out_index, const float* W2, const float* p6,
                               const float* dpred, int32_t N, int32_t H, float* dhid, float* parts, void* stream);
 

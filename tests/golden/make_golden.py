@@ -1,0 +1,194 @@
+"""Generate the golden vectors under tests/golden/ from the REFERENCE ITSELF (build container only).
+
+Runs the reference's own ``models/cartnet.py`` (CartNet forward + autograd backward) and ``dataset/utils.py``
+(radius_graph_pbc) imported read-only from /root/reference (see _ref_import.py for how its absent third-party
+imports are stood in), on synthetic crystals from cartnet_amd.synthetic and weights from
+cartnet_amd.model.make_state_dict, and stores inputs + outputs as plain arrays (.npz).  The reference's source
+never enters the repo; only tensors do.
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+
+Fixtures (all fp32 unless suffixed _f64):
+  tiny_*      D=16, R=8, L=2, 2 crystals of 7/9 atoms, four model variants; weights stored in the fixture
+  config1     D=64, R=64, L=2, 4 crystals of 30..70 atoms (BASELINE.json configs[0] shape); weights from seed
+  config2     D=256, R=64, L=4, 2 crystals of 194 atoms (configs[1] shape); weights from seed
+  radius_graph  reference radius_graph_pbc output for 3 crystals (integers compared bit-exactly)
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from _ref_import import import_reference  # noqa: E402
+
+from cartnet_amd.data import Batch, Data  # noqa: E402
+from cartnet_amd.model import make_state_dict  # noqa: E402
+from cartnet_amd.synthetic import make_crystal, radius_graph_pbc_single  # noqa: E402
+
+ref_cfg, ref_cartnet, ref_dutils = import_reference()
+
+
+def to_np(t):
+    return t.detach().cpu().numpy()
+
+
+def batch_inputs(batch):
+    out = {}
+    for k in ("x", "batch", "ptr", "edge_index", "cart_dist", "cart_dir", "temperature", "non_H_mask", "y", "cell"):
+        if hasattr(batch, k):
+            out["in_" + k] = to_np(getattr(batch, k))
+    out["in_num_graphs"] = np.int64(batch.num_graphs)
+    return out
+
+
+def clone_batch(batch, dtype=None):
+    b = batch.clone()
+    b.num_graphs = batch.num_graphs
+    if dtype is not None:
+        for k, v in list(b.__dict__.items()):
+            if torch.is_tensor(v) and v.is_floating_point():
+                setattr(b, k, v.to(dtype))
+    return b
+
+
+def run_reference(sd, batch, hp, training, dtype=torch.float32, want_grads=False, trace=False):
+    """One forward (+ backward) of the reference CartNet.  Returns dict of outputs."""
+    ref_cfg.invariant = hp["invariant"]
+    ref_cfg.radius = hp["radius"]
+    torch.manual_seed(0)
+    m = ref_cartnet.CartNet(dim_in=hp["dim_in"], dim_rbf=hp["dim_rbf"], num_layers=hp["num_layers"],
+                            radius=hp["radius"], invariant=hp["invariant"], temperature=hp["temperature"],
+                            use_envelope=hp["use_envelope"], atom_types=hp["atom_types"], cholesky=hp["cholesky"])
+    missing = m.load_state_dict(sd, strict=True)     # also proves key / shape parity of make_state_dict
+    assert not missing.missing_keys and not missing.unexpected_keys
+    m = m.to(dtype)
+    m.train(training)
+    b = clone_batch(batch, dtype)
+    out = {}
+    if trace:
+        b2 = clone_batch(batch, dtype)
+        bb = m.encoder(b2)
+        out["x0"], out["e0"] = to_np(bb.x), to_np(bb.edge_attr)
+        for l, layer in enumerate(m.layers):
+            bb = layer(bb)
+            out[f"x{l + 1}"], out[f"e{l + 1}"] = to_np(bb.x), to_np(bb.edge_attr)
+        # the trace pass updated running stats once; rebuild the module so the measured pass starts clean
+        return {**out, **run_reference(sd, batch, hp, training, dtype, want_grads, trace=False)}
+    pred, true = m(b)
+    out["pred"] = to_np(pred)
+    mae = torch.nn.functional.l1_loss(pred, true)          # train/metrics.py:26
+    mse = torch.nn.functional.mse_loss(pred, true)         # train/metrics.py:27
+    out["mae"], out["mse"] = to_np(mae), to_np(mse)
+    if want_grads:
+        mae.mean().backward()                              # train/train.py:183
+        out["grads"] = {k: to_np(p.grad) for k, p in m.named_parameters()}
+        out["new_state"] = {k: to_np(v) for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    return out
+
+
+def hp_dict(dim_in, dim_rbf, num_layers, **kw):
+    hp = dict(dim_in=dim_in, dim_rbf=dim_rbf, num_layers=num_layers, radius=5.0, invariant=False, temperature=True,
+              use_envelope=True, atom_types=True, cholesky=True)
+    hp.update(kw)
+    return hp
+
+
+def save_model_fixture(name, hp, batch, seed, store_weights, full_grads, trace):
+    sd = make_state_dict(hp["dim_in"], hp["dim_rbf"], hp["num_layers"], seed=seed, cholesky=hp["cholesky"],
+                         temperature=hp["temperature"], atom_types=hp["atom_types"], invariant=hp["invariant"],
+                         radius=hp["radius"])
+    arrays = batch_inputs(batch)
+    for k, v in hp.items():
+        arrays["hp_" + k] = np.array(v)
+    arrays["weights_seed"] = np.int64(seed)
+    arrays["weights_abs_sum"] = np.float64(sum(v.double().abs().sum().item() for v in sd.values()))
+    if store_weights:
+        for k, v in sd.items():
+            arrays["w_" + k] = to_np(v)
+    tr = run_reference(sd, batch, hp, True, torch.float32, want_grads=True, trace=trace)
+    ev = run_reference(sd, batch, hp, False, torch.float32)
+    tr64 = run_reference({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, batch, hp, True,
+                         torch.float64, want_grads=True)
+    ev64 = run_reference({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, batch, hp, False,
+                         torch.float64)
+    arrays["train_pred"], arrays["train_mae"], arrays["train_mse"] = tr["pred"], tr["mae"], tr["mse"]
+    arrays["eval_pred"], arrays["eval_mae"] = ev["pred"], ev["mae"]
+    arrays["train_pred_f64"], arrays["eval_pred_f64"] = tr64["pred"], ev64["pred"]
+    if trace:
+        for k, v in tr.items():
+            if k[0] in "xe" and k[1:].isdigit():
+                arrays["trace_" + k] = v
+    for k, v in tr["new_state"].items():
+        arrays["state_" + k] = v
+    rng = np.random.default_rng(12345)
+    for k, g in tr["grads"].items():
+        g64 = tr64["grads"][k]
+        if full_grads:
+            arrays["grad_" + k] = g
+            arrays["grad64_" + k] = g64.astype(np.float64)
+        else:
+            probe = rng.standard_normal(g.size)
+            arrays["gradnorm_" + k] = np.float64(np.linalg.norm(g64.ravel()))
+            arrays["gradprobe_" + k] = np.float64(np.dot(g64.ravel(), probe))
+            arrays["gradhead_" + k] = g64.ravel()[:64].astype(np.float64)
+            arrays["gradnorm32_" + k] = np.float64(np.linalg.norm(g.ravel().astype(np.float64)))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    err = np.abs(tr["pred"] - tr64["pred"]).max() / np.abs(tr64["pred"]).max()
+    print(f"{name}: N={batch.x.shape[0]} E={batch.edge_index.shape[1]} fp32-vs-fp64 train err {err:.2e} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def tiny_batch(adp=True):
+    items = [make_crystal(100, 7, adp=adp), make_crystal(101, 9, adp=adp)]
+    return Batch.from_data_list(items)
+
+
+def radius_graph_fixture():
+    arrays = {}
+    for i, (g, n) in enumerate([(200, 12), (201, 25), (202, 40)]):
+        d = make_crystal(g, n)
+        data = type("D", (), {})()
+        data.pos, data.cell, data.natoms = d.pos, d.cell, torch.tensor([n])
+        data.pbc = torch.tensor([[True, True, True]])
+        ei, _, _, vec = ref_dutils.radius_graph_pbc(data, 5.0, None)
+        dist = torch.norm(vec, p=2, dim=-1)                     # dataset/figshare_dataset.py:67
+        dirn = torch.nn.functional.normalize(vec, p=2, dim=-1)  # dataset/figshare_dataset.py:68
+        mine_ei, mine_dist, mine_dir = radius_graph_pbc_single(d.pos, d.cell[0], 5.0)
+        assert torch.equal(ei, mine_ei), "edge_index differs from the reference"
+        assert torch.equal(dist, mine_dist) and torch.equal(dirn, mine_dir), "edge geometry differs"
+        assert bool((ei[1][1:] >= ei[1][:-1]).all()), "reference edge_index[1] is expected to be sorted"
+        arrays[f"pos{i}"], arrays[f"cell{i}"] = to_np(d.pos), to_np(d.cell[0])
+        arrays[f"edge_index{i}"], arrays[f"dist{i}"], arrays[f"dir{i}"] = to_np(ei), to_np(dist), to_np(dirn)
+        print(f"radius_graph[{i}]: n={n} E={ei.shape[1]} identical to reference")
+    np.savez_compressed(os.path.join(HERE, "radius_graph.npz"), **arrays)
+
+
+def main():
+    torch.set_num_threads(4)
+    radius_graph_fixture()
+    save_model_fixture("tiny_adp", hp_dict(16, 8, 2), tiny_batch(), seed=11, store_weights=True, full_grads=True,
+                       trace=True)
+    save_model_fixture("tiny_scalar", hp_dict(16, 8, 2, temperature=False, cholesky=False), tiny_batch(adp=False),
+                       seed=12, store_weights=True, full_grads=True, trace=False)
+    save_model_fixture("tiny_invariant", hp_dict(16, 8, 2, invariant=True, use_envelope=False), tiny_batch(),
+                       seed=13, store_weights=True, full_grads=True, trace=False)
+    save_model_fixture("tiny_noatom", hp_dict(16, 8, 2, atom_types=False), tiny_batch(), seed=14,
+                       store_weights=True, full_grads=True, trace=False)
+    b1 = Batch.from_data_list([make_crystal(300 + g, None, n_range=(30, 70)) for g in range(4)])
+    save_model_fixture("config1", hp_dict(64, 64, 2), b1, seed=21, store_weights=False, full_grads=True, trace=False)
+    b2 = Batch.from_data_list([make_crystal(400 + g, 194) for g in range(2)])
+    save_model_fixture("config2", hp_dict(256, 64, 4), b2, seed=22, store_weights=False, full_grads=False,
+                       trace=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -75,8 +75,8 @@ def test_gemm_nt_strided_views_and_epilogue(ops):
     src = torch.randint(0, Nn, (M,), generator=g).to(torch.int32).to(dev())
     out = torch.empty(M, 2 * D, device=dev())
     tiles = ops.gemm_tiles_m(M)
-    cs = torch.zeros(tiles * D, device=dev())
-    cq = torch.zeros(tiles * D, device=dev())
+    cs = torch.zeros(tiles * D, device=dev(), dtype=torch.float64)
+    cq = torch.zeros(tiles * D, device=dev(), dtype=torch.float64)
     ops.gemm(A, W[:, 2 * D:], out[:, D:], bias=bias, gather_i=Pi[:, D:], gather_j=Pj[:, D:], tgt=tgt, src=src,
              colsum=cs, colsq=cq)
     ref = A.double() @ W[:, 2 * D:].double().t() + bias.double() + Pi[:, D:].double()[tgt.long()] + \
@@ -162,7 +162,7 @@ def test_gemm_rejects_bad_shapes(ops):
 
 
 def test_colsum_finalize(ops):
-    parts = rnd(37, 100, seed=1)
+    parts = rnd(37, 100, seed=1).double()
     out = torch.empty(100, device=dev())
     ops.colsum_finalize(parts, 37, out)
     assert rel_err(out, parts.double().sum(0)) < 1e-6
@@ -267,7 +267,7 @@ def test_gate_scatter_fwd_bwd(ops, D):
     gamma, beta = rnd(D, seed=6), rnd(D, seed=7)
     e_out, aggr = torch.empty(E, D, device=dev()), torch.empty(N, D, device=dev())
     nparts = ops.gate_nparts(N)
-    ps, pq = torch.zeros(nparts * D, device=dev()), torch.zeros(nparts * D, device=dev())
+    ps, pq = (torch.zeros(nparts * D, device=dev(), dtype=torch.float64) for _ in range(2))
     ops.gate_scatter_fwd(gs, e_in, env, lay, mean_rstd, gamma, beta, e_out, aggr, ps, pq)
 
     c = lambda t: t.detach().double().cpu()
@@ -287,13 +287,13 @@ def test_gate_scatter_fwd_bwd(ops, D):
     eo_ref, ag_ref = _gate_reference(gs64, c(e_in), c(env), ei[1], N, bmean, brstd, c(gamma), c(beta))
     de_out, daggr = rnd(E, D, seed=8), rnd(N, D, seed=9)
     (eo_ref * c(de_out)).sum().add((ag_ref * c(daggr)).sum()).backward()
-    pa, pb = torch.zeros(nparts * D, device=dev()), torch.zeros(nparts * D, device=dev())
+    pa, pb = (torch.zeros(nparts * D, device=dev(), dtype=torch.float64) for _ in range(2))
     ops.gate_scatter_bwd_stats(gs, de_out, daggr, env, lay, mean_rstd_b, gamma, beta, pa, pb)
     sums = torch.empty(2 * D, device=dev())
     ops.colsum_finalize(pa, nparts, sums[:D])
     ops.colsum_finalize(pb, nparts, sums[D:])
     gs_work = gs.clone()
-    pdg, pds = torch.zeros(nparts * D, device=dev()), torch.zeros(nparts * D, device=dev())
+    pdg, pds = (torch.zeros(nparts * D, device=dev(), dtype=torch.float64) for _ in range(2))
     ops.gate_scatter_bwd_apply(gs_work, de_out, daggr, env, lay, mean_rstd_b, gamma, beta, sums, True, pdg, pds)
     assert rel_err(gs_work, gs64.grad) < 2e-5
     assert rel_err(pds.view(nparts, D).sum(0), gs64.grad[:, D:].sum(0)) < 1e-4
@@ -321,8 +321,8 @@ def test_bn_finalize_and_node_update(ops):
     gamma, beta = rnd(D, seed=3), rnd(D, seed=4)
     # statistics from 5 partial blocks
     chunks = torch.chunk(aggr, 5, dim=0)
-    ps = torch.stack([ch.sum(0) for ch in chunks]).contiguous().view(-1)
-    pq = torch.stack([(ch * ch).sum(0) for ch in chunks]).contiguous().view(-1)
+    ps = torch.stack([ch.double().sum(0) for ch in chunks]).contiguous().view(-1)
+    pq = torch.stack([(ch.double() ** 2).sum(0) for ch in chunks]).contiguous().view(-1)
     rm, rv = torch.zeros(D, device=dev()), torch.ones(D, device=dev())
     nbt = torch.zeros(1, dtype=torch.int64, device=dev())
     mean_rstd = torch.empty(2 * D, device=dev())
@@ -345,7 +345,7 @@ def test_bn_finalize_and_node_update(ops):
     dx = rnd(N, D, seed=5)
     (ref * dx.double().cpu()).sum().backward()
     nparts = ops.node_nparts(N)
-    pa, pb = torch.zeros(nparts * D, device=dev()), torch.zeros(nparts * D, device=dev())
+    pa, pb = (torch.zeros(nparts * D, device=dev(), dtype=torch.float64) for _ in range(2))
     ops.node_update_bwd_stats(aggr, dx, mean_rstd, gamma, beta, pa, pb)
     sums = torch.empty(2 * D, device=dev())
     ops.colsum_finalize(pa, nparts, sums[:D])
@@ -377,7 +377,7 @@ def test_node_embed_fwd_bwd(ops):
     (ref * dx0.double().cpu()).sum().backward()
     demb = torch.empty(119, Cc, device=dev())
     nparts = ops.node_nparts(N)
-    pw, pb = torch.zeros(nparts * Cc, device=dev()), torch.zeros(nparts * Cc, device=dev())
+    pw, pb = (torch.zeros(nparts * Cc, device=dev(), dtype=torch.float64) for _ in range(2))
     ops.node_embed_bwd(z.to(dev()), batch.to(dev()), T.to(dev()), dx0, 119, demb, pw, pb)
     dwt, dbt = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
     ops.colsum_finalize(pw, nparts, dwt)
@@ -416,10 +416,11 @@ def test_cholesky_head_fwd_bwd(ops, H):
     (ref * dpred.double().cpu()).sum().backward()
     dhid = torch.empty(N, H, device=dev())
     nparts = ops.node_nparts(N)
-    parts = torch.zeros(nparts * (6 * H + 8), device=dev())
+    parts = torch.zeros(nparts * (7 * H + 8), device=dev())
     ops.cholesky_head_bwd(hid, idx, W2, p6, dpred.contiguous(), dhid, parts)
     assert rel_err(dhid, h64.grad) < TOL
-    tot = parts.view(nparts, 6 * H + 8).double().sum(0)
+    tot = parts.view(nparts, 7 * H + 8).double().sum(0)
+    assert rel_err(tot[6 * H + 8:], h64.grad.sum(0)) < TOL
     assert rel_err(tot[:6 * H].view(6, H), w64.grad) < TOL
     assert rel_err(tot[6 * H:6 * H + 6], bb64.grad) < TOL
 
@@ -446,10 +447,11 @@ def test_scalar_head_fwd_bwd(ops):
     (ref * dout.double().cpu()).sum().backward()
     dhid = torch.empty(N, H, device=dev())
     nparts = ops.node_nparts(N)
-    parts = torch.zeros(nparts * (H + 8), device=dev())
+    parts = torch.zeros(nparts * (2 * H + 8), device=dev())
     ops.scalar_head_bwd(hid, w2, ptr.to(dev()), batch.to(dev()), dout, dhid, parts)
     assert rel_err(dhid, h64.grad) < TOL
-    tot = parts.view(nparts, H + 8).double().sum(0)
+    tot = parts.view(nparts, 2 * H + 8).double().sum(0)
+    assert rel_err(tot[H + 8:], h64.grad.sum(0)) < TOL
     assert rel_err(tot[:H], w64.grad.view(-1)) < TOL
     assert rel_err(tot[H:H + 1], bb64.grad) < TOL
 

@@ -1,0 +1,105 @@
+"""Pin the oracle (oracle/cartnet_ref.py) against golden vectors generated from the reference itself.
+
+The reference ships no tests or fixtures for this path; tests/golden/*.npz hold outputs of its own
+models/cartnet.py + dataset/utils.py run in the build container (tests/golden/make_golden.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as gu
+from conftest import rel_err
+from oracle import cartnet_ref as orc
+
+
+def _f(sd, dtype):
+    return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def _b(b, dtype):
+    c = gu.clone_batch(b)
+    for k, v in list(c.__dict__.items()):
+        if torch.is_tensor(v) and v.is_floating_point():
+            setattr(c, k, v.to(dtype))
+    return c
+
+
+@pytest.mark.parametrize("name", gu.MODEL_FIXTURES)
+def test_forward_matches_reference(name):
+    z, hp, b, sd = gu.load(name)
+    kw = gu.oracle_kwargs(hp)
+    for mode, training in (("train", True), ("eval", False)):
+        pred = orc.cartnet_forward(sd, b, training=training, **kw)
+        ref32 = torch.from_numpy(z[f"{mode}_pred"])
+        assert pred.shape == ref32.shape
+        assert rel_err(pred, ref32) < 1e-5, (name, mode)   # fp32 noise floor of the reference itself is ~4e-6
+        pred64 = orc.cartnet_forward(_f(sd, torch.float64), _b(b, torch.float64), training=training, **kw)
+        assert rel_err(pred64, torch.from_numpy(z[f"{mode}_pred_f64"])) < 1e-12, (name, mode)
+    # the oracle does not mutate its input
+    assert b.x.dtype == torch.int64
+
+
+def test_per_layer_trace_matches_reference():
+    z, hp, b, sd = gu.load("tiny_adp")
+    trace = {}
+    orc.cartnet_forward(sd, b, training=True, trace=trace, **gu.oracle_kwargs(hp))
+    for k, v in trace.items():
+        assert rel_err(v, torch.from_numpy(z["trace_" + k])) < 1e-5, k
+
+
+@pytest.mark.parametrize("name", gu.MODEL_FIXTURES)
+def test_loss_gradients_and_bn_state_match_reference(name):
+    z, hp, b, sd = gu.load(name)
+    is_param = lambda k: ("grad64_" + k) in z.files or ("gradnorm_" + k) in z.files   # parameters, not buffers
+    sd64 = {k: (v.double().requires_grad_(is_param(k)) if v.is_floating_point() else v) for k, v in sd.items()}
+    new_stats = {}
+    pred = orc.cartnet_forward(sd64, _b(b, torch.float64), training=True, new_stats=new_stats, **gu.oracle_kwargs(hp))
+    mae, mse = orc.compute_loss(pred, b.y.double())
+    assert abs(mae.item() - float(z["train_mae"])) < 1e-5 * abs(float(z["train_mae"]))
+    assert abs(mse.item() - float(z["train_mse"])) < 1e-5 * abs(float(z["train_mse"])) + 1e-12
+    mae.backward()
+    names = [k for k, v in sd64.items() if torch.is_tensor(v) and v.requires_grad]
+    gmax = max(float(np.abs(z["grad64_" + k]).max()) if ("grad64_" + k) in z.files else float(z["gradnorm_" + k])
+               for k in names)
+    for k in names:
+        g = sd64[k].grad
+        assert g is not None, k
+        if ("grad64_" + k) in z.files:
+            ref = torch.from_numpy(z["grad64_" + k])
+            assert (g - ref).abs().max().item() < 1e-9 * gmax, k
+        else:
+            assert abs(g.norm().item() - float(z["gradnorm_" + k])) < 1e-9 * gmax, k
+            assert torch.allclose(g.flatten()[:64], torch.from_numpy(z["gradhead_" + k]), rtol=0, atol=1e-9 * gmax), k
+    for k, v in new_stats.items():
+        ref = torch.from_numpy(z["state_" + k])
+        if v.is_floating_point():
+            assert rel_err(v, ref) < 1e-5, k
+        else:
+            assert int(v) == int(ref), k
+
+
+def test_radius_graph_matches_reference_bit_exact():
+    from cartnet_amd.synthetic import radius_graph_pbc_single
+    z = np.load(gu.GOLDEN + "/radius_graph.npz")
+    for i in range(3):
+        ei, dist, dirn = radius_graph_pbc_single(torch.from_numpy(z[f"pos{i}"]), torch.from_numpy(z[f"cell{i}"]), 5.0)
+        assert torch.equal(ei, torch.from_numpy(z[f"edge_index{i}"]))
+        assert torch.equal(dist, torch.from_numpy(z[f"dist{i}"]))
+        assert torch.equal(dirn, torch.from_numpy(z[f"dir{i}"]))
+        assert bool((ei[1][1:] >= ei[1][:-1]).all())      # target index sorted: CSR is a bincount + cumsum
+
+
+def test_equivariance_of_the_oracle():
+    """Rotating cart_dir by R rotates the predicted ADP tensors: pred' = R^T pred R (reference main.py:96-97)."""
+    from cartnet_amd.synthetic import random_rotation
+    z, hp, b, sd = gu.load("tiny_adp")
+    kw = gu.oracle_kwargs(hp)
+    sd64, b64 = _f(sd, torch.float64), _b(b, torch.float64)
+    R = random_rotation(torch.Generator().manual_seed(3)).double()
+    p0 = orc.cartnet_forward(sd64, b64, training=False, **kw)
+    b64.cart_dir = b64.cart_dir @ R
+    p1 = orc.cartnet_forward(sd64, b64, training=False, **kw)
+    # the network is only approximately equivariant (it sees raw direction components); the head output is SPD
+    assert p1.shape == p0.shape
+    evals = torch.linalg.eigvalsh(p1)
+    assert bool((evals > 0).all())
