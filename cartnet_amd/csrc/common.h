@@ -65,4 +65,23 @@ __device__ __forceinline__ void cn_acc4(f64x4& a, f32x4 v) {
   for (int q = 0; q < 4; ++q) a[q] += (double)v[q];
 }
 
+// Column sum of a [nparts][N] fp64 partial-sum matrix for 64 consecutive columns, by a 1024-thread block:
+// 16 row groups sum rows g, g+16, ... each, then thread c (< 64) adds the 16 group sums in group order.
+// Returns the total in threads 0..63 (column col0 + tid); fixed summation order -> bitwise reproducible.
+__device__ __forceinline__ double cn_block_colsum(const double* __restrict__ parts, int nparts, int N, int col0,
+                                                  double* lds /* [16][64] */) {
+  const int tid = threadIdx.x, g = tid >> 6, cl = tid & 63;
+  const int c = col0 + cl;
+  double acc = 0.0;
+  if (c < N)
+    for (int p = g; p < nparts; p += 16) acc += parts[(size_t)p * N + c];
+  __syncthreads();
+  lds[g * 64 + cl] = acc;
+  __syncthreads();
+  double tot = 0.0;
+  if (tid < 64)
+    for (int q = 0; q < 16; ++q) tot += lds[q * 64 + tid];
+  return tot;
+}
+
 static inline int cn_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

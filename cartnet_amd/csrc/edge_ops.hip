@@ -182,6 +182,67 @@ __global__ __launch_bounds__(256) void cn_segment_sum_kernel(const float* __rest
   }
 }
 
+// Long-segment variant (few, very uneven segments, e.g. atoms grouped by element): pass 1 cuts the sorted positions
+// into chunks of LONG_CHUNK rows, one wave per (chunk, 256-column slab), and writes one partial row per run of equal
+// segment id at tmp[first position of the run]; pass 2 adds each segment's partial rows in position order.
+constexpr int LONG_CHUNK = 128;
+
+__global__ __launch_bounds__(256) void cn_segment_long_pass1_kernel(const float* __restrict__ rows, int ld,
+                                                                    const int* __restrict__ ptr,
+                                                                    const int* __restrict__ perm, int nseg, int total,
+                                                                    int W, float* __restrict__ tmp) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int slabs = (W + 255) / 256;
+  const int nchunks = (total + LONG_CHUNK - 1) / LONG_CHUNK;
+  for (long long it = (long long)blockIdx.x * NODES_PER_BLOCK + wid; it < (long long)nchunks * slabs;
+       it += (long long)gridDim.x * NODES_PER_BLOCK) {
+    const int chunk = (int)(it / slabs);
+    const int c = (int)(it % slabs) * 256 + lane * 4;
+    const int p0 = chunk * LONG_CHUNK, p1 = min(total, p0 + LONG_CHUNK);
+    // segment of position p0: largest s with ptr[s] <= p0
+    int lo = 0, hi = nseg;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (ptr[mid] <= p0) lo = mid; else hi = mid;
+    }
+    int seg = lo;
+    while (seg + 1 < nseg && ptr[seg + 1] <= p0) ++seg;
+    int run_start = p0;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int p = p0; p < p1; ++p) {
+      while (seg + 1 <= nseg && p >= ptr[seg + 1]) {   // p starts a new segment: flush the finished run
+        if (p > run_start && c < W) st4(tmp + (size_t)run_start * W + c, acc);
+        acc = f32x4{0, 0, 0, 0};
+        run_start = p;
+        ++seg;
+      }
+      if (c < W) acc += ld4(rows + (size_t)(perm ? perm[p] : p) * ld + c);
+    }
+    if (p1 > run_start && c < W) st4(tmp + (size_t)run_start * W + c, acc);
+  }
+}
+
+__global__ __launch_bounds__(256) void cn_segment_long_pass2_kernel(const float* __restrict__ tmp,
+                                                                    const int* __restrict__ ptr, int nseg, int W,
+                                                                    float* __restrict__ out, int ldo) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int slabs = (W + 255) / 256;
+  for (long long it = (long long)blockIdx.x * NODES_PER_BLOCK + wid; it < (long long)nseg * slabs;
+       it += (long long)gridDim.x * NODES_PER_BLOCK) {
+    const int s = (int)(it / slabs);
+    const int c = (int)(it % slabs) * 256 + lane * 4;
+    if (c >= W) continue;
+    const int b = ptr[s], e = ptr[s + 1];
+    f32x4 acc = {0, 0, 0, 0};
+    int p = b;
+    while (p < e) {
+      acc += ld4(tmp + (size_t)p * W + c);
+      p = (p / LONG_CHUNK + 1) * LONG_CHUNK;
+    }
+    st4(out + (size_t)s * ldo + c, acc);
+  }
+}
+
 inline int gate_parts(int N) {
   int b = cn_ceil_div(N, NODES_PER_BLOCK);
   if (b > MAX_PARTS) b = MAX_PARTS;
@@ -265,5 +326,28 @@ extern "C" int cartnet_segment_sum(const float* rows, int32_t ld, const int32_t*
   hipLaunchKernelGGL(cn_segment_sum_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      rows, ld, ptr, perm, N, W, out, ldo);
   CN_LAUNCH_CHECK("cartnet_segment_sum");
+  return 0;
+}
+
+extern "C" int cartnet_segment_sum_long(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm,
+                                        int32_t nseg, int32_t total, int32_t W, float* tmp, float* out, int32_t ldo,
+                                        void* stream) {
+  CN_CHECK(nseg >= 1 && total >= 0 && W >= 4 && W % 4 == 0 && ld % 4 == 0 && ldo % 4 == 0 && ld >= W && ldo >= W,
+           "cartnet_segment_sum_long: W=%d ld=%d ldo=%d must be multiples of 4", W, ld, ldo);
+  CN_CHECK((rows || total == 0) && ptr && tmp && out, "cartnet_segment_sum_long: null pointer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int slabs = (W + 255) / 256;
+  if (total > 0) {
+    long long items = (long long)((total + LONG_CHUNK - 1) / LONG_CHUNK) * slabs;
+    long long blocks = (items + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cn_segment_long_pass1_kernel, dim3((int)blocks), dim3(256), 0, st, rows, ld, ptr, perm, nseg,
+                       total, W, tmp);
+    CN_LAUNCH_CHECK("cartnet_segment_sum_long/pass1");
+  }
+  long long blocks2 = ((long long)nseg * slabs + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;
+  if (blocks2 > 4096) blocks2 = 4096;
+  hipLaunchKernelGGL(cn_segment_long_pass2_kernel, dim3((int)blocks2), dim3(256), 0, st, tmp, ptr, nseg, W, out, ldo);
+  CN_LAUNCH_CHECK("cartnet_segment_sum_long/pass2");
   return 0;
 }

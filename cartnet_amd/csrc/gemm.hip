@@ -271,8 +271,16 @@ __global__ void cn_splitk_reduce_kernel(const float* __restrict__ slabs, int spl
   }
 }
 
-template <typename T>
-__global__ void cn_colsum_finalize_kernel(const T* __restrict__ parts, int nparts, int N, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void cn_colsum_finalize_kernel(const double* __restrict__ parts, int nparts, int N,
+                                                                  float* __restrict__ out) {
+  __shared__ double red[16 * 64];
+  const double tot = cn_block_colsum(parts, nparts, N, blockIdx.x * 64, red);
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x < 64 && c < N) out[c] = (float)tot;
+}
+
+__global__ void cn_colsum_finalize_f32_kernel(const float* __restrict__ parts, int nparts, int N,
+                                              float* __restrict__ out) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   double acc = 0.0;
@@ -365,7 +373,7 @@ extern "C" int cartnet_colsum_finalize(const double* parts, int32_t nparts, int3
   CN_CHECK(parts && out, "cartnet_colsum_finalize: null pointer");
   CN_CHECK(nparts >= 0 && N >= 0, "cartnet_colsum_finalize: bad shape");
   if (N == 0) return 0;
-  hipLaunchKernelGGL(cn_colsum_finalize_kernel<double>, dim3(cn_ceil_div(N, 128)), dim3(128), 0,
+  hipLaunchKernelGGL(cn_colsum_finalize_kernel, dim3(cn_ceil_div(N, 64)), dim3(1024), 0,
                      reinterpret_cast<hipStream_t>(stream), parts, nparts, N, out);
   CN_LAUNCH_CHECK("cartnet_colsum_finalize");
   return 0;
@@ -375,7 +383,7 @@ extern "C" int cartnet_colsum_finalize_f32(const float* parts, int32_t nparts, i
   CN_CHECK(parts && out, "cartnet_colsum_finalize_f32: null pointer");
   CN_CHECK(nparts >= 0 && N >= 0, "cartnet_colsum_finalize_f32: bad shape");
   if (N == 0) return 0;
-  hipLaunchKernelGGL(cn_colsum_finalize_kernel<float>, dim3(cn_ceil_div(N, 128)), dim3(128), 0,
+  hipLaunchKernelGGL(cn_colsum_finalize_f32_kernel, dim3(cn_ceil_div(N, 128)), dim3(128), 0,
                      reinterpret_cast<hipStream_t>(stream), parts, nparts, N, out);
   CN_LAUNCH_CHECK("cartnet_colsum_finalize_f32");
   return 0;

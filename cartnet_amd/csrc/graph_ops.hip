@@ -112,7 +112,70 @@ __global__ __launch_bounds__(256) void cn_csc_build_kernel(const int* __restrict
   }
 }
 
+// Stable counting sort of N items by an int64 key in [0, nkeys), one workgroup (atom types: nkeys = 119).
+__global__ __launch_bounds__(1024) void cn_sort_by_key_kernel(const int64_t* __restrict__ keys, int N, int nkeys,
+                                                              int* __restrict__ perm, int* __restrict__ ptr,
+                                                              int* __restrict__ status) {
+  __shared__ int cnt[1024];
+  __shared__ int skey[1024];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nkeys; i += 1024) cnt[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < N; i += 1024) {
+    const long long k = keys[i];
+    if (k < 0 || k >= nkeys) atomicOr(status, 16);
+    else atomicAdd(&cnt[(int)k], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < nkeys; ++i) {
+      const int v = cnt[i];
+      cnt[i] = run;
+      ptr[i] = run;
+      run += v;
+    }
+    ptr[nkeys] = run;
+  }
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {
+    const int i = base + tid;
+    int key = -1;
+    if (i < N) {
+      const long long k = keys[i];
+      key = (k < 0 || k >= nkeys) ? -1 : (int)k;
+    }
+    skey[tid] = key;
+    __syncthreads();
+    int cur = 0, rank = 0;
+    if (key >= 0) {
+      cur = cnt[key];
+      for (int t = 0; t < tid; ++t) rank += (skey[t] == key) ? 1 : 0;
+    }
+    __syncthreads();
+    if (key >= 0) {
+      perm[cur + rank] = i;
+      atomicAdd(&cnt[key], 1);
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
+
+extern "C" int cartnet_sort_by_key(const int64_t* keys, int32_t N, int32_t nkeys, int32_t* perm, int32_t* ptr,
+                                   int32_t* status, void* stream) {
+  CN_CHECK(N >= 0 && nkeys >= 1 && nkeys <= 1024, "cartnet_sort_by_key: nkeys=%d out of range (1..1024)", nkeys);
+  CN_CHECK((keys || N == 0) && perm && ptr && status, "cartnet_sort_by_key: null pointer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) {
+    cartnet_set_error("cartnet_sort_by_key: memset failed");
+    return 2;
+  }
+  hipLaunchKernelGGL(cn_sort_by_key_kernel, dim3(1), dim3(1024), 0, st, keys, N, nkeys, perm, ptr, status);
+  CN_LAUNCH_CHECK("cartnet_sort_by_key");
+  return 0;
+}
 
 extern "C" int cartnet_csr_build(const int64_t* edge_index, int64_t E, int32_t N, const int64_t* graph_ptr,
                                  int32_t Bg, int32_t* src32, int32_t* tgt32, int32_t* rowptr, int32_t* colptr,

@@ -46,26 +46,6 @@ __global__ void cn_node_embed_kernel(const int64_t* __restrict__ z, const int64_
   }
 }
 
-// One wave per (atom type a, 256-channel chunk): fixed node order -> reproducible embedding gradient.
-__global__ __launch_bounds__(64) void cn_embed_bwd_types_kernel(const int64_t* __restrict__ z,
-                                                                const float* __restrict__ dx0, int N, int C,
-                                                                float* __restrict__ demb) {
-  const int a = blockIdx.x, lane = threadIdx.x;
-  const int c = blockIdx.y * 256 + lane * 4;
-  f32x4 acc = {0, 0, 0, 0};
-  for (int n0 = 0; n0 < N; n0 += 64) {
-    const int n = n0 + lane;
-    const bool hit = (n < N) && (z[n] == a);
-    unsigned long long m = __ballot(hit);
-    while (m) {
-      const int b = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      if (c < C) acc += ld4(dx0 + (size_t)(n0 + b) * C + c);
-    }
-  }
-  if (c < C) st4(demb + (size_t)a * C + c, acc);
-}
-
 // Column sums of dx0 and of T[batch[n]] * dx0 (temperature projection gradients), per-block partials.
 __global__ __launch_bounds__(256) void cn_embed_bwd_cols_kernel(const int64_t* __restrict__ batch,
                                                                 const float* __restrict__ temperature,
@@ -91,19 +71,17 @@ __global__ __launch_bounds__(256) void cn_embed_bwd_cols_kernel(const int64_t* _
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm stats
-__global__ void cn_bn_finalize_kernel(const double* __restrict__ parts_sum, const double* __restrict__ parts_sq,
-                                      int nparts, long long count, int C, float eps, float momentum, int training,
-                                      float* __restrict__ running_mean, float* __restrict__ running_var,
-                                      int64_t* __restrict__ nbt, float* __restrict__ mean_rstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && training && nbt) nbt[0] += 1;
-  if (c >= C) return;
+__global__ __launch_bounds__(1024) void cn_bn_finalize_kernel(
+    const double* __restrict__ parts_sum, const double* __restrict__ parts_sq, int nparts, long long count, int C,
+    float eps, float momentum, int training, float* __restrict__ running_mean, float* __restrict__ running_var,
+    int64_t* __restrict__ nbt, float* __restrict__ mean_rstd) {
+  __shared__ double red[16 * 64];
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && training && nbt) nbt[0] += 1;
   if (training) {
-    double s = 0.0, q = 0.0;
-    for (int p = 0; p < nparts; ++p) {
-      s += parts_sum[(size_t)p * C + c];
-      q += parts_sq[(size_t)p * C + c];
-    }
+    const double s = cn_block_colsum(parts_sum, nparts, C, blockIdx.x * 64, red);
+    const double q = cn_block_colsum(parts_sq, nparts, C, blockIdx.x * 64, red);
+    if (threadIdx.x >= 64 || c >= C) return;
     const double n = (double)count;
     const double mean = n > 0 ? s / n : 0.0;
     double var = n > 0 ? q / n - mean * mean : 0.0;
@@ -116,6 +94,7 @@ __global__ void cn_bn_finalize_kernel(const double* __restrict__ parts_sum, cons
       running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
     }
   } else {
+    if (threadIdx.x >= 64 || c >= C) return;
     mean_rstd[c] = running_mean[c];
     mean_rstd[C + c] = (float)(1.0 / sqrt((double)running_var[c] + (double)eps));
   }
@@ -424,24 +403,14 @@ extern "C" int cartnet_node_embed(const int64_t* z, const int64_t* batch, const 
 
 extern "C" int cartnet_node_nparts(int32_t N) { return node_parts(N); }
 
-extern "C" int cartnet_node_embed_bwd(const int64_t* z, const int64_t* batch, const float* temperature,
-                                      const float* dx0, int32_t N, int32_t C, int32_t n_types, float* demb,
-                                      double* parts_w, double* parts_b, void* stream) {
+extern "C" int cartnet_node_embed_bwd(const int64_t* batch, const float* temperature, const float* dx0, int32_t N,
+                                      int32_t C, double* parts_w, double* parts_b, void* stream) {
   CN_CHECK(N >= 0 && C >= 4 && C % 4 == 0, "cartnet_node_embed_bwd: C=%d must be a multiple of 4", C);
-  CN_CHECK(dx0 || N == 0, "cartnet_node_embed_bwd: null dx0");
-  if (demb) {
-    CN_CHECK(z && n_types >= 1, "cartnet_node_embed_bwd: embedding gradient needs z");
-    hipLaunchKernelGGL(cn_embed_bwd_types_kernel, dim3(n_types, cn_ceil_div(C, 256)), dim3(64), 0, ST(stream), z, dx0,
-                       N, C, demb);
-    CN_LAUNCH_CHECK("cartnet_node_embed_bwd/types");
-  }
-  if (parts_b) {
-    CN_CHECK(parts_w, "cartnet_node_embed_bwd: parts_w and parts_b must pair");
-    CN_CHECK(!temperature || batch, "cartnet_node_embed_bwd: temperature needs batch");
-    hipLaunchKernelGGL(cn_embed_bwd_cols_kernel, dim3(node_parts(N)), dim3(256), 0, ST(stream), batch, temperature,
-                       dx0, N, C, parts_w, parts_b);
-    CN_LAUNCH_CHECK("cartnet_node_embed_bwd/cols");
-  }
+  CN_CHECK((dx0 || N == 0) && parts_w && parts_b, "cartnet_node_embed_bwd: null pointer");
+  CN_CHECK(!temperature || batch, "cartnet_node_embed_bwd: temperature needs batch");
+  hipLaunchKernelGGL(cn_embed_bwd_cols_kernel, dim3(node_parts(N)), dim3(256), 0, ST(stream), batch, temperature, dx0,
+                     N, C, parts_w, parts_b);
+  CN_LAUNCH_CHECK("cartnet_node_embed_bwd");
   return 0;
 }
 
@@ -452,7 +421,7 @@ extern "C" int cartnet_bn_finalize(const double* parts_sum, const double* parts_
   if (training) CN_CHECK(parts_sum && parts_sq && nparts >= 0 && count >= 0, "cartnet_bn_finalize: missing partial sums");
   else CN_CHECK(running_mean && running_var, "cartnet_bn_finalize: eval mode needs running statistics");
   CN_CHECK((running_mean == nullptr) == (running_var == nullptr), "cartnet_bn_finalize: running stats must pair");
-  hipLaunchKernelGGL(cn_bn_finalize_kernel, dim3(cn_ceil_div(C, 64)), dim3(64), 0, ST(stream), parts_sum, parts_sq,
+  hipLaunchKernelGGL(cn_bn_finalize_kernel, dim3(cn_ceil_div(C, 64)), dim3(1024), 0, ST(stream), parts_sum, parts_sq,
                      nparts, (long long)count, C, eps, momentum, training, running_mean, running_var,
                      num_batches_tracked, mean_rstd);
   CN_LAUNCH_CHECK("cartnet_bn_finalize");

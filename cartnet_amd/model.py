@@ -201,7 +201,9 @@ class _CartNetFunction(torch.autograd.Function):
             x = _empty((N, D), dev)
             ops.gemm(x0, P["encoder.encoder_atom.1.weight"], x, a_act=True, out_act=True,
                      bias=P["encoder.encoder_atom.1.bias"], cpre=xa_pre)
-            st.x0, st.xa_pre, st.z, st.gid, st.T = x0, xa_pre, z, gid, T
+            st.x0, st.xa_pre, st.gid, st.T = x0, xa_pre, gid, T
+            if need_grad and enc.atom_types:   # atoms grouped by element (stable) for the embedding gradient
+                st.zperm, st.zptr, _ = ops.sort_by_key(z, N_ATOM_TYPES)
         else:  # cartnet.py:150-151: one learned row for every atom
             x = P["encoder.embedding.weight"].detach().repeat(N, 1).contiguous()
 
@@ -397,11 +399,11 @@ class _CartNetFunction(torch.autograd.Function):
             _wgrad([dx], [st.x0], [G["encoder.encoder_atom.1.weight"]], b_act=True)
             dx0 = _empty((N, 2 * D), dev)
             ops.gemm(dx, P["encoder.encoder_atom.1.weight"], dx0, b_kstrided=True, dact=st.x0)
-            demb = _empty((N_ATOM_TYPES, 2 * D), dev) if enc.atom_types else None
             pw, pb = _parts(nparts_n * 2 * D, dev), _parts(nparts_n * 2 * D, dev)
-            ops.node_embed_bwd(st.z if enc.atom_types else None, st.gid if enc.temperature else None, st.T, dx0,
-                               N_ATOM_TYPES, demb, pw, pb)
+            ops.node_embed_bwd(st.gid if enc.temperature else None, st.T, dx0, pw, pb)
             if enc.atom_types:
+                demb = _empty((N_ATOM_TYPES, 2 * D), dev)
+                ops.segment_sum_long(dx0, st.zptr, st.zperm, N, demb)
                 G["encoder.embedding.weight"] = demb
             if enc.temperature:
                 G["encoder.temperature_proj_atom.weight"] = _finalize(pw, nparts_n, 2 * D).view(2 * D, 1)

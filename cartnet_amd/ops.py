@@ -17,6 +17,28 @@ from . import lib as _l
 Tensor = torch.Tensor
 
 
+class KernelTimer:
+    """HIP-event timing of GEMM launches on torch's current stream (the stream the kernels are enqueued on).
+    bench.py uses it to price the dominant kernel inside the timed region: events are recorded around every
+    cartnet_gemm launch while ``active``; ``summary()`` (after a device sync) returns per-variant totals."""
+
+    def __init__(self):
+        self.records = []
+        self.active = False
+
+    def summary(self):
+        out = {}
+        for key, flops, e0, e1 in self.records:
+            d = out.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+TIMER = KernelTimer()
+
+
 def _f32_2d(t: Tensor, name: str) -> None:
     if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2):
         raise ValueError(f"{name}: expected a 2-D fp32 CUDA tensor, got {type(t).__name__} "
@@ -151,6 +173,14 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
                 continue
             _vec(t, tiles_m * N, f"gemm {name}[{g}]", torch.float64)
             getattr(args, field)[g] = t.data_ptr()
+    if TIMER.active:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _l.check(lib.cartnet_gemm(C.byref(args), _l.stream_ptr()), "cartnet_gemm")
+        e1.record()
+        key = ("tn" if a_kstrided else ("nn" if b_kstrided else "nt")) + ("256" if N > 128 else "128" if N > 64 else "64")
+        TIMER.records.append((key, 2.0 * M * N * K * nptr, e0, e1))
+        return
     _l.check(lib.cartnet_gemm(C.byref(args), _l.stream_ptr()), "cartnet_gemm")
 
 
@@ -276,22 +306,50 @@ def gate_nparts(N: int) -> int:
     return int(_l.load().cartnet_gate_scatter_nparts(int(N)))
 
 
-def node_embed_bwd(z, batch, temperature, dx0: Tensor, n_types: int, demb, parts_w, parts_b) -> None:
+def node_embed_bwd(batch, temperature, dx0: Tensor, parts_w, parts_b) -> None:
     _f32_2d(dx0, "node_embed_bwd dx0")
     N, Cc = dx0.shape
     if not dx0.is_contiguous():
         raise ValueError("node_embed_bwd: dx0 must be contiguous")
-    if demb is not None:
-        _vec(z, N, "node_embed_bwd z", torch.int64)
-        _vec(demb, n_types * Cc, "node_embed_bwd demb")
     npart = node_nparts(N)
     _vec(parts_w, npart * Cc, "node_embed_bwd parts_w", torch.float64)
     _vec(parts_b, npart * Cc, "node_embed_bwd parts_b", torch.float64)
     if batch is not None:
         _vec(batch, N, "node_embed_bwd batch", torch.int64)
-    _l.check(_l.load().cartnet_node_embed_bwd(_l.ptr(z), _l.ptr(batch), _l.ptr(temperature), dx0.data_ptr(), N, Cc,
-                                              int(n_types), _l.ptr(demb), _l.ptr(parts_w), _l.ptr(parts_b),
-                                              _l.stream_ptr()), "cartnet_node_embed_bwd")
+    if temperature is not None and batch is None:
+        raise ValueError("node_embed_bwd: temperature needs batch")
+    _l.check(_l.load().cartnet_node_embed_bwd(_l.ptr(batch), _l.ptr(temperature), dx0.data_ptr(), N, Cc,
+                                              parts_w.data_ptr(), parts_b.data_ptr(), _l.stream_ptr()),
+             "cartnet_node_embed_bwd")
+
+
+def sort_by_key(keys: Tensor, nkeys: int):
+    """Stable counting sort on the device: returns (perm int32 [N], ptr int32 [nkeys+1], status int32 [1])."""
+    N = int(keys.numel())
+    _vec(keys, N, "sort_by_key keys", torch.int64)
+    dev = keys.device
+    perm = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    ptr_ = torch.empty(nkeys + 1, dtype=torch.int32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    _l.check(_l.load().cartnet_sort_by_key(keys.data_ptr(), N, int(nkeys), perm.data_ptr(), ptr_.data_ptr(),
+                                           status.data_ptr(), _l.stream_ptr()), "cartnet_sort_by_key")
+    return perm, ptr_, status
+
+
+def segment_sum_long(rows: Tensor, ptr_: Tensor, perm: Optional[Tensor], total: int, out: Tensor) -> None:
+    """out[s] = sum of rows[perm[p]] for p in [ptr[s], ptr[s+1]) -- for few, uneven segments."""
+    _f32_2d(rows, "segment_sum_long rows")
+    _f32_2d(out, "segment_sum_long out")
+    nseg, W = out.shape
+    if rows.shape[1] != W or rows.shape[0] < total:
+        raise ValueError("segment_sum_long: shape mismatch")
+    _vec(ptr_, nseg + 1, "segment_sum_long ptr", torch.int32)
+    if perm is not None:
+        _vec(perm, total, "segment_sum_long perm", torch.int32)
+    tmp = torch.empty((max(total, 1), W), dtype=torch.float32, device=rows.device)
+    _l.check(_l.load().cartnet_segment_sum_long(rows.data_ptr(), _ld(rows), ptr_.data_ptr(), _l.ptr(perm), nseg,
+                                                int(total), W, tmp.data_ptr(), out.data_ptr(), _ld(out),
+                                                _l.stream_ptr()), "cartnet_segment_sum_long")
 
 
 def bn_finalize(parts_sum, parts_sq, nparts: int, count: int, Cc: int, eps: float, momentum: float, training: bool,

@@ -1,0 +1,93 @@
+"""Flat-buffer Adam for CartNet: all parameters (2.5 M fp32 at D=256, L=4) live in ONE contiguous device buffer, all
+gradients in another, so the optimiser is a single fused kernel launch (cartnet_adam_step) and the data-parallel
+gradient exchange is a single RCCL all-reduce of 10 MB.
+
+Update rule = torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0) as the reference constructs it
+(reference: main.py:208); ``set_lr`` lets a scheduler (OneCycleLR in the reference, train/train.py:59) drive it.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+class FlatAdam:
+    def __init__(self, model: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        params = [p for p in model.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("model has no trainable parameters")
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdam needs the model on the GPU (there is no CPU path)")
+        n = sum(p.numel() for p in params)
+        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.flat_param[off:off + k].copy_(p.data.reshape(-1))
+                p.data = self.flat_param[off:off + k].view(p.shape)      # parameters become views of the flat buffer
+                p.grad = self.flat_grad[off:off + k].view(p.shape)       # autograd accumulates in place into the views
+                off += k
+        self.params = params
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.step_count = 0
+        self.param_groups = [{"lr": self.lr}]     # enough of torch's surface for a scheduler / logger to read lr
+
+    def set_lr(self, lr: float) -> None:
+        self.lr = float(lr)
+        self.param_groups[0]["lr"] = self.lr
+
+    def zero_grad(self) -> None:
+        self.flat_grad.zero_()
+        for p in self.params:                      # re-attach views if a caller reset them to None
+            if p.grad is None or p.grad.data_ptr() < self.flat_grad.data_ptr():
+                self._reattach()
+                break
+
+    def _reattach(self) -> None:
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            p.grad = self.flat_grad[off:off + k].view(p.shape)
+            off += k
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        """One Adam update.  ``grad_scale`` multiplies the gradient first (1/world_size after an all-reduce SUM)."""
+        self.step_count += 1
+        ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
+                      self.betas[1], self.eps, self.step_count, grad_scale)
+
+    def state_dict(self):
+        return {"step": self.step_count, "lr": self.lr, "exp_avg": self.exp_avg.clone(),
+                "exp_avg_sq": self.exp_avg_sq.clone()}
+
+    def load_state_dict(self, sd) -> None:
+        self.step_count = int(sd["step"])
+        self.set_lr(sd["lr"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+def one_cycle_lr(step: int, total_steps: int, max_lr: float, pct_start: float = 0.3, div_factor: float = 25.0,
+                 final_div_factor: float = 1e4) -> float:
+    """torch.optim.lr_scheduler.OneCycleLR (cosine annealing, two phases) as the reference configures it
+    (train/train.py:59: max_lr=cfg.lr, pct_start=cfg.warmup): learning rate AFTER ``step`` scheduler steps."""
+    import math
+    initial_lr = max_lr / div_factor
+    min_lr = initial_lr / final_div_factor
+    end1 = float(pct_start * total_steps) - 1.0
+    end2 = float(total_steps) - 1.0
+
+    def cos(a, b, pct):
+        return b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+
+    if step <= end1:
+        return cos(initial_lr, max_lr, step / end1 if end1 > 0 else 1.0)
+    return cos(max_lr, min_lr, (step - end1) / (end2 - end1) if end2 > end1 else 1.0)

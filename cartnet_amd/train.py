@@ -1,0 +1,70 @@
+"""Training / evaluation loops with the reference's semantics (reference: train/train.py:148-243,
+train/metrics.py:15-28): MAE or MSE loss, unscaled gradient accumulation over ``batch_accumulation`` micro-batches
+with a flush on the last iteration, optimiser + scheduler step at the boundary.  Logging / wandb are out of scope;
+the loops return plain numbers (graphs/s is what this build reports)."""
+from __future__ import annotations
+
+import time
+from typing import Callable, Optional
+
+import torch
+
+from .config import cfg
+from . import distributed as cdist
+
+
+def compute_loss(pred: torch.Tensor, true: torch.Tensor):
+    """(MAE, MSE) with mean reduction over all elements (train/metrics.py:26-27)."""
+    diff = pred - true
+    return diff.abs().mean(), (diff * diff).mean()
+
+
+def _pick_loss(mae, mse):
+    if cfg.loss == "MAE":
+        return mae
+    if cfg.loss == "MSE":
+        return mse
+    raise Exception("Loss not implemented")
+
+
+def train_epoch(loader, model, optimizer, batch_accumulation: int, scheduler: Optional[Callable[[], None]] = None,
+                device="cuda:0"):
+    """One pass over ``loader`` (train/train.py:148-199).  Returns dict(loss, mae, graphs, seconds)."""
+    model.train()
+    optimizer.zero_grad()
+    n_iter = len(loader)
+    tot_mae = torch.zeros((), device=device)
+    graphs = 0
+    t0 = time.perf_counter()
+    for it, batch in enumerate(loader):
+        batch.to(device)
+        pred, true = model(batch)
+        mae, mse = compute_loss(pred, true)
+        loss = _pick_loss(mae, mse)
+        loss.mean().backward()                      # not divided by the accumulation count (train/train.py:183)
+        if ((it + 1) % batch_accumulation == 0) or (it + 1 == n_iter):
+            scale = cdist.all_reduce_gradients(optimizer.flat_grad) if hasattr(optimizer, "flat_grad") else 1.0
+            optimizer.step(scale) if hasattr(optimizer, "flat_grad") else optimizer.step()
+            if scheduler is not None:
+                scheduler()
+            optimizer.zero_grad()
+        tot_mae += mae.detach()
+        graphs += int(batch.num_graphs)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"mae": float(tot_mae.item()) / max(n_iter, 1), "graphs": graphs, "seconds": dt}
+
+
+def eval_epoch(loader, model, device="cuda:0"):
+    """train/train.py:202-243: eval mode, no grad."""
+    model.eval()
+    tot_mae = torch.zeros((), device=device)
+    n = 0
+    with torch.no_grad():
+        for batch in loader:
+            batch.to(device)
+            pred, true = model(batch)
+            mae, _ = compute_loss(pred, true)
+            tot_mae += mae
+            n += 1
+    return {"mae": float(tot_mae.item()) / max(n, 1)}

@@ -116,14 +116,19 @@ int cartnet_edge_features(const float* cart_dist, const float* cart_dir, const f
 int cartnet_node_embed(const int64_t* z, const int64_t* batch, const float* temperature, const float* emb,
                        const float* wt, const float* bt, const float* bias, int32_t N, int32_t C, float* x0,
                        void* stream);
-/* Backward of the above: demb[a, c] = sum_{n: z[n]=a} dx0[n,c] for a < n_types (fixed node order, no atomics);
- * parts_w[p][c] / parts_b[p][c]: per-block partial sums over atoms of T[batch[n]]*dx0[n,c] and dx0[n,c]
- * (p < cartnet_node_nparts(N)); reduce with cartnet_colsum_finalize into the gradients of
- * temperature_proj_atom.weight and .bias (or encoder.bias).  demb, or the parts pair, may be NULL. */
+/* Backward of the above, temperature projection / bias part: parts_w[p][c] / parts_b[p][c] = per-block partial sums
+ * over atoms of T[batch[n]]*dx0[n,c] and dx0[n,c] (p < cartnet_node_nparts(N)); reduce with cartnet_colsum_finalize
+ * into the gradients of temperature_proj_atom.weight and .bias (or encoder.bias).
+ * The embedding-table gradient demb[a] = sum_{n: z[n]=a} dx0[n] is cartnet_sort_by_key(z) once per batch +
+ * cartnet_segment_sum_long (fixed order, no atomics). */
 int cartnet_node_nparts(int32_t N);
-int cartnet_node_embed_bwd(const int64_t* z, const int64_t* batch, const float* temperature, const float* dx0,
-                           int32_t N, int32_t C, int32_t n_types, float* demb, double* parts_w, double* parts_b,
-                           void* stream);
+int cartnet_node_embed_bwd(const int64_t* batch, const float* temperature, const float* dx0, int32_t N, int32_t C,
+                           double* parts_w, double* parts_b, void* stream);
+
+/* Stable counting sort of N items by key in [0, nkeys), nkeys <= 1024: items with key k are
+ * perm[ptr[k] .. ptr[k+1]) in ascending item order.  status[0] |= 16 if a key is out of range. */
+int cartnet_sort_by_key(const int64_t* keys, int32_t N, int32_t nkeys, int32_t* perm, int32_t* ptr, int32_t* status,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * BatchNorm statistics (nn.BatchNorm1d at models/cartnet.py:198-199, used at :238 over E rows and :269 over
@@ -169,6 +174,11 @@ int cartnet_gate_scatter_bwd_apply(float* gs, const float* de_out, const float* 
  * Backward of the two index_selects PyG performs per layer (x_i by target: perm = NULL; x_j by source: CSC). */
 int cartnet_segment_sum(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t N,
                         int32_t W, float* out, int32_t ldo, void* stream);
+/* Same sums for FEW, very uneven segments (atoms grouped by element): sorted positions [0,total) are cut into
+ * 128-row chunks summed by independent wavefronts into tmp [total, W] (one partial row per run), then each segment
+ * adds its partial rows in position order -- evenly loaded and still bitwise reproducible. */
+int cartnet_segment_sum_long(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t nseg,
+                             int32_t total, int32_t W, float* tmp, float* out, int32_t ldo, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Node update (models/cartnet.py:269 norm2, :223 SiLU + residual):  x_out = silu(bn(aggr)) + x_in.

@@ -361,10 +361,12 @@ def test_bn_finalize_and_node_update(ops):
     assert rel_err(mean_rstd[D:], torch.rsqrt(rv.double() + 1e-5)) < 1e-6
 
 
-def test_node_embed_fwd_bwd(ops):
-    N, Cc, Bg = 500, 128, 6
+@pytest.mark.parametrize("N", [500, 5, 3000])
+def test_node_embed_fwd_bwd(ops, N):
+    Cc, Bg = 128, 6
     g = torch.Generator().manual_seed(0)
-    z = torch.randint(1, 119, (N,), generator=g)
+    z = torch.where(torch.rand(N, generator=g) < 0.8, torch.randint(1, 4, (N,), generator=g),
+                    torch.randint(1, 119, (N,), generator=g))      # a few very common elements, like H/C/N/O
     batch = torch.sort(torch.randint(0, Bg, (N,), generator=g)).values
     T = torch.randn(Bg, generator=g)
     emb, wt, bt = rnd(119, Cc, seed=1), rnd(Cc, 1, seed=2), rnd(Cc, seed=3)
@@ -378,7 +380,12 @@ def test_node_embed_fwd_bwd(ops):
     demb = torch.empty(119, Cc, device=dev())
     nparts = ops.node_nparts(N)
     pw, pb = (torch.zeros(nparts * Cc, device=dev(), dtype=torch.float64) for _ in range(2))
-    ops.node_embed_bwd(z.to(dev()), batch.to(dev()), T.to(dev()), dx0, 119, demb, pw, pb)
+    ops.node_embed_bwd(batch.to(dev()), T.to(dev()), dx0, pw, pb)
+    perm, zptr, status = ops.sort_by_key(z.to(dev()), 119)
+    assert int(status.item()) == 0
+    assert torch.equal(perm[:N].cpu().long(), torch.argsort(z, stable=True))
+    assert torch.equal(zptr.cpu().long()[1:], torch.cumsum(torch.bincount(z, minlength=119), 0))
+    ops.segment_sum_long(dx0, zptr, perm, N, demb)
     dwt, dbt = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
     ops.colsum_finalize(pw, nparts, dwt)
     ops.colsum_finalize(pb, nparts, dbt)
