@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcartnet_hip.so")
-SOURCES = ["abi.hip", "gemm.hip", "graph_ops.hip", "edge_ops.hip", "node_ops.hip", "optim.hip"]
+SOURCES = ["abi.hip", "gemm.hip", "gemm_bn256.hip", "gemm_bn128.hip", "gemm_bn64.hip", "graph_ops.hip", "edge_ops.hip", "node_ops.hip", "optim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(cc, srcs))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     if verbose:

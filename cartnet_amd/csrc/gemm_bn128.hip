@@ -1,0 +1,6 @@
+// Instantiations of the fp32 MFMA GEMM for 128-column output tiles (split per tile width to compile in parallel).
+#include "gemm_kernel.h"
+
+namespace cn_gemm {
+template bool launch_bn<128>(const CartnetGemmArgs&, const GemmFlags&, hipStream_t);
+}

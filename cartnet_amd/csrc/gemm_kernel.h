@@ -1,0 +1,393 @@
+// fp32 MFMA GEMM for the dense per-edge / per-node Linears of CartNet and their gradients (gfx950).
+//
+// Workgroup: 512 threads = 8 wavefronts (2 per SIMD) computing a 128 x BN output tile (BN = 256 / 128 / 64) with
+// v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain, 16 accumulator VGPRs per 32x32 tile).  Waves form a 2x4 grid
+// (4x2 for BN = 64); each owns (128/WGM) x (BN/WGN) outputs = at most 2x2 MFMA tiles = 64 accumulator VGPRs, so the
+// kernel stays under 128 VGPRs and two workgroups (4 waves per SIMD) share a CU: while some waves stage operands or
+// run their epilogue the others keep the matrix pipe busy.
+//
+// K loop: K-step 16, operands staged global -> registers -> LDS (SiLU can be applied in flight), LDS double
+// buffered so there is ONE barrier per K-step: iteration t writes tile t+1 (loaded during t-1) into the other
+// buffer, issues the global loads of tile t+2, then runs the MFMAs of tile t.
+// A k-contiguous operand is read from LDS with one ds_read_b128 per four MFMAs: inside an 8-deep k group lane half
+// h takes k = 4h..4h+3 (both operands use the same permutation; it only reorders an fp32 sum).
+// Full tiles take a predicate-free load path; edge tiles / odd K / unaligned operands a checked one.
+#pragma once
+#include "common.h"
+
+namespace cn_gemm {
+
+constexpr int BM = 128;
+constexpr int BK = 16;
+constexpr int KPAD = BK + 4;  // LDS row stride (floats) of a k-contiguous tile: 5 x 16 B slots -> conflict-free b128
+constexpr int NTHREADS = 512;
+
+struct GemmFlags {
+  int vecA, vecB, kchunk;
+  int tile_m0;   // first row tile this launch covers (full tiles and the ragged last row tile are separate launches)
+};
+
+// SiLU inside the GEMM uses the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each); forward and backward use the
+// same functions, so the recomputed activation in the weight-gradient GEMM equals the forward one bit for bit.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_silu(float x) { return x * fast_sigmoid(x); }
+__device__ __forceinline__ float fast_dsilu(float x) {
+  const float s = fast_sigmoid(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+// One operand tile (ROWS x BK) per K-step: global -> registers -> LDS.
+template <int ROWS, bool KS, bool ACT>
+struct Stager {
+  static constexpr int UNITS = ROWS * BK / 4;                       // float4 units per K-step
+  static constexpr int NU = (UNITS + NTHREADS - 1) / NTHREADS;      // per thread
+  static constexpr bool PARTIAL = (UNITS % NTHREADS) != 0;
+  static constexpr int LDS_FLOATS = KS ? BK * ROWS : ROWS * KPAD;
+  f32x4 reg[NU];
+
+  template <bool FAST>
+  __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int rows_limit, int k0,
+                                       int kend, bool vec, int tid) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int unit = tid + u * NTHREADS;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (!PARTIAL || unit < UNITS) {
+        if (!KS) {
+          const int row = unit >> 2, kq = unit & 3;
+          const int grow = row0 + row, gk = k0 + kq * 4;
+          const float* ptr = base + (size_t)grow * ld + gk;
+          if (FAST) {
+            v = *reinterpret_cast<const f32x4*>(ptr);
+          } else if (grow < rows_limit && gk < kend) {
+            if (vec && gk + 3 < kend) {
+              v = *reinterpret_cast<const f32x4*>(ptr);
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (gk + c < kend) v[c] = ptr[c];
+            }
+          }
+        } else {
+          const int k = unit / (ROWS / 4), r4 = unit % (ROWS / 4);
+          const int gk = k0 + k, grow = row0 + r4 * 4;
+          const float* ptr = base + (size_t)gk * ld + grow;
+          if (FAST) {
+            v = *reinterpret_cast<const f32x4*>(ptr);
+          } else if (gk < kend && grow < rows_limit) {
+            if (vec && grow + 3 < rows_limit) {
+              v = *reinterpret_cast<const f32x4*>(ptr);
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (grow + c < rows_limit) v[c] = ptr[c];
+            }
+          }
+        }
+      }
+      reg[u] = v;
+    }
+  }
+
+  __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int unit = tid + u * NTHREADS;
+      if (PARTIAL && unit >= UNITS) continue;
+      f32x4 v = reg[u];
+      if (ACT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fast_silu(v[c]);
+      }
+      if (!KS) {
+        const int row = unit >> 2, kq = unit & 3;
+        *reinterpret_cast<f32x4*>(lds + row * KPAD + kq * 4) = v;
+      } else {
+        const int k = unit / (ROWS / 4), r4 = unit % (ROWS / 4);
+        *reinterpret_cast<f32x4*>(lds + k * ROWS + r4 * 4) = v;
+      }
+    }
+  }
+};
+
+template <int BN>
+struct Shape {
+  static constexpr int WGM = (BN >= 128) ? 2 : 4;   // wave grid
+  static constexpr int WGN = (BN >= 128) ? 4 : 2;
+  static constexpr int WM = BM / WGM;               // rows per wave
+  static constexpr int WN = BN / WGN;               // columns per wave
+  static constexpr int TM = WM / 32;
+  static constexpr int TN = WN / 32;
+};
+
+// Epilogue flags: bit 0 gather, 1 resid, 2 dact, 3 column sums (fp32 per lane), 4 column sums + squares (fp64),
+// 5 cpre, 6 out_act.  KIND >= 0: compile-time flags (branch-free per-element code); KIND < 0: read at run time.
+template <int BN, int KIND>
+__device__ __forceinline__ void epilogue(const CartnetGemmArgs& p, f32x16 (&acc)[Shape<BN>::TM][Shape<BN>::TN], int g,
+                                         int row0, int col0, int tile_m, int wm, int wn, int li, int lh, int tid,
+                                         double* red, int rt_kind) {
+  using S = Shape<BN>;
+  const int kind = (KIND >= 0) ? KIND : rt_kind;
+  const bool GATHER = kind & 1, RESID = kind & 2, DACT = kind & 4, SUM1 = kind & 8, SUM2 = kind & 16,
+             CPRE = kind & 32, OUTACT = kind & 64;
+  float* C = p.C[g];                       // may alias resid / dact (in-place use): no __restrict__
+  const float* __restrict__ bias = p.bias[g];
+  const float* __restrict__ gi = p.gather_i[g];
+  const float* __restrict__ gj = p.gather_j[g];
+  const float* resid = p.resid[g];
+  const float* dact = p.dact[g];
+  float* cpre = p.cpre[g];
+
+  float biasv[S::TN];
+  double cs[S::TN], cq[S::TN];
+  float csf[S::TN];
+#pragma unroll
+  for (int b = 0; b < S::TN; ++b) {
+    const int gcol = col0 + wn * S::WN + b * 32 + li;
+    biasv[b] = (bias && gcol < p.N) ? bias[gcol] : 0.f;
+    cs[b] = 0.0;
+    cq[b] = 0.0;
+    csf[b] = 0.f;
+  }
+#pragma unroll
+  for (int a = 0; a < S::TM; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int grow = row0 + wm * S::WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (grow >= p.M) continue;
+      int ti = 0, sj = 0;
+      if (GATHER) {
+        ti = p.tgt[grow];
+        sj = p.src[grow];
+      }
+#pragma unroll
+      for (int b = 0; b < S::TN; ++b) {
+        const int gcol = col0 + wn * S::WN + b * 32 + li;
+        if (gcol >= p.N) continue;
+        float v = acc[a][b][r] + biasv[b];
+        if (GATHER) v += gi[(size_t)ti * p.ldg + gcol] + gj[(size_t)sj * p.ldg + gcol];
+        if (RESID) v += resid[(size_t)grow * p.ldr + gcol];
+        if (DACT) v *= fast_dsilu(dact[(size_t)grow * p.ldd + gcol]);
+        if (SUM1) csf[b] += v;
+        if (SUM2) {
+          cs[b] += (double)v;
+          cq[b] += (double)v * (double)v;
+        }
+        if (CPRE) cpre[(size_t)grow * p.ldc + gcol] = v;
+        if (OUTACT) v = fast_silu(v);
+        C[(size_t)grow * p.ldc + gcol] = v;
+      }
+    }
+  if (SUM1 || SUM2) {
+    // rows of this block -> one fp64 partial per column: lane halves, then the WGM waves stacked in M.
+    double* __restrict__ colsum = p.colsum[g];
+    double* __restrict__ colsq = p.colsq[g];
+    __syncthreads();   // the LDS staging buffers are dead after the K loop's last barrier: reuse as red[2][WGM][BN]
+#pragma unroll
+    for (int b = 0; b < S::TN; ++b) {
+      double s = SUM2 ? cs[b] : (double)csf[b];
+      double q = cq[b];
+      s += __shfl_xor(s, 32);
+      q += __shfl_xor(q, 32);
+      if (lh == 0) {
+        red[(0 * S::WGM + wm) * BN + wn * S::WN + b * 32 + li] = s;
+        red[(1 * S::WGM + wm) * BN + wn * S::WN + b * 32 + li] = q;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += NTHREADS) {
+      const int gcol = col0 + c;
+      if (gcol < p.N) {
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int w = 0; w < S::WGM; ++w) {
+          s += red[(0 * S::WGM + w) * BN + c];
+          q += red[(1 * S::WGM + w) * BN + c];
+        }
+        colsum[(size_t)tile_m * p.N + gcol] = s;
+        if (SUM2) colsq[(size_t)tile_m * p.N + gcol] = q;
+      }
+    }
+  }
+}
+
+// FAST: every tile of the launch is full, K is a whole number of K-steps and rows are 16-byte aligned -> the operand
+// loads carry no predicates.  The checked variant is a separate kernel so its register needs do not leak into this one.
+template <bool A_KS, bool B_KS, int BN, bool A_ACT, bool B_ACT, bool FAST>
+__global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_kernel(const CartnetGemmArgs p, const GemmFlags fl) {
+  using S = Shape<BN>;
+  using StA = Stager<BM, A_KS, A_ACT>;
+  using StB = Stager<BN, B_KS, B_ACT>;
+  constexpr int BUF = StA::LDS_FLOATS + StB::LDS_FLOATS;
+  static_assert(2 * BUF * sizeof(float) >= 2 * S::WGM * BN * sizeof(double), "statistics scratch must fit in LDS");
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / S::WGN, wn = wid % S::WGN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile_m = fl.tile_m0 + blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int row0 = tile_m * BM, col0 = tile_n * BN;
+  const int g = blockIdx.z;
+  const int split = blockIdx.y;
+
+  f32x16 acc[S::TM][S::TN];
+#pragma unroll
+  for (int a = 0; a < S::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < S::TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int kbeg = split * fl.kchunk;
+  const int kend = min(p.K, kbeg + fl.kchunk);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  StA stA;
+  StB stB;
+
+  auto compute = [&](const float* __restrict__ sA, const float* __restrict__ sB) {
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      float af[S::TM][4], bf[S::TN][4];
+#pragma unroll
+      for (int a = 0; a < S::TM; ++a) {
+        if (!A_KS) {
+          const f32x4 v =
+              *reinterpret_cast<const f32x4*>(&sA[(wm * S::WM + a * 32 + li) * KPAD + kg * 8 + lh * 4]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) af[a][j] = v[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) af[a][j] = sA[(kg * 8 + lh * 4 + j) * BM + wm * S::WM + a * 32 + li];
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < S::TN; ++b) {
+        if (!B_KS) {
+          const f32x4 v =
+              *reinterpret_cast<const f32x4*>(&sB[(wn * S::WN + b * 32 + li) * KPAD + kg * 8 + lh * 4]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[b][j] = v[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[b][j] = sB[(kg * 8 + lh * 4 + j) * BN + wn * S::WN + b * 32 + li];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < S::TM; ++a)
+#pragma unroll
+          for (int b = 0; b < S::TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  auto kloop = [&](const float* __restrict__ Ab, const float* __restrict__ Bb) {
+    const bool va = fl.vecA != 0, vb = fl.vecB != 0;
+    stA.template load<FAST>(Ab, p.lda, row0, p.M, kbeg, kend, va, tid);
+    stB.template load<FAST>(Bb, p.ldb, col0, p.N, kbeg, kend, vb, tid);
+    stA.store(smem, tid);
+    stB.store(smem + StA::LDS_FLOATS, tid);
+    if (nk > 1) {
+      stA.template load<FAST>(Ab, p.lda, row0, p.M, kbeg + BK, kend, va, tid);
+      stB.template load<FAST>(Bb, p.ldb, col0, p.N, kbeg + BK, kend, vb, tid);
+    }
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+      float* cur = smem + (t & 1) * BUF;
+      float* nxt = smem + ((t & 1) ^ 1) * BUF;
+      if (t + 1 < nk) {               // tile t+1 (loaded during iteration t-1) -> the other LDS buffer
+        stA.store(nxt, tid);
+        stB.store(nxt + StA::LDS_FLOATS, tid);
+      }
+      if (t + 2 < nk) {               // tile t+2 -> registers, lands while tile t is multiplied
+        stA.template load<FAST>(Ab, p.lda, row0, p.M, kbeg + (t + 2) * BK, kend, va, tid);
+        stB.template load<FAST>(Bb, p.ldb, col0, p.N, kbeg + (t + 2) * BK, kend, vb, tid);
+      }
+      compute(cur, cur + StA::LDS_FLOATS);
+      __syncthreads();
+    }
+  };
+
+  if (nk > 0) {
+    for (int s = 0; s < p.nsegs; ++s) {
+      const int idx = (p.ngroups > 1) ? g : s;
+      kloop(p.A[idx], p.B[idx]);
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  if (p.splitk > 1) {
+    float* __restrict__ C = p.C[g] + (size_t)split * p.M * p.ldc;
+#pragma unroll
+    for (int a = 0; a < S::TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int grow = row0 + wm * S::WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (grow >= p.M) continue;
+#pragma unroll
+        for (int b = 0; b < S::TN; ++b) {
+          const int gcol = col0 + wn * S::WN + b * 32 + li;
+          if (gcol < p.N) C[(size_t)grow * p.ldc + gcol] = acc[a][b][r];
+        }
+      }
+    return;
+  }
+  double* red = reinterpret_cast<double*>(smem);
+  const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
+                   (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);
+#define CN_EPI(K) epilogue<BN, K>(p, acc, g, row0, col0, tile_m, wm, wn, li, lh, tid, red, kind)
+  switch (kind) {               // the combinations the CartNet path uses get branch-free code
+    case 0: CN_EPI(0); break;    // (+bias) store                          node projections, heads, 2nd-Linear sender
+    case 1: CN_EPI(1); break;    // gather node terms                      layer GEMM1
+    case 16: CN_EPI(16); break;  // BatchNorm statistics                   layer GEMM2 (gate)
+    case 96: CN_EPI(96); break;  // keep pre-activation, SiLU              encoders
+    case 2: CN_EPI(2); break;    // + resid                                dE, dX
+    case 4: CN_EPI(4); break;    // * silu'(pre)
+    case 12: CN_EPI(12); break;  // * silu'(pre), bias gradient            dpre
+    case 14: CN_EPI(14); break;  // + resid, * silu'(pre), bias gradient   layer 0 into the encoders
+    default: CN_EPI(-1); break;  // anything else: flags read at run time
+  }
+#undef CN_EPI
+}
+
+template <bool A_KS, bool B_KS, int BN, bool A_ACT, bool B_ACT>
+void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
+  const int tiles_n = cn_ceil_div(a.N, BN);
+  const int full_m = a.M / BM, rag_m = (a.M % BM) ? 1 : 0;
+  const bool fast_ok = fl.vecA && fl.vecB && (a.N % BN == 0) && (a.K % BK == 0) && (fl.kchunk % BK == 0);
+  if (fast_ok && full_m > 0) {
+    fl.tile_m0 = 0;
+    hipLaunchKernelGGL((cn_gemm_kernel<A_KS, B_KS, BN, A_ACT, B_ACT, true>), dim3(full_m * tiles_n, a.splitk, a.ngroups),
+                       dim3(NTHREADS), 0, st, a, fl);
+    if (rag_m) {
+      fl.tile_m0 = full_m;
+      hipLaunchKernelGGL((cn_gemm_kernel<A_KS, B_KS, BN, A_ACT, B_ACT, false>), dim3(tiles_n, a.splitk, a.ngroups),
+                         dim3(NTHREADS), 0, st, a, fl);
+    }
+  } else {
+    fl.tile_m0 = 0;
+    hipLaunchKernelGGL((cn_gemm_kernel<A_KS, B_KS, BN, A_ACT, B_ACT, false>),
+                       dim3((full_m + rag_m) * tiles_n, a.splitk, a.ngroups), dim3(NTHREADS), 0, st, a, fl);
+  }
+}
+
+// Operand layouts / fused activations the CartNet path uses.  Returns false for an unsupported combination.
+template <int BN>
+bool launch_bn(const CartnetGemmArgs& a, const GemmFlags& fl, hipStream_t st) {
+  const int combo = (a.a_kstrided ? 1 : 0) | (a.b_kstrided ? 2 : 0) | (a.a_act ? 4 : 0) | (a.b_act ? 8 : 0);
+  switch (combo) {
+    case 0: launch_variant<false, false, BN, false, false>(a, fl, st); return true;   // Y = X W^T
+    case 4: launch_variant<false, false, BN, true, false>(a, fl, st); return true;    // Y = silu(X) W^T
+    case 2: launch_variant<false, true, BN, false, false>(a, fl, st); return true;    // dX = dY W
+    case 3: launch_variant<true, true, BN, false, false>(a, fl, st); return true;     // dW = dY^T X
+    case 11: launch_variant<true, true, BN, false, true>(a, fl, st); return true;     // dW = dY^T silu(X)
+    default: return false;
+  }
+}
+
+}  // namespace cn_gemm
