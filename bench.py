@@ -134,6 +134,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(batches[args.warmup + i])
+    t_enq = time.perf_counter() - t0          # host time to enqueue all steps (GPU-bound when << dt)
     torch.cuda.synchronize()
     cdist.barrier()
     torch.cuda.synchronize()
@@ -153,6 +154,7 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: CartNet L=4 D=256 R=64 fp32 train step, {args.graphs} synthetic "
                                f"ADP crystals x {args.atoms} atoms per GPU per step (N={N} atoms, E={E} edges per GPU)",
                    "graphs_per_gpu_per_step": args.graphs, "parallelism": f"graph-sharded dp{world}"},
+        "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3),
         "path_tflops_executed": round(value * FLOPS_EXEC_PER_GRAPH * (E / args.graphs / 2800.0) / 1e12 / world, 2),
         "path_tflops_reference_equiv": round(value * FLOPS_REF_PER_GRAPH * (E / args.graphs / 2800.0) / 1e12 / world, 2),
     }

@@ -10,8 +10,14 @@ extern template bool launch_bn<64>(const CartnetGemmArgs&, const GemmFlags&, hip
 
 namespace {
 
-__global__ void cn_splitk_reduce_kernel(const float* __restrict__ slabs, int splitk, int M, int N,
-                                        float* __restrict__ out, int ldo) {
+struct ReduceJobs {
+  const float* slabs[CARTNET_MAX_GROUPS];
+  float* out[CARTNET_MAX_GROUPS];
+};
+
+__global__ void cn_splitk_reduce_kernel(const ReduceJobs jobs, int splitk, int M, int N, int ldo) {
+  const float* __restrict__ slabs = jobs.slabs[blockIdx.y];
+  float* __restrict__ out = jobs.out[blockIdx.y];
   const size_t total = (size_t)M * N;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     float acc = 0.f;
@@ -21,9 +27,15 @@ __global__ void cn_splitk_reduce_kernel(const float* __restrict__ slabs, int spl
   }
 }
 
-__global__ __launch_bounds__(1024) void cn_colsum_finalize_kernel(const double* __restrict__ parts, int nparts, int N,
-                                                                  float* __restrict__ out) {
+struct FinalizeJobs {
+  const double* parts[8];
+  float* out[8];
+};
+
+__global__ __launch_bounds__(1024) void cn_colsum_finalize_kernel(const FinalizeJobs jobs, int nparts, int N) {
   __shared__ double red[16 * 64];
+  const double* __restrict__ parts = jobs.parts[blockIdx.y];
+  float* __restrict__ out = jobs.out[blockIdx.y];
   const double tot = cn_block_colsum(parts, nparts, N, blockIdx.x * 64, red);
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (threadIdx.x < 64 && c < N) out[c] = (float)tot;
@@ -50,6 +62,7 @@ extern "C" int cartnet_gemm(const CartnetGemmArgs* args, void* stream) {
   CN_CHECK(a.nsegs >= 1 && a.nsegs <= CARTNET_MAX_GROUPS, "cartnet_gemm: nsegs=%d out of range", a.nsegs);
   CN_CHECK(!(a.ngroups > 1 && a.nsegs > 1), "cartnet_gemm: groups and K-segments are mutually exclusive");
   CN_CHECK(a.splitk >= 1, "cartnet_gemm: splitk=%d", a.splitk);
+  CN_CHECK(a.splitk == 1 || a.K >= 2 * cn_gemm::BK, "cartnet_gemm: split-K needs K >= %d", 2 * cn_gemm::BK);
   if (a.M == 0 || a.N == 0) return 0;
   const int nptr = a.ngroups > 1 ? a.ngroups : a.nsegs;
   bool vecA = (a.lda % 4 == 0), vecB = (a.ldb % 4 == 0);
@@ -76,6 +89,9 @@ extern "C" int cartnet_gemm(const CartnetGemmArgs* args, void* stream) {
   }
   cn_gemm::GemmFlags fl;
   fl.tile_m0 = 0;
+  fl.split0 = 0;
+  fl.k_lo = 0;
+  fl.k_hi = a.K;
   fl.vecA = vecA ? 1 : 0;
   fl.vecB = vecB ? 1 : 0;
   int kchunk = (a.K + a.splitk - 1) / a.splitk;
@@ -93,26 +109,40 @@ extern "C" int cartnet_gemm(const CartnetGemmArgs* args, void* stream) {
   return 0;
 }
 
-extern "C" int cartnet_splitk_reduce(const float* slabs, int32_t splitk, int32_t M, int32_t N, float* out,
-                                     int32_t ldo, void* stream) {
-  CN_CHECK(slabs && out, "cartnet_splitk_reduce: null pointer");
+extern "C" int cartnet_splitk_reduce(const float* const* slabs, float* const* outs, int32_t njobs, int32_t splitk,
+                                     int32_t M, int32_t N, int32_t ldo, void* stream) {
+  CN_CHECK(slabs && outs && njobs >= 1 && njobs <= CARTNET_MAX_GROUPS, "cartnet_splitk_reduce: njobs=%d out of range",
+           njobs);
   CN_CHECK(splitk >= 1 && M >= 0 && N >= 0 && ldo >= N, "cartnet_splitk_reduce: bad shape");
   if (M == 0 || N == 0) return 0;
+  ReduceJobs jobs;
+  for (int j = 0; j < CARTNET_MAX_GROUPS; ++j) {
+    jobs.slabs[j] = j < njobs ? slabs[j] : nullptr;
+    jobs.out[j] = j < njobs ? outs[j] : nullptr;
+    if (j < njobs) CN_CHECK(slabs[j] && outs[j], "cartnet_splitk_reduce: null pointer in job %d", j);
+  }
   const size_t total = (size_t)M * N;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(cn_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     slabs, splitk, M, N, out, ldo);
+  hipLaunchKernelGGL(cn_splitk_reduce_kernel, dim3(blocks, njobs), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     jobs, splitk, M, N, ldo);
   CN_LAUNCH_CHECK("cartnet_splitk_reduce");
   return 0;
 }
 
-extern "C" int cartnet_colsum_finalize(const double* parts, int32_t nparts, int32_t N, float* out, void* stream) {
-  CN_CHECK(parts && out, "cartnet_colsum_finalize: null pointer");
+extern "C" int cartnet_colsum_finalize(const double* const* parts, float* const* outs, int32_t njobs, int32_t nparts,
+                                       int32_t N, void* stream) {
+  CN_CHECK(parts && outs && njobs >= 1 && njobs <= 8, "cartnet_colsum_finalize: njobs=%d out of range (1..8)", njobs);
   CN_CHECK(nparts >= 0 && N >= 0, "cartnet_colsum_finalize: bad shape");
   if (N == 0) return 0;
-  hipLaunchKernelGGL(cn_colsum_finalize_kernel, dim3(cn_ceil_div(N, 64)), dim3(1024), 0,
-                     reinterpret_cast<hipStream_t>(stream), parts, nparts, N, out);
+  FinalizeJobs jobs;
+  for (int j = 0; j < 8; ++j) {
+    jobs.parts[j] = j < njobs ? parts[j] : nullptr;
+    jobs.out[j] = j < njobs ? outs[j] : nullptr;
+    if (j < njobs) CN_CHECK(parts[j] && outs[j], "cartnet_colsum_finalize: null pointer in job %d", j);
+  }
+  hipLaunchKernelGGL(cn_colsum_finalize_kernel, dim3(cn_ceil_div(N, 64), njobs), dim3(1024), 0,
+                     reinterpret_cast<hipStream_t>(stream), jobs, nparts, N);
   CN_LAUNCH_CHECK("cartnet_colsum_finalize");
   return 0;
 }

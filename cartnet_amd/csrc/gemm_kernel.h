@@ -14,6 +14,7 @@
 // Full tiles take a predicate-free load path; edge tiles / odd K / unaligned operands a checked one.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace cn_gemm {
 
@@ -25,6 +26,8 @@ constexpr int NTHREADS = 512;
 struct GemmFlags {
   int vecA, vecB, kchunk;
   int tile_m0;   // first row tile this launch covers (full tiles and the ragged last row tile are separate launches)
+  int split0;    // slab index of this launch's first K chunk (split-K: whole K-steps and the < 16-row tail are separate launches)
+  int k_lo, k_hi;  // K range this launch reduces over; chunk y covers [k_lo + y*kchunk, min(k_hi, ...))
 };
 
 // SiLU inside the GEMM uses the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each); forward and backward use the
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_kernel(const CartnetGemmA
   const int tile_m = fl.tile_m0 + blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
   const int g = blockIdx.z;
-  const int split = blockIdx.y;
+  const int split = fl.split0 + blockIdx.y;
 
   f32x16 acc[S::TM][S::TN];
 #pragma unroll
@@ -241,8 +244,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_kernel(const CartnetGemmA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int kbeg = split * fl.kchunk;
-  const int kend = min(p.K, kbeg + fl.kchunk);
+  const int kbeg = fl.k_lo + blockIdx.y * fl.kchunk;
+  const int kend = min(fl.k_hi, kbeg + fl.kchunk);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
   StA stA;
@@ -359,21 +362,41 @@ template <bool A_KS, bool B_KS, int BN, bool A_ACT, bool B_ACT>
 void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
   const int tiles_n = cn_ceil_div(a.N, BN);
   const int full_m = a.M / BM, rag_m = (a.M % BM) ? 1 : 0;
-  const bool fast_ok = fl.vecA && fl.vecB && (a.N % BN == 0) && (a.K % BK == 0) && (fl.kchunk % BK == 0);
-  if (fast_ok && full_m > 0) {
-    fl.tile_m0 = 0;
-    hipLaunchKernelGGL((cn_gemm_kernel<A_KS, B_KS, BN, A_ACT, B_ACT, true>), dim3(full_m * tiles_n, a.splitk, a.ngroups),
+  auto launch = [&](auto fast_tag, int m0, int nm, int s0, int ns, int k_lo, int k_hi, int kchunk) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    if (nm <= 0 || ns <= 0) return;
+    fl.tile_m0 = m0;
+    fl.split0 = s0;
+    fl.k_lo = k_lo;
+    fl.k_hi = k_hi;
+    fl.kchunk = kchunk;
+    hipLaunchKernelGGL((cn_gemm_kernel<A_KS, B_KS, BN, A_ACT, B_ACT, FAST>), dim3(nm * tiles_n, ns, a.ngroups),
                        dim3(NTHREADS), 0, st, a, fl);
-    if (rag_m) {
-      fl.tile_m0 = full_m;
-      hipLaunchKernelGGL((cn_gemm_kernel<A_KS, B_KS, BN, A_ACT, B_ACT, false>), dim3(tiles_n, a.splitk, a.ngroups),
-                         dim3(NTHREADS), 0, st, a, fl);
+  };
+  auto round_up = [](int v) { return ((v + BK - 1) / BK) * BK; };
+  const bool fast_ok = fl.vecA && fl.vecB && (a.N % BN == 0) && full_m > 0;
+  const int K16 = (a.K / BK) * BK, tail = a.K - K16;
+  if (a.splitk == 1) {
+    const int kc = round_up(a.K > 0 ? a.K : 1);
+    if (fast_ok && tail == 0 && a.K > 0) {
+      launch(std::true_type{}, 0, full_m, 0, 1, 0, a.K, kc);
+      launch(std::false_type{}, full_m, rag_m, 0, 1, 0, a.K, kc);
+    } else {
+      launch(std::false_type{}, 0, full_m + rag_m, 0, 1, 0, a.K, kc);
     }
-  } else {
-    fl.tile_m0 = 0;
-    hipLaunchKernelGGL((cn_gemm_kernel<A_KS, B_KS, BN, A_ACT, B_ACT, false>),
-                       dim3((full_m + rag_m) * tiles_n, a.splitk, a.ngroups), dim3(NTHREADS), 0, st, a, fl);
+    return;
   }
+  // split-K: slabs 0..nfast-1 cover whole K-steps of [0, K16) (predicate-free kernel); if K has a < 16-row tail it
+  // becomes the last slab, computed by the checked kernel over just those rows.
+  const int nfast = tail ? a.splitk - 1 : a.splitk;
+  const int kc = round_up(cn_ceil_div(K16 > 0 ? K16 : 1, nfast));
+  if (fast_ok) {
+    launch(std::true_type{}, 0, full_m, 0, nfast, 0, K16, kc);
+    launch(std::false_type{}, full_m, rag_m, 0, nfast, 0, K16, kc);
+  } else {
+    launch(std::false_type{}, 0, full_m + rag_m, 0, nfast, 0, K16, kc);
+  }
+  if (tail) launch(std::false_type{}, 0, full_m + rag_m, nfast, 1, K16, a.K, BK);
 }
 
 // Operand layouts / fused activations the CartNet path uses.  Returns false for an unsupported combination.

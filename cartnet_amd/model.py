@@ -137,8 +137,7 @@ def _wgrad(dY: List[torch.Tensor], X: List[torch.Tensor], outs: List[torch.Tenso
         return
     slabs = [_empty((S * M, N), dY[0].device) for _ in dY]
     ops.gemm(dY, X, slabs, a_kstrided=True, b_kstrided=True, b_act=b_act, splitk=S)
-    for s, o in zip(slabs, outs):
-        ops.splitk_reduce(s, S, o)
+    ops.splitk_reduce(slabs, S, outs)
 
 
 class _CartNetFunction(torch.autograd.Function):
@@ -320,8 +319,7 @@ class _CartNetFunction(torch.autograd.Function):
             pa, pb = _parts(nparts_n * D, dev), _parts(nparts_n * D, dev)
             ops.node_update_bwd_stats(aggr, dx, mr2, P[p + ".norm2.weight"], P[p + ".norm2.bias"], pa, pb)
             sums2 = _empty((2 * D,), dev)
-            ops.colsum_finalize(pa, nparts_n, sums2[:D])
-            ops.colsum_finalize(pb, nparts_n, sums2[D:])
+            ops.colsum_finalize([pa, pb], nparts_n, [sums2[:D], sums2[D:]])
             G[p + ".norm2.bias"], G[p + ".norm2.weight"] = sums2[:D], sums2[D:]
             daggr = _empty((N, D), dev)
             ops.node_update_bwd_apply(aggr, dx, mr2, P[p + ".norm2.weight"], P[p + ".norm2.bias"], sums2, training,
@@ -331,14 +329,13 @@ class _CartNetFunction(torch.autograd.Function):
             ops.gate_scatter_bwd_stats(gs, de, daggr, env, lay, mr1, P[p + ".norm.weight"], P[p + ".norm.bias"], pa,
                                        pb)
             sums1 = _empty((2 * D,), dev)
-            ops.colsum_finalize(pa, gparts, sums1[:D])
-            ops.colsum_finalize(pb, gparts, sums1[D:])
+            ops.colsum_finalize([pa, pb], gparts, [sums1[:D], sums1[D:]])
             G[p + ".norm.bias"], G[p + ".norm.weight"] = sums1[:D], sums1[D:]
             pdg, pds = _parts(gparts * D, dev), _parts(gparts * D, dev)
             ops.gate_scatter_bwd_apply(gs, de, daggr, env, lay, mr1, P[p + ".norm.weight"], P[p + ".norm.bias"],
                                        sums1, training, pdg, pds)          # gs now holds [dg | ds]
-            G[p + ".MLP_gate.2.bias"] = _finalize(pdg, gparts, D)
-            G[p + ".MLP_aggr.2.bias"] = _finalize(pds, gparts, D)
+            G[p + ".MLP_gate.2.bias"], G[p + ".MLP_aggr.2.bias"] = _empty((D,), dev), _empty((D,), dev)
+            ops.colsum_finalize([pdg, pds], gparts, [G[p + ".MLP_gate.2.bias"], G[p + ".MLP_aggr.2.bias"]])
             # second Linears: weight gradients need silu(pre), then pre is overwritten with dpre
             G[p + ".MLP_gate.2.weight"], G[p + ".MLP_aggr.2.weight"] = _empty((D, D), dev), _empty((D, D), dev)
             _wgrad([gs[:, :D], gs[:, D:]], [pre[:, :D], pre[:, D:]],
@@ -347,8 +344,8 @@ class _CartNetFunction(torch.autograd.Function):
             csg, csa = _parts(tiles_e * D, dev), _parts(tiles_e * D, dev)
             ops.gemm([gs[:, :D], gs[:, D:]], [W2g, W2a], [pre[:, :D], pre[:, D:]], b_kstrided=True,
                      dact=[pre[:, :D], pre[:, D:]], colsum=[csg, csa])      # pre now holds dpre = [dpre_gate | dpre_aggr]
-            G[p + ".MLP_gate.0.bias"] = _finalize(csg, tiles_e, D)
-            G[p + ".MLP_aggr.0.bias"] = _finalize(csa, tiles_e, D)
+            G[p + ".MLP_gate.0.bias"], G[p + ".MLP_aggr.0.bias"] = _empty((D,), dev), _empty((D,), dev)
+            ops.colsum_finalize([csg, csa], tiles_e, [G[p + ".MLP_gate.0.bias"], G[p + ".MLP_aggr.0.bias"]])
             dW1g, dW1a = _empty((D, 3 * D), dev), _empty((D, 3 * D), dev)
             G[p + ".MLP_gate.0.weight"], G[p + ".MLP_aggr.0.weight"] = dW1g, dW1a
             _wgrad([pre[:, :D], pre[:, D:]], [e_in, e_in], [dW1g[:, 2 * D:], dW1a[:, 2 * D:]])
@@ -406,8 +403,10 @@ class _CartNetFunction(torch.autograd.Function):
                 ops.segment_sum_long(dx0, st.zptr, st.zperm, N, demb)
                 G["encoder.embedding.weight"] = demb
             if enc.temperature:
-                G["encoder.temperature_proj_atom.weight"] = _finalize(pw, nparts_n, 2 * D).view(2 * D, 1)
-                G["encoder.temperature_proj_atom.bias"] = _finalize(pb, nparts_n, 2 * D)
+                gw, gb = _empty((2 * D,), dev), _empty((2 * D,), dev)
+                ops.colsum_finalize([pw, pb], nparts_n, [gw, gb])
+                G["encoder.temperature_proj_atom.weight"] = gw.view(2 * D, 1)
+                G["encoder.temperature_proj_atom.bias"] = gb
             else:
                 G["encoder.bias"] = _finalize(pb, nparts_n, 2 * D)
         else:

@@ -189,25 +189,51 @@ def gemm_tiles_m(M: int) -> int:
     return (int(M) + 127) // 128
 
 
-def splitk_reduce(slabs: Tensor, splitk: int, out: Tensor) -> None:
-    _f32_2d(out, "splitk_reduce out")
-    M, N = out.shape
-    _vec(slabs, splitk * M * N, "splitk_reduce slabs")
-    _l.check(_l.load().cartnet_splitk_reduce(slabs.data_ptr(), splitk, M, N, out.data_ptr(), _ld(out),
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def splitk_reduce(slabs, splitk: int, outs) -> None:
+    """outs[j] = sum over the ``splitk`` slabs of slabs[j] (fixed order); up to 4 same-shaped jobs per launch."""
+    slabs, outs = _aslist(slabs, 1), _aslist(outs, 1)
+    if len(slabs) != len(outs) or not (1 <= len(outs) <= _l.MAX_GROUPS):
+        raise ValueError("splitk_reduce: need 1..4 matching slab/out pairs")
+    M, N = outs[0].shape
+    ldo = _ld(outs[0])
+    for sl, o in zip(slabs, outs):
+        _f32_2d(o, "splitk_reduce out")
+        if tuple(o.shape) != (M, N) or _ld(o) != ldo:
+            raise ValueError("splitk_reduce: outputs must share shape and leading dimension")
+        _vec(sl, splitk * M * N, "splitk_reduce slabs")
+    _l.check(_l.load().cartnet_splitk_reduce(_ptr_array(slabs), _ptr_array(outs), len(outs), int(splitk), M, N, ldo,
                                              _l.stream_ptr()), "cartnet_splitk_reduce")
 
 
-def colsum_finalize(parts: Tensor, nparts: int, out: Tensor) -> None:
-    """out[n] = sum_p parts[p, n] in fixed order; parts are the fp64 (or, for the head kernels, fp32) partial rows."""
-    n = out.numel()
-    _vec(out, n, "colsum_finalize out")
-    if parts.dtype == torch.float64:
-        _vec(parts, nparts * n, "colsum_finalize parts", torch.float64)
-        fn = _l.load().cartnet_colsum_finalize
+def colsum_finalize(parts, nparts: int, outs) -> None:
+    """outs[j][n] = sum_p parts[j][p, n] in fixed order.  parts: fp64 partial rows (up to 8 same-shaped jobs per
+    launch) or, for the head kernels, one fp32 partial matrix."""
+    parts, outs = _aslist(parts, 1), _aslist(outs, 1)
+    if len(parts) != len(outs) or not (1 <= len(outs) <= 8):
+        raise ValueError("colsum_finalize: need 1..8 matching parts/out pairs")
+    n = outs[0].numel()
+    for o in outs:
+        _vec(o, n, "colsum_finalize out")
+        if o.numel() != n:
+            raise ValueError("colsum_finalize: outputs must have equal length")
+    if parts[0].dtype == torch.float64:
+        for pt in parts:
+            _vec(pt, nparts * n, "colsum_finalize parts", torch.float64)
+        _l.check(_l.load().cartnet_colsum_finalize(_ptr_array(parts), _ptr_array(outs), len(outs), int(nparts), n,
+                                                   _l.stream_ptr()), "cartnet_colsum_finalize")
     else:
-        _vec(parts, nparts * n, "colsum_finalize parts", torch.float32)
-        fn = _l.load().cartnet_colsum_finalize_f32
-    _l.check(fn(parts.data_ptr(), nparts, n, out.data_ptr(), _l.stream_ptr()), "cartnet_colsum_finalize")
+        if len(parts) != 1:
+            raise ValueError("colsum_finalize: fp32 partials are finalised one at a time")
+        _vec(parts[0], nparts * n, "colsum_finalize parts", torch.float32)
+        _l.check(_l.load().cartnet_colsum_finalize_f32(parts[0].data_ptr(), int(nparts), n, outs[0].data_ptr(),
+                                                       _l.stream_ptr()), "cartnet_colsum_finalize_f32")
 
 
 class GraphLayout:

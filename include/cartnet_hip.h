@@ -75,15 +75,19 @@ typedef struct CartnetGemmArgs {
 
 int cartnet_gemm(const CartnetGemmArgs* args, void* stream);
 
-/* out[m*ldo + n] = sum_{s<splitk} slabs[s*M*N + m*N + n]  (fixed order s = 0..splitk-1). */
-int cartnet_splitk_reduce(const float* slabs, int32_t splitk, int32_t M, int32_t N, float* out, int32_t ldo,
-                          void* stream);
+/* For each job j < njobs (<= 4; host arrays of device pointers):
+ * outs[j][m*ldo + n] = sum_{s<splitk} slabs[j][s*M*N + m*N + n]  (fixed order s = 0..splitk-1). */
+int cartnet_splitk_reduce(const float* const* slabs, float* const* outs, int32_t njobs, int32_t splitk, int32_t M,
+                          int32_t N, int32_t ldo, void* stream);
 
 /* Partial sums.  Kernels that reduce over rows (BatchNorm statistics, bias / affine gradients) never use atomics:
  * every workgroup writes one fp64 row of per-column partial sums (fp64 so that var = E[v^2] - mean^2 keeps its
  * digits), and a finalise kernel adds the rows in fixed order.
- * out[n] = (float) sum_{p<nparts} parts[p*N + n].  The _f32 form reads the fp32 partial rows of the head kernels. */
-int cartnet_colsum_finalize(const double* parts, int32_t nparts, int32_t N, float* out, void* stream);
+ * For each job j < njobs (<= 8; host arrays of device pointers, all with the same nparts and N):
+ * outs[j][n] = (float) sum_{p<nparts} parts[j][p*N + n].
+ * The _f32 form (single job) reads the fp32 partial rows of the head kernels. */
+int cartnet_colsum_finalize(const double* const* parts, float* const* outs, int32_t njobs, int32_t nparts, int32_t N,
+                            void* stream);
 int cartnet_colsum_finalize_f32(const float* parts, int32_t nparts, int32_t N, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -126,8 +126,7 @@ def test_gemm_tn_splitk_groups(ops, E, Dout, Din, splitk):
         slabs = [torch.empty(splitk * Dout, Din, device=dev()) for _ in range(2)]
         ops.gemm(dY, X, slabs, a_kstrided=True, b_kstrided=True, b_act=True, splitk=splitk)
         outs = [torch.empty(Dout, 3 * Din, device=dev()) for _ in range(2)]
-        for s, o in zip(slabs, outs):
-            ops.splitk_reduce(s, splitk, o[:, Din:2 * Din])
+        ops.splitk_reduce(slabs, splitk, [o[:, Din:2 * Din] for o in outs])
         got = [o[:, Din:2 * Din] for o in outs]
     else:
         got = [torch.empty(Dout, Din, device=dev()) for _ in range(2)]
@@ -290,8 +289,7 @@ def test_gate_scatter_fwd_bwd(ops, D):
     pa, pb = (torch.zeros(nparts * D, device=dev(), dtype=torch.float64) for _ in range(2))
     ops.gate_scatter_bwd_stats(gs, de_out, daggr, env, lay, mean_rstd_b, gamma, beta, pa, pb)
     sums = torch.empty(2 * D, device=dev())
-    ops.colsum_finalize(pa, nparts, sums[:D])
-    ops.colsum_finalize(pb, nparts, sums[D:])
+    ops.colsum_finalize([pa, pb], nparts, [sums[:D], sums[D:]])
     gs_work = gs.clone()
     pdg, pds = (torch.zeros(nparts * D, device=dev(), dtype=torch.float64) for _ in range(2))
     ops.gate_scatter_bwd_apply(gs_work, de_out, daggr, env, lay, mean_rstd_b, gamma, beta, sums, True, pdg, pds)
@@ -348,8 +346,7 @@ def test_bn_finalize_and_node_update(ops):
     pa, pb = (torch.zeros(nparts * D, device=dev(), dtype=torch.float64) for _ in range(2))
     ops.node_update_bwd_stats(aggr, dx, mean_rstd, gamma, beta, pa, pb)
     sums = torch.empty(2 * D, device=dev())
-    ops.colsum_finalize(pa, nparts, sums[:D])
-    ops.colsum_finalize(pb, nparts, sums[D:])
+    ops.colsum_finalize([pa, pb], nparts, [sums[:D], sums[D:]])
     daggr = torch.empty(N, D, device=dev())
     ops.node_update_bwd_apply(aggr, dx, mean_rstd, gamma, beta, sums, True, daggr)
     assert rel_err(daggr, a64.grad) < 2e-5
@@ -387,8 +384,7 @@ def test_node_embed_fwd_bwd(ops, N):
     assert torch.equal(zptr.cpu().long()[1:], torch.cumsum(torch.bincount(z, minlength=119), 0))
     ops.segment_sum_long(dx0, zptr, perm, N, demb)
     dwt, dbt = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
-    ops.colsum_finalize(pw, nparts, dwt)
-    ops.colsum_finalize(pb, nparts, dbt)
+    ops.colsum_finalize([pw, pb], nparts, [dwt, dbt])
     assert rel_err(demb, e64.grad) < TOL
     assert rel_err(dwt, w64.grad.view(-1)) < TOL
     assert rel_err(dbt, b64.grad) < TOL
