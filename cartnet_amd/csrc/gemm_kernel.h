@@ -58,7 +58,9 @@ struct Stager {
       if (!PARTIAL || unit < UNITS) {
         if (!KS) {
           const int row = unit >> 2, kq = unit & 3;
-          const int grow = row0 + row, gk = k0 + kq * 4;
+          // FAST: rows past the end of a ragged last tile are clamped to the last valid row (their products are
+          // computed and dropped by the epilogue's row check) so the load needs no predicate.
+          const int grow = FAST ? min(row0 + row, rows_limit - 1) : row0 + row, gk = k0 + kq * 4;
           const float* ptr = base + (size_t)grow * ld + gk;
           if (FAST) {
             v = *reinterpret_cast<const f32x4*>(ptr);
@@ -374,13 +376,16 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
                        dim3(NTHREADS), 0, st, a, fl);
   };
   auto round_up = [](int v) { return ((v + BK - 1) / BK) * BK; };
-  const bool fast_ok = fl.vecA && fl.vecB && (a.N % BN == 0) && full_m > 0;
+  // the predicate-free kernel covers ragged row tiles too when A is k-contiguous (row clamp in Stager::load)
+  const bool fast_ok = fl.vecA && fl.vecB && (a.N % BN == 0) && (full_m > 0 || !A_KS) && a.M > 0;
+  const int fast_m = A_KS ? full_m : full_m + rag_m;      // row tiles the predicate-free kernel takes
+  const int slow_m = (full_m + rag_m) - fast_m;
   const int K16 = (a.K / BK) * BK, tail = a.K - K16;
   if (a.splitk == 1) {
     const int kc = round_up(a.K > 0 ? a.K : 1);
     if (fast_ok && tail == 0 && a.K > 0) {
-      launch(std::true_type{}, 0, full_m, 0, 1, 0, a.K, kc);
-      launch(std::false_type{}, full_m, rag_m, 0, 1, 0, a.K, kc);
+      launch(std::true_type{}, 0, fast_m, 0, 1, 0, a.K, kc);
+      launch(std::false_type{}, fast_m, slow_m, 0, 1, 0, a.K, kc);
     } else {
       launch(std::false_type{}, 0, full_m + rag_m, 0, 1, 0, a.K, kc);
     }
@@ -391,8 +396,8 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
   const int nfast = tail ? a.splitk - 1 : a.splitk;
   const int kc = round_up(cn_ceil_div(K16 > 0 ? K16 : 1, nfast));
   if (fast_ok) {
-    launch(std::true_type{}, 0, full_m, 0, nfast, 0, K16, kc);
-    launch(std::false_type{}, full_m, rag_m, 0, nfast, 0, K16, kc);
+    launch(std::true_type{}, 0, fast_m, 0, nfast, 0, K16, kc);
+    launch(std::false_type{}, fast_m, slow_m, 0, nfast, 0, K16, kc);
   } else {
     launch(std::false_type{}, 0, full_m + rag_m, 0, nfast, 0, K16, kc);
   }
