@@ -92,6 +92,16 @@ extern "C" int cartnet_gemm(const CartnetGemmArgs* args, void* stream) {
   fl.split0 = 0;
   fl.k_lo = 0;
   fl.k_hi = a.K;
+  {  // vector epilogue: every row any epilogue operand touches must be 16-byte aligned
+    bool w = (a.ldc % 4 == 0) && (a.N % 4 == 0);
+    for (int gI = 0; gI < a.ngroups && w; ++gI) {
+      w = w && aligned16(a.C[gI]) && (!a.bias[gI] || aligned16(a.bias[gI])) && (!a.cpre[gI] || aligned16(a.cpre[gI]));
+      if (a.gather_i[gI]) w = w && aligned16(a.gather_i[gI]) && aligned16(a.gather_j[gI]) && (a.ldg % 4 == 0);
+      if (a.resid[gI]) w = w && aligned16(a.resid[gI]) && (a.ldr % 4 == 0);
+      if (a.dact[gI]) w = w && aligned16(a.dact[gI]) && (a.ldd % 4 == 0);
+    }
+    fl.wide = w ? 1 : 0;
+  }
   fl.vecA = vecA ? 1 : 0;
   fl.vecB = vecB ? 1 : 0;
   int kchunk = (a.K + a.splitk - 1) / a.splitk;

@@ -28,6 +28,7 @@ struct GemmFlags {
   int tile_m0;   // first row tile this launch covers (full tiles and the ragged last row tile are separate launches)
   int split0;    // slab index of this launch's first K chunk (split-K: whole K-steps and the < 16-row tail are separate launches)
   int k_lo, k_hi;  // K range this launch reduces over; chunk y covers [k_lo + y*kchunk, min(k_hi, ...))
+  int wide;        // every epilogue operand has 16-byte aligned rows -> vector epilogue
 };
 
 // SiLU inside the GEMM uses the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each); forward and backward use the
@@ -216,6 +217,149 @@ __device__ __forceinline__ void epilogue(const CartnetGemmArgs& p, f32x16 (&acc)
   }
 }
 
+
+// Wide epilogue: each 32x32 accumulator tile is transposed through a per-wave LDS scratch (32 rows x 36 floats) so
+// that a lane owns 4 consecutive columns of a row: node-term gathers, residual / pre-activation reads and the output
+// go to memory as 16-byte vectors (8 rows x 128 B per wave instruction) instead of 4-byte scalars -- a quarter of the
+// memory instructions of the scalar epilogue.  Needs 16-byte aligned rows everywhere (checked on the host: fl.wide).
+constexpr int SCR_LD = 36;
+constexpr int SCR_FLOATS = 32 * SCR_LD;
+
+__device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void stv4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+template <int BN, int KIND>
+__device__ __forceinline__ void epilogue_wide(const CartnetGemmArgs& p, f32x16 (&acc)[Shape<BN>::TM][Shape<BN>::TN],
+                                              int g, int row0, int col0, int tile_m, int wm, int wn, int lane, int tid,
+                                              float* smem, int rt_kind) {
+  using S = Shape<BN>;
+  const int kind = (KIND >= 0) ? KIND : rt_kind;
+  const bool GATHER = kind & 1, RESID = kind & 2, DACT = kind & 4, SUM1 = kind & 8, SUM2 = kind & 16,
+             CPRE = kind & 32, OUTACT = kind & 64;
+  const int li = lane & 31, lh = lane >> 5;
+  const int c4 = lane & 7, rsub = lane >> 3;
+  float* C = p.C[g];
+  const float* __restrict__ bias = p.bias[g];
+  const float* __restrict__ gi = p.gather_i[g];
+  const float* __restrict__ gj = p.gather_j[g];
+  const float* resid = p.resid[g];
+  const float* dact = p.dact[g];
+  float* cpre = p.cpre[g];
+  float* scr = smem + (tid >> 6) * SCR_FLOATS;
+
+  f32x4 bias4[S::TN], sum4[S::TN];
+  double cs[S::TN], cq[S::TN];
+#pragma unroll
+  for (int b = 0; b < S::TN; ++b) {
+    const int gcol = col0 + wn * S::WN + b * 32 + c4 * 4;
+    bias4[b] = bias ? ldv4(bias + gcol) : f32x4{0.f, 0.f, 0.f, 0.f};
+    sum4[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    cs[b] = 0.0;
+    cq[b] = 0.0;
+  }
+  if (SUM2) {   // BatchNorm statistics of v = acc + bias, taken in the accumulator layout (column = lane)
+#pragma unroll
+    for (int b = 0; b < S::TN; ++b) {
+      const float bv = bias ? bias[col0 + wn * S::WN + b * 32 + li] : 0.f;
+#pragma unroll
+      for (int a = 0; a < S::TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int grow = row0 + wm * S::WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (grow < p.M) {
+            const double v = (double)(acc[a][b][r] + bv);
+            cs[b] += v;
+            cq[b] += v * v;
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < S::TM; ++a) {
+    int grow[4], ti[4], sj[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      grow[i] = row0 + wm * S::WM + a * 32 + rsub + 8 * i;
+      ti[i] = 0;
+      sj[i] = 0;
+      if (GATHER && grow[i] < p.M) {
+        ti[i] = p.tgt[grow[i]];
+        sj[i] = p.src[grow[i]];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < S::TN; ++b) {
+      const int gcol = col0 + wn * S::WN + b * 32 + c4 * 4;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * SCR_LD + li] = acc[a][b][r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = ldv4(scr + (rsub + 8 * i) * SCR_LD + c4 * 4);
+        if (grow[i] >= p.M) continue;
+        v += bias4[b];
+        if (GATHER) v += ldv4(gi + (size_t)ti[i] * p.ldg + gcol) + ldv4(gj + (size_t)sj[i] * p.ldg + gcol);
+        if (RESID) v += ldv4(resid + (size_t)grow[i] * p.ldr + gcol);
+        if (DACT) {
+          const f32x4 d = ldv4(dact + (size_t)grow[i] * p.ldd + gcol);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] *= fast_dsilu(d[q]);
+        }
+        if (SUM1) sum4[b] += v;
+        if (CPRE) stv4(cpre + (size_t)grow[i] * p.ldc + gcol, v);
+        if (OUTACT) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fast_silu(v[q]);
+        }
+        stv4(C + (size_t)grow[i] * p.ldc + gcol, v);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (SUM1 || SUM2) {
+    double* red = reinterpret_cast<double*>(smem);   // [2][WGM][BN]
+    double* __restrict__ colsum = p.colsum[g];
+    double* __restrict__ colsq = p.colsq[g];
+    __syncthreads();   // every wave is done with its transpose scratch
+#pragma unroll
+    for (int b = 0; b < S::TN; ++b) {
+      if (SUM2) {
+        double s = cs[b], q = cq[b];
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        if (lh == 0) {
+          red[(0 * S::WGM + wm) * BN + wn * S::WN + b * 32 + li] = s;
+          red[(1 * S::WGM + wm) * BN + wn * S::WN + b * 32 + li] = q;
+        }
+      } else {
+        f32x4 s = sum4[b];     // rows of this wave's tile are spread over the 8 lanes that share c4
+#pragma unroll
+        for (int o = 8; o <= 32; o <<= 1)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s[q] += __shfl_xor(s[q], o);
+        if (rsub == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) red[(0 * S::WGM + wm) * BN + wn * S::WN + b * 32 + c4 * 4 + q] = (double)s[q];
+        }
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += NTHREADS) {
+      const int gcol = col0 + c;
+      if (gcol < p.N) {
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int w = 0; w < S::WGM; ++w) {
+          s += red[(0 * S::WGM + w) * BN + c];
+          if (SUM2) q += red[(1 * S::WGM + w) * BN + c];
+        }
+        colsum[(size_t)tile_m * p.N + gcol] = s;
+        if (SUM2) colsq[(size_t)tile_m * p.N + gcol] = q;
+      }
+    }
+  }
+}
+
 // FAST: every tile of the launch is full, K is a whole number of K-steps and rows are 16-byte aligned -> the operand
 // loads carry no predicates.  The checked variant is a separate kernel so its register needs do not leak into this one.
 template <bool A_KS, bool B_KS, int BN, bool A_ACT, bool B_ACT, bool FAST>
@@ -342,9 +486,26 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_kernel(const CartnetGemmA
       }
     return;
   }
+  constexpr bool WIDE_OK = FAST && (2 * BUF >= (NTHREADS / 64) * SCR_FLOATS);
   double* red = reinterpret_cast<double*>(smem);
   const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
                    (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);
+  if (WIDE_OK && fl.wide) {
+#define CN_EPIW(K) epilogue_wide<BN, K>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem, kind)
+    switch (kind) {
+      case 0: CN_EPIW(0); break;
+      case 1: CN_EPIW(1); break;
+      case 16: CN_EPIW(16); break;
+      case 96: CN_EPIW(96); break;
+      case 2: CN_EPIW(2); break;
+      case 4: CN_EPIW(4); break;
+      case 12: CN_EPIW(12); break;
+      case 14: CN_EPIW(14); break;
+      default: CN_EPIW(-1); break;
+    }
+#undef CN_EPIW
+    return;
+  }
 #define CN_EPI(K) epilogue<BN, K>(p, acc, g, row0, col0, tile_m, wm, wn, li, lh, tid, red, kind)
   switch (kind) {               // the combinations the CartNet path uses get branch-free code
     case 0: CN_EPI(0); break;    // (+bias) store                          node projections, heads, 2nd-Linear sender
