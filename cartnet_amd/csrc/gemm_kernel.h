@@ -572,7 +572,8 @@ bool launch_bn(const CartnetGemmArgs& a, const GemmFlags& fl, hipStream_t st) {
   switch (combo) {
     case 0: launch_variant<false, false, BN, false, false>(a, fl, st); return true;   // Y = X W^T
     case 4: launch_variant<false, false, BN, true, false>(a, fl, st); return true;    // Y = silu(X) W^T
-    case 2: launch_variant<false, true, BN, false, false>(a, fl, st); return true;    // dX = dY W
+    case 2: launch_variant<false, true, BN, false, false>(a, fl, st); return true;    // dX = dY W ; Y = X Wt
+    case 6: launch_variant<false, true, BN, true, false>(a, fl, st); return true;     // Y = silu(X) Wt
     case 3: launch_variant<true, true, BN, false, false>(a, fl, st); return true;     // dW = dY^T X
     case 11: launch_variant<true, true, BN, false, true>(a, fl, st); return true;     // dW = dY^T silu(X)
     default: return false;

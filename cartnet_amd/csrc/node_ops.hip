@@ -70,6 +70,31 @@ __global__ __launch_bounds__(256) void cn_embed_bwd_cols_kernel(const int64_t* _
   }
 }
 
+// ------------------------------------------------------------------------------------------------ transpose
+// dst[c, r] = src[r, c] for up to 8 matrices per launch (weights -> [in, out] once per forward, so that every forward
+// GEMM streams its weight tile with fully coalesced rows).
+struct TransposeJobs {
+  const float* src[8];
+  float* dst[8];
+  int rows[8], cols[8], lds[8], ldd[8];
+};
+
+__global__ __launch_bounds__(256) void cn_transpose_kernel(const TransposeJobs jobs) {
+  __shared__ float tile[32][33];
+  const int j = blockIdx.z;
+  const int rows = jobs.rows[j], cols = jobs.cols[j];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  if (r0 >= rows || c0 >= cols) return;
+  const float* __restrict__ src = jobs.src[j];
+  float* __restrict__ dst = jobs.dst[j];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = src[(size_t)(r0 + i) * jobs.lds[j] + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) dst[(size_t)(c0 + i) * jobs.ldd[j] + r0 + tx] = tile[tx][i];
+}
+
 // ------------------------------------------------------------------------------------------------ BatchNorm stats
 __global__ __launch_bounds__(1024) void cn_bn_finalize_kernel(
     const double* __restrict__ parts_sum, const double* __restrict__ parts_sq, int nparts, long long count, int C,
@@ -514,5 +539,33 @@ extern "C" int cartnet_scalar_head_bwd(const float* hid, const float* w2, const 
   hipLaunchKernelGGL(cn_scalar_head_bwd_kernel, dim3(node_parts(N)), dim3(256), 0, ST(stream), hid, w2, graph_ptr,
                      batch, dout, N, H, dhid, parts);
   CN_LAUNCH_CHECK("cartnet_scalar_head_bwd");
+  return 0;
+}
+
+extern "C" int cartnet_transpose(const float* const* src, float* const* dst, const int32_t* rows, const int32_t* cols,
+                                 const int32_t* lds, const int32_t* ldd, int32_t njobs, void* stream) {
+  CN_CHECK(src && dst && rows && cols && lds && ldd && njobs >= 1 && njobs <= 8,
+           "cartnet_transpose: njobs=%d out of range (1..8)", njobs);
+  TransposeJobs jobs;
+  int max_r = 0, max_c = 0;
+  for (int j = 0; j < 8; ++j) {
+    const bool on = j < njobs;
+    jobs.src[j] = on ? src[j] : nullptr;
+    jobs.dst[j] = on ? dst[j] : nullptr;
+    jobs.rows[j] = on ? rows[j] : 0;
+    jobs.cols[j] = on ? cols[j] : 0;
+    jobs.lds[j] = on ? lds[j] : 0;
+    jobs.ldd[j] = on ? ldd[j] : 0;
+    if (on) {
+      CN_CHECK(src[j] && dst[j] && rows[j] >= 0 && cols[j] >= 0 && lds[j] >= cols[j] && ldd[j] >= rows[j],
+               "cartnet_transpose: bad job %d", j);
+      if (rows[j] > max_r) max_r = rows[j];
+      if (cols[j] > max_c) max_c = cols[j];
+    }
+  }
+  if (max_r == 0 || max_c == 0) return 0;
+  hipLaunchKernelGGL(cn_transpose_kernel, dim3(cn_ceil_div(max_c, 32), cn_ceil_div(max_r, 32), njobs), dim3(256), 0,
+                     ST(stream), jobs);
+  CN_LAUNCH_CHECK("cartnet_transpose");
   return 0;
 }

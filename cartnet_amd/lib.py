@@ -88,6 +88,8 @@ PROTOTYPES = {
     "cartnet_scalar_head_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, C.c_int32, C.c_int32, c_f32p, c_stream]),
     "cartnet_scalar_head_bwd": (C.c_int, [c_f32p, c_f32p, c_i64p, c_i64p, c_f32p, C.c_int32, C.c_int32, C.c_int32,
                                           c_f32p, c_f32p, c_stream]),
+    "cartnet_transpose": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, c_stream]),
     "cartnet_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_int32, C.c_float, c_stream]),
 }

@@ -120,6 +120,31 @@ def _parts(n, dev):
     return torch.empty((n,), dtype=torch.float64, device=dev)
 
 
+class _GradBuffer(dict):
+    """All parameter gradients of one backward pass as views of ONE flat buffer (parameter order), so the hand-off to
+    the optimiser's flat gradient buffer is a single add instead of one autograd accumulation per parameter."""
+
+    def __init__(self, model, dev):
+        super().__init__()
+        shapes = model._param_shapes
+        total = sum(math.prod(sh) if len(sh) else 1 for sh in shapes.values())
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        off = 0
+        for name, sh in shapes.items():
+            k = math.prod(sh) if len(sh) else 1
+            dict.__setitem__(self, name, self.flat[off:off + k].view(sh))
+            off += k
+        self.written = set()
+
+    def out(self, name):
+        """The view a kernel should write the gradient of ``name`` into."""
+        self.written.add(name)
+        return dict.__getitem__(self, name)
+
+    def put(self, name, value):
+        self.out(name).copy_(value.reshape(dict.__getitem__(self, name).shape))
+
+
 def _finalize(parts: torch.Tensor, nparts: int, n: int) -> torch.Tensor:
     out = _empty((n,), parts.device)
     ops.colsum_finalize(parts, nparts, out)
@@ -169,6 +194,10 @@ class _CartNetFunction(torch.autograd.Function):
         st.lay, st.N, st.E = lay, N, E
         dist = batch.cart_dist.contiguous()
         enc = model.encoder
+        # weights as [in, out] for the forward GEMMs (k-strided B operand = coalesced weight rows); one small launch set
+        tnames = [n for n in model._param_names if n.endswith(".weight") and P[n].dim() == 2 and n != "head.MLP.2.weight"
+                  and ("MLP" in n or "encoder_edge" in n or "encoder_atom" in n)]
+        WT = dict(zip(tnames, ops.transpose([P[n] for n in tnames])))
 
         # ---- encoder, edges: Cartesian features -> Linear -> SiLU -> Linear -> SiLU   (cartnet.py:159)
         R = enc.rbf.num_rbf
@@ -180,10 +209,11 @@ class _CartNetFunction(torch.autograd.Function):
                           B["encoder.rbf.betas"], enc.invariant, enc.rbf.cutoff_upper,
                           model.layers[0].envelope_radius if L else enc.rbf.cutoff_upper, feat, env)
         he_pre = _empty((E, 2 * D), dev)
-        ops.gemm(feat[:, :kf], P["encoder.encoder_edge.0.weight"], he_pre, bias=P["encoder.encoder_edge.0.bias"])
+        ops.gemm(feat[:, :kf], WT["encoder.encoder_edge.0.weight"], he_pre, b_kstrided=True,
+                 bias=P["encoder.encoder_edge.0.bias"])
         e0_pre = _empty((E, D), dev)
         e = _empty((E, D), dev)
-        ops.gemm(he_pre, P["encoder.encoder_edge.2.weight"], e, a_act=True, out_act=True,
+        ops.gemm(he_pre, WT["encoder.encoder_edge.2.weight"], e, b_kstrided=True, a_act=True, out_act=True,
                  bias=P["encoder.encoder_edge.2.bias"], cpre=e0_pre)
         st.feat, st.kf, st.he_pre, st.e0_pre, st.env = feat, kf, he_pre, e0_pre, env
 
@@ -198,7 +228,7 @@ class _CartNetFunction(torch.autograd.Function):
                            P.get("encoder.bias"), x0)
             xa_pre = _empty((N, D), dev)
             x = _empty((N, D), dev)
-            ops.gemm(x0, P["encoder.encoder_atom.1.weight"], x, a_act=True, out_act=True,
+            ops.gemm(x0, WT["encoder.encoder_atom.1.weight"], x, b_kstrided=True, a_act=True, out_act=True,
                      bias=P["encoder.encoder_atom.1.bias"], cpre=xa_pre)
             st.x0, st.xa_pre, st.gid, st.T = x0, xa_pre, gid, T
             if need_grad and enc.atom_types:   # atoms grouped by element (stable) for the embedding gradient
@@ -213,18 +243,19 @@ class _CartNetFunction(torch.autograd.Function):
         for l in range(L):
             p = f"layers.{l}"
             W1g, W1a = P[p + ".MLP_gate.0.weight"], P[p + ".MLP_aggr.0.weight"]
+            W1gT, W1aT = WT[p + ".MLP_gate.0.weight"], WT[p + ".MLP_aggr.0.weight"]       # [3D, D]
             Pn = _empty((N, 4 * D), dev)          # node-side halves of the first Linears: [gate_i | aggr_i | gate_j | aggr_j]
-            ops.gemm([x, x, x, x], [W1g[:, :D], W1a[:, :D], W1g[:, D:2 * D], W1a[:, D:2 * D]],
-                     [Pn[:, 0:D], Pn[:, D:2 * D], Pn[:, 2 * D:3 * D], Pn[:, 3 * D:]],
+            ops.gemm([x, x, x, x], [W1gT[:D], W1aT[:D], W1gT[D:2 * D], W1aT[D:2 * D]],
+                     [Pn[:, 0:D], Pn[:, D:2 * D], Pn[:, 2 * D:3 * D], Pn[:, 3 * D:]], b_kstrided=True,
                      bias=[P[p + ".MLP_gate.0.bias"], P[p + ".MLP_aggr.0.bias"], None, None])
             pre = _empty((E, 2 * D), dev)         # [gate | sender] pre-activations of the first Linears
-            ops.gemm([e, e], [W1g[:, 2 * D:], W1a[:, 2 * D:]], [pre[:, :D], pre[:, D:]],
+            ops.gemm([e, e], [W1gT[2 * D:], W1aT[2 * D:]], [pre[:, :D], pre[:, D:]], b_kstrided=True,
                      gather_i=[Pn[:, 0:D], Pn[:, D:2 * D]], gather_j=[Pn[:, 2 * D:3 * D], Pn[:, 3 * D:]],
                      tgt=lay.tgt, src=lay.src)
             gs = _empty((E, 2 * D), dev)          # [g (pre-BatchNorm gate) | s (sender)]
             cs, cq = _parts(tiles_e * D, dev), _parts(tiles_e * D, dev)
-            ops.gemm([pre[:, :D], pre[:, D:]], [P[p + ".MLP_gate.2.weight"], P[p + ".MLP_aggr.2.weight"]],
-                     [gs[:, :D], gs[:, D:]], a_act=True, bias=[P[p + ".MLP_gate.2.bias"], P[p + ".MLP_aggr.2.bias"]],
+            ops.gemm([pre[:, :D], pre[:, D:]], [WT[p + ".MLP_gate.2.weight"], WT[p + ".MLP_aggr.2.weight"]],
+                     [gs[:, :D], gs[:, D:]], b_kstrided=True, a_act=True, bias=[P[p + ".MLP_gate.2.bias"], P[p + ".MLP_aggr.2.bias"]],
                      colsum=[cs, None], colsq=[cq, None])
             mr1 = _empty((2 * D,), dev)
             ops.bn_finalize(cs, cq, tiles_e, E, D, BN_EPS, BN_MOMENTUM, training, B[p + ".norm.running_mean"],
@@ -246,7 +277,7 @@ class _CartNetFunction(torch.autograd.Function):
         # ---- head
         H = D // 2
         hid = _empty((N, H), dev)
-        ops.gemm(x, P["head.MLP.0.weight"], hid, bias=P["head.MLP.0.bias"])
+        ops.gemm(x, WT["head.MLP.0.weight"], hid, b_kstrided=True, bias=P["head.MLP.0.bias"])
         if model.cholesky:
             M = int(batch.y.shape[0])
             idx = getattr(batch, "_cartnet_mask_index", None)
@@ -279,7 +310,7 @@ class _CartNetFunction(torch.autograd.Function):
         D, L, H = model.dim_in, model.num_layers, model.dim_in // 2
         dev = dpred.device
         training = st.training
-        G: Dict[str, torch.Tensor] = {}
+        G = _GradBuffer(model, dev)
         dpred = dpred.contiguous()
         nparts_n = ops.node_nparts(N)
 
@@ -290,19 +321,18 @@ class _CartNetFunction(torch.autograd.Function):
             parts = _empty((nparts_n * row,), dev)
             ops.cholesky_head_bwd(st.hid, st.idx, P["head.MLP.2.weight"], st.p6, dpred, dhid, parts)
             tot = _finalize(parts, nparts_n, row)
-            G["head.MLP.2.weight"] = tot[:6 * H].view(6, H)
-            G["head.MLP.2.bias"] = tot[6 * H:6 * H + 6]
-            G["head.MLP.0.bias"] = tot[6 * H + 8:]
+            G.put("head.MLP.2.weight", tot[:6 * H])
+            G.put("head.MLP.2.bias", tot[6 * H:6 * H + 6])
+            G.put("head.MLP.0.bias", tot[6 * H + 8:])
         else:
             row = 2 * H + 8
             parts = _empty((nparts_n * row,), dev)
             ops.scalar_head_bwd(st.hid, P["head.MLP.2.weight"], st.gptr, st.gid, dpred, dhid, parts)
             tot = _finalize(parts, nparts_n, row)
-            G["head.MLP.2.weight"] = tot[:H].view(1, H)
-            G["head.MLP.2.bias"] = tot[H:H + 1]
-            G["head.MLP.0.bias"] = tot[H + 8:]
-        G["head.MLP.0.weight"] = _empty((H, D), dev)
-        _wgrad([dhid], [st.x_final], [G["head.MLP.0.weight"]])
+            G.put("head.MLP.2.weight", tot[:H])
+            G.put("head.MLP.2.bias", tot[H:H + 1])
+            G.put("head.MLP.0.bias", tot[H + 8:])
+        _wgrad([dhid], [st.x_final], [G.out("head.MLP.0.weight")])
         dx = _empty((N, D), dev)
         ops.gemm(dhid, P["head.MLP.0.weight"], dx, b_kstrided=True)
         de = None   # the head does not read the edge features
@@ -320,7 +350,8 @@ class _CartNetFunction(torch.autograd.Function):
             ops.node_update_bwd_stats(aggr, dx, mr2, P[p + ".norm2.weight"], P[p + ".norm2.bias"], pa, pb)
             sums2 = _empty((2 * D,), dev)
             ops.colsum_finalize([pa, pb], nparts_n, [sums2[:D], sums2[D:]])
-            G[p + ".norm2.bias"], G[p + ".norm2.weight"] = sums2[:D], sums2[D:]
+            G.put(p + ".norm2.bias", sums2[:D])
+            G.put(p + ".norm2.weight", sums2[D:])
             daggr = _empty((N, D), dev)
             ops.node_update_bwd_apply(aggr, dx, mr2, P[p + ".norm2.weight"], P[p + ".norm2.bias"], sums2, training,
                                       daggr)
@@ -330,24 +361,21 @@ class _CartNetFunction(torch.autograd.Function):
                                        pb)
             sums1 = _empty((2 * D,), dev)
             ops.colsum_finalize([pa, pb], gparts, [sums1[:D], sums1[D:]])
-            G[p + ".norm.bias"], G[p + ".norm.weight"] = sums1[:D], sums1[D:]
+            G.put(p + ".norm.bias", sums1[:D])
+            G.put(p + ".norm.weight", sums1[D:])
             pdg, pds = _parts(gparts * D, dev), _parts(gparts * D, dev)
             ops.gate_scatter_bwd_apply(gs, de, daggr, env, lay, mr1, P[p + ".norm.weight"], P[p + ".norm.bias"],
                                        sums1, training, pdg, pds)          # gs now holds [dg | ds]
-            G[p + ".MLP_gate.2.bias"], G[p + ".MLP_aggr.2.bias"] = _empty((D,), dev), _empty((D,), dev)
-            ops.colsum_finalize([pdg, pds], gparts, [G[p + ".MLP_gate.2.bias"], G[p + ".MLP_aggr.2.bias"]])
+            ops.colsum_finalize([pdg, pds], gparts, [G.out(p + ".MLP_gate.2.bias"), G.out(p + ".MLP_aggr.2.bias")])
             # second Linears: weight gradients need silu(pre), then pre is overwritten with dpre
-            G[p + ".MLP_gate.2.weight"], G[p + ".MLP_aggr.2.weight"] = _empty((D, D), dev), _empty((D, D), dev)
             _wgrad([gs[:, :D], gs[:, D:]], [pre[:, :D], pre[:, D:]],
-                   [G[p + ".MLP_gate.2.weight"], G[p + ".MLP_aggr.2.weight"]], b_act=True)
+                   [G.out(p + ".MLP_gate.2.weight"), G.out(p + ".MLP_aggr.2.weight")], b_act=True)
             tiles_e = ops.gemm_tiles_m(E)
             csg, csa = _parts(tiles_e * D, dev), _parts(tiles_e * D, dev)
             ops.gemm([gs[:, :D], gs[:, D:]], [W2g, W2a], [pre[:, :D], pre[:, D:]], b_kstrided=True,
                      dact=[pre[:, :D], pre[:, D:]], colsum=[csg, csa])      # pre now holds dpre = [dpre_gate | dpre_aggr]
-            G[p + ".MLP_gate.0.bias"], G[p + ".MLP_aggr.0.bias"] = _empty((D,), dev), _empty((D,), dev)
-            ops.colsum_finalize([csg, csa], tiles_e, [G[p + ".MLP_gate.0.bias"], G[p + ".MLP_aggr.0.bias"]])
-            dW1g, dW1a = _empty((D, 3 * D), dev), _empty((D, 3 * D), dev)
-            G[p + ".MLP_gate.0.weight"], G[p + ".MLP_aggr.0.weight"] = dW1g, dW1a
+            ops.colsum_finalize([csg, csa], tiles_e, [G.out(p + ".MLP_gate.0.bias"), G.out(p + ".MLP_aggr.0.bias")])
+            dW1g, dW1a = G.out(p + ".MLP_gate.0.weight"), G.out(p + ".MLP_aggr.0.weight")
             _wgrad([pre[:, :D], pre[:, D:]], [e_in, e_in], [dW1g[:, 2 * D:], dW1a[:, 2 * D:]])
             # edge features: de_in = de_out + dpre @ W1[:, 2D:]  (layer 0: continue through the encoder's last SiLU)
             de_in = _empty((E, D), dev)
@@ -355,7 +383,7 @@ class _CartNetFunction(torch.autograd.Function):
                 cse = _parts(tiles_e * D, dev)
                 ops.gemm([pre[:, :D], pre[:, D:]], [W1g[:, 2 * D:], W1a[:, 2 * D:]], de_in, b_kstrided=True,
                          segments=True, resid=de, dact=st.e0_pre, colsum=cse)
-                G["encoder.encoder_edge.2.bias"] = _finalize(cse, tiles_e, D)
+                ops.colsum_finalize(cse, tiles_e, G.out("encoder.encoder_edge.2.bias"))
             else:
                 ops.gemm([pre[:, :D], pre[:, D:]], [W1g[:, 2 * D:], W1a[:, 2 * D:]], de_in, b_kstrided=True,
                          segments=True, resid=de)
@@ -371,7 +399,7 @@ class _CartNetFunction(torch.autograd.Function):
             if l == 0 and st.has_atom_mlp:
                 csx = _parts(ops.gemm_tiles_m(N) * D, dev)
                 ops.gemm(segsA, segsB, dx_in, b_kstrided=True, segments=True, resid=dx, dact=st.xa_pre, colsum=csx)
-                G["encoder.encoder_atom.1.bias"] = _finalize(csx, ops.gemm_tiles_m(N), D)
+                ops.colsum_finalize(csx, ops.gemm_tiles_m(N), G.out("encoder.encoder_atom.1.bias"))
             else:
                 ops.gemm(segsA, segsB, dx_in, b_kstrided=True, segments=True, resid=dx)
             dx, de = dx_in, de_in
@@ -381,43 +409,40 @@ class _CartNetFunction(torch.autograd.Function):
         if L == 0:
             raise NotImplementedError("backward with num_layers == 0 is not supported")
         # edges: de now holds d(e0_pre)
-        G["encoder.encoder_edge.2.weight"] = _empty((D, 2 * D), dev)
-        _wgrad([de], [st.he_pre], [G["encoder.encoder_edge.2.weight"]], b_act=True)
+        _wgrad([de], [st.he_pre], [G.out("encoder.encoder_edge.2.weight")], b_act=True)
         tiles_e = ops.gemm_tiles_m(E)
         cs = _parts(tiles_e * 2 * D, dev)
         ops.gemm(de, P["encoder.encoder_edge.2.weight"], st.he_pre, b_kstrided=True, dact=st.he_pre, colsum=cs)
-        G["encoder.encoder_edge.0.bias"] = _finalize(cs, tiles_e, 2 * D)
-        G["encoder.encoder_edge.0.weight"] = _empty((2 * D, st.kf), dev)
-        _wgrad([st.he_pre], [st.feat[:, :st.kf]], [G["encoder.encoder_edge.0.weight"]])
+        ops.colsum_finalize(cs, tiles_e, G.out("encoder.encoder_edge.0.bias"))
+        _wgrad([st.he_pre], [st.feat[:, :st.kf]], [G.out("encoder.encoder_edge.0.weight")])
         # atoms: dx now holds d(xa_pre)
         enc = model.encoder
         if st.has_atom_mlp:
-            G["encoder.encoder_atom.1.weight"] = _empty((D, 2 * D), dev)
-            _wgrad([dx], [st.x0], [G["encoder.encoder_atom.1.weight"]], b_act=True)
+            _wgrad([dx], [st.x0], [G.out("encoder.encoder_atom.1.weight")], b_act=True)
             dx0 = _empty((N, 2 * D), dev)
             ops.gemm(dx, P["encoder.encoder_atom.1.weight"], dx0, b_kstrided=True, dact=st.x0)
             pw, pb = _parts(nparts_n * 2 * D, dev), _parts(nparts_n * 2 * D, dev)
             ops.node_embed_bwd(st.gid if enc.temperature else None, st.T, dx0, pw, pb)
             if enc.atom_types:
-                demb = _empty((N_ATOM_TYPES, 2 * D), dev)
-                ops.segment_sum_long(dx0, st.zptr, st.zperm, N, demb)
-                G["encoder.embedding.weight"] = demb
+                ops.segment_sum_long(dx0, st.zptr, st.zperm, N, G.out("encoder.embedding.weight"))
             if enc.temperature:
-                gw, gb = _empty((2 * D,), dev), _empty((2 * D,), dev)
-                ops.colsum_finalize([pw, pb], nparts_n, [gw, gb])
-                G["encoder.temperature_proj_atom.weight"] = gw.view(2 * D, 1)
-                G["encoder.temperature_proj_atom.bias"] = gb
+                ops.colsum_finalize([pw, pb], nparts_n, [G.out("encoder.temperature_proj_atom.weight").view(-1),
+                                                         G.out("encoder.temperature_proj_atom.bias")])
             else:
-                G["encoder.bias"] = _finalize(pb, nparts_n, 2 * D)
+                ops.colsum_finalize(pb, nparts_n, G.out("encoder.bias"))
         else:
             # x = embedding row repeated for every atom: its gradient is the column sum of dx
             ones = torch.ones(N, 1, device=dev)
-            g1 = _empty((1, D), dev)
-            _wgrad([ones], [dx], [g1])
-            G["encoder.embedding.weight"] = g1
+            _wgrad([ones], [dx], [G.out("encoder.embedding.weight")])
 
-        grads = tuple(G.get(name) for name in model._param_names)
-        return (None, None, None) + grads
+        missing = [n for n in model._param_names if n not in G.written]
+        if missing:
+            raise RuntimeError(f"backward produced no gradient for {missing}")
+        sink = model._flat_grad
+        if sink is not None and sink.numel() == G.flat.numel():
+            sink.add_(G.flat)              # one accumulation into the optimiser's flat gradient buffer
+            return (None, None, None) + (None,) * len(model._param_names)
+        return (None, None, None) + tuple(G[name] for name in model._param_names)
 
 
 class CartNet(nn.Module):
@@ -446,6 +471,8 @@ class CartNet(nn.Module):
         self.head = Cholesky_head(dim_in) if cholesky else Scalar_head(dim_in)
         self.validate_graph = False     # set True to sync-check edge_index ordering / ranges once per batch
         self._param_names = [n for n, _ in self.named_parameters()]
+        self._param_shapes = {n: tuple(p.shape) for n, p in self.named_parameters()}
+        self._flat_grad = None          # set by cartnet_amd.optim.FlatAdam: gradients are accumulated here directly
 
     def forward(self, batch):
         params = [p for _, p in self.named_parameters()]

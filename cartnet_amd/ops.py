@@ -592,6 +592,26 @@ def scalar_head_bwd(hid, w2, graph_ptr, batch, dout, dhid, parts) -> None:
                                                _l.stream_ptr()), "cartnet_scalar_head_bwd")
 
 
+def transpose(srcs: Sequence[Tensor]) -> list:
+    """Returns contiguous transposes of 2-D fp32 views (up to 8 matrices per launch)."""
+    outs = []
+    srcs = list(srcs)
+    for i in range(0, len(srcs), 8):
+        chunk = srcs[i:i + 8]
+        dsts = []
+        for t in chunk:
+            _f32_2d(t, "transpose src")
+            dsts.append(torch.empty((t.shape[1], t.shape[0]), dtype=torch.float32, device=t.device))
+        n = len(chunk)
+        I32 = C.c_int32 * n
+        _l.check(_l.load().cartnet_transpose(
+            _ptr_array(chunk), _ptr_array(dsts), I32(*[int(t.shape[0]) for t in chunk]),
+            I32(*[int(t.shape[1]) for t in chunk]), I32(*[_ld(t) for t in chunk]), I32(*[int(t.shape[0]) for t in chunk]),
+            n, _l.stream_ptr()), "cartnet_transpose")
+        outs.extend(dsts)
+    return outs
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0) -> None:
     n = int(param.numel())
     for name, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):

@@ -36,6 +36,8 @@ class FlatAdam:
                 p.grad = self.flat_grad[off:off + k].view(p.shape)       # autograd accumulates in place into the views
                 off += k
         self.params = params
+        if hasattr(model, "_flat_grad") and len(params) == len(list(model.parameters())):
+            model._flat_grad = self.flat_grad     # CartNet.backward adds its gradients here in one pass
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.step_count = 0
         self.param_groups = [{"lr": self.lr}]     # enough of torch's surface for a scheduler / logger to read lr
