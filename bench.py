@@ -8,8 +8,9 @@ rank per step (weak scaling: every rank owns its own crystals; one 10 MB gradien
 Inputs are resident in HBM before the timed region.
 
 Extra objects on the line:
-  roofline      the dominant kernel (fp32-MFMA NT GEMM, cn_gemm_kernel<0,0,256>) priced live with HIP events on the
-                launch stream over the timed steps: executed 2*M*N*K FLOPs / measured time vs 157.3 TFLOP/s
+  roofline      the dominant kernel (the fp32-MFMA GEMM variant with the largest share of the step) priced live with HIP events on the
+                launch stream over the timed steps (cartnet_profile_gemm): executed 2*M*N*K FLOPs / measured time vs
+                157.3 TFLOP/s
   cpu_baseline  the oracle (CPU restatement of the reference forward + autograd backward) timed on the host cores
                 on a bounded sample (rank 0, N = 1 only)
 """
@@ -130,7 +131,7 @@ def main():
         step(batches[i])
     cdist.barrier()
     torch.cuda.synchronize()
-    ops.TIMER.active = not args.no_kernel_timer
+    ops.profile_gemm(not args.no_kernel_timer)
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(batches[args.warmup + i])
@@ -139,7 +140,7 @@ def main():
     cdist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ops.TIMER.active = False
+    ops.profile_gemm(False)
     dt = cdist.max_over_ranks(dt, dev)
     if not torch.isfinite(loss):
         raise SystemExit("non-finite loss")
@@ -159,7 +160,7 @@ def main():
         "path_tflops_reference_equiv": round(value * FLOPS_REF_PER_GRAPH * (E / args.graphs / 2800.0) / 1e12 / world, 2),
     }
     if rank == 0:
-        summ = ops.TIMER.summary() if not args.no_kernel_timer else {}
+        summ = ops.profile_gemm_read() if not args.no_kernel_timer else {}
         if summ:
             key = max(summ, key=lambda k: summ[k]["ms"])
             d = summ[key]

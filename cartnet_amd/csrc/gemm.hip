@@ -1,6 +1,7 @@
 // Host side of the GEMM entry points + the small deterministic reduction kernels (split-K slabs, partial sums).
 // The MFMA kernel itself is in gemm_kernel.h, instantiated per tile width in gemm_bn{256,128,64}.hip.
 #include "gemm_kernel.h"
+#include <vector>
 
 namespace cn_gemm {
 extern template bool launch_bn<256>(const CartnetGemmArgs&, const GemmFlags&, hipStream_t);
@@ -54,7 +55,70 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+// ---- opt-in launch timing (bench.py): HIP events on the launch stream around every cartnet_gemm call ------------
+namespace {
+struct GemmRecord {
+  int variant;       // bit0 a_kstrided, bit1 b_kstrided, bit2 a_act, bit3 b_act, bits 4.. tile width / 64
+  double flops;
+  hipEvent_t e0, e1;
+};
+bool g_prof_on = false;
+std::vector<GemmRecord> g_prof;
+}  // namespace
+
+static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream);
+
+extern "C" int cartnet_profile_gemm(int32_t enable) {
+  if (enable && !g_prof_on) {
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_prof.clear();
+  }
+  g_prof_on = enable != 0;
+  return 0;
+}
+
+extern "C" int cartnet_profile_gemm_read(CartnetGemmProfile* out, int32_t max_entries) {
+  CN_CHECK(out && max_entries > 0, "cartnet_profile_gemm_read: bad arguments");
+  int n = 0;
+  for (auto& r : g_prof) {
+    if (hipEventSynchronize(r.e1) != hipSuccess) { cartnet_set_error("cartnet_profile_gemm_read: event sync failed"); return -1; }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    int slot = -1;
+    for (int i = 0; i < n; ++i) if (out[i].variant == r.variant) slot = i;
+    if (slot < 0) {
+      if (n == max_entries) continue;
+      slot = n++;
+      out[slot].variant = r.variant;
+      out[slot].launches = 0;
+      out[slot].flops = 0.0;
+      out[slot].ms = 0.0;
+    }
+    out[slot].launches += 1;
+    out[slot].flops += r.flops;
+    out[slot].ms += ms;
+  }
+  return n;
+}
+
 extern "C" int cartnet_gemm(const CartnetGemmArgs* args, void* stream) {
+  if (!g_prof_on || !args) return cartnet_gemm_impl(args, stream);
+  GemmRecord r;
+  const int bn = args->N > 128 ? 4 : (args->N > 64 ? 2 : 1);
+  r.variant = (args->a_kstrided ? 1 : 0) | (args->b_kstrided ? 2 : 0) | (args->a_act ? 4 : 0) | (args->b_act ? 8 : 0) |
+              (bn << 4);
+  const int nptr = args->ngroups > 1 ? args->ngroups : args->nsegs;
+  r.flops = 2.0 * args->M * args->N * (double)args->K * nptr;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return cartnet_gemm_impl(args, stream);
+  (void)hipEventRecord(r.e0, st);
+  const int rc = cartnet_gemm_impl(args, stream);
+  (void)hipEventRecord(r.e1, st);
+  g_prof.push_back(r);
+  return rc;
+}
+
+static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
   CN_CHECK(args != nullptr, "cartnet_gemm: null args");
   CartnetGemmArgs a = *args;
   CN_CHECK(a.M >= 0 && a.N >= 0 && a.K >= 0, "cartnet_gemm: negative shape M=%d N=%d K=%d", a.M, a.N, a.K);

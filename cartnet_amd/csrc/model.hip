@@ -1,0 +1,596 @@
+// Whole-network orchestration: CartNet.forward / backward as one host call each (include/cartnet_hip.h,
+// "Whole-network entry points").  No kernels here -- this file only sequences the launches of the other
+// translation units in the order the reference executes its modules (models/cartnet.py:65-73,142-161,204-274,293-327)
+// and carves every intermediate out of one caller-owned workspace.
+#include "common.h"
+
+namespace {
+
+constexpr int BM_TILE = 128;
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+inline int tiles_m(long long M) { return (int)((M + BM_TILE - 1) / BM_TILE); }
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up(off);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+inline int split_k(long long K, int tiles) {
+  long long s = (512 + tiles - 1) / tiles;
+  if (s > K / 256) s = K / 256;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+inline int wgrad_tiles(int groups, int M, int N) { return groups * ((M + 127) / 128) * (N > 128 ? (N + 255) / 256 : 1); }
+inline size_t wgrad_slab_floats(int groups, long long K, int M, int N) {
+  const int S = split_k(K, wgrad_tiles(groups, M, N));
+  return S > 1 ? (size_t)groups * S * M * N : 0;
+}
+
+struct Work {
+  // graph layout
+  int *src32, *tgt32, *rowptr, *colptr, *perm, *zperm, *zptr, *zstatus, *idx;
+  // encoder
+  float *feat, *env, *he_pre, *e0_pre, *e0, *x0, *xa_pre, *xenc;
+  int kf, ldf;
+  // layers
+  float *pre[CARTNET_MAX_LAYERS], *gs[CARTNET_MAX_LAYERS], *mr1[CARTNET_MAX_LAYERS], *aggr[CARTNET_MAX_LAYERS],
+      *mr2[CARTNET_MAX_LAYERS], *xl[CARTNET_MAX_LAYERS], *el[CARTNET_MAX_LAYERS];
+  // head
+  float *hid, *p6;
+  // transposed weights [in, out]
+  float *edge0T, *edge2T, *atomT, *head0T;
+  float *gate0T[CARTNET_MAX_LAYERS], *aggr0T[CARTNET_MAX_LAYERS], *gate2T[CARTNET_MAX_LAYERS],
+      *aggr2T[CARTNET_MAX_LAYERS];
+  // forward transients
+  float* Pn;
+  double *cs, *cq, *ps, *pq;
+  // backward transients
+  float *dhid, *head_parts, *head_tot, *dx[2], *de[2], *daggr, *sums1, *sums2, *dPn, *dx0, *seg_tmp, *slabs;
+  double *pa, *pb, *pc, *pd, *cs_big;
+  size_t slab_floats;
+  int gparts, nparts_n, tiles_e, tiles_n;
+};
+
+Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_bwd, char* base, size_t* total) {
+  Work w;
+  memset(&w, 0, sizeof(w));
+  Carver c{base};
+  const int D = m.D, L = m.L, H = m.D / 2;
+  const size_t En = (size_t)(E > 0 ? E : 1), Nn = (size_t)(N > 0 ? N : 1);
+  w.kf = m.invariant ? m.R : m.R + 3;
+  w.ldf = (w.kf + 3) / 4 * 4;
+  w.gparts = cartnet_gate_scatter_nparts(N);
+  w.nparts_n = cartnet_node_nparts(N);
+  w.tiles_e = tiles_m(E);
+  w.tiles_n = tiles_m(N);
+  w.src32 = c.take<int>(En);
+  w.tgt32 = c.take<int>(En);
+  w.rowptr = c.take<int>(Nn + 1);
+  w.colptr = c.take<int>(Nn + 1);
+  w.perm = c.take<int>(En);
+  w.zperm = c.take<int>(Nn);
+  w.zptr = c.take<int>((size_t)m.n_types + 2);
+  w.zstatus = c.take<int>(4);
+  w.idx = c.take<int>(Nn);
+  w.feat = c.take<float>(En * w.ldf);
+  w.env = c.take<float>(En);
+  w.he_pre = c.take<float>(En * 2 * D);
+  w.e0_pre = c.take<float>(En * D);
+  w.e0 = c.take<float>(En * D);
+  w.x0 = c.take<float>(Nn * 2 * D);
+  w.xa_pre = c.take<float>(Nn * D);
+  w.xenc = c.take<float>(Nn * D);
+  float* xping[2] = {nullptr, nullptr};
+  float* eping[2] = {nullptr, nullptr};
+  if (!need_bwd) {
+    xping[0] = c.take<float>(Nn * D);
+    xping[1] = c.take<float>(Nn * D);
+    eping[0] = c.take<float>(En * D);
+    eping[1] = c.take<float>(En * D);
+  }
+  for (int l = 0; l < L; ++l) {
+    if (need_bwd || l == 0) {
+      w.pre[l] = c.take<float>(En * 2 * D);
+      w.gs[l] = c.take<float>(En * 2 * D);
+      w.aggr[l] = c.take<float>(Nn * D);
+    } else {
+      w.pre[l] = w.pre[0];
+      w.gs[l] = w.gs[0];
+      w.aggr[l] = w.aggr[0];
+    }
+    w.mr1[l] = c.take<float>(2 * D);
+    w.mr2[l] = c.take<float>(2 * D);
+    if (l < L - 1) {   // the last layer writes straight into the caller's x_out / e_out
+      w.xl[l] = need_bwd ? c.take<float>(Nn * D) : xping[l & 1];
+      w.el[l] = need_bwd ? c.take<float>(En * D) : eping[l & 1];
+    }
+  }
+  w.hid = c.take<float>(Nn * H);
+  w.p6 = c.take<float>((size_t)(M > 0 ? M : 1) * 6);
+  w.edge0T = c.take<float>((size_t)w.kf * 2 * D);
+  w.edge2T = c.take<float>((size_t)2 * D * D);
+  w.atomT = c.take<float>((size_t)2 * D * D);
+  w.head0T = c.take<float>((size_t)D * H);
+  for (int l = 0; l < L; ++l) {
+    w.gate0T[l] = c.take<float>((size_t)3 * D * D);
+    w.aggr0T[l] = c.take<float>((size_t)3 * D * D);
+    w.gate2T[l] = c.take<float>((size_t)D * D);
+    w.aggr2T[l] = c.take<float>((size_t)D * D);
+  }
+  w.Pn = c.take<float>(Nn * 4 * D);
+  const size_t big = (size_t)(w.tiles_e > w.gparts ? w.tiles_e : w.gparts);
+  w.cs = c.take<double>(big * D);
+  w.cq = c.take<double>(big * D);
+  w.ps = c.take<double>((size_t)w.gparts * D);
+  w.pq = c.take<double>((size_t)w.gparts * D);
+  if (need_bwd) {
+    w.dhid = c.take<float>(Nn * H);
+    w.head_parts = c.take<float>((size_t)w.nparts_n * (7 * H + 8));
+    w.head_tot = c.take<float>((size_t)7 * H + 8);
+    w.dx[0] = c.take<float>(Nn * D);
+    w.dx[1] = c.take<float>(Nn * D);
+    w.de[0] = c.take<float>(En * D);
+    w.de[1] = c.take<float>(En * D);
+    w.daggr = c.take<float>(Nn * D);
+    w.sums1 = c.take<float>(2 * D);
+    w.sums2 = c.take<float>(2 * D);
+    w.dPn = c.take<float>(Nn * 4 * D);
+    w.dx0 = c.take<float>(Nn * 2 * D);
+    w.seg_tmp = c.take<float>(Nn * 2 * D);
+    const size_t pmax = (size_t)(w.gparts > w.nparts_n ? w.gparts : w.nparts_n) * 2 * D;
+    w.pa = c.take<double>(pmax);
+    w.pb = c.take<double>(pmax);
+    w.pc = c.take<double>(pmax);
+    w.pd = c.take<double>(pmax);
+    w.cs_big = c.take<double>((size_t)(w.tiles_e > w.tiles_n ? w.tiles_e : w.tiles_n) * 2 * D * 2);
+    size_t sl = 0;
+    auto mx = [&](size_t v) { if (v > sl) sl = v; };
+    mx(wgrad_slab_floats(1, N, H, D));
+    mx(wgrad_slab_floats(2, E, D, D));
+    mx(wgrad_slab_floats(4, N, D, D));
+    mx(wgrad_slab_floats(1, E, D, 2 * D));
+    mx(wgrad_slab_floats(1, E, 2 * D, w.kf));
+    mx(wgrad_slab_floats(1, N, D, 2 * D));
+    w.slab_floats = sl;
+    w.slabs = c.take<float>(sl > 0 ? sl : 1);
+  }
+  *total = align_up(c.off);
+  return w;
+}
+
+inline CartnetGemmArgs gemm_args(int M, int N, int K, int lda, int ldb, int ldc) {
+  CartnetGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = M; a.N = N; a.K = K;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.ngroups = 1; a.nsegs = 1; a.splitk = 1;
+  return a;
+}
+
+#define RUN(call)            \
+  do {                       \
+    int _rc = (call);        \
+    if (_rc != 0) return _rc; \
+  } while (0)
+
+// outs[g] = dY[g]^T @ (silu?)(X[g]): reduction over `K` rows, split over workgroups, slabs summed in fixed order.
+int wgrad(const float* const* dY, int ldy, const float* const* X, int ldx, float* const* outs, int ldo, long long K,
+          int M, int N, int groups, bool b_act, const Work& w, void* st) {
+  if (K <= 0) {   // no rows: the gradient is zero
+    for (int g = 0; g < groups; ++g)
+      for (int r = 0; r < M; ++r)
+        if (hipMemsetAsync(outs[g] + (size_t)r * ldo, 0, sizeof(float) * N, (hipStream_t)st) != hipSuccess) return 2;
+    return 0;
+  }
+  const int S = split_k(K, wgrad_tiles(groups, M, N));
+  CartnetGemmArgs a = gemm_args(M, N, (int)K, ldy, ldx, S > 1 ? N : ldo);
+  a.ngroups = groups;
+  a.a_kstrided = 1;
+  a.b_kstrided = 1;
+  a.b_act = b_act ? 1 : 0;
+  a.splitk = S;
+  const float* slabp[CARTNET_MAX_GROUPS];
+  for (int g = 0; g < groups; ++g) {
+    a.A[g] = dY[g];
+    a.B[g] = X[g];
+    a.C[g] = S > 1 ? w.slabs + (size_t)g * S * M * N : outs[g];
+    slabp[g] = a.C[g];
+  }
+  RUN(cartnet_gemm(&a, st));
+  if (S > 1) RUN(cartnet_splitk_reduce(slabp, outs, groups, S, M, N, ldo, st));
+  return 0;
+}
+
+int check_model(const CartnetModel* m, const CartnetBatch* b, const char* who) {
+  CN_CHECK(m && b, "%s: null model/batch", who);
+  CN_CHECK(m->D >= 8 && m->D % 8 == 0 && m->D / 2 <= 512, "%s: dim_in=%d must be a multiple of 8, <= 1024", who, m->D);
+  CN_CHECK(m->L >= 1 && m->L <= CARTNET_MAX_LAYERS, "%s: num_layers=%d out of range (1..%d)", who, m->L,
+           CARTNET_MAX_LAYERS);
+  CN_CHECK(m->R >= 1, "%s: dim_rbf=%d", who, m->R);
+  CN_CHECK(m->use_temperature || m->atom_types, "%s: a model without atom types and without temperature is not built",
+           who);
+  CN_CHECK(b->N >= 0 && b->E >= 0 && b->Bg >= 1 && b->M >= 0, "%s: bad batch sizes", who);
+  CN_CHECK(b->E < 2147483647LL, "%s: E does not fit int32", who);
+  CN_CHECK((long long)b->E * 2 * m->D < 2147483647LL * 4, "%s: batch too large for 32-bit tile indexing", who);
+  CN_CHECK(b->z && b->batch && b->graph_ptr && (b->edge_index || b->E == 0) && (b->cart_dist || b->E == 0),
+           "%s: null batch pointer", who);
+  CN_CHECK(m->invariant || b->cart_dir || b->E == 0, "%s: cart_dir missing", who);
+  CN_CHECK(!m->use_temperature || b->temperature, "%s: temperature missing", who);
+  CN_CHECK(!m->cholesky || b->non_h_mask, "%s: non_H_mask missing", who);
+  const CartnetParams& p = m->p;
+  CN_CHECK(m->rbf_means && m->rbf_betas && p.atom_w && p.atom_b && p.edge0_w && p.edge0_b && p.edge2_w && p.edge2_b &&
+               p.head0_w && p.head0_b && p.head2_w && p.head2_b,
+           "%s: null parameter", who);
+  CN_CHECK(!m->atom_types || p.embedding, "%s: embedding missing", who);
+  CN_CHECK(!m->use_temperature || (p.temp_w && p.temp_b), "%s: temperature projection missing", who);
+  CN_CHECK(m->use_temperature || p.enc_bias, "%s: encoder.bias missing", who);
+  for (int l = 0; l < m->L; ++l) {
+    const CartnetLayerParams& q = p.layer[l];
+    CN_CHECK(q.gate0_w && q.gate0_b && q.gate2_w && q.gate2_b && q.aggr0_w && q.aggr0_b && q.aggr2_w && q.aggr2_b &&
+                 q.norm_w && q.norm_b && q.norm2_w && q.norm2_b,
+             "%s: null parameter in layer %d", who, l);
+    CN_CHECK(m->buf[l].norm_mean && m->buf[l].norm_var && m->buf[l].norm2_mean && m->buf[l].norm2_var,
+             "%s: null BatchNorm buffer in layer %d", who, l);
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t cartnet_workspace_bytes(const CartnetModel* model, int32_t N, int64_t E, int32_t Bg, int32_t M,
+                                          int32_t need_backward) {
+  if (!model || model->L < 1 || model->L > CARTNET_MAX_LAYERS) return 0;
+  size_t total = 0;
+  carve(*model, N, E, Bg, M, need_backward != 0, nullptr, &total);
+  return total;
+}
+
+extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBatch* batch, void* workspace,
+                                     size_t workspace_bytes, int32_t training, int32_t need_backward, float* pred,
+                                     float* x_out, float* e_out, int32_t* status, void* st) {
+  RUN(check_model(model, batch, "cartnet_model_forward"));
+  const CartnetModel& m = *model;
+  const CartnetBatch& b = *batch;
+  const CartnetParams& P = m.p;
+  CN_CHECK(workspace && pred && x_out && e_out && status, "cartnet_model_forward: null output/workspace");
+  CN_CHECK((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "cartnet_model_forward: workspace must be 256-byte aligned");
+  size_t need = 0;
+  const Work w = carve(m, b.N, b.E, b.Bg, b.M, need_backward != 0, static_cast<char*>(workspace), &need);
+  CN_CHECK(workspace_bytes >= need, "cartnet_model_forward: workspace %zu < required %zu bytes", workspace_bytes, need);
+  const int D = m.D, L = m.L, H = D / 2, N = b.N;
+  const int E = (int)b.E;
+
+  RUN(cartnet_csr_build(b.edge_index, b.E, N, b.graph_ptr, b.Bg, w.src32, w.tgt32, w.rowptr, w.colptr, w.perm, status,
+                        st));
+  // weights -> [in, out]
+  {
+    const float* src[8]; float* dst[8]; int32_t rows[8], cols[8], lds[8], ldd[8];
+    int n = 0;
+    auto flush = [&]() -> int {
+      if (n == 0) return 0;
+      int rc = cartnet_transpose(src, dst, rows, cols, lds, ldd, n, st);
+      n = 0;
+      return rc;
+    };
+    auto add = [&](const float* s, float* d, int r, int c) -> int {
+      src[n] = s; dst[n] = d; rows[n] = r; cols[n] = c; lds[n] = c; ldd[n] = r;
+      if (++n == 8) return flush();
+      return 0;
+    };
+    RUN(add(P.edge0_w, w.edge0T, 2 * D, w.kf));
+    RUN(add(P.edge2_w, w.edge2T, D, 2 * D));
+    RUN(add(P.atom_w, w.atomT, D, 2 * D));
+    RUN(add(P.head0_w, w.head0T, H, D));
+    for (int l = 0; l < L; ++l) {
+      RUN(add(P.layer[l].gate0_w, w.gate0T[l], D, 3 * D));
+      RUN(add(P.layer[l].aggr0_w, w.aggr0T[l], D, 3 * D));
+      RUN(add(P.layer[l].gate2_w, w.gate2T[l], D, D));
+      RUN(add(P.layer[l].aggr2_w, w.aggr2T[l], D, D));
+    }
+    RUN(flush());
+  }
+
+  // ---- encoder, edges (cartnet.py:159)
+  RUN(cartnet_edge_features(b.cart_dist, b.cart_dir, m.rbf_means, m.rbf_betas, b.E, m.R, m.invariant, m.radius,
+                            m.env_radius, w.feat, w.ldf, w.env, st));
+  {
+    CartnetGemmArgs a = gemm_args(E, 2 * D, w.kf, w.ldf, 2 * D, 2 * D);
+    a.A[0] = w.feat; a.B[0] = w.edge0T; a.C[0] = w.he_pre; a.bias[0] = P.edge0_b; a.b_kstrided = 1;
+    RUN(cartnet_gemm(&a, st));
+  }
+  {
+    CartnetGemmArgs a = gemm_args(E, D, 2 * D, 2 * D, D, D);
+    a.A[0] = w.he_pre; a.B[0] = w.edge2T; a.C[0] = w.e0; a.cpre[0] = w.e0_pre; a.bias[0] = P.edge2_b;
+    a.b_kstrided = 1; a.a_act = 1; a.out_act = 1;
+    RUN(cartnet_gemm(&a, st));
+  }
+  // ---- encoder, atoms (cartnet.py:145-154)
+  RUN(cartnet_node_embed(m.atom_types ? b.z : nullptr, m.use_temperature ? b.batch : nullptr,
+                         m.use_temperature ? b.temperature : nullptr, m.atom_types ? P.embedding : nullptr,
+                         m.use_temperature ? P.temp_w : nullptr, m.use_temperature ? P.temp_b : nullptr,
+                         m.use_temperature ? nullptr : P.enc_bias, N, 2 * D, w.x0, st));
+  {
+    CartnetGemmArgs a = gemm_args(N, D, 2 * D, 2 * D, D, D);
+    a.A[0] = w.x0; a.B[0] = w.atomT; a.C[0] = w.xenc; a.cpre[0] = w.xa_pre; a.bias[0] = P.atom_b;
+    a.b_kstrided = 1; a.a_act = 1; a.out_act = 1;
+    RUN(cartnet_gemm(&a, st));
+  }
+  if (need_backward && m.atom_types)
+    RUN(cartnet_sort_by_key(b.z, N, m.n_types, w.zperm, w.zptr, w.zstatus, st));
+
+  // ---- message-passing layers (cartnet.py:204-274)
+  const float* x = w.xenc;
+  const float* e = w.e0;
+  for (int l = 0; l < L; ++l) {
+    const CartnetLayerParams& q = P.layer[l];
+    float* x_next = (l == L - 1) ? x_out : w.xl[l];
+    float* e_next = (l == L - 1) ? e_out : w.el[l];
+    {  // node-side halves of the first Linears: Pn = [gate_i | aggr_i | gate_j | aggr_j]
+      CartnetGemmArgs a = gemm_args(N, D, D, D, D, 4 * D);
+      a.ngroups = 4; a.b_kstrided = 1;
+      const float* Bt[4] = {w.gate0T[l], w.aggr0T[l], w.gate0T[l] + (size_t)D * D, w.aggr0T[l] + (size_t)D * D};
+      for (int g = 0; g < 4; ++g) { a.A[g] = x; a.B[g] = Bt[g]; a.C[g] = w.Pn + (size_t)g * D; }
+      a.bias[0] = q.gate0_b; a.bias[1] = q.aggr0_b;
+      RUN(cartnet_gemm(&a, st));
+    }
+    {  // pre = e W1e^T + Pn_i[tgt] + Pn_j[src]
+      CartnetGemmArgs a = gemm_args(E, D, D, D, D, 2 * D);
+      a.ngroups = 2; a.b_kstrided = 1;
+      a.A[0] = e; a.A[1] = e;
+      a.B[0] = w.gate0T[l] + (size_t)2 * D * D; a.B[1] = w.aggr0T[l] + (size_t)2 * D * D;
+      a.C[0] = w.pre[l]; a.C[1] = w.pre[l] + D;
+      a.gather_i[0] = w.Pn; a.gather_i[1] = w.Pn + D; a.gather_j[0] = w.Pn + 2 * D; a.gather_j[1] = w.Pn + 3 * D;
+      a.ldg = 4 * D; a.tgt = w.tgt32; a.src = w.src32;
+      RUN(cartnet_gemm(&a, st));
+    }
+    {  // gs = silu(pre) W2^T + b2, BatchNorm statistics of the gate half
+      CartnetGemmArgs a = gemm_args(E, D, D, 2 * D, D, 2 * D);
+      a.ngroups = 2; a.b_kstrided = 1; a.a_act = 1;
+      a.A[0] = w.pre[l]; a.A[1] = w.pre[l] + D; a.B[0] = w.gate2T[l]; a.B[1] = w.aggr2T[l];
+      a.C[0] = w.gs[l]; a.C[1] = w.gs[l] + D; a.bias[0] = q.gate2_b; a.bias[1] = q.aggr2_b;
+      a.colsum[0] = w.cs; a.colsq[0] = w.cq;
+      RUN(cartnet_gemm(&a, st));
+    }
+    RUN(cartnet_bn_finalize(w.cs, w.cq, w.tiles_e, b.E, D, m.bn_eps, m.bn_momentum, training, m.buf[l].norm_mean,
+                            m.buf[l].norm_var, m.buf[l].norm_nbt, w.mr1[l], st));
+    RUN(cartnet_gate_scatter_fwd(w.gs[l], e, m.use_envelope[l] ? w.env : nullptr, w.rowptr, w.mr1[l], q.norm_w,
+                                 q.norm_b, N, D, e_next, w.aggr[l], w.ps, w.pq, st));
+    RUN(cartnet_bn_finalize(w.ps, w.pq, w.gparts, N, D, m.bn_eps, m.bn_momentum, training, m.buf[l].norm2_mean,
+                            m.buf[l].norm2_var, m.buf[l].norm2_nbt, w.mr2[l], st));
+    RUN(cartnet_node_update_fwd(w.aggr[l], x, w.mr2[l], q.norm2_w, q.norm2_b, N, D, x_next, st));
+    x = x_next;
+    e = e_next;
+  }
+
+  // ---- head
+  {
+    CartnetGemmArgs a = gemm_args(N, H, D, D, H, H);
+    a.A[0] = x; a.B[0] = w.head0T; a.C[0] = w.hid; a.bias[0] = P.head0_b; a.b_kstrided = 1;
+    RUN(cartnet_gemm(&a, st));
+  }
+  if (m.cholesky) {
+    RUN(cartnet_mask_index(b.non_h_mask, N, w.idx, nullptr, st));
+    RUN(cartnet_cholesky_head_fwd(w.hid, w.idx, P.head2_w, P.head2_b, N, H, w.p6, pred, st));
+  } else {
+    RUN(cartnet_scalar_head_fwd(w.hid, P.head2_w, P.head2_b, b.graph_ptr, b.Bg, H, pred, st));
+  }
+  return 0;
+}
+
+extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBatch* batch, void* workspace,
+                                      size_t workspace_bytes, int32_t training, const float* dpred, const float* x_out,
+                                      const CartnetParams* grads, void* st) {
+  RUN(check_model(model, batch, "cartnet_model_backward"));
+  const CartnetModel& m = *model;
+  const CartnetBatch& b = *batch;
+  const CartnetParams& P = m.p;
+  CN_CHECK(workspace && dpred && x_out && grads, "cartnet_model_backward: null argument");
+  const CartnetParams& G = *grads;
+  CN_CHECK(G.atom_w && G.atom_b && G.edge0_w && G.edge0_b && G.edge2_w && G.edge2_b && G.head0_w && G.head0_b &&
+               G.head2_w && G.head2_b && (!m.atom_types || G.embedding) &&
+               (!m.use_temperature || (G.temp_w && G.temp_b)) && (m.use_temperature || G.enc_bias),
+           "cartnet_model_backward: a gradient destination is missing");
+  size_t need = 0;
+  const Work w = carve(m, b.N, b.E, b.Bg, b.M, true, static_cast<char*>(workspace), &need);
+  CN_CHECK(workspace_bytes >= need, "cartnet_model_backward: workspace %zu < required %zu bytes", workspace_bytes, need);
+  const int D = m.D, L = m.L, H = D / 2, N = b.N;
+  const int E = (int)b.E;
+
+  // ---- head
+  {
+    const int row = m.cholesky ? 7 * H + 8 : 2 * H + 8;
+    if (m.cholesky)
+      RUN(cartnet_cholesky_head_bwd(w.hid, w.idx, P.head2_w, w.p6, dpred, N, H, w.dhid, w.head_parts, st));
+    else
+      RUN(cartnet_scalar_head_bwd(w.hid, P.head2_w, b.graph_ptr, b.batch, dpred, N, b.Bg, H, w.dhid, w.head_parts, st));
+    RUN(cartnet_colsum_finalize_f32(w.head_parts, w.nparts_n, row, w.head_tot, st));
+    const int nw2 = m.cholesky ? 6 * H : H, nb2 = m.cholesky ? 6 : 1;
+    hipStream_t hs = (hipStream_t)st;
+    if (hipMemcpyAsync(G.head2_w, w.head_tot, sizeof(float) * nw2, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
+        hipMemcpyAsync(G.head2_b, w.head_tot + nw2, sizeof(float) * nb2, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
+        hipMemcpyAsync(G.head0_b, w.head_tot + nw2 + 8, sizeof(float) * H, hipMemcpyDeviceToDevice, hs) != hipSuccess) {
+      cartnet_set_error("cartnet_model_backward: head gradient copy failed");
+      return 2;
+    }
+    const float* dY[1] = {w.dhid};
+    const float* X[1] = {x_out};
+    float* o[1] = {G.head0_w};
+    RUN(wgrad(dY, H, X, D, o, D, N, H, D, 1, false, w, st));
+    CartnetGemmArgs a = gemm_args(N, D, H, H, D, D);
+    a.A[0] = w.dhid; a.B[0] = P.head0_w; a.C[0] = w.dx[0]; a.b_kstrided = 1;
+    RUN(cartnet_gemm(&a, st));
+  }
+  float* dx = w.dx[0];
+  float* dx_other = w.dx[1];
+  float* de = nullptr;   // the head does not read the edge features
+  int de_slot = 0;
+
+  // ---- layers, last to first
+  for (int l = L - 1; l >= 0; --l) {
+    const CartnetLayerParams& q = P.layer[l];
+    const CartnetLayerParams& gq = G.layer[l];
+    CN_CHECK(gq.gate0_w && gq.gate0_b && gq.gate2_w && gq.gate2_b && gq.aggr0_w && gq.aggr0_b && gq.aggr2_w &&
+                 gq.aggr2_b && gq.norm_w && gq.norm_b && gq.norm2_w && gq.norm2_b,
+             "cartnet_model_backward: gradient destination missing in layer %d", l);
+    const float* x_in = (l == 0) ? w.xenc : w.xl[l - 1];
+    const float* e_in = (l == 0) ? w.e0 : w.el[l - 1];
+    const float* env = m.use_envelope[l] ? w.env : nullptr;
+    float* pre = w.pre[l];
+    float* gs = w.gs[l];
+    // node update: x_out = silu(bn2(aggr)) + x_in
+    RUN(cartnet_node_update_bwd_stats(w.aggr[l], dx, w.mr2[l], q.norm2_w, q.norm2_b, N, D, w.pa, w.pb, st));
+    {
+      const double* parts[2] = {w.pa, w.pb};
+      float* outs[2] = {w.sums2, w.sums2 + D};
+      RUN(cartnet_colsum_finalize(parts, outs, 2, w.nparts_n, D, st));
+    }
+    hipStream_t hs = (hipStream_t)st;
+    if (hipMemcpyAsync(gq.norm2_b, w.sums2, sizeof(float) * D, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
+        hipMemcpyAsync(gq.norm2_w, w.sums2 + D, sizeof(float) * D, hipMemcpyDeviceToDevice, hs) != hipSuccess) {
+      cartnet_set_error("cartnet_model_backward: norm2 gradient copy failed");
+      return 2;
+    }
+    RUN(cartnet_node_update_bwd_apply(w.aggr[l], dx, w.mr2[l], q.norm2_w, q.norm2_b, w.sums2, training, N, D, w.daggr,
+                                      st));
+    // gate * sender aggregation and the edge BatchNorm
+    RUN(cartnet_gate_scatter_bwd_stats(gs, de, w.daggr, env, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, N, D, w.pa, w.pb,
+                                       st));
+    {
+      const double* parts[2] = {w.pa, w.pb};
+      float* outs[2] = {w.sums1, w.sums1 + D};
+      RUN(cartnet_colsum_finalize(parts, outs, 2, w.gparts, D, st));
+    }
+    if (hipMemcpyAsync(gq.norm_b, w.sums1, sizeof(float) * D, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
+        hipMemcpyAsync(gq.norm_w, w.sums1 + D, sizeof(float) * D, hipMemcpyDeviceToDevice, hs) != hipSuccess) {
+      cartnet_set_error("cartnet_model_backward: norm gradient copy failed");
+      return 2;
+    }
+    RUN(cartnet_gate_scatter_bwd_apply(gs, de, w.daggr, env, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, w.sums1, b.E,
+                                       training, N, D, w.pc, w.pd, st));   // gs = [dg | ds]
+    {
+      const double* parts[2] = {w.pc, w.pd};
+      float* outs[2] = {gq.gate2_b, gq.aggr2_b};
+      RUN(cartnet_colsum_finalize(parts, outs, 2, w.gparts, D, st));
+    }
+    {  // second Linears: weight gradients need silu(pre); then pre is overwritten with dpre
+      const float* dY[2] = {gs, gs + D};
+      const float* X[2] = {pre, pre + D};
+      float* o[2] = {gq.gate2_w, gq.aggr2_w};
+      RUN(wgrad(dY, 2 * D, X, 2 * D, o, D, b.E, D, D, 2, true, w, st));
+    }
+    double* csg = w.cs_big;
+    double* csa = w.cs_big + (size_t)w.tiles_e * D;
+    {
+      CartnetGemmArgs a = gemm_args(E, D, D, 2 * D, D, 2 * D);
+      a.ngroups = 2; a.b_kstrided = 1;
+      a.A[0] = gs; a.A[1] = gs + D; a.B[0] = q.gate2_w; a.B[1] = q.aggr2_w;
+      a.C[0] = pre; a.C[1] = pre + D; a.dact[0] = pre; a.dact[1] = pre + D; a.ldd = 2 * D;
+      a.colsum[0] = csg; a.colsum[1] = csa;
+      RUN(cartnet_gemm(&a, st));     // pre = dpre = [dpre_gate | dpre_aggr]
+    }
+    {
+      const double* parts[2] = {csg, csa};
+      float* outs[2] = {gq.gate0_b, gq.aggr0_b};
+      RUN(cartnet_colsum_finalize(parts, outs, 2, w.tiles_e, D, st));
+    }
+    {
+      const float* dY[2] = {pre, pre + D};
+      const float* X[2] = {e_in, e_in};
+      float* o[2] = {gq.gate0_w + 2 * D, gq.aggr0_w + 2 * D};
+      RUN(wgrad(dY, 2 * D, X, D, o, 3 * D, b.E, D, D, 2, false, w, st));
+    }
+    // edge features: de_in = de_out + dpre @ W1[:, 2D:]  (layer 0: continue through the encoder's last SiLU)
+    float* de_in = w.de[de_slot];
+    {
+      CartnetGemmArgs a = gemm_args(E, D, D, 2 * D, 3 * D, D);
+      a.nsegs = 2; a.b_kstrided = 1;
+      a.A[0] = pre; a.A[1] = pre + D; a.B[0] = q.gate0_w + 2 * D; a.B[1] = q.aggr0_w + 2 * D;
+      a.C[0] = de_in; a.resid[0] = de; a.ldr = D;
+      if (l == 0) { a.dact[0] = w.e0_pre; a.ldd = D; a.colsum[0] = w.cs_big; }
+      RUN(cartnet_gemm(&a, st));
+      if (l == 0) {
+        const double* parts[1] = {w.cs_big};
+        float* outs[1] = {G.edge2_b};
+        RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_e, D, st));
+      }
+    }
+    // node-side halves: reduce dpre over each atom's incoming (target) and outgoing (source) edges
+    RUN(cartnet_segment_sum(pre, 2 * D, w.rowptr, nullptr, N, 2 * D, w.dPn, 4 * D, st));
+    RUN(cartnet_segment_sum(pre, 2 * D, w.colptr, w.perm, N, 2 * D, w.dPn + 2 * D, 4 * D, st));
+    {
+      const float* dY[4] = {w.dPn, w.dPn + D, w.dPn + 2 * D, w.dPn + 3 * D};
+      const float* X[4] = {x_in, x_in, x_in, x_in};
+      float* o[4] = {gq.gate0_w, gq.aggr0_w, gq.gate0_w + D, gq.aggr0_w + D};
+      RUN(wgrad(dY, 4 * D, X, D, o, 3 * D, N, D, D, 4, false, w, st));
+    }
+    {
+      CartnetGemmArgs a = gemm_args(N, D, D, 4 * D, 3 * D, D);
+      a.nsegs = 4; a.b_kstrided = 1;
+      a.A[0] = w.dPn; a.A[1] = w.dPn + D; a.A[2] = w.dPn + 2 * D; a.A[3] = w.dPn + 3 * D;
+      a.B[0] = q.gate0_w; a.B[1] = q.aggr0_w; a.B[2] = q.gate0_w + D; a.B[3] = q.aggr0_w + D;
+      a.C[0] = dx_other; a.resid[0] = dx; a.ldr = D;
+      if (l == 0) { a.dact[0] = w.xa_pre; a.ldd = D; a.colsum[0] = w.cs_big; }
+      RUN(cartnet_gemm(&a, st));
+      if (l == 0) {
+        const double* parts[1] = {w.cs_big};
+        float* outs[1] = {G.atom_b};
+        RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_n, D, st));
+      }
+    }
+    float* t = dx; dx = dx_other; dx_other = t;
+    de = de_in;
+    de_slot ^= 1;
+  }
+
+  // ---- encoder: de = d(e0_pre), dx = d(xa_pre)
+  {
+    const float* dY[1] = {de};
+    const float* X[1] = {w.he_pre};
+    float* o[1] = {G.edge2_w};
+    RUN(wgrad(dY, D, X, 2 * D, o, 2 * D, b.E, D, 2 * D, 1, true, w, st));
+    CartnetGemmArgs a = gemm_args(E, 2 * D, D, D, 2 * D, 2 * D);
+    a.A[0] = de; a.B[0] = P.edge2_w; a.C[0] = w.he_pre; a.dact[0] = w.he_pre; a.ldd = 2 * D; a.b_kstrided = 1;
+    a.colsum[0] = w.cs_big;
+    RUN(cartnet_gemm(&a, st));       // he_pre = d(he_pre)
+    const double* parts[1] = {w.cs_big};
+    float* outs[1] = {G.edge0_b};
+    RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_e, 2 * D, st));
+    const float* dY2[1] = {w.he_pre};
+    const float* X2[1] = {w.feat};
+    float* o2[1] = {G.edge0_w};
+    RUN(wgrad(dY2, 2 * D, X2, w.ldf, o2, w.kf, b.E, 2 * D, w.kf, 1, false, w, st));
+  }
+  {
+    const float* dY[1] = {dx};
+    const float* X[1] = {w.x0};
+    float* o[1] = {G.atom_w};
+    RUN(wgrad(dY, D, X, 2 * D, o, 2 * D, N, D, 2 * D, 1, true, w, st));
+    CartnetGemmArgs a = gemm_args(N, 2 * D, D, D, 2 * D, 2 * D);
+    a.A[0] = dx; a.B[0] = P.atom_w; a.C[0] = w.dx0; a.dact[0] = w.x0; a.ldd = 2 * D; a.b_kstrided = 1;
+    RUN(cartnet_gemm(&a, st));
+    RUN(cartnet_node_embed_bwd(m.use_temperature ? b.batch : nullptr, m.use_temperature ? b.temperature : nullptr, w.dx0,
+                               N, 2 * D, w.pa, w.pb, st));
+    if (m.use_temperature) {
+      const double* parts[2] = {w.pa, w.pb};
+      float* outs[2] = {G.temp_w, G.temp_b};
+      RUN(cartnet_colsum_finalize(parts, outs, 2, w.nparts_n, 2 * D, st));
+    } else {
+      const double* parts[1] = {w.pb};
+      float* outs[1] = {G.enc_bias};
+      RUN(cartnet_colsum_finalize(parts, outs, 1, w.nparts_n, 2 * D, st));
+    }
+    if (m.atom_types)
+      RUN(cartnet_segment_sum_long(w.dx0, 2 * D, w.zptr, w.zperm, m.n_types, N, 2 * D, w.seg_tmp, G.embedding, 2 * D,
+                                   st));
+  }
+  return 0;
+}

@@ -41,6 +41,58 @@ class GemmArgs(C.Structure):
     ]
 
 
+MAX_LAYERS = 16
+
+
+class GemmProfile(C.Structure):
+    _fields_ = [("variant", C.c_int32), ("launches", C.c_int64), ("flops", C.c_double), ("ms", C.c_double)]
+
+_LAYER_PARAM_FIELDS = ["gate0_w", "gate0_b", "gate2_w", "gate2_b", "aggr0_w", "aggr0_b", "aggr2_w", "aggr2_b",
+                       "norm_w", "norm_b", "norm2_w", "norm2_b"]
+# CartnetLayerParams field -> suffix of the reference state_dict key under "layers.{l}."
+LAYER_PARAM_KEYS = {"gate0_w": "MLP_gate.0.weight", "gate0_b": "MLP_gate.0.bias", "gate2_w": "MLP_gate.2.weight",
+                    "gate2_b": "MLP_gate.2.bias", "aggr0_w": "MLP_aggr.0.weight", "aggr0_b": "MLP_aggr.0.bias",
+                    "aggr2_w": "MLP_aggr.2.weight", "aggr2_b": "MLP_aggr.2.bias", "norm_w": "norm.weight",
+                    "norm_b": "norm.bias", "norm2_w": "norm2.weight", "norm2_b": "norm2.bias"}
+# CartnetParams field -> reference state_dict key
+PARAM_KEYS = {"embedding": "encoder.embedding.weight", "temp_w": "encoder.temperature_proj_atom.weight",
+              "temp_b": "encoder.temperature_proj_atom.bias", "enc_bias": "encoder.bias",
+              "atom_w": "encoder.encoder_atom.1.weight", "atom_b": "encoder.encoder_atom.1.bias",
+              "edge0_w": "encoder.encoder_edge.0.weight", "edge0_b": "encoder.encoder_edge.0.bias",
+              "edge2_w": "encoder.encoder_edge.2.weight", "edge2_b": "encoder.encoder_edge.2.bias",
+              "head0_w": "head.MLP.0.weight", "head0_b": "head.MLP.0.bias", "head2_w": "head.MLP.2.weight",
+              "head2_b": "head.MLP.2.bias"}
+
+
+class LayerParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _LAYER_PARAM_FIELDS]
+
+
+class LayerBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("norm_mean", "norm_var", "norm_nbt", "norm2_mean", "norm2_var", "norm2_nbt")]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("embedding", "temp_w", "temp_b", "enc_bias", "atom_w", "atom_b", "edge0_w",
+                                          "edge0_b", "edge2_w", "edge2_b")] + \
+               [("layer", LayerParams * MAX_LAYERS)] + \
+               [(n, C.c_void_p) for n in ("head0_w", "head0_b", "head2_w", "head2_b")]
+
+
+class Model(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("D", "R", "L", "invariant", "use_temperature", "atom_types", "cholesky",
+                                         "n_types")] + \
+               [("use_envelope", C.c_int32 * MAX_LAYERS)] + \
+               [(n, C.c_float) for n in ("radius", "env_radius", "bn_eps", "bn_momentum")] + \
+               [("rbf_means", C.c_void_p), ("rbf_betas", C.c_void_p), ("p", Params), ("buf", LayerBuffers * MAX_LAYERS)]
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("z", "batch", "graph_ptr", "edge_index", "temperature", "cart_dist",
+                                          "cart_dir", "non_h_mask")] + \
+               [("N", C.c_int32), ("Bg", C.c_int32), ("M", C.c_int32), ("E", C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/cartnet_hip.h declares
 PROTOTYPES = {
     "cartnet_last_error": (C.c_char_p, []),
@@ -90,6 +142,13 @@ PROTOTYPES = {
                                           c_f32p, c_f32p, c_stream]),
     "cartnet_transpose": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, c_stream]),
+    "cartnet_profile_gemm": (C.c_int, [C.c_int32]),
+    "cartnet_profile_gemm_read": (C.c_int, [C.POINTER(GemmProfile), C.c_int32]),
+    "cartnet_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "cartnet_model_forward": (C.c_int, [C.POINTER(Model), C.POINTER(BatchDesc), C.c_void_p, C.c_size_t, C.c_int32,
+                                        C.c_int32, c_f32p, c_f32p, c_f32p, c_i32p, c_stream]),
+    "cartnet_model_backward": (C.c_int, [C.POINTER(Model), C.POINTER(BatchDesc), C.c_void_p, C.c_size_t, C.c_int32,
+                                         c_f32p, c_f32p, C.POINTER(Params), c_stream]),
     "cartnet_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_int32, C.c_float, c_stream]),
 }

@@ -17,26 +17,24 @@ from . import lib as _l
 Tensor = torch.Tensor
 
 
-class KernelTimer:
-    """HIP-event timing of GEMM launches on torch's current stream (the stream the kernels are enqueued on).
-    bench.py uses it to price the dominant kernel inside the timed region: events are recorded around every
-    cartnet_gemm launch while ``active``; ``summary()`` (after a device sync) returns per-variant totals."""
-
-    def __init__(self):
-        self.records = []
-        self.active = False
-
-    def summary(self):
-        out = {}
-        for key, flops, e0, e1 in self.records:
-            d = out.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0})
-            d["launches"] += 1
-            d["flops"] += flops
-            d["ms"] += e0.elapsed_time(e1)
-        return out
+def profile_gemm(enable: bool) -> None:
+    """Start / stop HIP-event timing of every cartnet_gemm launch (see include/cartnet_hip.h)."""
+    _l.check(_l.load().cartnet_profile_gemm(int(enable)), "cartnet_profile_gemm")
 
 
-TIMER = KernelTimer()
+def profile_gemm_read() -> dict:
+    """Per-variant totals {name: {launches, flops, ms}} of the launches recorded since profiling was enabled."""
+    buf = (_l.GemmProfile * 64)()
+    n = _l.load().cartnet_profile_gemm_read(buf, 64)
+    if n < 0:
+        _l.check(1, "cartnet_profile_gemm_read")
+    out = {}
+    for i in range(n):
+        v = buf[i].variant
+        name = ("tn" if v & 1 else ("nn" if v & 2 else "nt")) + str(64 * (v >> 4)) + ("+silu(A)" if v & 4 else "") + \
+            ("+silu(B)" if v & 8 else "")
+        out[name] = {"launches": int(buf[i].launches), "flops": float(buf[i].flops), "ms": float(buf[i].ms)}
+    return out
 
 
 def _f32_2d(t: Tensor, name: str) -> None:
@@ -173,14 +171,6 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
                 continue
             _vec(t, tiles_m * N, f"gemm {name}[{g}]", torch.float64)
             getattr(args, field)[g] = t.data_ptr()
-    if TIMER.active:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _l.check(lib.cartnet_gemm(C.byref(args), _l.stream_ptr()), "cartnet_gemm")
-        e1.record()
-        key = ("tn" if a_kstrided else ("nn" if b_kstrided else "nt")) + ("256" if N > 128 else "128" if N > 64 else "64")
-        TIMER.records.append((key, 2.0 * M * N * K * nptr, e0, e1))
-        return
     _l.check(lib.cartnet_gemm(C.byref(args), _l.stream_ptr()), "cartnet_gemm")
 
 
@@ -266,18 +256,22 @@ class GraphLayout:
 
     def validate(self) -> None:
         """Host check of the device status word (one sync; call once per batch in debug / tests)."""
-        s = int(self.status.item())
-        if s:
-            why = []
-            if s & 1:
-                why.append("edge_index[1] is not sorted ascending")
-            if s & 2:
-                why.append("an index is outside [0, N)")
-            if s & 4:
-                why.append("an edge connects two different crystals")
-            if s & 8:
-                why.append("a crystal has more than 8192 atoms")
-            raise ValueError("invalid graph: " + "; ".join(why))
+        raise_on_graph_status(int(self.status.item()))
+
+
+def raise_on_graph_status(s: int) -> None:
+    """Decode the status word cartnet_csr_build leaves on the device."""
+    if s:
+        why = []
+        if s & 1:
+            why.append("edge_index[1] is not sorted ascending")
+        if s & 2:
+            why.append("an index is outside [0, N)")
+        if s & 4:
+            why.append("an edge connects two different crystals")
+        if s & 8:
+            why.append("a crystal has more than 8192 atoms")
+        raise ValueError("invalid graph: " + "; ".join(why))
 
 
 def edge_features(cart_dist: Tensor, cart_dir: Optional[Tensor], means: Tensor, betas: Tensor, invariant: bool,

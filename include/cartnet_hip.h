@@ -15,6 +15,7 @@
 #ifndef CARTNET_HIP_H
 #define CARTNET_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -74,6 +75,19 @@ typedef struct CartnetGemmArgs {
 } CartnetGemmArgs;
 
 int cartnet_gemm(const CartnetGemmArgs* args, void* stream);
+
+/* Opt-in timing of cartnet_gemm launches (the only process-global state in the library; used by bench.py):
+ * while enabled, every cartnet_gemm call -- also those issued inside cartnet_model_forward/backward -- is bracketed
+ * by HIP events on its launch stream.  cartnet_profile_gemm_read waits for the events and returns per-variant totals
+ * (variant: bit0 a_kstrided, bit1 b_kstrided, bit2 a_act, bit3 b_act, bits 4.. = tile width / 64). */
+typedef struct CartnetGemmProfile {
+  int32_t variant;
+  int64_t launches;
+  double flops;      /* executed: sum of 2*M*N*K*(groups or segments) */
+  double ms;
+} CartnetGemmProfile;
+int cartnet_profile_gemm(int32_t enable);
+int cartnet_profile_gemm_read(CartnetGemmProfile* out, int32_t max_entries);
 
 /* For each job j < njobs (<= 4; host arrays of device pointers):
  * outs[j][m*ldo + n] = sum_{s<splitk} slabs[j][s*M*N + m*N + n]  (fixed order s = 0..splitk-1). */
@@ -225,6 +239,80 @@ int cartnet_scalar_head_bwd(const float* hid, const float* w2, const int64_t* gr
  * once per forward so that forward GEMMs read them with b_kstrided = 1 (coalesced rows). */
 int cartnet_transpose(const float* const* src, float* const* dst, const int32_t* rows, const int32_t* cols,
                       const int32_t* lds, const int32_t* ldd, int32_t njobs, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------------
+ * Whole-network entry points: CartNet.forward (models/cartnet.py:65-73) and its backward as ONE host call each.
+ * They enqueue the kernels above in the order the reference executes its layers; nothing else happens on the host
+ * (no allocation, no synchronisation), so a training step costs two ABI calls and can be captured in a hipGraph.
+ *
+ * CartnetModel: borrowed pointers to every parameter / buffer in the reference's state_dict layout.
+ * CartnetGrads: one output pointer per parameter (same fields), each receiving a FRESH gradient (not accumulated).
+ * CartnetBatch: the PyG batch attributes the model reads + sizes.
+ * Workspace: one caller-owned device buffer of cartnet_workspace_bytes(...) bytes, 256-byte aligned.  It holds every
+ *   intermediate including what backward needs, so it must stay untouched between forward and backward of a batch.
+ * ---------------------------------------------------------------------------------------------------- */
+#define CARTNET_MAX_LAYERS 16
+
+typedef struct CartnetLayerParams {
+  float* gate0_w; float* gate0_b; float* gate2_w; float* gate2_b;     /* MLP_gate.0 [D,3D], MLP_gate.2 [D,D] */
+  float* aggr0_w; float* aggr0_b; float* aggr2_w; float* aggr2_b;     /* MLP_aggr.*                           */
+  float* norm_w; float* norm_b; float* norm2_w; float* norm2_b;       /* BatchNorm affine                     */
+} CartnetLayerParams;
+
+typedef struct CartnetLayerBuffers {
+  float* norm_mean; float* norm_var; int64_t* norm_nbt;               /* running statistics (updated in training) */
+  float* norm2_mean; float* norm2_var; int64_t* norm2_nbt;
+} CartnetLayerBuffers;
+
+typedef struct CartnetParams {                  /* used both for parameters (inputs) and for gradients (outputs) */
+  float* embedding;                             /* [n_types, 2D] or NULL                 */
+  float* temp_w; float* temp_b;                 /* temperature_proj_atom [2D,1], [2D] or NULL */
+  float* enc_bias;                              /* encoder.bias [2D] or NULL             */
+  float* atom_w; float* atom_b;                 /* encoder_atom.1 [D,2D], [D]            */
+  float* edge0_w; float* edge0_b;               /* encoder_edge.0 [2D,R(+3)], [2D]       */
+  float* edge2_w; float* edge2_b;               /* encoder_edge.2 [D,2D], [D]            */
+  CartnetLayerParams layer[CARTNET_MAX_LAYERS];
+  float* head0_w; float* head0_b;               /* head.MLP.0 [D/2,D], [D/2]             */
+  float* head2_w; float* head2_b;               /* head.MLP.2 [6 or 1, D/2]              */
+} CartnetParams;
+
+typedef struct CartnetModel {
+  int32_t D, R, L;                              /* dim_in, dim_rbf, num_layers                       */
+  int32_t invariant, use_temperature, atom_types, cholesky, n_types;
+  int32_t use_envelope[CARTNET_MAX_LAYERS];
+  float radius, env_radius, bn_eps, bn_momentum;
+  const float* rbf_means; const float* rbf_betas;
+  CartnetParams p;
+  CartnetLayerBuffers buf[CARTNET_MAX_LAYERS];
+} CartnetModel;
+
+typedef struct CartnetBatch {
+  const int64_t* z;            /* [N] atomic numbers                                  */
+  const int64_t* batch;        /* [N] crystal of each atom (sorted)                   */
+  const int64_t* graph_ptr;    /* [Bg+1] atom offsets per crystal                     */
+  const int64_t* edge_index;   /* [2,E], row 1 (target) sorted ascending              */
+  const float* temperature;    /* [Bg] or NULL                                        */
+  const float* cart_dist;      /* [E]                                                 */
+  const float* cart_dir;       /* [E,3] or NULL (invariant)                           */
+  const uint8_t* non_h_mask;   /* [N] or NULL (scalar head)                           */
+  int32_t N, Bg, M;            /* atoms, crystals, masked atoms (rows of pred)        */
+  int64_t E;
+} CartnetBatch;
+
+size_t cartnet_workspace_bytes(const CartnetModel* model, int32_t N, int64_t E, int32_t Bg, int32_t M,
+                               int32_t need_backward);
+/* pred [M,3,3] (Cholesky head) or [Bg] (scalar head); x_out [N,D] and e_out [E,D] receive the final node / edge
+ * features (what the reference leaves in batch.x / batch.edge_attr).  status[0] (device int32) reports graph-layout
+ * problems (cartnet_csr_build bits).  need_backward = 0 lets the layers reuse one set of activation buffers. */
+int cartnet_model_forward(const CartnetModel* model, const CartnetBatch* batch, void* workspace, size_t workspace_bytes,
+                          int32_t training, int32_t need_backward, float* pred, float* x_out, float* e_out,
+                          int32_t* status, void* stream);
+/* dpred: gradient of the loss w.r.t. pred.  grads: where each parameter's gradient is written (every non-NULL
+ * parameter of the model must have a destination).  Consumes the workspace of the matching forward call. */
+int cartnet_model_backward(const CartnetModel* model, const CartnetBatch* batch, void* workspace, size_t workspace_bytes,
+                           int32_t training, const float* dpred, const float* x_out, const CartnetParams* grads,
+                           void* stream);
 
 /* Fused Adam step over a flat fp32 parameter buffer (torch.optim.Adam semantics, reference main.py:208):
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr * (m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps).
