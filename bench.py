@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--atoms", type=int, default=194)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA GEMMs, 1: bf16x3 split-operand MFMA")
     args = ap.parse_args()
 
     from cartnet_amd import distributed as cdist
@@ -101,6 +102,7 @@ def main():
     cfg.radius = 5.0
     torch.manual_seed(0)
     model = CartNet(dim_in=256, dim_rbf=64, num_layers=4).to(dev).train()
+    model.gemm_precision = args.precision
     opt = FlatAdam(model, lr=1e-3)
     base = build_batch(args.graphs, 100_000 + rank * args.graphs, args.atoms).to(dev)
     N, E = int(base.x.shape[0]), int(base.edge_index.shape[1])

@@ -166,6 +166,8 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
     }
     fl.wide = w ? 1 : 0;
   }
+  CN_CHECK(a.precision == 0 || a.precision == 1, "cartnet_gemm: precision=%d (0 = fp32 MFMA, 1 = bf16x3 split)", a.precision);
+  fl.x3 = a.precision;
   fl.vecA = vecA ? 1 : 0;
   fl.vecB = vecB ? 1 : 0;
   int kchunk = (a.K + a.splitk - 1) / a.splitk;

@@ -167,9 +167,12 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
   return w;
 }
 
+thread_local int g_precision = 0;   // set per call from CartnetModel.gemm_precision
+
 inline CartnetGemmArgs gemm_args(int M, int N, int K, int lda, int ldb, int ldc) {
   CartnetGemmArgs a;
   memset(&a, 0, sizeof(a));
+  a.precision = g_precision;
   a.M = M; a.N = N; a.K = K;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.ngroups = 1; a.nsegs = 1; a.splitk = 1;
@@ -216,6 +219,7 @@ int check_model(const CartnetModel* m, const CartnetBatch* b, const char* who) {
   CN_CHECK(m->L >= 1 && m->L <= CARTNET_MAX_LAYERS, "%s: num_layers=%d out of range (1..%d)", who, m->L,
            CARTNET_MAX_LAYERS);
   CN_CHECK(m->R >= 1, "%s: dim_rbf=%d", who, m->R);
+  CN_CHECK(m->gemm_precision == 0 || m->gemm_precision == 1, "%s: gemm_precision=%d", who, m->gemm_precision);
   CN_CHECK(m->use_temperature || m->atom_types, "%s: a model without atom types and without temperature is not built",
            who);
   CN_CHECK(b->N >= 0 && b->E >= 0 && b->Bg >= 1 && b->M >= 0, "%s: bad batch sizes", who);
@@ -258,6 +262,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
                                      size_t workspace_bytes, int32_t training, int32_t need_backward, float* pred,
                                      float* x_out, float* e_out, int32_t* status, void* st) {
   RUN(check_model(model, batch, "cartnet_model_forward"));
+  g_precision = model->gemm_precision;
   const CartnetModel& m = *model;
   const CartnetBatch& b = *batch;
   const CartnetParams& P = m.p;
@@ -390,6 +395,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
                                       size_t workspace_bytes, int32_t training, const float* dpred, const float* x_out,
                                       const CartnetParams* grads, void* st) {
   RUN(check_model(model, batch, "cartnet_model_backward"));
+  g_precision = model->gemm_precision;
   const CartnetModel& m = *model;
   const CartnetBatch& b = *batch;
   const CartnetParams& P = m.p;

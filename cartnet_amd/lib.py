@@ -37,7 +37,7 @@ class GemmArgs(C.Structure):
         ("ldd", C.c_int32),
         ("ngroups", C.c_int32), ("nsegs", C.c_int32), ("splitk", C.c_int32),
         ("a_kstrided", C.c_int32), ("b_kstrided", C.c_int32), ("a_act", C.c_int32), ("b_act", C.c_int32),
-        ("out_act", C.c_int32),
+        ("out_act", C.c_int32), ("precision", C.c_int32),
     ]
 
 
@@ -84,6 +84,7 @@ class Model(C.Structure):
                                          "n_types")] + \
                [("use_envelope", C.c_int32 * MAX_LAYERS)] + \
                [(n, C.c_float) for n in ("radius", "env_radius", "bn_eps", "bn_momentum")] + \
+               [("gemm_precision", C.c_int32)] + \
                [("rbf_means", C.c_void_p), ("rbf_betas", C.c_void_p), ("p", Params), ("buf", LayerBuffers * MAX_LAYERS)]
 
 

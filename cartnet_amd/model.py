@@ -250,6 +250,7 @@ class CartNet(nn.Module):
         self.cholesky = cholesky
         self.head = Cholesky_head(dim_in) if cholesky else Scalar_head(dim_in)
         self.validate_graph = False     # set True to sync-check edge_index ordering / ranges once per batch
+        self.gemm_precision = 0         # 0: fp32 MFMA.  1: bf16x3 split-operand MFMA (see csrc/gemm_kernel.h)
         self._param_names = [n for n, _ in self.named_parameters()]
         self._param_shapes = {n: tuple(p.shape) for n, p in self.named_parameters()}
         self._flat_grad = None          # set by cartnet_amd.optim.FlatAdam: gradients are accumulated here directly
@@ -263,6 +264,7 @@ class CartNet(nn.Module):
         md.cholesky, md.n_types = int(self.cholesky), N_ATOM_TYPES
         md.radius, md.env_radius = float(enc.rbf.cutoff_upper), float(self.layers[0].envelope_radius)
         md.bn_eps, md.bn_momentum = BN_EPS, BN_MOMENTUM
+        md.gemm_precision = int(self.gemm_precision)
         B = dict(self.named_buffers())
         md.rbf_means, md.rbf_betas = B["encoder.rbf.means"].data_ptr(), B["encoder.rbf.betas"].data_ptr()
         for n, t in P.items():

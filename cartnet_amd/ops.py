@@ -70,7 +70,7 @@ def _aslist(x, n):
 def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequence[Tensor] | Tensor, *,
          a_kstrided: bool = False, b_kstrided: bool = False, a_act: bool = False, b_act: bool = False,
          out_act: bool = False, segments: bool = False, bias=None, gather_i=None, gather_j=None, tgt=None, src=None,
-         resid=None, dact=None, cpre=None, colsum=None, colsq=None, splitk: int = 1) -> None:
+         resid=None, dact=None, cpre=None, colsum=None, colsq=None, splitk: int = 1, precision: int = 0) -> None:
     """C[g] = epilogue(sum_s opA(A[s]) @ opB(B[s])) on the fp32 matrix cores (see include/cartnet_hip.h).
 
     A / B / C_out: one tensor or a list.  With ``segments=False`` the lists are independent problems (groups) of
@@ -112,6 +112,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
     args.ngroups, args.nsegs, args.splitk = ngroups, nsegs, int(splitk)
     args.a_kstrided, args.b_kstrided = int(a_kstrided), int(b_kstrided)
     args.a_act, args.b_act, args.out_act = int(a_act), int(b_act), int(out_act)
+    args.precision = int(precision)
     for i in range(nptr):
         args.A[i] = A[i].data_ptr()
         args.B[i] = B[i].data_ptr()

@@ -72,6 +72,9 @@ typedef struct CartnetGemmArgs {
   int32_t lda, ldb, ldc, ldg, ldr, ldd;
   int32_t ngroups, nsegs, splitk;
   int32_t a_kstrided, b_kstrided, a_act, b_act, out_act;
+  int32_t precision;   /* 0: fp32 MFMA (exact fp32 products).  1: bf16x3 split operands, 6 bf16 MFMAs per product,
+                          fp32 accumulate (fp32-level accuracy, see gemm_kernel.h); falls back to 0 where no
+                          such kernel exists (narrow tiles, ragged K tail, unaligned operands). */
 } CartnetGemmArgs;
 
 int cartnet_gemm(const CartnetGemmArgs* args, void* stream);
@@ -282,6 +285,7 @@ typedef struct CartnetModel {
   int32_t invariant, use_temperature, atom_types, cholesky, n_types;
   int32_t use_envelope[CARTNET_MAX_LAYERS];
   float radius, env_radius, bn_eps, bn_momentum;
+  int32_t gemm_precision;                       /* CartnetGemmArgs.precision for every GEMM of the network */
   const float* rbf_means; const float* rbf_betas;
   CartnetParams p;
   CartnetLayerBuffers buf[CARTNET_MAX_LAYERS];

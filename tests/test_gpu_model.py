@@ -23,7 +23,10 @@ GRAD_TOL = 3e-5
 GRAD_TOL_PARAM = 1e-3
 
 
-def _model(hp, sd):
+PRECISIONS = [0, 1]      # 0: fp32 MFMA, 1: bf16x3 split-operand MFMA -- both must meet the same parity budget
+
+
+def _model(hp, sd, precision=0):
     from cartnet_amd.config import cfg
     from cartnet_amd.model import CartNet
     cfg.radius = hp["radius"]
@@ -33,6 +36,7 @@ def _model(hp, sd):
                 cholesky=hp["cholesky"])
     m.load_state_dict(sd, strict=True)
     m.validate_graph = True
+    m.gemm_precision = precision
     return m.to("cuda:0")
 
 
@@ -51,10 +55,11 @@ def _check_grads(got, ref, what=""):
             (what, k, d.norm().item(), r.norm().item())
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", gu.MODEL_FIXTURES)
-def test_forward_against_reference_golden(name):
+def test_forward_against_reference_golden(name, precision):
     z, hp, b, sd = gu.load(name)
-    m = _model(hp, sd)
+    m = _model(hp, sd, precision)
     for mode in ("eval", "train"):
         m.train(mode == "train")
         bb = gu.clone_batch(b).to("cuda:0")
@@ -80,10 +85,11 @@ def test_per_layer_features_against_reference_golden():
     assert rel_err(bb.edge_attr, torch.from_numpy(z[f"trace_e{L}"])) < PRED_TOL
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", gu.MODEL_FIXTURES)
-def test_train_step_gradients_and_bn_state_against_reference_golden(name):
+def test_train_step_gradients_and_bn_state_against_reference_golden(name, precision):
     z, hp, b, sd = gu.load(name)
-    m = _model(hp, sd).train()
+    m = _model(hp, sd, precision).train()
     bb = gu.clone_batch(b).to("cuda:0")
     pred, true = m(bb)
     loss = (pred - true).abs().mean()                 # MAE, train/metrics.py:26 -- the reference's default loss
@@ -151,7 +157,8 @@ def test_against_oracle_on_ragged_batches(seed, n_graphs, dim, layers, cholesky)
                  {k: sd64[k].grad for k, _ in m.named_parameters()}, "ragged")
 
 
-def test_bitwise_reproducible_and_graph_order_invariant_at_full_size():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_bitwise_reproducible_and_graph_order_invariant_at_full_size(precision):
     """BASELINE.json configs[1] shapes (D=256, L=4, 194-atom crystals): two runs are bit-identical (no atomics),
     and permuting the crystals inside the batch permutes the per-crystal outputs (CSR/CSC built per batch)."""
     from cartnet_amd.data import Batch
@@ -161,7 +168,7 @@ def test_bitwise_reproducible_and_graph_order_invariant_at_full_size():
     hp = dict(dim_in=256, dim_rbf=64, num_layers=4, radius=5.0, invariant=False, temperature=True,
               use_envelope=True, atom_types=True, cholesky=True)
     sd = make_state_dict(256, 64, 4, seed=5)
-    m = _model(hp, sd).train()
+    m = _model(hp, sd, precision).train()
 
     def run(order):
         b = Batch.from_data_list([items[i] for i in order]).to("cuda:0")
