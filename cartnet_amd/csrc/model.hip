@@ -3,6 +3,7 @@
 // translation units in the order the reference executes its modules (models/cartnet.py:65-73,142-161,204-274,293-327)
 // and carves every intermediate out of one caller-owned workspace.
 #include "common.h"
+#include <vector>
 
 namespace {
 
@@ -54,8 +55,9 @@ struct Work {
   float* Pn;
   double *cs, *cq, *ps, *pq;
   // backward transients
-  float *dhid, *head_parts, *head_tot, *dx[2], *de[2], *daggr, *sums1, *sums2, *dPn, *dx0, *seg_tmp, *slabs;
-  double *pa, *pb, *pc, *pd, *cs_big;
+  float *dhid, *head_parts, *head_tot, *dx[2], *de[2], *daggr, *sums1, *sums2, *dPn[2], *dpre[2], *dhe, *dx0, *seg_tmp,
+      *slabs;
+  double *pa, *pb, *pc[2], *pd[2], *csg[2], *csa[2], *cs_misc[4];
   size_t slab_floats;
   int gparts, nparts_n, tiles_e, tiles_n;
 };
@@ -143,15 +145,24 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
     w.daggr = c.take<float>(Nn * D);
     w.sums1 = c.take<float>(2 * D);
     w.sums2 = c.take<float>(2 * D);
-    w.dPn = c.take<float>(Nn * 4 * D);
+    for (int i = 0; i < 2; ++i) {   // double-buffered: the weight-gradient stream reads them while the next layer runs
+      w.dPn[i] = c.take<float>(Nn * 4 * D);
+      w.dpre[i] = c.take<float>(En * 2 * D);
+    }
+    w.dhe = c.take<float>(En * 2 * D);
     w.dx0 = c.take<float>(Nn * 2 * D);
     w.seg_tmp = c.take<float>(Nn * 2 * D);
     const size_t pmax = (size_t)(w.gparts > w.nparts_n ? w.gparts : w.nparts_n) * 2 * D;
     w.pa = c.take<double>(pmax);
     w.pb = c.take<double>(pmax);
-    w.pc = c.take<double>(pmax);
-    w.pd = c.take<double>(pmax);
-    w.cs_big = c.take<double>((size_t)(w.tiles_e > w.tiles_n ? w.tiles_e : w.tiles_n) * 2 * D * 2);
+    const size_t tmax = (size_t)(w.tiles_e > w.tiles_n ? w.tiles_e : w.tiles_n);
+    for (int i = 0; i < 2; ++i) {
+      w.pc[i] = c.take<double>(pmax);
+      w.pd[i] = c.take<double>(pmax);
+      w.csg[i] = c.take<double>(tmax * D);
+      w.csa[i] = c.take<double>(tmax * D);
+    }
+    for (int i = 0; i < 4; ++i) w.cs_misc[i] = c.take<double>(tmax * 2 * D);
     size_t sl = 0;
     auto mx = [&](size_t v) { if (v > sl) sl = v; };
     mx(wgrad_slab_floats(1, N, H, D));
@@ -391,9 +402,52 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
   return 0;
 }
 
+namespace {
+// Events that order the weight-gradient stream against the main stream (created once per thread, timing disabled).
+struct EventPool {
+  std::vector<hipEvent_t> ev;
+  size_t next = 0;
+  hipEvent_t get() {
+    if (next == ev.size()) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      ev.push_back(e);
+    }
+    return ev[next++];
+  }
+};
+thread_local EventPool g_events;
+
+struct Streams {
+  hipStream_t main, side;
+  bool dual;
+  // after(main) -> side waits; returns 0 on success
+  int fork() {
+    if (!dual) return 0;
+    hipEvent_t e = g_events.get();
+    if (!e || hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return 2;
+    return 0;
+  }
+  hipEvent_t mark_side() {
+    if (!dual) return nullptr;
+    hipEvent_t e = g_events.get();
+    if (!e || hipEventRecord(e, side) != hipSuccess) return nullptr;
+    return e;
+  }
+  int main_waits(hipEvent_t e) {
+    if (!dual || !e) return 0;
+    return hipStreamWaitEvent(main, e, 0) == hipSuccess ? 0 : 2;
+  }
+};
+}  // namespace
+
+// Two streams: the MAIN stream carries the chain of activation gradients (dx, de from layer to layer); everything that
+// only produces parameter gradients -- the weight-gradient GEMMs with their split-K reductions and the bias-gradient
+// finalisers, a third of the FLOPs -- goes to the SIDE stream, so it fills the tails of the main-stream GEMM grids and
+// overlaps the HBM-bound gate / segment kernels.  Buffers the side stream reads are double-buffered per layer parity.
 extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBatch* batch, void* workspace,
                                       size_t workspace_bytes, int32_t training, const float* dpred, const float* x_out,
-                                      const CartnetParams* grads, void* st) {
+                                      const CartnetParams* grads, void* stream, void* aux_stream) {
   RUN(check_model(model, batch, "cartnet_model_backward"));
   g_precision = model->gemm_precision;
   const CartnetModel& m = *model;
@@ -410,6 +464,13 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
   CN_CHECK(workspace_bytes >= need, "cartnet_model_backward: workspace %zu < required %zu bytes", workspace_bytes, need);
   const int D = m.D, L = m.L, H = D / 2, N = b.N;
   const int E = (int)b.E;
+  g_events.next = 0;
+  Streams S{(hipStream_t)stream, aux_stream ? (hipStream_t)aux_stream : (hipStream_t)stream,
+            aux_stream != nullptr && aux_stream != stream};
+  void* st = stream;            // main: activation-gradient chain
+  void* sw = (void*)S.side;     // side: parameter gradients
+  hipStream_t hs = S.main;
+#define FORK() do { if (S.fork() != 0) { cartnet_set_error("cartnet_model_backward: stream fork failed"); return 2; } } while (0)
 
   // ---- head
   {
@@ -418,19 +479,19 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       RUN(cartnet_cholesky_head_bwd(w.hid, w.idx, P.head2_w, w.p6, dpred, N, H, w.dhid, w.head_parts, st));
     else
       RUN(cartnet_scalar_head_bwd(w.hid, P.head2_w, b.graph_ptr, b.batch, dpred, N, b.Bg, H, w.dhid, w.head_parts, st));
-    RUN(cartnet_colsum_finalize_f32(w.head_parts, w.nparts_n, row, w.head_tot, st));
+    FORK();
+    RUN(cartnet_colsum_finalize_f32(w.head_parts, w.nparts_n, row, w.head_tot, sw));
     const int nw2 = m.cholesky ? 6 * H : H, nb2 = m.cholesky ? 6 : 1;
-    hipStream_t hs = (hipStream_t)st;
-    if (hipMemcpyAsync(G.head2_w, w.head_tot, sizeof(float) * nw2, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
-        hipMemcpyAsync(G.head2_b, w.head_tot + nw2, sizeof(float) * nb2, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
-        hipMemcpyAsync(G.head0_b, w.head_tot + nw2 + 8, sizeof(float) * H, hipMemcpyDeviceToDevice, hs) != hipSuccess) {
+    if (hipMemcpyAsync(G.head2_w, w.head_tot, sizeof(float) * nw2, hipMemcpyDeviceToDevice, S.side) != hipSuccess ||
+        hipMemcpyAsync(G.head2_b, w.head_tot + nw2, sizeof(float) * nb2, hipMemcpyDeviceToDevice, S.side) != hipSuccess ||
+        hipMemcpyAsync(G.head0_b, w.head_tot + nw2 + 8, sizeof(float) * H, hipMemcpyDeviceToDevice, S.side) != hipSuccess) {
       cartnet_set_error("cartnet_model_backward: head gradient copy failed");
       return 2;
     }
     const float* dY[1] = {w.dhid};
     const float* X[1] = {x_out};
     float* o[1] = {G.head0_w};
-    RUN(wgrad(dY, H, X, D, o, D, N, H, D, 1, false, w, st));
+    RUN(wgrad(dY, H, X, D, o, D, N, H, D, 1, false, w, sw));
     CartnetGemmArgs a = gemm_args(N, D, H, H, D, D);
     a.A[0] = w.dhid; a.B[0] = P.head0_w; a.C[0] = w.dx[0]; a.b_kstrided = 1;
     RUN(cartnet_gemm(&a, st));
@@ -439,6 +500,8 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
   float* dx_other = w.dx[1];
   float* de = nullptr;   // the head does not read the edge features
   int de_slot = 0;
+  hipEvent_t side_done[CARTNET_MAX_LAYERS + 2];
+  for (int i = 0; i < CARTNET_MAX_LAYERS + 2; ++i) side_done[i] = nullptr;
 
   // ---- layers, last to first
   for (int l = L - 1; l >= 0; --l) {
@@ -447,11 +510,16 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     CN_CHECK(gq.gate0_w && gq.gate0_b && gq.gate2_w && gq.gate2_b && gq.aggr0_w && gq.aggr0_b && gq.aggr2_w &&
                  gq.aggr2_b && gq.norm_w && gq.norm_b && gq.norm2_w && gq.norm2_b,
              "cartnet_model_backward: gradient destination missing in layer %d", l);
+    const int par = l & 1;
     const float* x_in = (l == 0) ? w.xenc : w.xl[l - 1];
     const float* e_in = (l == 0) ? w.e0 : w.el[l - 1];
     const float* env = m.use_envelope[l] ? w.env : nullptr;
-    float* pre = w.pre[l];
+    const float* pre = w.pre[l];
     float* gs = w.gs[l];
+    float* dpre = w.dpre[par];
+    float* dPn = w.dPn[par];
+    // the side stream must be done with this parity's buffers (used two layers ago)
+    if (l + 2 < L && S.main_waits(side_done[l + 2]) != 0) { cartnet_set_error("cartnet_model_backward: wait failed"); return 2; }
     // node update: x_out = silu(bn2(aggr)) + x_in
     RUN(cartnet_node_update_bwd_stats(w.aggr[l], dx, w.mr2[l], q.norm2_w, q.norm2_b, N, D, w.pa, w.pb, st));
     {
@@ -459,7 +527,6 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       float* outs[2] = {w.sums2, w.sums2 + D};
       RUN(cartnet_colsum_finalize(parts, outs, 2, w.nparts_n, D, st));
     }
-    hipStream_t hs = (hipStream_t)st;
     if (hipMemcpyAsync(gq.norm2_b, w.sums2, sizeof(float) * D, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
         hipMemcpyAsync(gq.norm2_w, w.sums2 + D, sizeof(float) * D, hipMemcpyDeviceToDevice, hs) != hipSuccess) {
       cartnet_set_error("cartnet_model_backward: norm2 gradient copy failed");
@@ -481,73 +548,71 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       return 2;
     }
     RUN(cartnet_gate_scatter_bwd_apply(gs, de, w.daggr, env, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, w.sums1, b.E,
-                                       training, N, D, w.pc, w.pd, st));   // gs = [dg | ds]
-    {
-      const double* parts[2] = {w.pc, w.pd};
+                                       training, N, D, w.pc[par], w.pd[par], st));   // gs = [dg | ds]
+    FORK();
+    {  // side: bias gradients of the second Linears, then their weight gradients (need silu(pre), which stays intact)
+      const double* parts[2] = {w.pc[par], w.pd[par]};
       float* outs[2] = {gq.gate2_b, gq.aggr2_b};
-      RUN(cartnet_colsum_finalize(parts, outs, 2, w.gparts, D, st));
-    }
-    {  // second Linears: weight gradients need silu(pre); then pre is overwritten with dpre
+      RUN(cartnet_colsum_finalize(parts, outs, 2, w.gparts, D, sw));
       const float* dY[2] = {gs, gs + D};
       const float* X[2] = {pre, pre + D};
       float* o[2] = {gq.gate2_w, gq.aggr2_w};
-      RUN(wgrad(dY, 2 * D, X, 2 * D, o, D, b.E, D, D, 2, true, w, st));
+      RUN(wgrad(dY, 2 * D, X, 2 * D, o, D, b.E, D, D, 2, true, w, sw));
     }
-    double* csg = w.cs_big;
-    double* csa = w.cs_big + (size_t)w.tiles_e * D;
-    {
+    {  // main: dpre = (dgs @ W2) * silu'(pre), into this parity's buffer
       CartnetGemmArgs a = gemm_args(E, D, D, 2 * D, D, 2 * D);
       a.ngroups = 2; a.b_kstrided = 1;
       a.A[0] = gs; a.A[1] = gs + D; a.B[0] = q.gate2_w; a.B[1] = q.aggr2_w;
-      a.C[0] = pre; a.C[1] = pre + D; a.dact[0] = pre; a.dact[1] = pre + D; a.ldd = 2 * D;
-      a.colsum[0] = csg; a.colsum[1] = csa;
-      RUN(cartnet_gemm(&a, st));     // pre = dpre = [dpre_gate | dpre_aggr]
+      a.C[0] = dpre; a.C[1] = dpre + D; a.dact[0] = pre; a.dact[1] = pre + D; a.ldd = 2 * D;
+      a.colsum[0] = w.csg[par]; a.colsum[1] = w.csa[par];
+      RUN(cartnet_gemm(&a, st));
     }
-    {
-      const double* parts[2] = {csg, csa};
+    FORK();
+    {  // side: bias and edge-block weight gradients of the first Linears
+      const double* parts[2] = {w.csg[par], w.csa[par]};
       float* outs[2] = {gq.gate0_b, gq.aggr0_b};
-      RUN(cartnet_colsum_finalize(parts, outs, 2, w.tiles_e, D, st));
-    }
-    {
-      const float* dY[2] = {pre, pre + D};
+      RUN(cartnet_colsum_finalize(parts, outs, 2, w.tiles_e, D, sw));
+      const float* dY[2] = {dpre, dpre + D};
       const float* X[2] = {e_in, e_in};
       float* o[2] = {gq.gate0_w + 2 * D, gq.aggr0_w + 2 * D};
-      RUN(wgrad(dY, 2 * D, X, D, o, 3 * D, b.E, D, D, 2, false, w, st));
+      RUN(wgrad(dY, 2 * D, X, D, o, 3 * D, b.E, D, D, 2, false, w, sw));
     }
-    // edge features: de_in = de_out + dpre @ W1[:, 2D:]  (layer 0: continue through the encoder's last SiLU)
+    // main: de_in = de_out + dpre @ W1[:, 2D:]  (layer 0: continue through the encoder's last SiLU)
     float* de_in = w.de[de_slot];
     {
       CartnetGemmArgs a = gemm_args(E, D, D, 2 * D, 3 * D, D);
       a.nsegs = 2; a.b_kstrided = 1;
-      a.A[0] = pre; a.A[1] = pre + D; a.B[0] = q.gate0_w + 2 * D; a.B[1] = q.aggr0_w + 2 * D;
+      a.A[0] = dpre; a.A[1] = dpre + D; a.B[0] = q.gate0_w + 2 * D; a.B[1] = q.aggr0_w + 2 * D;
       a.C[0] = de_in; a.resid[0] = de; a.ldr = D;
-      if (l == 0) { a.dact[0] = w.e0_pre; a.ldd = D; a.colsum[0] = w.cs_big; }
+      if (l == 0) { a.dact[0] = w.e0_pre; a.ldd = D; a.colsum[0] = w.cs_misc[0]; }
       RUN(cartnet_gemm(&a, st));
       if (l == 0) {
-        const double* parts[1] = {w.cs_big};
+        const double* parts[1] = {w.cs_misc[0]};
         float* outs[1] = {G.edge2_b};
         RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_e, D, st));
       }
     }
     // node-side halves: reduce dpre over each atom's incoming (target) and outgoing (source) edges
-    RUN(cartnet_segment_sum(pre, 2 * D, w.rowptr, nullptr, N, 2 * D, w.dPn, 4 * D, st));
-    RUN(cartnet_segment_sum(pre, 2 * D, w.colptr, w.perm, N, 2 * D, w.dPn + 2 * D, 4 * D, st));
+    RUN(cartnet_segment_sum(dpre, 2 * D, w.rowptr, nullptr, N, 2 * D, dPn, 4 * D, st));
+    RUN(cartnet_segment_sum(dpre, 2 * D, w.colptr, w.perm, N, 2 * D, dPn + 2 * D, 4 * D, st));
+    FORK();
     {
-      const float* dY[4] = {w.dPn, w.dPn + D, w.dPn + 2 * D, w.dPn + 3 * D};
+      const float* dY[4] = {dPn, dPn + D, dPn + 2 * D, dPn + 3 * D};
       const float* X[4] = {x_in, x_in, x_in, x_in};
       float* o[4] = {gq.gate0_w, gq.aggr0_w, gq.gate0_w + D, gq.aggr0_w + D};
-      RUN(wgrad(dY, 4 * D, X, D, o, 3 * D, N, D, D, 4, false, w, st));
+      RUN(wgrad(dY, 4 * D, X, D, o, 3 * D, N, D, D, 4, false, w, sw));
     }
+    side_done[l] = S.mark_side();
     {
       CartnetGemmArgs a = gemm_args(N, D, D, 4 * D, 3 * D, D);
       a.nsegs = 4; a.b_kstrided = 1;
-      a.A[0] = w.dPn; a.A[1] = w.dPn + D; a.A[2] = w.dPn + 2 * D; a.A[3] = w.dPn + 3 * D;
+      a.A[0] = dPn; a.A[1] = dPn + D; a.A[2] = dPn + 2 * D; a.A[3] = dPn + 3 * D;
       a.B[0] = q.gate0_w; a.B[1] = q.aggr0_w; a.B[2] = q.gate0_w + D; a.B[3] = q.aggr0_w + D;
       a.C[0] = dx_other; a.resid[0] = dx; a.ldr = D;
-      if (l == 0) { a.dact[0] = w.xa_pre; a.ldd = D; a.colsum[0] = w.cs_big; }
+      if (l == 0) { a.dact[0] = w.xa_pre; a.ldd = D; a.colsum[0] = w.cs_misc[1]; }
       RUN(cartnet_gemm(&a, st));
       if (l == 0) {
-        const double* parts[1] = {w.cs_big};
+        const double* parts[1] = {w.cs_misc[1]};
         float* outs[1] = {G.atom_b};
         RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_n, D, st));
       }
@@ -559,27 +624,29 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
 
   // ---- encoder: de = d(e0_pre), dx = d(xa_pre)
   {
+    FORK();
     const float* dY[1] = {de};
     const float* X[1] = {w.he_pre};
     float* o[1] = {G.edge2_w};
-    RUN(wgrad(dY, D, X, 2 * D, o, 2 * D, b.E, D, 2 * D, 1, true, w, st));
+    RUN(wgrad(dY, D, X, 2 * D, o, 2 * D, b.E, D, 2 * D, 1, true, w, sw));
     CartnetGemmArgs a = gemm_args(E, 2 * D, D, D, 2 * D, 2 * D);
-    a.A[0] = de; a.B[0] = P.edge2_w; a.C[0] = w.he_pre; a.dact[0] = w.he_pre; a.ldd = 2 * D; a.b_kstrided = 1;
-    a.colsum[0] = w.cs_big;
-    RUN(cartnet_gemm(&a, st));       // he_pre = d(he_pre)
-    const double* parts[1] = {w.cs_big};
+    a.A[0] = de; a.B[0] = P.edge2_w; a.C[0] = w.dhe; a.dact[0] = w.he_pre; a.ldd = 2 * D; a.b_kstrided = 1;
+    a.colsum[0] = w.cs_misc[2];
+    RUN(cartnet_gemm(&a, st));       // dhe = d(he_pre)
+    FORK();
+    const double* parts[1] = {w.cs_misc[2]};
     float* outs[1] = {G.edge0_b};
-    RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_e, 2 * D, st));
-    const float* dY2[1] = {w.he_pre};
+    RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_e, 2 * D, sw));
+    const float* dY2[1] = {w.dhe};
     const float* X2[1] = {w.feat};
     float* o2[1] = {G.edge0_w};
-    RUN(wgrad(dY2, 2 * D, X2, w.ldf, o2, w.kf, b.E, 2 * D, w.kf, 1, false, w, st));
+    RUN(wgrad(dY2, 2 * D, X2, w.ldf, o2, w.kf, b.E, 2 * D, w.kf, 1, false, w, sw));
   }
   {
     const float* dY[1] = {dx};
     const float* X[1] = {w.x0};
     float* o[1] = {G.atom_w};
-    RUN(wgrad(dY, D, X, 2 * D, o, 2 * D, N, D, 2 * D, 1, true, w, st));
+    RUN(wgrad(dY, D, X, 2 * D, o, 2 * D, N, D, 2 * D, 1, true, w, sw));
     CartnetGemmArgs a = gemm_args(N, 2 * D, D, D, 2 * D, 2 * D);
     a.A[0] = dx; a.B[0] = P.atom_w; a.C[0] = w.dx0; a.dact[0] = w.x0; a.ldd = 2 * D; a.b_kstrided = 1;
     RUN(cartnet_gemm(&a, st));
@@ -598,5 +665,8 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       RUN(cartnet_segment_sum_long(w.dx0, 2 * D, w.zptr, w.zperm, m.n_types, N, 2 * D, w.seg_tmp, G.embedding, 2 * D,
                                    st));
   }
+  // join: everything queued on the side stream precedes whatever the caller enqueues next on the main stream
+  if (S.main_waits(S.mark_side()) != 0) { cartnet_set_error("cartnet_model_backward: stream join failed"); return 2; }
+#undef FORK
   return 0;
 }

@@ -210,8 +210,9 @@ class _CartNetFunction(torch.autograd.Function):
         G = _GradBuffer(model, dpred.device)
         gd = _l.Params()
         _fill_params(gd, G, model.num_layers)
+        aux = model._aux_stream_ptr(dpred.device)
         _l.check(lib.cartnet_model_backward(C.byref(md), C.byref(bd), ws.data_ptr(), nbytes, int(training),
-                                            dpred.data_ptr(), x_out.data_ptr(), C.byref(gd), _l.stream_ptr()),
+                                            dpred.data_ptr(), x_out.data_ptr(), C.byref(gd), _l.stream_ptr(), aux),
                  "cartnet_model_backward")
         sink = model._flat_grad
         if sink is not None and sink.numel() == G.flat.numel():
@@ -251,6 +252,8 @@ class CartNet(nn.Module):
         self.head = Cholesky_head(dim_in) if cholesky else Scalar_head(dim_in)
         self.validate_graph = False     # set True to sync-check edge_index ordering / ranges once per batch
         self.gemm_precision = 0         # 0: fp32 MFMA.  1: bf16x3 split-operand MFMA (see csrc/gemm_kernel.h)
+        self.overlap_weight_gradients = True   # run weight-gradient GEMMs on a second stream during backward
+        self._aux_stream = None
         self._param_names = [n for n, _ in self.named_parameters()]
         self._param_shapes = {n: tuple(p.shape) for n, p in self.named_parameters()}
         self._flat_grad = None          # set by cartnet_amd.optim.FlatAdam: gradients are accumulated here directly
@@ -279,6 +282,14 @@ class CartNet(nn.Module):
                                ("norm2_var", "norm2.running_var"), ("norm2_nbt", "norm2.num_batches_tracked")):
                 setattr(bl, field, B[f"layers.{l}.{key}"].data_ptr())
         return md
+
+    def _aux_stream_ptr(self, dev):
+        """Second HIP stream for the parameter-gradient work of backward (None -> single stream)."""
+        if not self.overlap_weight_gradients:
+            return None
+        if self._aux_stream is None or self._aux_stream.device != dev:
+            self._aux_stream = torch.cuda.Stream(device=dev)
+        return self._aux_stream.cuda_stream
 
     def forward(self, batch):
         params = [p for _, p in self.named_parameters()]

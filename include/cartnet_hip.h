@@ -313,10 +313,14 @@ int cartnet_model_forward(const CartnetModel* model, const CartnetBatch* batch, 
                           int32_t training, int32_t need_backward, float* pred, float* x_out, float* e_out,
                           int32_t* status, void* stream);
 /* dpred: gradient of the loss w.r.t. pred.  grads: where each parameter's gradient is written (every non-NULL
- * parameter of the model must have a destination).  Consumes the workspace of the matching forward call. */
+ * parameter of the model must have a destination).  Consumes the workspace of the matching forward call.
+ * aux_stream (optional second hipStream_t): when given, the parameter-gradient work (weight-gradient GEMMs, split-K
+ * and bias reductions -- a third of the FLOPs, none of it on the dx/de dependency chain) is enqueued there and
+ * overlaps the main stream; the call orders the two streams with events and joins them before returning to the
+ * caller's stream order, so the caller sees single-stream semantics on `stream`. */
 int cartnet_model_backward(const CartnetModel* model, const CartnetBatch* batch, void* workspace, size_t workspace_bytes,
                            int32_t training, const float* dpred, const float* x_out, const CartnetParams* grads,
-                           void* stream);
+                           void* stream, void* aux_stream);
 
 /* Fused Adam step over a flat fp32 parameter buffer (torch.optim.Adam semantics, reference main.py:208):
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr * (m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps).
