@@ -1,0 +1,564 @@
+"""iComformer (BASELINE.json configs[4]: the alternative, edge-attention message-passing path) on the gfx950 kernels.
+
+Drop-in for ``models/comformer.py:iComformer`` of the reference (same constructor, ``forward(data) -> (pred, true)``,
+``state_dict`` keys incl. the two parameters the reference declares but never uses, ``lemb`` and ``lin_edge_len``).
+The sub-modules only hold parameters; forward and backward are sequences of libcartnet_hip.so kernels issued from
+``_IComformerFunction`` (this path is orchestrated from Python -- it is a parity case, not the benchmarked path).
+
+Mapping onto the kernels (C = dim_in, heads = 1):
+  * every Linear = ``cartnet_gemm``; ``key_update`` / ``lin_msg_update`` on ``cat[k_i, k_j, e]`` use the same algebraic
+    split as the CartNet layer: node halves once per atom, gathered in the edge GEMM's epilogue
+    (comformer_conv.py:90-99);
+  * ``alpha = q_i * key / sqrt(C)`` and its BatchNorm statistics = ``cartnet_rowmul_fwd`` over the CSR rows;
+  * ``msg * sigmoid(bn_att(alpha))`` + scatter-add = ``cartnet_gate_scatter_fwd`` (no envelope, no edge residual);
+  * ``softplus(x + bn(lin_concate(out)))`` = ``cartnet_softplus_update_fwd``;
+  * the edge layer (comformer_conv.py:156-193) runs the same machinery on 3E rows (edge x lattice vector) with
+    "segments" of three rows per edge; the lattice-length terms are per crystal (3 rows each) and are gathered, not
+    expanded to E rows; ``lin_concate`` is applied after the sum over the three lattice vectors
+    (sum_i (m_i W^T + b) = (sum_i m_i) W^T + 3 b).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .model import BN_EPS, BN_MOMENTUM, Cholesky_head, N_ATOM_TYPES
+
+
+class _RBF(nn.Module):
+    def __init__(self, vmin, vmax, bins):
+        super().__init__()
+        self.vmin, self.vmax, self.bins = vmin, vmax, bins
+        centers = torch.linspace(vmin, vmax, bins)
+        self.register_buffer("centers", centers)
+        # models/utils.py:118-119: gamma = 1 / np.diff(centers).mean(), evaluated in float32 like the reference does
+        self.gamma = float(1 / np.diff(centers.numpy()).mean())
+
+
+class _MLP(nn.Sequential):
+    def __init__(self, c):
+        super().__init__(nn.Linear(3 * c, c), nn.SiLU(), nn.Linear(c, c))
+
+
+class ComformerConv(nn.Module):
+    """Parameter container (reference: models/comformer_conv.py:24-69)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.lin_key, self.lin_query, self.lin_value = nn.Linear(c, c), nn.Linear(c, c), nn.Linear(c, c)
+        self.lin_edge, self.lin_concate = nn.Linear(c, c), nn.Linear(c, c)
+        self.lin_msg_update, self.key_update = _MLP(c), _MLP(c)
+        self.bn, self.bn_att = nn.BatchNorm1d(c), nn.BatchNorm1d(c)
+
+
+class ComformerConv_edge(nn.Module):
+    """Parameter container (reference: models/comformer_conv.py:103-154)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.lemb = nn.Embedding(3, 32)                       # declared by the reference, never used
+        self.lin_key, self.lin_query, self.lin_value = nn.Linear(c, c), nn.Linear(c, c), nn.Linear(c, c)
+        self.lin_key_e1, self.lin_value_e1 = nn.Linear(c, c), nn.Linear(c, c)
+        self.lin_key_e2, self.lin_value_e2 = nn.Linear(c, c), nn.Linear(c, c)
+        self.lin_key_e3, self.lin_value_e3 = nn.Linear(c, c), nn.Linear(c, c)
+        self.lin_edge = nn.Linear(c, c, bias=False)
+        self.lin_edge_len = nn.Linear(c + 32, c)              # declared by the reference, never used
+        self.lin_concate = nn.Linear(c, c)
+        self.lin_msg_update, self.key_update = _MLP(c), _MLP(c)
+        self.bn_att, self.bn = nn.BatchNorm1d(c), nn.BatchNorm1d(c)
+
+
+def _e(shape, dev, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+def _parts(n, dev):
+    return torch.empty((n,), dtype=torch.float64, device=dev)
+
+
+def _split_k(K, tiles):
+    return int(max(1, min((512 + tiles - 1) // tiles, K // 256)))
+
+
+def _wgrad(dY: List[torch.Tensor], X: List[torch.Tensor], outs: List[torch.Tensor], b_act=False):
+    """outs[g] = dY[g]^T @ (silu?)(X[g]) (row reduction split over workgroups, slabs summed in fixed order)."""
+    K, M = dY[0].shape
+    N = X[0].shape[1]
+    if K == 0:
+        for o in outs:
+            o.zero_()
+        return
+    tiles = len(dY) * ((M + 127) // 128) * ((N + 255) // 256 if N > 128 else 1)
+    S = _split_k(K, tiles)
+    if S == 1:
+        ops.gemm(dY, X, outs, a_kstrided=True, b_kstrided=True, b_act=b_act)
+        return
+    slabs = [_e((S * M, N), dY[0].device) for _ in dY]
+    ops.gemm(dY, X, slabs, a_kstrided=True, b_kstrided=True, b_act=b_act, splitk=S)
+    ops.splitk_reduce(slabs, S, outs)
+
+
+class _Attention:
+    """Shared forward/backward of the gated attention block on ``R`` rows grouped into ``S`` segments.
+
+    ComformerConv: rows = edges, segments = target atoms (CSR), node terms gathered by (tgt, src).
+    ComformerConv_edge: rows = (edge, lattice vector), segments = edges (3 rows each), "node" terms gathered by
+    (edge id, crystal*3 + lattice vector)."""
+
+    @staticmethod
+    def forward(P, B, pre, q, term_i, term_j, idx_i, idx_j, ea, seg_layout, count, training, sv):
+        """pre-activation GEMM of key_update / lin_msg_update on the per-row operand ``ea`` with gathered terms,
+        second Linears, alpha = q*key/sqrt(C), bn_att statistics, gated sum per segment.  Returns aggr [S, C]."""
+        dev = ea.device
+        R, C = ea.shape
+        S = seg_layout.N
+        W1k, W1m = P[pre + ".key_update.0.weight"], P[pre + ".lin_msg_update.0.weight"]
+        pr = _e((R, 2 * C), dev)
+        ops.gemm([ea, ea], [W1k[:, 2 * C:], W1m[:, 2 * C:]], [pr[:, :C], pr[:, C:]],
+                 gather_i=[term_i[:, :C], term_i[:, C:]], gather_j=[term_j[:, :C], term_j[:, C:]], tgt=idx_i, src=idx_j)
+        keyb = _e((R, 2 * C), dev)      # key' in the first half (second half unused: groups share a leading dim)
+        gs = _e((R, 2 * C), dev)        # [alpha | msg]
+        ops.gemm([pr[:, :C], pr[:, C:]], [P[pre + ".key_update.2.weight"], P[pre + ".lin_msg_update.2.weight"]],
+                 [keyb[:, :C], gs[:, C:]], a_act=True,
+                 bias=[P[pre + ".key_update.2.bias"], P[pre + ".lin_msg_update.2.bias"]])
+        npart = ops.segment_nparts(S)
+        ps, pq = _parts(npart * C, dev), _parts(npart * C, dev)
+        scale = 1.0 / math.sqrt(C)
+        ops.rowmul_fwd(keyb[:, :C], q, seg_layout.rowptr, scale, gs[:, :C], ps, pq)
+        mr1 = _e((2 * C,), dev)
+        ops.bn_finalize(ps, pq, npart, count, C, BN_EPS, BN_MOMENTUM, training, B[pre + ".bn_att.running_mean"],
+                        B[pre + ".bn_att.running_var"], B[pre + ".bn_att.num_batches_tracked"], mr1)
+        aggr = _e((S, C), dev)
+        gp = ops.gate_nparts(S)
+        ops.gate_scatter_fwd(gs, None, None, seg_layout, mr1, P[pre + ".bn_att.weight"], P[pre + ".bn_att.bias"], None,
+                             aggr, _parts(gp * C, dev), _parts(gp * C, dev))
+        sv.update(pr=pr, keyb=keyb, gs=gs, mr1=mr1, aggr=aggr)
+        return aggr
+
+    @staticmethod
+    def backward(P, G, pre, daggr, q, ea, seg_layout, count, training, sv, dq_out):
+        """Consumes sv; returns dpre [R, 2C] (gradient at the first Linears' pre-activation, key | msg) after
+        writing the parameter gradients of the second Linears / bn_att and dq into ``dq_out``."""
+        dev = ea.device
+        R, C = ea.shape
+        S = seg_layout.N
+        pr, keyb, gs, mr1 = sv["pr"], sv["keyb"], sv["gs"], sv["mr1"]
+        gp = ops.gate_nparts(S)
+        pa, pb = _parts(gp * C, dev), _parts(gp * C, dev)
+        ga, gb = P[pre + ".bn_att.weight"], P[pre + ".bn_att.bias"]
+        ops.gate_scatter_bwd_stats(gs, None, daggr, None, seg_layout, mr1, ga, gb, pa, pb)
+        sums1 = _e((2 * C,), dev)
+        ops.colsum_finalize([pa, pb], gp, [sums1[:C], sums1[C:]])
+        G[pre + ".bn_att.bias"], G[pre + ".bn_att.weight"] = sums1[:C], sums1[C:]
+        pdg, pds = _parts(gp * C, dev), _parts(gp * C, dev)
+        ops.gate_scatter_bwd_apply(gs, None, daggr, None, seg_layout, mr1, ga, gb, sums1, training, pdg, pds)
+        G[pre + ".lin_msg_update.2.bias"] = _e((C,), dev)
+        ops.colsum_finalize(pds, gp, G[pre + ".lin_msg_update.2.bias"])
+        ops.rowmul_bwd(gs[:, :C], keyb[:, :C], q, seg_layout.rowptr, 1.0 / math.sqrt(C), dq_out)   # gs = [dkey | dmsg]
+        G[pre + ".key_update.2.bias"] = _e((C,), dev)
+        ops.colsum(gs[:, :C], G[pre + ".key_update.2.bias"])
+        G[pre + ".key_update.2.weight"], G[pre + ".lin_msg_update.2.weight"] = _e((C, C), dev), _e((C, C), dev)
+        _wgrad([gs[:, :C], gs[:, C:]], [pr[:, :C], pr[:, C:]],
+               [G[pre + ".key_update.2.weight"], G[pre + ".lin_msg_update.2.weight"]], b_act=True)
+        tiles = ops.gemm_tiles_m(R)
+        csk, csm = _parts(tiles * C, dev), _parts(tiles * C, dev)
+        ops.gemm([gs[:, :C], gs[:, C:]], [P[pre + ".key_update.2.weight"], P[pre + ".lin_msg_update.2.weight"]],
+                 [pr[:, :C], pr[:, C:]], b_kstrided=True, dact=[pr[:, :C], pr[:, C:]], colsum=[csk, csm])   # pr = dpre
+        G[pre + ".key_update.0.bias"], G[pre + ".lin_msg_update.0.bias"] = _e((C,), dev), _e((C,), dev)
+        ops.colsum_finalize([csk, csm], tiles, [G[pre + ".key_update.0.bias"], G[pre + ".lin_msg_update.0.bias"]])
+        dW1k, dW1m = _e((C, 3 * C), dev), _e((C, 3 * C), dev)
+        G[pre + ".key_update.0.weight"], G[pre + ".lin_msg_update.0.weight"] = dW1k, dW1m
+        _wgrad([pr[:, :C], pr[:, C:]], [ea, ea], [dW1k[:, 2 * C:], dW1m[:, 2 * C:]])
+        return pr, dW1k, dW1m
+
+
+class _IComformerFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model: "iComformer", batch, training: bool, *params):
+        P: Dict[str, torch.Tensor] = dict(zip(model._param_names, params))
+        B: Dict[str, torch.Tensor] = dict(model.named_buffers())
+        need_grad = any(ctx.needs_input_grad)
+        C = model.dim_in
+        dev = params[0].device
+        z = batch.x
+        if not (torch.is_tensor(z) and z.dtype == torch.int64 and z.dim() == 1):
+            raise ValueError("batch.x must hold int64 atomic numbers [N]")
+        N, E, Bg = int(z.shape[0]), int(batch.edge_index.shape[1]), int(batch.num_graphs)
+        gptr = batch.ptr.to(dev)
+        lay = ops.GraphLayout(batch.edge_index, N, gptr)
+        if model.validate_graph:
+            lay.validate()
+        sv = {"lay": lay, "N": N, "E": E, "Bg": Bg, "training": training}
+
+        # ---- embeddings (comformer.py:116-124)
+        x = _e((N, C), dev)
+        T = batch.temperature.contiguous()
+        ops.node_embed(z, batch.batch, T, P["embedding.weight"], P["temperature_proj_atom.weight"],
+                       P["temperature_proj_atom.bias"], None, x)
+        cell = batch.cell.contiguous()
+        edge_feat, nl, nc = _e((max(E, 1),), dev), _e((Bg * 3,), dev), _e((max(E, 1) * 3,), dev)
+        ops.lattice_features(cell, batch.batch, lay.src, batch.cart_dist.contiguous(), batch.cart_dir.contiguous(),
+                             edge_feat, nl, nc)
+
+        def rbf_branch(vals, n, rbf_mod, cbuf, lin, tag):
+            r = _e((n, C), dev)
+            ops.rbf_expand(vals, B[cbuf], rbf_mod.gamma, r)
+            pre = _e((n, C), dev)
+            ops.gemm(r, P[lin + ".weight"], pre, bias=P[lin + ".bias"])
+            out = _e((n, C), dev)
+            ops.eltwise(0, pre, None, out)
+            sv[tag] = (r, pre)
+            return out
+
+        e = rbf_branch(edge_feat[:E], E, model.rbf[0], "rbf.0.centers", "rbf.1", "rbf_e")
+        NLt = rbf_branch(nl, Bg * 3, model.rbf[0], "rbf.0.centers", "rbf.1", "rbf_nl")           # [Bg*3, C]
+        NA = rbf_branch(nc[:3 * E], 3 * E, model.rbf_angle[0], "rbf_angle.0.centers", "rbf_angle.1", "rbf_na")  # [3E,C]
+        # index helpers for the edge layer: row r = 3*edge + lattice vector
+        ar3 = torch.arange(3 * E, device=dev, dtype=torch.int32)
+        idx_edge = torch.div(ar3, 3, rounding_mode="floor").to(torch.int32).contiguous()
+        g_of_e = batch.batch[batch.edge_index[0]].to(torch.int32)
+        idx_gl = (g_of_e.repeat_interleave(3) * 3 + ar3 % 3).to(torch.int32).contiguous()
+        ptr3 = (3 * torch.arange(E + 1, device=dev, dtype=torch.int32)).contiguous()
+        seg3 = ops.SegmentLayout(ptr3, 3 * E)
+        gedge_ptr = lay.rowptr[gptr.long()].contiguous()          # edge range of every crystal
+        sv.update(idx_edge=idx_edge, idx_gl=idx_gl, seg3=seg3, gedge_ptr=gedge_ptr, z=z, gid=batch.batch, T=T)
+
+        def conv(l, x, e):
+            p = f"att_layers.{l}"
+            s = {}
+            QKV = _e((N, 3 * C), dev)
+            ops.gemm([x, x, x], [P[p + ".lin_query.weight"], P[p + ".lin_key.weight"], P[p + ".lin_value.weight"]],
+                     [QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:]],
+                     bias=[P[p + ".lin_query.bias"], P[p + ".lin_key.bias"], P[p + ".lin_value.bias"]])
+            ea = _e((E, C), dev)
+            ops.gemm(e, P[p + ".lin_edge.weight"], ea, bias=P[p + ".lin_edge.bias"])
+            W1k, W1m = P[p + ".key_update.0.weight"], P[p + ".lin_msg_update.0.weight"]
+            k, v = QKV[:, C:2 * C], QKV[:, 2 * C:]
+            KPi, KPj = _e((N, 2 * C), dev), _e((N, 2 * C), dev)      # [key | msg] node terms for target / source
+            ops.gemm([k, v, k, v], [W1k[:, :C], W1m[:, :C], W1k[:, C:2 * C], W1m[:, C:2 * C]],
+                     [KPi[:, :C], KPi[:, C:], KPj[:, :C], KPj[:, C:]],
+                     bias=[P[p + ".key_update.0.bias"], P[p + ".lin_msg_update.0.bias"], None, None])
+            aggr = _Attention.forward(P, B, p, QKV[:, :C], KPi, KPj, lay.tgt, lay.src, ea, lay, E, training, s)
+            tiles = ops.gemm_tiles_m(N)
+            cs, cq = _parts(tiles * C, dev), _parts(tiles * C, dev)
+            o = _e((N, C), dev)
+            ops.gemm(aggr, P[p + ".lin_concate.weight"], o, bias=P[p + ".lin_concate.bias"], colsum=cs, colsq=cq)
+            mr2 = _e((2 * C,), dev)
+            ops.bn_finalize(cs, cq, tiles, N, C, BN_EPS, BN_MOMENTUM, training, B[p + ".bn.running_mean"],
+                            B[p + ".bn.running_var"], B[p + ".bn.num_batches_tracked"], mr2)
+            y = _e((N, C), dev)
+            ops.softplus_update_fwd(o, x, mr2, P[p + ".bn.weight"], P[p + ".bn.bias"], y)
+            s.update(x=x, e=e, QKV=QKV, ea=ea, o=o, mr2=mr2)
+            sv[p] = s
+            return y
+
+        def conv_edge(e):
+            p = "edge_update_layer"
+            s = {}
+            QKV = _e((E, 3 * C), dev)
+            ops.gemm([e, e, e], [P[p + ".lin_query.weight"], P[p + ".lin_key.weight"], P[p + ".lin_value.weight"]],
+                     [QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:]],
+                     bias=[P[p + ".lin_query.bias"], P[p + ".lin_key.bias"], P[p + ".lin_value.bias"]])
+            NL3 = NLt.view(Bg, 3 * C)
+            KY, VY = _e((Bg, 3 * C), dev), _e((Bg, 3 * C), dev)
+            for out, kind in ((KY, "key"), (VY, "value")):
+                ops.gemm([NL3[:, i * C:(i + 1) * C] for i in range(3)],
+                         [P[p + f".lin_{kind}_e{i + 1}.weight"] for i in range(3)],
+                         [out[:, i * C:(i + 1) * C] for i in range(3)],
+                         bias=[P[p + f".lin_{kind}_e{i + 1}.bias"] for i in range(3)])
+            exy = _e((3 * E, C), dev)
+            ops.gemm(NA, P[p + ".lin_edge.weight"], exy)
+            W1k, W1m = P[p + ".key_update.0.weight"], P[p + ".lin_msg_update.0.weight"]
+            Ka = _e((E, 2 * C), dev)            # per-edge term   [key | msg]
+            ops.gemm([QKV[:, C:2 * C], QKV[:, 2 * C:]], [W1k[:, :C], W1m[:, :C]], [Ka[:, :C], Ka[:, C:]],
+                     bias=[P[p + ".key_update.0.bias"], P[p + ".lin_msg_update.0.bias"]])
+            KYb = _e((Bg * 3, 2 * C), dev)      # per (crystal, lattice vector) term
+            ops.gemm([KY.view(Bg * 3, C), VY.view(Bg * 3, C)], [W1k[:, C:2 * C], W1m[:, C:2 * C]],
+                     [KYb[:, :C], KYb[:, C:]])
+            aggr = _Attention.forward(P, B, p, QKV[:, :C], Ka, KYb, idx_edge, idx_gl, exy, seg3, 3 * E, training, s)
+            bias3 = _e((1, C), dev)
+            ops.eltwise(3, P[p + ".lin_concate.bias"].view(1, C), None, bias3, 3.0)
+            tiles = ops.gemm_tiles_m(E)
+            cs, cq = _parts(tiles * C, dev), _parts(tiles * C, dev)
+            o = _e((E, C), dev)
+            ops.gemm(aggr, P[p + ".lin_concate.weight"], o, bias=bias3.view(C), colsum=cs, colsq=cq)
+            mr2 = _e((2 * C,), dev)
+            ops.bn_finalize(cs, cq, tiles, E, C, BN_EPS, BN_MOMENTUM, training, B[p + ".bn.running_mean"],
+                            B[p + ".bn.running_var"], B[p + ".bn.num_batches_tracked"], mr2)
+            y = _e((E, C), dev)
+            ops.softplus_update_fwd(o, e, mr2, P[p + ".bn.weight"], P[p + ".bn.bias"], y)
+            s.update(e=e, QKV=QKV, KY=KY, VY=VY, exy=exy, o=o, mr2=mr2)
+            sv[p] = s
+            return y
+
+        x = conv(0, x, e)
+        sv["NLt"], sv["NA"] = NLt, NA
+        e = conv_edge(e)
+        for l in (1, 2, 3):
+            x = conv(l, x, e)
+
+        # ---- Cholesky head (shared with CartNet)
+        H = C // 2
+        hid = _e((N, H), dev)
+        ops.gemm(x, P["cholesky.MLP.0.weight"], hid, bias=P["cholesky.MLP.0.bias"])
+        M = int(batch.y.shape[0])
+        idx = torch.empty(N, dtype=torch.int32, device=dev)
+        ops.mask_index(batch.non_H_mask.contiguous(), idx, None)
+        p6, pred = _e((M, 6), dev), _e((M, 3, 3), dev)
+        ops.cholesky_head_fwd(hid, idx, P["cholesky.MLP.2.weight"], P["cholesky.MLP.2.bias"], p6, pred)
+        sv.update(hid=hid, idx=idx, p6=p6, x_final=x, P=P, model=model)
+        ctx.sv = sv if need_grad else None
+        ctx.mark_non_differentiable(x)
+        return pred, x
+
+    @staticmethod
+    def backward(ctx, dpred, _dx_unused):
+        sv = ctx.sv
+        if sv is None:
+            raise RuntimeError("iComformer backward called without saved state")
+        ctx.sv = None
+        P, model, lay = sv["P"], sv["model"], sv["lay"]
+        N, E, Bg, training = sv["N"], sv["E"], sv["Bg"], sv["training"]
+        C = model.dim_in
+        H = C // 2
+        dev = dpred.device
+        G: Dict[str, torch.Tensor] = {}
+
+        # ---- head
+        nparts_n = ops.node_nparts(N)
+        row = 7 * H + 8
+        parts = _e((nparts_n * row,), dev)
+        dhid = _e((N, H), dev)
+        ops.cholesky_head_bwd(sv["hid"], sv["idx"], P["cholesky.MLP.2.weight"], sv["p6"], dpred.contiguous(), dhid, parts)
+        tot = _e((row,), dev)
+        ops.colsum_finalize(parts, nparts_n, tot)
+        G["cholesky.MLP.2.weight"], G["cholesky.MLP.2.bias"] = tot[:6 * H].view(6, H), tot[6 * H:6 * H + 6]
+        G["cholesky.MLP.0.bias"] = tot[6 * H + 8:]
+        G["cholesky.MLP.0.weight"] = _e((H, C), dev)
+        _wgrad([dhid], [sv["x_final"]], [G["cholesky.MLP.0.weight"]])
+        dx = _e((N, C), dev)
+        ops.gemm(dhid, P["cholesky.MLP.0.weight"], dx, b_kstrided=True)
+
+        def softplus_bwd(p, s, dy, rows, x_in):
+            """Backward of y = softplus(x_in + bn(o)): returns (d_o, d_residual)."""
+            np_ = ops.segment_nparts(rows)
+            pa, pb = _parts(np_ * C, dev), _parts(np_ * C, dev)
+            ops.softplus_update_bwd_stats(s["o"], x_in, dy, s["mr2"], P[p + ".bn.weight"], P[p + ".bn.bias"], pa, pb)
+            sums = _e((2 * C,), dev)
+            ops.colsum_finalize([pa, pb], np_, [sums[:C], sums[C:]])
+            G[p + ".bn.bias"], G[p + ".bn.weight"] = sums[:C], sums[C:]
+            d_o, dres = _e((rows, C), dev), _e((rows, C), dev)
+            ops.softplus_update_bwd_apply(s["o"], x_in, dy, s["mr2"], P[p + ".bn.weight"], P[p + ".bn.bias"], sums,
+                                          training, d_o, None, dres)
+            return d_o, dres
+
+        def linear3_bwd(p, dQKV, inp, resid):
+            """Backward of the query / key / value Linears that share the input ``inp``: returns d(inp) + resid."""
+            for j, nm in enumerate(("query", "key", "value")):
+                G[p + f".lin_{nm}.bias"] = _e((C,), dev)
+                ops.colsum(dQKV[:, j * C:(j + 1) * C], G[p + f".lin_{nm}.bias"])
+                G[p + f".lin_{nm}.weight"] = _e((C, C), dev)
+            _wgrad([dQKV[:, :C], dQKV[:, C:2 * C], dQKV[:, 2 * C:]], [inp, inp, inp],
+                   [G[p + ".lin_query.weight"], G[p + ".lin_key.weight"], G[p + ".lin_value.weight"]])
+            d_in = _e(tuple(inp.shape), dev)
+            ops.gemm([dQKV[:, :C], dQKV[:, C:2 * C], dQKV[:, 2 * C:]],
+                     [P[p + ".lin_query.weight"], P[p + ".lin_key.weight"], P[p + ".lin_value.weight"]], d_in,
+                     b_kstrided=True, segments=True, resid=resid)
+            return d_in
+
+        def conv_bwd(l, dy):
+            """Returns (dx, de) of att_layers[l]."""
+            p = f"att_layers.{l}"
+            s = sv.pop(p)
+            x_in, e_in, QKV, ea = s["x"], s["e"], s["QKV"], s["ea"]
+            d_o, dres = softplus_bwd(p, s, dy, N, x_in)
+            G[p + ".lin_concate.bias"] = _e((C,), dev)
+            ops.colsum(d_o, G[p + ".lin_concate.bias"])
+            G[p + ".lin_concate.weight"] = _e((C, C), dev)
+            _wgrad([d_o], [s["aggr"]], [G[p + ".lin_concate.weight"]])
+            daggr = _e((N, C), dev)
+            ops.gemm(d_o, P[p + ".lin_concate.weight"], daggr, b_kstrided=True)
+            dQKV = _e((N, 3 * C), dev)
+            dpre, dW1k, dW1m = _Attention.backward(P, G, p, daggr, QKV[:, :C], ea, lay, E, training, s, dQKV[:, :C])
+            W1k, W1m = P[p + ".key_update.0.weight"], P[p + ".lin_msg_update.0.weight"]
+            # lin_edge: d(ea) = dpre @ W1[:, 2C:], then into e
+            dea = _e((E, C), dev)
+            tiles = ops.gemm_tiles_m(E)
+            cs = _parts(tiles * C, dev)
+            ops.gemm([dpre[:, :C], dpre[:, C:]], [W1k[:, 2 * C:], W1m[:, 2 * C:]], dea, b_kstrided=True, segments=True,
+                     colsum=cs)
+            G[p + ".lin_edge.bias"] = _e((C,), dev)
+            ops.colsum_finalize(cs, tiles, G[p + ".lin_edge.bias"])
+            G[p + ".lin_edge.weight"] = _e((C, C), dev)
+            _wgrad([dea], [e_in], [G[p + ".lin_edge.weight"]])
+            de = _e((E, C), dev)
+            ops.gemm(dea, P[p + ".lin_edge.weight"], de, b_kstrided=True)
+            # node terms: reduce dpre over incoming (target) / outgoing (source) edges
+            dKPi, dKPj = _e((N, 2 * C), dev), _e((N, 2 * C), dev)
+            ops.segment_sum(dpre, lay.rowptr, None, dKPi)
+            ops.segment_sum(dpre, lay.colptr, lay.perm, dKPj)
+            k, v = QKV[:, C:2 * C], QKV[:, 2 * C:]
+            _wgrad([dKPi[:, :C], dKPi[:, C:], dKPj[:, :C], dKPj[:, C:]], [k, v, k, v],
+                   [dW1k[:, :C], dW1m[:, :C], dW1k[:, C:2 * C], dW1m[:, C:2 * C]])
+            ops.gemm([dKPi[:, :C], dKPj[:, :C]], [W1k[:, :C], W1k[:, C:2 * C]], dQKV[:, C:2 * C], b_kstrided=True,
+                     segments=True)
+            ops.gemm([dKPi[:, C:], dKPj[:, C:]], [W1m[:, :C], W1m[:, C:2 * C]], dQKV[:, 2 * C:], b_kstrided=True,
+                     segments=True)
+            dx_in = linear3_bwd(p, dQKV, x_in, dres)
+            return dx_in, de
+
+        def conv_edge_bwd(dy):
+            """Returns (de, dNLt [Bg*3, C], dNA [3E, C]) of the edge update layer."""
+            p = "edge_update_layer"
+            s = sv.pop(p)
+            e_in, QKV, KY, VY, exy = s["e"], s["QKV"], s["KY"], s["VY"], s["exy"]
+            seg3 = sv["seg3"]
+            d_o, dres = softplus_bwd(p, s, dy, E, e_in)
+            G[p + ".lin_concate.bias"] = _e((C,), dev)
+            tmpb = _e((1, C), dev)
+            ops.colsum(d_o, tmpb.view(C))
+            ops.eltwise(3, tmpb, None, G[p + ".lin_concate.bias"].view(1, C), 3.0)
+            G[p + ".lin_concate.weight"] = _e((C, C), dev)
+            _wgrad([d_o], [s["aggr"]], [G[p + ".lin_concate.weight"]])
+            daggr = _e((E, C), dev)
+            ops.gemm(d_o, P[p + ".lin_concate.weight"], daggr, b_kstrided=True)
+            dQKV = _e((E, 3 * C), dev)
+            dpre, dW1k, dW1m = _Attention.backward(P, G, p, daggr, QKV[:, :C], exy, seg3, 3 * E, training, s,
+                                                   dQKV[:, :C])
+            W1k, W1m = P[p + ".key_update.0.weight"], P[p + ".lin_msg_update.0.weight"]
+            # angle branch: d(exy) -> lin_edge (no bias) -> dNA
+            dexy = _e((3 * E, C), dev)
+            ops.gemm([dpre[:, :C], dpre[:, C:]], [W1k[:, 2 * C:], W1m[:, 2 * C:]], dexy, b_kstrided=True, segments=True)
+            G[p + ".lin_edge.weight"] = _e((C, C), dev)
+            _wgrad([dexy], [sv["NA"]], [G[p + ".lin_edge.weight"]])
+            dNA = _e((3 * E, C), dev)
+            ops.gemm(dexy, P[p + ".lin_edge.weight"], dNA, b_kstrided=True)
+            # per-edge term (sum over the three lattice vectors) and per-(crystal, lattice vector) term
+            dKa = _e((E, 2 * C), dev)
+            ops.segment_sum(dpre, seg3.rowptr, None, dKa)
+            dKYb = _e((Bg * 3, 2 * C), dev)
+            dpre6, dKYb6 = dpre.view(E, 6 * C), dKYb.view(Bg, 6 * C)
+            for i in range(3):
+                ops.segment_sum(dpre6[:, i * 2 * C:(i + 1) * 2 * C], sv["gedge_ptr"], None,
+                                dKYb6[:, i * 2 * C:(i + 1) * 2 * C])
+            kx, vx = QKV[:, C:2 * C], QKV[:, 2 * C:]
+            KYf, VYf = KY.view(Bg * 3, C), VY.view(Bg * 3, C)
+            _wgrad([dKa[:, :C], dKa[:, C:]], [kx, vx], [dW1k[:, :C], dW1m[:, :C]])
+            _wgrad([dKYb[:, :C], dKYb[:, C:]], [KYf, VYf], [dW1k[:, C:2 * C], dW1m[:, C:2 * C]])
+            ops.gemm(dKa[:, :C], W1k[:, :C], dQKV[:, C:2 * C], b_kstrided=True)
+            ops.gemm(dKa[:, C:], W1m[:, :C], dQKV[:, 2 * C:], b_kstrided=True)
+            dKY, dVY = _e((Bg, 3 * C), dev), _e((Bg, 3 * C), dev)
+            ops.gemm(dKYb[:, :C], W1k[:, C:2 * C], dKY.view(Bg * 3, C), b_kstrided=True)
+            ops.gemm(dKYb[:, C:], W1m[:, C:2 * C], dVY.view(Bg * 3, C), b_kstrided=True)
+            # lin_key_e{i} / lin_value_e{i} on the lattice-length features
+            NL3 = sv["NLt"].view(Bg, 3 * C)
+            dNL3 = _e((Bg, 3 * C), dev)
+            for i in range(3):
+                sl = slice(i * C, (i + 1) * C)
+                for dT, kind in ((dKY, "key"), (dVY, "value")):
+                    nm = p + f".lin_{kind}_e{i + 1}"
+                    G[nm + ".bias"] = _e((C,), dev)
+                    ops.colsum(dT[:, sl], G[nm + ".bias"])
+                    G[nm + ".weight"] = _e((C, C), dev)
+                    _wgrad([dT[:, sl]], [NL3[:, sl]], [G[nm + ".weight"]])
+                ops.gemm([dKY[:, sl], dVY[:, sl]], [P[p + f".lin_key_e{i + 1}.weight"], P[p + f".lin_value_e{i + 1}.weight"]],
+                         dNL3[:, sl], b_kstrided=True, segments=True)
+            de = linear3_bwd(p, dQKV, e_in, dres)
+            return de, dNL3.view(Bg * 3, C), dNA
+
+        # ---- layers in reverse: att 3, 2, 1 (all read the updated edge features), edge layer, att 0
+        de_new = None
+        for l in (3, 2, 1):
+            dx, de_l = conv_bwd(l, dx)
+            if de_new is None:
+                de_new = de_l
+            else:
+                acc = _e((E, C), dev)
+                ops.eltwise(2, de_new, de_l, acc)
+                de_new = acc
+        de_old, dNLt, dNA = conv_edge_bwd(de_new)
+        dx, de0 = conv_bwd(0, dx)
+        de_tot = _e((E, C), dev)
+        ops.eltwise(2, de_old, de0, de_tot)
+
+        # ---- RBF branches: out = softplus(pre), pre = rbf @ W^T + b ; rbf.1 is shared by the distance and the
+        #      lattice-length features, so its gradients add up
+        def rbf_bwd(tag, dout):
+            r, pre = sv[tag]
+            dpre = _e(tuple(pre.shape), dev)
+            ops.eltwise(1, dout, pre, dpre)
+            gw, gb = _e((C, C), dev), _e((C,), dev)
+            _wgrad([dpre], [r], [gw])
+            ops.colsum(dpre, gb)
+            return gw, gb
+
+        gw1, gb1 = rbf_bwd("rbf_e", de_tot)
+        gw2, gb2 = rbf_bwd("rbf_nl", dNLt)
+        G["rbf.1.weight"], G["rbf.1.bias"] = _e((C, C), dev), _e((C,), dev)
+        ops.eltwise(2, gw1, gw2, G["rbf.1.weight"])
+        ops.eltwise(2, gb1.view(1, C), gb2.view(1, C), G["rbf.1.bias"].view(1, C))
+        G["rbf_angle.1.weight"], G["rbf_angle.1.bias"] = rbf_bwd("rbf_na", dNA)
+
+        # ---- atom embedding and temperature projection
+        pw, pb = _parts(nparts_n * C, dev), _parts(nparts_n * C, dev)
+        ops.node_embed_bwd(sv["gid"], sv["T"], dx, pw, pb)
+        gw, gb = _e((C,), dev), _e((C,), dev)
+        ops.colsum_finalize([pw, pb], nparts_n, [gw, gb])
+        G["temperature_proj_atom.weight"], G["temperature_proj_atom.bias"] = gw.view(C, 1), gb
+        zperm, zptr, _ = ops.sort_by_key(sv["z"], N_ATOM_TYPES)
+        G["embedding.weight"] = _e((N_ATOM_TYPES, C), dev)
+        ops.segment_sum_long(dx, zptr, zperm, N, G["embedding.weight"])
+        return (None, None, None) + tuple(G.get(n) for n in model._param_names)
+
+
+class iComformer(nn.Module):
+    """iComformer (reference: models/comformer.py:75-132) on the gfx950 kernels.  ``forward(data)`` returns
+    ``(pred [M,3,3], data.y)`` and, like the reference, replaces ``data.x`` with the final atom features."""
+
+    def __init__(self, dim_in: int):
+        super().__init__()
+        if dim_in % 8 != 0 or dim_in // 2 > 512:
+            raise ValueError("dim_in must be a multiple of 8 and at most 1024")
+        c = dim_in
+        self.dim_in = c
+        self.embedding = nn.Embedding(N_ATOM_TYPES, c)
+        self.temperature_proj_atom = nn.Linear(1, c, bias=True)
+        self.rbf = nn.Sequential(_RBF(-4.0, 0.0, c), nn.Linear(c, c), nn.Softplus())
+        self.rbf_angle = nn.Sequential(_RBF(-1.0, 1.0, c), nn.Linear(c, c), nn.Softplus())
+        self.att_layers = nn.ModuleList([ComformerConv(c) for _ in range(4)])
+        self.edge_update_layer = ComformerConv_edge(c)
+        self.cholesky = Cholesky_head(c)
+        self.validate_graph = False
+        self._param_names = [n for n, _ in self.named_parameters()]
+
+    def forward(self, data):
+        params = [p for _, p in self.named_parameters()]
+        if not params[0].is_cuda:
+            raise RuntimeError("cartnet_amd.iComformer runs only on an AMD GPU (HIP kernels); there is no CPU fallback")
+        pred, x = _IComformerFunction.apply(self, data, self.training, *params)
+        data.x = x
+        return pred, data.y
+
+
+def make_icomformer_state_dict(dim_in: int, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Deterministic reference-shaped state_dict (CPU) for the parity fixtures; BatchNorm affine / running statistics
+    are randomised so that eval mode is exercised."""
+    torch.manual_seed(seed)
+    m = iComformer(dim_in)
+    g = torch.Generator().manual_seed(seed + 1)
+    sd = m.state_dict()
+    for k, v in sd.items():
+        if k.endswith("running_mean"):
+            v.copy_(0.1 * torch.randn(v.shape, generator=g))
+        elif k.endswith("running_var"):
+            v.copy_(0.5 + torch.rand(v.shape, generator=g))
+        elif (".bn." in k or ".bn_att." in k) and k.endswith(".weight"):
+            v.copy_(1.0 + 0.2 * torch.randn(v.shape, generator=g))
+        elif (".bn." in k or ".bn_att." in k) and k.endswith(".bias"):
+            v.copy_(0.2 * torch.randn(v.shape, generator=g))
+    return {k: v.clone() for k, v in sd.items()}

@@ -1,0 +1,361 @@
+// Kernels that only the iComformer path needs (reference: models/comformer.py:75-132, models/comformer_conv.py:21-193):
+// Gaussian RBF expansion, lattice length / angle features, element-wise softplus pieces, the query x key product with
+// its BatchNorm statistics, and the softplus(x + bn(o)) residual update.  The dense work reuses cartnet_gemm, the
+// gated aggregation reuses cartnet_gate_scatter_*, reductions reuse the fp64 partial-sum machinery.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int NODES_PER_BLOCK = 4;
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+inline int seg_parts(int S) {
+  int b = cn_ceil_div(S, NODES_PER_BLOCK);
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return b;
+}
+
+// out[r, k] = exp(-gamma (v[r] - centers[k])^2)      (models/utils.py:125-129)
+__global__ void cn_rbf_expand_kernel(const float* __restrict__ v, long long n, const float* __restrict__ centers,
+                                     int bins, float gamma, float* __restrict__ out, int ldo) {
+  const long long total = n * bins;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / bins;
+    const int k = (int)(i - r * bins);
+    const float d = v[r] - centers[k];
+    out[r * ldo + k] = expf(-gamma * (d * d));
+  }
+}
+
+// edge_feat[e] = -0.75 / dist[e];  nei_len[g, i] = -0.75 / |cell[g, i]|;
+// nei_cos[e, i] = clamp(<cell[g(e), i], dir[e]> / (|cell[g(e), i]| |dir[e]|), -1, 1), g(e) = batch[src[e]]
+// (models/comformer.py:117-120, bond_cosine :18-23)
+__global__ void cn_lattice_features_kernel(const float* __restrict__ cell, const int64_t* __restrict__ batch,
+                                           const int* __restrict__ src, const float* __restrict__ dist,
+                                           const float* __restrict__ dir, long long E, int Bg,
+                                           float* __restrict__ edge_feat, float* __restrict__ nei_len,
+                                           float* __restrict__ nei_cos) {
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = i0; i < (long long)Bg * 3; i += stride) {
+    const float* c = cell + i * 3;
+    nei_len[i] = -0.75f / sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+  }
+  for (long long e = i0; e < E; e += stride) {
+    edge_feat[e] = -0.75f / dist[e];
+    const int g = (int)batch[src[e]];
+    const float dx = dir[e * 3], dy = dir[e * 3 + 1], dz = dir[e * 3 + 2];
+    const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float* c = cell + ((size_t)g * 3 + a) * 3;
+      const float cn = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+      float v = (c[0] * dx + c[1] * dy + c[2] * dz) / (cn * dn);
+      v = fminf(fmaxf(v, -1.f), 1.f);
+      nei_cos[e * 3 + a] = v;
+    }
+  }
+}
+
+// Element-wise helpers on [rows, cols] views (16-byte aligned rows).
+// op 0: out = softplus(a); 1: out = a * sigmoid(b)  (softplus backward); 2: out = a + b; 3: out = a * scale
+__global__ void cn_eltwise_kernel(int op, const float* a, const float* b, float* out, long long rows, int cols4,
+                                  int lda, int ldb, int ldo, float scale) {
+  const long long total = rows * cols4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cols4;
+    const int c = (int)(i - r * cols4) * 4;
+    const f32x4 x = ld4(a + r * lda + c);
+    f32x4 y = {0, 0, 0, 0};
+    if (op == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y[q] = softplus_f(x[q]);
+    } else if (op == 1) {
+      const f32x4 p = ld4(b + r * ldb + c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y[q] = x[q] * (p[q] > 20.f ? 1.f : cn_sigmoid(p[q]));
+    } else if (op == 2) {
+      y = x + ld4(b + r * ldb + c);
+    } else {
+      y = x * scale;
+    }
+    st4(out + r * ldo + c, y);
+  }
+}
+
+// alpha[r] = key[r] * q[s] * scale for the rows r of segment s (+ fp64 column statistics of alpha).
+__global__ __launch_bounds__(256) void cn_rowmul_fwd_kernel(const float* __restrict__ key, int ldk,
+                                                            const float* __restrict__ q, int ldq,
+                                                            const int* __restrict__ ptr, int S, int C, float scale,
+                                                            float* __restrict__ alpha, int lda,
+                                                            double* __restrict__ parts_sum,
+                                                            double* __restrict__ parts_sq) {
+  __shared__ double red[NODES_PER_BLOCK * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + lane * 4;
+    const bool active = c < C;
+    f64x4 ps = {0, 0, 0, 0}, pq = {0, 0, 0, 0};
+    for (int s = blockIdx.x * NODES_PER_BLOCK + wid; s < S; s += gridDim.x * NODES_PER_BLOCK) {
+      if (!active) continue;
+      const f32x4 qv = ld4(q + (size_t)s * ldq + c) * scale;
+      for (int r = ptr[s]; r < ptr[s + 1]; ++r) {
+        const f32x4 a = ld4(key + (size_t)r * ldk + c) * qv;
+        st4(alpha + (size_t)r * lda + c, a);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ps[k] += (double)a[k];
+          pq[k] += (double)a[k] * (double)a[k];
+        }
+      }
+    }
+    cn_block_store_parts(ps, red, parts_sum, C, c, active, wid, lane);
+    cn_block_store_parts(pq, red, parts_sq, C, c, active, wid, lane);
+  }
+}
+
+// dalpha (in place) <- dkey = dalpha * q[s] * scale;  dq[s] = sum_r dalpha[r] * key[r] * scale   (fixed row order)
+__global__ __launch_bounds__(256) void cn_rowmul_bwd_kernel(float* dalpha, int lda, const float* __restrict__ key,
+                                                            int ldk, const float* __restrict__ q, int ldq,
+                                                            const int* __restrict__ ptr, int S, int C, float scale,
+                                                            float* __restrict__ dq, int lddq) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int chunks = (C + 255) / 256;
+  for (long long it = (long long)blockIdx.x * NODES_PER_BLOCK + wid; it < (long long)S * chunks;
+       it += (long long)gridDim.x * NODES_PER_BLOCK) {
+    const int s = (int)(it / chunks);
+    const int c = (int)(it % chunks) * 256 + lane * 4;
+    if (c >= C) continue;
+    const f32x4 qv = ld4(q + (size_t)s * ldq + c) * scale;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int r = ptr[s]; r < ptr[s + 1]; ++r) {
+      const f32x4 da = ld4(dalpha + (size_t)r * lda + c);
+      acc += da * ld4(key + (size_t)r * ldk + c);
+      st4(dalpha + (size_t)r * lda + c, da * qv);
+    }
+    st4(dq + (size_t)s * lddq + c, acc * scale);
+  }
+}
+
+// y = softplus(x + bn(o))   (ComformerConv.forward, comformer_conv.py:88)
+__global__ void cn_softplus_update_fwd_kernel(const float* __restrict__ o, const float* __restrict__ x,
+                                              const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, long long N, int D,
+                                              float* __restrict__ y) {
+  const long long total4 = N * D / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % D);
+    const f32x4 a = ld4(o + i * 4), xi = ld4(x + i * 4);
+    const f32x4 mean = ld4(mean_rstd + c), rstd = ld4(mean_rstd + D + c), gam = ld4(gamma + c), bet = ld4(beta + c);
+    f32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = softplus_f(xi[q] + (a[q] - mean[q]) * rstd[q] * gam[q] + bet[q]);
+    st4(y + i * 4, r);
+  }
+}
+
+// MODE 0: du = dy * sigmoid(u), u = x + bn(o); partial sums of du and du * ohat.
+// MODE 1: do = gamma * rstd * (du - sum_a/N - ohat * sum_b/N); dx = du (+ dx_add).
+template <int MODE>
+__global__ __launch_bounds__(256) void cn_softplus_update_bwd_kernel(
+    const float* __restrict__ o, const float* __restrict__ x, const float* __restrict__ dy,
+    const float* __restrict__ mean_rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ sums, float inv_count, int N, int D, double* __restrict__ parts_a,
+    double* __restrict__ parts_b, float* __restrict__ d_o, const float* dx_add, float* dx) {
+  __shared__ double red[NODES_PER_BLOCK * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < D; c0 += 256) {
+    const int c = c0 + lane * 4;
+    const bool active = c < D;
+    f32x4 mean = {0, 0, 0, 0}, rstd = {0, 0, 0, 0}, gam = {0, 0, 0, 0}, bet = {0, 0, 0, 0};
+    f32x4 m_a = {0, 0, 0, 0}, m_b = {0, 0, 0, 0};
+    if (active) {
+      mean = ld4(mean_rstd + c);
+      rstd = ld4(mean_rstd + D + c);
+      gam = ld4(gamma + c);
+      bet = ld4(beta + c);
+      if (MODE == 1) {
+        m_a = ld4(sums + c) * inv_count;
+        m_b = ld4(sums + D + c) * inv_count;
+      }
+    }
+    f64x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+    for (int n = blockIdx.x * NODES_PER_BLOCK + wid; n < N; n += gridDim.x * NODES_PER_BLOCK) {
+      if (!active) continue;
+      const f32x4 a = ld4(o + (size_t)n * D + c), xi = ld4(x + (size_t)n * D + c), g = ld4(dy + (size_t)n * D + c);
+      f32x4 vo, vx;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float ohat = (a[q] - mean[q]) * rstd[q];
+        const float u = xi[q] + ohat * gam[q] + bet[q];
+        const float du = g[q] * (u > 20.f ? 1.f : cn_sigmoid(u));
+        if (MODE == 0) {
+          pa[q] += (double)du;
+          pb[q] += (double)du * (double)ohat;
+        } else {
+          vo[q] = gam[q] * rstd[q] * (du - m_a[q] - ohat * m_b[q]);
+          vx[q] = du;
+        }
+      }
+      if (MODE == 1) {
+        st4(d_o + (size_t)n * D + c, vo);
+        if (dx_add) vx += ld4(dx_add + (size_t)n * D + c);
+        st4(dx + (size_t)n * D + c, vx);
+      }
+    }
+    if (MODE == 0) {
+      cn_block_store_parts(pa, red, parts_a, D, c, active, wid, lane);
+      cn_block_store_parts(pb, red, parts_b, D, c, active, wid, lane);
+    }
+  }
+}
+
+// Column partial sums of a [R, C] view (bias gradients): parts[block][c], fp64.
+__global__ __launch_bounds__(256) void cn_colsum_partial_kernel(const float* __restrict__ x, int ld, int R, int C,
+                                                                double* __restrict__ parts) {
+  __shared__ double red[NODES_PER_BLOCK * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + lane * 4;
+    const bool active = c < C;
+    f64x4 ps = {0, 0, 0, 0};
+    for (int r = blockIdx.x * NODES_PER_BLOCK + wid; r < R; r += gridDim.x * NODES_PER_BLOCK)
+      if (active) cn_acc4(ps, ld4(x + (size_t)r * ld + c));
+    cn_block_store_parts(ps, red, parts, C, c, active, wid, lane);
+  }
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int cartnet_rbf_expand(const float* v, int64_t n, const float* centers, int32_t bins, float gamma,
+                                  float* out, int32_t ldo, void* stream) {
+  CN_CHECK(n >= 0 && bins >= 1 && ldo >= bins, "cartnet_rbf_expand: bad sizes");
+  if (n == 0) return 0;
+  CN_CHECK(v && centers && out, "cartnet_rbf_expand: null pointer");
+  long long blocks = (n * bins + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(cn_rbf_expand_kernel, dim3((int)blocks), dim3(256), 0, ST(stream), v, (long long)n, centers, bins,
+                     gamma, out, ldo);
+  CN_LAUNCH_CHECK("cartnet_rbf_expand");
+  return 0;
+}
+
+extern "C" int cartnet_lattice_features(const float* cell, const int64_t* batch, const int32_t* src32,
+                                        const float* cart_dist, const float* cart_dir, int64_t E, int32_t Bg,
+                                        float* edge_feat, float* nei_len, float* nei_cos, void* stream) {
+  CN_CHECK(E >= 0 && Bg >= 1, "cartnet_lattice_features: bad sizes");
+  CN_CHECK(cell && nei_len && (E == 0 || (batch && src32 && cart_dist && cart_dir && edge_feat && nei_cos)),
+           "cartnet_lattice_features: null pointer");
+  long long blocks = ((E > Bg * 3 ? E : Bg * 3) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cn_lattice_features_kernel, dim3((int)blocks), dim3(256), 0, ST(stream), cell, batch, src32,
+                     cart_dist, cart_dir, (long long)E, Bg, edge_feat, nei_len, nei_cos);
+  CN_LAUNCH_CHECK("cartnet_lattice_features");
+  return 0;
+}
+
+extern "C" int cartnet_eltwise(int32_t op, const float* a, const float* b, float* out, int64_t rows, int32_t cols,
+                               int32_t lda, int32_t ldb, int32_t ldo, float scale, void* stream) {
+  CN_CHECK(op >= 0 && op <= 3, "cartnet_eltwise: op=%d", op);
+  CN_CHECK(rows >= 0 && cols >= 4 && cols % 4 == 0 && lda % 4 == 0 && ldo % 4 == 0 && lda >= cols && ldo >= cols,
+           "cartnet_eltwise: cols / leading dimensions must be multiples of 4");
+  if (rows == 0) return 0;
+  CN_CHECK(a && out, "cartnet_eltwise: null pointer");
+  if (op == 1 || op == 2) CN_CHECK(b && ldb % 4 == 0 && ldb >= cols, "cartnet_eltwise: second operand missing");
+  long long blocks = (rows * (cols / 4) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(cn_eltwise_kernel, dim3((int)blocks), dim3(256), 0, ST(stream), op, a, b, out, (long long)rows,
+                     cols / 4, lda, ldb, ldo, scale);
+  CN_LAUNCH_CHECK("cartnet_eltwise");
+  return 0;
+}
+
+extern "C" int cartnet_rowmul_fwd(const float* key, int32_t ldk, const float* q, int32_t ldq, const int32_t* ptr,
+                                  int32_t S, int32_t C, float scale, float* alpha, int32_t lda, double* parts_sum,
+                                  double* parts_sq, void* stream) {
+  CN_CHECK(S >= 0 && C >= 4 && C % 4 == 0 && ldk % 4 == 0 && ldq % 4 == 0 && lda % 4 == 0,
+           "cartnet_rowmul_fwd: C and leading dimensions must be multiples of 4");
+  CN_CHECK(key && q && ptr && alpha && parts_sum && parts_sq, "cartnet_rowmul_fwd: null pointer");
+  hipLaunchKernelGGL(cn_rowmul_fwd_kernel, dim3(seg_parts(S)), dim3(256), 0, ST(stream), key, ldk, q, ldq, ptr, S, C,
+                     scale, alpha, lda, parts_sum, parts_sq);
+  CN_LAUNCH_CHECK("cartnet_rowmul_fwd");
+  return 0;
+}
+
+extern "C" int cartnet_rowmul_bwd(float* dalpha, int32_t lda, const float* key, int32_t ldk, const float* q,
+                                  int32_t ldq, const int32_t* ptr, int32_t S, int32_t C, float scale, float* dq,
+                                  int32_t lddq, void* stream) {
+  CN_CHECK(S >= 0 && C >= 4 && C % 4 == 0 && ldk % 4 == 0 && ldq % 4 == 0 && lda % 4 == 0 && lddq % 4 == 0,
+           "cartnet_rowmul_bwd: C and leading dimensions must be multiples of 4");
+  if (S == 0) return 0;
+  CN_CHECK(dalpha && key && q && ptr && dq, "cartnet_rowmul_bwd: null pointer");
+  long long blocks = ((long long)S * ((C + 255) / 256) + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cn_rowmul_bwd_kernel, dim3((int)blocks), dim3(256), 0, ST(stream), dalpha, lda, key, ldk, q, ldq,
+                     ptr, S, C, scale, dq, lddq);
+  CN_LAUNCH_CHECK("cartnet_rowmul_bwd");
+  return 0;
+}
+
+extern "C" int cartnet_softplus_update_fwd(const float* o, const float* x, const float* mean_rstd, const float* gamma,
+                                           const float* beta, int64_t N, int32_t D, float* y, void* stream) {
+  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_softplus_update_fwd: D=%d must be a multiple of 4", D);
+  if (N == 0) return 0;
+  CN_CHECK(o && x && mean_rstd && gamma && beta && y, "cartnet_softplus_update_fwd: null pointer");
+  long long blocks = (N * D / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cn_softplus_update_fwd_kernel, dim3((int)blocks), dim3(256), 0, ST(stream), o, x, mean_rstd, gamma,
+                     beta, (long long)N, D, y);
+  CN_LAUNCH_CHECK("cartnet_softplus_update_fwd");
+  return 0;
+}
+
+extern "C" int cartnet_softplus_update_bwd_stats(const float* o, const float* x, const float* dy,
+                                                 const float* mean_rstd, const float* gamma, const float* beta,
+                                                 int32_t N, int32_t D, double* parts_a, double* parts_b,
+                                                 void* stream) {
+  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_softplus_update_bwd_stats: D=%d must be a multiple of 4", D);
+  CN_CHECK(o && x && dy && mean_rstd && gamma && beta && parts_a && parts_b,
+           "cartnet_softplus_update_bwd_stats: null pointer");
+  hipLaunchKernelGGL(cn_softplus_update_bwd_kernel<0>, dim3(seg_parts(N)), dim3(256), 0, ST(stream), o, x, dy,
+                     mean_rstd, gamma, beta, (const float*)nullptr, 0.f, N, D, parts_a, parts_b, (float*)nullptr,
+                     (const float*)nullptr, (float*)nullptr);
+  CN_LAUNCH_CHECK("cartnet_softplus_update_bwd_stats");
+  return 0;
+}
+
+extern "C" int cartnet_softplus_update_bwd_apply(const float* o, const float* x, const float* dy,
+                                                 const float* mean_rstd, const float* gamma, const float* beta,
+                                                 const float* sums, int32_t training, int32_t N, int32_t D, float* d_o,
+                                                 const float* dx_add, float* dx, void* stream) {
+  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_softplus_update_bwd_apply: D=%d must be a multiple of 4", D);
+  if (N == 0) return 0;
+  CN_CHECK(o && x && dy && mean_rstd && gamma && beta && sums && d_o && dx,
+           "cartnet_softplus_update_bwd_apply: null pointer");
+  const float inv = (training && N > 0) ? (float)(1.0 / (double)N) : 0.f;
+  hipLaunchKernelGGL(cn_softplus_update_bwd_kernel<1>, dim3(seg_parts(N)), dim3(256), 0, ST(stream), o, x, dy,
+                     mean_rstd, gamma, beta, sums, inv, N, D, (double*)nullptr, (double*)nullptr, d_o, dx_add, dx);
+  CN_LAUNCH_CHECK("cartnet_softplus_update_bwd_apply");
+  return 0;
+}
+
+extern "C" int cartnet_segment_nparts(int32_t S) { return seg_parts(S); }
+
+extern "C" int cartnet_colsum_partial(const float* x, int32_t ld, int32_t R, int32_t C, double* parts, void* stream) {
+  CN_CHECK(R >= 0 && C >= 4 && C % 4 == 0 && ld % 4 == 0 && ld >= C, "cartnet_colsum_partial: C/ld must be multiples of 4");
+  CN_CHECK((x || R == 0) && parts, "cartnet_colsum_partial: null pointer");
+  hipLaunchKernelGGL(cn_colsum_partial_kernel, dim3(seg_parts(R)), dim3(256), 0, ST(stream), x, ld, R, C, parts);
+  CN_LAUNCH_CHECK("cartnet_colsum_partial");
+  return 0;
+}

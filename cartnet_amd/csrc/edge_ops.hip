@@ -68,12 +68,11 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
         for (int k = k0; k < k1; ++k) {
           const f32x4 g = ld4(gs + (size_t)k * ld + c);
           const f32x4 s = ld4(gs + (size_t)k * ld + D + c);
-          const f32x4 ei = ld4(e_in + (size_t)k * D + c);
           const float ev = env ? env[k] : 1.0f;
           f32x4 sig;
 #pragma unroll
           for (int q = 0; q < 4; ++q) sig[q] = ev * cn_sigmoid((g[q] - mean[q]) * scale[q] + shift[q]);
-          st4(e_out + (size_t)k * D + c, ei + sig);
+          if (e_out) st4(e_out + (size_t)k * D + c, ld4(e_in + (size_t)k * D + c) + sig);
           acc += sig * s;
         }
         st4(aggr + (size_t)t * D + c, acc);
@@ -276,8 +275,9 @@ extern "C" int cartnet_gate_scatter_fwd(const float* gs, const float* e_in, cons
                                         int32_t D, float* e_out, float* aggr, double* parts_sum, double* parts_sq,
                                         void* stream) {
   CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_fwd: D=%d must be a positive multiple of 4", D);
-  CN_CHECK(gs && e_in && rowptr && mean_rstd && gamma && beta && e_out && aggr && parts_sum && parts_sq,
+  CN_CHECK(gs && rowptr && mean_rstd && gamma && beta && aggr && parts_sum && parts_sq,
            "cartnet_gate_scatter_fwd: null pointer");
+  CN_CHECK((e_in == nullptr) == (e_out == nullptr), "cartnet_gate_scatter_fwd: e_in and e_out must pair");
   hipLaunchKernelGGL(cn_gate_scatter_fwd_kernel, dim3(gate_parts(N)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), gs, e_in, env, rowptr, mean_rstd, gamma, beta, N, D,
                      e_out, aggr, parts_sum, parts_sq);

@@ -143,6 +143,23 @@ PROTOTYPES = {
                                           c_f32p, c_f32p, c_stream]),
     "cartnet_transpose": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, c_stream]),
+    "cartnet_rbf_expand": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int32, C.c_float, c_f32p, C.c_int32, c_stream]),
+    "cartnet_lattice_features": (C.c_int, [c_f32p, c_i64p, c_i32p, c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_f32p,
+                                           c_f32p, c_stream]),
+    "cartnet_eltwise": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_float, c_stream]),
+    "cartnet_segment_nparts": (C.c_int, [C.c_int32]),
+    "cartnet_rowmul_fwd": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_float,
+                                     c_f32p, C.c_int32, c_f32p, c_f32p, c_stream]),
+    "cartnet_rowmul_bwd": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_i32p, C.c_int32,
+                                     C.c_int32, C.c_float, c_f32p, C.c_int32, c_stream]),
+    "cartnet_softplus_update_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p,
+                                              c_stream]),
+    "cartnet_softplus_update_bwd_stats": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32,
+                                                    C.c_int32, c_f32p, c_f32p, c_stream]),
+    "cartnet_softplus_update_bwd_apply": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32,
+                                                    C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_stream]),
+    "cartnet_colsum_partial": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_stream]),
     "cartnet_profile_gemm": (C.c_int, [C.c_int32]),
     "cartnet_profile_gemm_read": (C.c_int, [C.POINTER(GemmProfile), C.c_int32]),
     "cartnet_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),

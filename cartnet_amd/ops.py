@@ -400,8 +400,11 @@ def gate_scatter_fwd(gs, e_in, env, layout: GraphLayout, mean_rstd, gamma, beta,
     E, N = layout.E, layout.N
     D = int(aggr.shape[1])
     _edge_rows(gs, E, 2 * D, "gate_scatter_fwd gs")
-    _edge_rows(e_in, E, D, "gate_scatter_fwd e_in")
-    _edge_rows(e_out, E, D, "gate_scatter_fwd e_out")
+    if (e_in is None) != (e_out is None):
+        raise ValueError("gate_scatter_fwd: e_in and e_out must both be given or both be None")
+    if e_in is not None:
+        _edge_rows(e_in, E, D, "gate_scatter_fwd e_in")
+        _edge_rows(e_out, E, D, "gate_scatter_fwd e_out")
     _edge_rows(aggr, N, D, "gate_scatter_fwd aggr")
     _vec(env, E, "gate_scatter_fwd env")
     _vec(mean_rstd, 2 * D, "gate_scatter_fwd mean_rstd")
@@ -410,9 +413,9 @@ def gate_scatter_fwd(gs, e_in, env, layout: GraphLayout, mean_rstd, gamma, beta,
     npart = gate_nparts(N)
     _vec(parts_sum, npart * D, "gate_scatter_fwd parts_sum", torch.float64)
     _vec(parts_sq, npart * D, "gate_scatter_fwd parts_sq", torch.float64)
-    _l.check(_l.load().cartnet_gate_scatter_fwd(gs.data_ptr(), e_in.data_ptr(), _l.ptr(env), layout.rowptr.data_ptr(),
+    _l.check(_l.load().cartnet_gate_scatter_fwd(gs.data_ptr(), _l.ptr(e_in), _l.ptr(env), layout.rowptr.data_ptr(),
                                                 mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, D,
-                                                e_out.data_ptr(), aggr.data_ptr(), parts_sum.data_ptr(),
+                                                _l.ptr(e_out), aggr.data_ptr(), parts_sum.data_ptr(),
                                                 parts_sq.data_ptr(), _l.stream_ptr()), "cartnet_gate_scatter_fwd")
 
 
@@ -614,3 +617,154 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, gra
     _l.check(_l.load().cartnet_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                                          n, float(lr), float(beta1), float(beta2), float(eps), int(step),
                                          float(grad_scale), _l.stream_ptr()), "cartnet_adam_step")
+
+
+# --------------------------------------------------------------------------------------------------- iComformer pieces
+class SegmentLayout:
+    """Minimal stand-in for GraphLayout where only (rowptr, N, E) matter: S segments of rows given by ``ptr``."""
+
+    def __init__(self, ptr: Tensor, n_rows: int):
+        _vec(ptr, ptr.numel(), "SegmentLayout ptr", torch.int32)
+        self.rowptr = ptr
+        self.N = int(ptr.numel()) - 1
+        self.E = int(n_rows)
+
+
+def rbf_expand(v: Tensor, centers: Tensor, gamma: float, out: Tensor) -> None:
+    n, bins = int(v.numel()), int(centers.numel())
+    _vec(v, n, "rbf_expand v")
+    _vec(centers, bins, "rbf_expand centers")
+    _f32_2d(out, "rbf_expand out")
+    if tuple(out.shape) != (n, bins):
+        raise ValueError("rbf_expand: out must be [n, bins]")
+    _l.check(_l.load().cartnet_rbf_expand(v.data_ptr(), n, centers.data_ptr(), bins, float(gamma), out.data_ptr(),
+                                          _ld(out), _l.stream_ptr()), "cartnet_rbf_expand")
+
+
+def lattice_features(cell: Tensor, batch: Tensor, src32: Tensor, cart_dist: Tensor, cart_dir: Tensor, edge_feat: Tensor,
+                     nei_len: Tensor, nei_cos: Tensor) -> None:
+    E, Bg = int(cart_dist.numel()), int(cell.shape[0])
+    _vec(cell, Bg * 9, "lattice_features cell")
+    _vec(batch, 1, "lattice_features batch", torch.int64)
+    _vec(src32, E, "lattice_features src", torch.int32)
+    _vec(cart_dist, E, "cart_dist")
+    _vec(cart_dir, 3 * E, "cart_dir")
+    _vec(edge_feat, E, "edge_feat")
+    _vec(nei_len, 3 * Bg, "nei_len")
+    _vec(nei_cos, 3 * E, "nei_cos")
+    _l.check(_l.load().cartnet_lattice_features(cell.data_ptr(), batch.data_ptr(), src32.data_ptr(), cart_dist.data_ptr(),
+                                                cart_dir.data_ptr(), E, Bg, edge_feat.data_ptr(), nei_len.data_ptr(),
+                                                nei_cos.data_ptr(), _l.stream_ptr()), "cartnet_lattice_features")
+
+
+def eltwise(op: int, a: Tensor, b: Optional[Tensor], out: Tensor, scale: float = 1.0) -> None:
+    """op 0: out = softplus(a); 1: out = a*sigmoid(b); 2: out = a+b; 3: out = a*scale (2-D views)."""
+    _f32_2d(a, "eltwise a")
+    _f32_2d(out, "eltwise out")
+    if tuple(a.shape) != tuple(out.shape):
+        raise ValueError("eltwise: shape mismatch")
+    if b is not None:
+        _f32_2d(b, "eltwise b")
+        if tuple(b.shape) != tuple(a.shape):
+            raise ValueError("eltwise: shape mismatch")
+    rows, cols = a.shape
+    _l.check(_l.load().cartnet_eltwise(int(op), a.data_ptr(), _l.ptr(b), out.data_ptr(), rows, cols, _ld(a),
+                                       _ld(b) if b is not None else 0, _ld(out), float(scale), _l.stream_ptr()),
+             "cartnet_eltwise")
+
+
+def segment_nparts(S: int) -> int:
+    return int(_l.load().cartnet_segment_nparts(int(S)))
+
+
+def rowmul_fwd(key: Tensor, q: Tensor, ptr_: Tensor, scale: float, alpha: Tensor, parts_sum: Tensor,
+               parts_sq: Tensor) -> None:
+    _f32_2d(key, "rowmul_fwd key")
+    _f32_2d(q, "rowmul_fwd q")
+    _f32_2d(alpha, "rowmul_fwd alpha")
+    R, Cc = key.shape
+    S = int(q.shape[0])
+    if tuple(alpha.shape) != (R, Cc) or q.shape[1] != Cc:
+        raise ValueError("rowmul_fwd: shape mismatch")
+    _vec(ptr_, S + 1, "rowmul_fwd ptr", torch.int32)
+    npart = segment_nparts(S)
+    _vec(parts_sum, npart * Cc, "rowmul_fwd parts_sum", torch.float64)
+    _vec(parts_sq, npart * Cc, "rowmul_fwd parts_sq", torch.float64)
+    _l.check(_l.load().cartnet_rowmul_fwd(key.data_ptr(), _ld(key), q.data_ptr(), _ld(q), ptr_.data_ptr(), S, Cc,
+                                          float(scale), alpha.data_ptr(), _ld(alpha), parts_sum.data_ptr(),
+                                          parts_sq.data_ptr(), _l.stream_ptr()), "cartnet_rowmul_fwd")
+
+
+def rowmul_bwd(dalpha: Tensor, key: Tensor, q: Tensor, ptr_: Tensor, scale: float, dq: Tensor) -> None:
+    _f32_2d(dalpha, "rowmul_bwd dalpha")
+    _f32_2d(key, "rowmul_bwd key")
+    _f32_2d(q, "rowmul_bwd q")
+    _f32_2d(dq, "rowmul_bwd dq")
+    R, Cc = key.shape
+    S = int(q.shape[0])
+    if tuple(dalpha.shape) != (R, Cc) or tuple(dq.shape) != (S, Cc) or q.shape[1] != Cc:
+        raise ValueError("rowmul_bwd: shape mismatch")
+    _vec(ptr_, S + 1, "rowmul_bwd ptr", torch.int32)
+    _l.check(_l.load().cartnet_rowmul_bwd(dalpha.data_ptr(), _ld(dalpha), key.data_ptr(), _ld(key), q.data_ptr(), _ld(q),
+                                          ptr_.data_ptr(), S, Cc, float(scale), dq.data_ptr(), _ld(dq),
+                                          _l.stream_ptr()), "cartnet_rowmul_bwd")
+
+
+def softplus_update_fwd(o, x, mean_rstd, gamma, beta, y) -> None:
+    _f32_2d(o, "softplus_update_fwd o")
+    N, D = o.shape
+    for name, t in (("o", o), ("x", x), ("y", y)):
+        _edge_rows(t, N, D, f"softplus_update_fwd {name}")
+    _vec(mean_rstd, 2 * D, "mean_rstd")
+    _vec(gamma, D, "gamma")
+    _vec(beta, D, "beta")
+    _l.check(_l.load().cartnet_softplus_update_fwd(o.data_ptr(), x.data_ptr(), mean_rstd.data_ptr(), gamma.data_ptr(),
+                                                   beta.data_ptr(), N, D, y.data_ptr(), _l.stream_ptr()),
+             "cartnet_softplus_update_fwd")
+
+
+def softplus_update_bwd_stats(o, x, dy, mean_rstd, gamma, beta, parts_a, parts_b) -> None:
+    _f32_2d(o, "softplus_update_bwd_stats o")
+    N, D = o.shape
+    for name, t in (("o", o), ("x", x), ("dy", dy)):
+        _edge_rows(t, N, D, f"softplus_update_bwd_stats {name}")
+    _vec(mean_rstd, 2 * D, "mean_rstd")
+    _vec(gamma, D, "gamma")
+    _vec(beta, D, "beta")
+    npart = segment_nparts(N)
+    _vec(parts_a, npart * D, "parts_a", torch.float64)
+    _vec(parts_b, npart * D, "parts_b", torch.float64)
+    _l.check(_l.load().cartnet_softplus_update_bwd_stats(o.data_ptr(), x.data_ptr(), dy.data_ptr(), mean_rstd.data_ptr(),
+                                                         gamma.data_ptr(), beta.data_ptr(), N, D, parts_a.data_ptr(),
+                                                         parts_b.data_ptr(), _l.stream_ptr()),
+             "cartnet_softplus_update_bwd_stats")
+
+
+def softplus_update_bwd_apply(o, x, dy, mean_rstd, gamma, beta, sums, training: bool, d_o, dx_add, dx) -> None:
+    _f32_2d(o, "softplus_update_bwd_apply o")
+    N, D = o.shape
+    for name, t in (("o", o), ("x", x), ("dy", dy), ("d_o", d_o), ("dx", dx)):
+        _edge_rows(t, N, D, f"softplus_update_bwd_apply {name}")
+    if dx_add is not None:
+        _edge_rows(dx_add, N, D, "softplus_update_bwd_apply dx_add")
+    _vec(mean_rstd, 2 * D, "mean_rstd")
+    _vec(gamma, D, "gamma")
+    _vec(beta, D, "beta")
+    _vec(sums, 2 * D, "sums")
+    _l.check(_l.load().cartnet_softplus_update_bwd_apply(o.data_ptr(), x.data_ptr(), dy.data_ptr(), mean_rstd.data_ptr(),
+                                                         gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(),
+                                                         int(training), N, D, d_o.data_ptr(), _l.ptr(dx_add),
+                                                         dx.data_ptr(), _l.stream_ptr()),
+             "cartnet_softplus_update_bwd_apply")
+
+
+def colsum(x: Tensor, out: Tensor) -> None:
+    """out[c] = sum_r x[r, c] (fp64 partials, fixed order) for a 2-D fp32 view."""
+    _f32_2d(x, "colsum x")
+    R, Cc = x.shape
+    _vec(out, Cc, "colsum out")
+    npart = segment_nparts(R)
+    parts = torch.empty(npart * Cc, dtype=torch.float64, device=x.device)
+    _l.check(_l.load().cartnet_colsum_partial(x.data_ptr(), _ld(x), R, Cc, parts.data_ptr(), _l.stream_ptr()),
+             "cartnet_colsum_partial")
+    colsum_finalize(parts, npart, out)

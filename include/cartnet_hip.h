@@ -79,6 +79,46 @@ typedef struct CartnetGemmArgs {
 
 int cartnet_gemm(const CartnetGemmArgs* args, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * iComformer-only pieces (models/comformer.py:75-132, models/comformer_conv.py:21-193); the dense work of that
+ * model reuses cartnet_gemm, its gated aggregation cartnet_gate_scatter_* (e_in = e_out = NULL: no edge residual).
+ * ---------------------------------------------------------------------------------------------------- */
+/* Gaussian RBF (models/utils.py:125-129): out[r, k] = exp(-gamma (v[r] - centers[k])^2). */
+int cartnet_rbf_expand(const float* v, int64_t n, const float* centers, int32_t bins, float gamma, float* out,
+                       int32_t ldo, void* stream);
+/* models/comformer.py:117-120: edge_feat[e] = -0.75/dist[e]; nei_len[g,i] = -0.75/|cell[g,i]|;
+ * nei_cos[e,i] = clamp(cos(cell[batch[src[e]], i], cart_dir[e]), -1, 1). */
+int cartnet_lattice_features(const float* cell, const int64_t* batch, const int32_t* src32, const float* cart_dist,
+                             const float* cart_dir, int64_t E, int32_t Bg, float* edge_feat, float* nei_len,
+                             float* nei_cos, void* stream);
+/* op 0: out = softplus(a); 1: out = a * sigmoid(b) (softplus backward); 2: out = a + b; 3: out = a * scale. */
+int cartnet_eltwise(int32_t op, const float* a, const float* b, float* out, int64_t rows, int32_t cols, int32_t lda,
+                    int32_t ldb, int32_t ldo, float scale, void* stream);
+/* alpha[r] = key[r] * q[s] * scale for rows r in [ptr[s], ptr[s+1])  (query_i * key / sqrt(C), comformer_conv.py:95)
+ * + fp64 column partial sums of alpha / alpha^2 [cartnet_segment_nparts(S)][C] for bn_att. */
+int cartnet_segment_nparts(int32_t S);
+int cartnet_rowmul_fwd(const float* key, int32_t ldk, const float* q, int32_t ldq, const int32_t* ptr, int32_t S,
+                       int32_t C, float scale, float* alpha, int32_t lda, double* parts_sum, double* parts_sq,
+                       void* stream);
+/* Backward, in place: dalpha <- dkey = dalpha * q[s] * scale;  dq[s] = scale * sum_r dalpha[r] * key[r]. */
+int cartnet_rowmul_bwd(float* dalpha, int32_t lda, const float* key, int32_t ldk, const float* q, int32_t ldq,
+                       const int32_t* ptr, int32_t S, int32_t C, float scale, float* dq, int32_t lddq, void* stream);
+/* y = softplus(x + bn(o)) (comformer_conv.py:88,193) and its backward in the two-pass BatchNorm form:
+ * stats: du = dy * sigmoid(x + bn(o)); partial sums of du and du*ohat -> parts [cartnet_segment_nparts(N)][D];
+ * apply: d_o = gamma*rstd*(du - sum_a/N - ohat*sum_b/N) (mean terms dropped when training == 0), dx = du (+ dx_add). */
+int cartnet_softplus_update_fwd(const float* o, const float* x, const float* mean_rstd, const float* gamma,
+                                const float* beta, int64_t N, int32_t D, float* y, void* stream);
+int cartnet_softplus_update_bwd_stats(const float* o, const float* x, const float* dy, const float* mean_rstd,
+                                      const float* gamma, const float* beta, int32_t N, int32_t D, double* parts_a,
+                                      double* parts_b, void* stream);
+int cartnet_softplus_update_bwd_apply(const float* o, const float* x, const float* dy, const float* mean_rstd,
+                                      const float* gamma, const float* beta, const float* sums, int32_t training,
+                                      int32_t N, int32_t D, float* d_o, const float* dx_add, float* dx, void* stream);
+
+/* parts[p][c] = partial column sums of the [R, C] view x (p < cartnet_segment_nparts(R)); finalise with
+ * cartnet_colsum_finalize (bias gradients of Linears whose output gradient is not produced by a GEMM epilogue). */
+int cartnet_colsum_partial(const float* x, int32_t ld, int32_t R, int32_t C, double* parts, void* stream);
+
 /* Opt-in timing of cartnet_gemm launches (the only process-global state in the library; used by bench.py):
  * while enabled, every cartnet_gemm call -- also those issued inside cartnet_model_forward/backward -- is bracketed
  * by HIP events on its launch stream.  cartnet_profile_gemm_read waits for the events and returns per-variant totals

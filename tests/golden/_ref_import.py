@@ -10,6 +10,8 @@ restate the published semantics the reference relies on:
         ``<name>_i`` = ``<name>.index_select(0, edge_index[1])``, ``<name>_j`` = ``...(0, edge_index[0])``,
         ``index`` = ``edge_index[1]``; message -> aggregate -> update, arguments matched by parameter name
   * ``torch_scatter.scatter(src, index, dim, out, dim_size, reduce)`` -> ``zeros.scatter_add_`` (sum / mean)
+  * default ``aggregate`` (aggr='add') = scatter-sum of the messages over ``index``; default ``update`` = identity
+  * ``e3nn.o3`` -> empty module (only the eComformer classes, which are out of scope, touch it)
   * ``torch_geometric.graphgym.config.cfg``      -> attribute bag (only ``invariant`` and ``radius`` are read)
 
 Nothing from /root/reference is copied; this file never travels as anything but test tooling and is not used on
@@ -77,6 +79,17 @@ class _MessagePassing(torch.nn.Module):
             else:
                 raise TypeError(f"cannot resolve propagate argument {name}")
         return args
+
+    # PyG defaults (aggr='add'): sum the messages of each target node; update is the identity
+    def aggregate(self, inputs, index, dim_size=None):
+        idx = index
+        while idx.dim() < inputs.dim():
+            idx = idx.unsqueeze(-1)
+        out = torch.zeros((dim_size,) + tuple(inputs.shape[1:]), dtype=inputs.dtype, device=inputs.device)
+        return out.scatter_add_(0, idx.expand_as(inputs), inputs)
+
+    def update(self, inputs):
+        return inputs
 
     def propagate(self, edge_index, size=None, **kw):
         first = next(v for v in kw.values() if torch.is_tensor(v) and v.dim() >= 2)

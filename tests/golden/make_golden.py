@@ -13,6 +13,7 @@ Fixtures (all fp32 unless suffixed _f64):
   config1     D=64, R=64, L=2, 4 crystals of 30..70 atoms (BASELINE.json configs[0] shape); weights from seed
   config2     D=256, R=64, L=4, 2 crystals of 194 atoms (configs[1] shape); weights from seed
   radius_graph  reference radius_graph_pbc output for 3 crystals (integers compared bit-exactly)
+  icomformer_tiny / icomformer_c32   the reference's iComformer (models/comformer.py) at C=16 / C=32
 """
 from __future__ import annotations
 
@@ -147,6 +148,63 @@ def save_model_fixture(name, hp, batch, seed, store_weights, full_grads, trace):
           f"-> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def icomformer_fixture(name, dim, batch, seed, store_weights):
+    """iComformer (BASELINE.json configs[4]) golden vectors from the reference's models/comformer.py."""
+    import importlib
+    import types
+    for modname in ("e3nn", "e3nn.o3"):
+        sys.modules.setdefault(modname, types.ModuleType(modname))
+    sys.modules["e3nn"].o3 = sys.modules["e3nn.o3"]
+    ref_cf = importlib.import_module("models.comformer")
+    from cartnet_amd.comformer import make_icomformer_state_dict
+    sd = make_icomformer_state_dict(dim, seed=seed)
+
+    def run(training, dtype, want_grads):
+        torch.manual_seed(0)
+        m = ref_cf.iComformer(dim)
+        res = m.load_state_dict(sd, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        m = m.to(dtype)
+        m.train(training)
+        b = clone_batch(batch, dtype)
+        pred, true = m(b)
+        out = {"pred": to_np(pred), "x_final": to_np(b.x)}
+        mae = torch.nn.functional.l1_loss(pred, true)
+        out["mae"] = to_np(mae)
+        if want_grads:
+            mae.mean().backward()
+            out["grads"] = {k: (to_np(p.grad) if p.grad is not None else None) for k, p in m.named_parameters()}
+            out["new_state"] = {k: to_np(v) for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+        return out
+
+    arrays = batch_inputs(batch)
+    arrays["hp_dim_in"] = np.array(dim)
+    arrays["weights_seed"] = np.int64(seed)
+    arrays["weights_abs_sum"] = np.float64(sum(v.double().abs().sum().item() for v in sd.values()))
+    if store_weights:
+        for k, v in sd.items():
+            arrays["w_" + k] = to_np(v)
+    tr, ev = run(True, torch.float32, True), run(False, torch.float32, False)
+    tr64, ev64 = run(True, torch.float64, True), run(False, torch.float64, False)
+    arrays["train_pred"], arrays["train_mae"], arrays["eval_pred"] = tr["pred"], tr["mae"], ev["pred"]
+    arrays["train_pred_f64"], arrays["eval_pred_f64"] = tr64["pred"], ev64["pred"]
+    arrays["train_x_final_f64"] = tr64["x_final"]
+    for k, v in tr["new_state"].items():
+        arrays["state_" + k] = v
+    unused = []
+    for k, g in tr64["grads"].items():
+        if g is None:
+            unused.append(k)
+            continue
+        arrays["grad64_" + k] = g.astype(np.float64)
+    arrays["unused_params"] = np.array(unused)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    err = np.abs(tr["pred"] - tr64["pred"]).max() / np.abs(tr64["pred"]).max()
+    print(f"{name}: N={batch.x.shape[0]} E={batch.edge_index.shape[1]} fp32-vs-fp64 train err {err:.2e}, unused params "
+          f"{unused} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def tiny_batch(adp=True):
     items = [make_crystal(100, 7, adp=adp), make_crystal(101, 9, adp=adp)]
     return Batch.from_data_list(items)
@@ -185,6 +243,9 @@ def main():
                        store_weights=True, full_grads=True, trace=False)
     b1 = Batch.from_data_list([make_crystal(300 + g, None, n_range=(30, 70)) for g in range(4)])
     save_model_fixture("config1", hp_dict(64, 64, 2), b1, seed=21, store_weights=False, full_grads=True, trace=False)
+    icomformer_fixture("icomformer_tiny", 16, tiny_batch(), seed=31, store_weights=True)
+    b5 = Batch.from_data_list([make_crystal(500 + g, None, n_range=(20, 40)) for g in range(3)])
+    icomformer_fixture("icomformer_c32", 32, b5, seed=32, store_weights=False)
     b2 = Batch.from_data_list([make_crystal(400 + g, 194) for g in range(2)])
     save_model_fixture("config2", hp_dict(256, 64, 4), b2, seed=22, store_weights=False, full_grads=False,
                        trace=False)
