@@ -1,0 +1,92 @@
+"""iComformer (BASELINE.json configs[4]) on the GPU against golden vectors generated from the reference's own
+models/comformer.py.  Same tolerances as the CartNet path (tests/test_gpu_model.py)."""
+import numpy as np
+import pytest
+import torch
+
+import icomformer_utils as iu
+from conftest import rel_err
+from test_gpu_model import PRED_TOL, _check_grads
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(z, sd):
+    from cartnet_amd.comformer import iComformer
+    m = iComformer(int(z["hp_dim_in"]))
+    m.load_state_dict(sd, strict=True)
+    m.validate_graph = True
+    return m.to("cuda:0")
+
+
+def _clone(b):
+    c = b.clone()
+    c.num_graphs = b.num_graphs
+    return c
+
+
+@pytest.mark.parametrize("name", iu.FIXTURES)
+def test_forward_against_reference_golden(name):
+    z, b, sd = iu.load(name)
+    m = _model(z, sd)
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        bb = _clone(b).to("cuda:0")
+        with torch.no_grad():
+            pred, true = m(bb)
+        assert true is bb.y
+        assert rel_err(pred, torch.from_numpy(z[f"{mode}_pred_f64"])) < PRED_TOL, (name, mode)
+        if mode == "train":
+            assert rel_err(bb.x, torch.from_numpy(z["train_x_final_f64"])) < PRED_TOL
+
+
+@pytest.mark.parametrize("name", iu.FIXTURES)
+def test_train_step_gradients_and_bn_state_against_reference_golden(name):
+    z, b, sd = iu.load(name)
+    m = _model(z, sd).train()
+    bb = _clone(b).to("cuda:0")
+    pred, true = m(bb)
+    loss = (pred - true).abs().mean()
+    assert abs(loss.item() - float(z["train_mae"])) < 1e-5 * abs(float(z["train_mae"]))
+    loss.backward()
+    params = dict(m.named_parameters())
+    unused = set(z["unused_params"].tolist())
+    got, ref = {}, {}
+    for k, p in params.items():
+        if k in unused:
+            assert p.grad is None, k        # the reference leaves these without a gradient too
+            continue
+        assert p.grad is not None, f"no gradient for {k}"
+        got[k], ref[k] = p.grad, torch.from_numpy(z["grad64_" + k])
+    _check_grads(got, ref, name)
+    sd_new = m.state_dict()
+    for k in z.files:
+        if k.startswith("state_"):
+            r = torch.from_numpy(z[k])
+            if r.is_floating_point():
+                assert rel_err(sd_new[k[6:]], r) < 1e-5, k
+            else:
+                assert int(sd_new[k[6:]]) == int(r), k
+
+
+def test_against_oracle_at_width_256():
+    """configs[4] width (C=256) on two small crystals: HIP path vs the fp64 oracle (forward and gradients)."""
+    from cartnet_amd.comformer import iComformer, make_icomformer_state_dict
+    from cartnet_amd.data import Batch
+    from cartnet_amd.synthetic import make_crystal
+    from oracle import icomformer_ref as orc
+    b = Batch.from_data_list([make_crystal(950, 12), make_crystal(951, 20)])
+    sd = make_icomformer_state_dict(256, seed=7)
+    m = iComformer(256)
+    m.load_state_dict(sd)
+    m = m.to("cuda:0").train()
+    bb = _clone(b).to("cuda:0")
+    pred, true = m(bb)
+    (pred - true).abs().mean().backward()
+    names = [k for k, p in m.named_parameters() if p.grad is not None]
+    sd64 = {k: (v.double().requires_grad_(k in names) if v.is_floating_point() else v) for k, v in sd.items()}
+    ref = orc.icomformer_forward(sd64, iu.batch64(b), training=True)
+    assert rel_err(pred, ref) < PRED_TOL
+    (ref - b.y.double()).abs().mean().backward()
+    _check_grads({k: p.grad for k, p in m.named_parameters() if p.grad is not None},
+                 {k: sd64[k].grad for k in names}, "icomformer256")
