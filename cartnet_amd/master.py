@@ -7,12 +7,17 @@ from .config import cfg
 def create_model():
     """cfg.model == "CartNet" -> CartNet(dim_in, dim_rbf, num_layers, invariant, use_temp, envelope, use_atom_types,
     cholesky = (dataset == "ADP")) moved to ``cfg.device`` (the reference hard-codes "cuda:0").
-    Other model names of the reference (eComformer / iComformer) are outside this hot path."""
+    cfg.model == "icomformer" -> iComformer(dim_in) (ADP only, models/master.py:40-43).  eComformer needs e3nn and is
+    outside this build."""
     if cfg.model == "CartNet":
         from .model import CartNet
         model = CartNet(dim_in=cfg.dim_in, dim_rbf=cfg.dim_rbf, num_layers=cfg.num_layers, invariant=cfg.invariant,
                         temperature=cfg.use_temp, use_envelope=cfg.envelope, atom_types=cfg.use_atom_types,
                         cholesky=True if cfg.dataset.name == "ADP" else False).to(getattr(cfg, "device", "cuda:0"))
+    elif cfg.model == "icomformer":
+        from .comformer import iComformer
+        assert cfg.dataset.name == "ADP", "iComformer only for ADP dataset"
+        model = iComformer(dim_in=cfg.dim_in).to(getattr(cfg, "device", "cuda:0"))
     else:
         raise Exception("Model not implemented")
     return model

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Entry point with the reference's flag surface and call order (reference: main.py:121-227), on the MI355X path.
+
+What is kept: the argparse flags and their defaults (main.py:123-154), the copy into the global ``cfg``
+(:156-188), seed -> loaders -> ``create_model()`` -> Adam -> ``train`` (:196-227), OneCycleLR, gradient accumulation
+with the last-iteration flush, best-validation checkpoint ``{"model_state", "optimizer_state"}`` under
+``results/<name>/<seed>/ckpt/best.ckpt`` (train/train.py:91-102) and its reload for the test pass (:114-115).
+What differs: the datasets (CSD / Jarvis need licences or the network) are replaced by synthetic ADP-shaped crystals
+(``--synthetic N`` graphs, ``--atoms lo hi``), wandb / GraphGym logging are dropped, ``--device`` replaces the hard-coded
+"cuda:0", and under ``torch.distributed.run`` the crystals are sharded across ranks with one gradient all-reduce per
+optimiser step.  There is no CPU path: the model runs on an AMD GPU only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+
+import torch
+
+from cartnet_amd import distributed as cdist
+from cartnet_amd.config import cfg, set_cfg
+from cartnet_amd.data import DataLoader
+from cartnet_amd.master import create_model
+from cartnet_amd.optim import FlatAdam, one_cycle_lr
+from cartnet_amd.synthetic import augment_data, make_crystal
+from cartnet_amd.train import eval_epoch, train_epoch
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser()
+    # --- the reference's flags (main.py:123-154), same names / defaults / store_false quirks
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--name", type=str, default="CartNet")
+    p.add_argument("--batch", type=int, default=4)
+    p.add_argument("--batch_accumulation", type=int, default=16)
+    p.add_argument("--dataset", type=str, default="ADP")
+    p.add_argument("--dataset_path", type=str, default="./dataset/ADP_DATASET/")
+    p.add_argument("--inference", action="store_true")
+    p.add_argument("--montecarlo", action="store_true")
+    p.add_argument("--checkpoint_path", type=str, default=None)
+    p.add_argument("--inference_output", type=str, default="./inference.pkl")
+    p.add_argument("--figshare_target", type=str, default="formation_energy_peratom")
+    p.add_argument("--wandb_project", type=str, default="ADP")
+    p.add_argument("--wandb_entity", type=str, default="aiquaneuro")
+    p.add_argument("--loss", type=str, default="MAE")
+    p.add_argument("--epochs", type=int, default=50)
+    p.add_argument("--lr", type=float, default=1e-3)
+    p.add_argument("--warmup", type=float, default=0.01)
+    p.add_argument("--model", type=str, default="CartNet")
+    p.add_argument("--max_neighbours", type=int, default=25)
+    p.add_argument("--radius", type=float, default=5.0)
+    p.add_argument("--num_layers", type=int, default=4)
+    p.add_argument("--dim_in", type=int, default=256)
+    p.add_argument("--dim_rbf", type=int, default=64)
+    p.add_argument("--augment", action="store_true")
+    p.add_argument("--invariant", action="store_true")
+    p.add_argument("--disable_temp", action="store_false")
+    p.add_argument("--no_standarize_temp", action="store_false")
+    p.add_argument("--disable_envelope", action="store_false")
+    p.add_argument("--disable_H", action="store_false")
+    p.add_argument("--disable_atom_types", action="store_false")
+    p.add_argument("--threads", type=int, default=8)
+    p.add_argument("--workers", type=int, default=5)
+    # --- this build
+    p.add_argument("--device", type=str, default="cuda:0")
+    p.add_argument("--synthetic", type=int, default=32, help="number of synthetic crystals (80/10/10 split)")
+    p.add_argument("--atoms", type=int, nargs=2, default=(30, 70), help="atoms per synthetic crystal: lo hi")
+    return p
+
+
+def fill_cfg(args) -> None:
+    """main.py:156-188."""
+    set_cfg()
+    cfg.seed, cfg.name = args.seed, args.name
+    cfg.run_dir = "results/" + cfg.name + "/" + str(cfg.seed)
+    cfg.batch, cfg.batch_accumulation = args.batch, args.batch_accumulation
+    cfg.dataset.name = args.dataset
+    cfg.loss, cfg.lr, cfg.warmup = args.loss, args.lr, args.warmup
+    cfg.optim.max_epoch = args.epochs
+    cfg.model = args.model
+    cfg.max_neighbours = -1 if cfg.model == "CartNet" else args.max_neighbours
+    cfg.radius, cfg.num_layers, cfg.dim_in, cfg.dim_rbf = args.radius, args.num_layers, args.dim_in, args.dim_rbf
+    cfg.augment = False if cfg.model in ("icomformer", "ecomformer") else args.augment
+    cfg.invariant = args.invariant
+    cfg.use_temp = False if cfg.dataset.name != "ADP" else args.disable_temp
+    cfg.standarize_temp = args.no_standarize_temp
+    cfg.envelope, cfg.use_H, cfg.use_atom_types = args.disable_envelope, args.disable_H, args.disable_atom_types
+    cfg.workers = args.workers
+    cfg.device = args.device
+
+
+def create_loaders(args, rank: int, world: int):
+    """Synthetic stand-in for loader/loader.py:create_loader: seed-123 80/10/10 split (loader.py:130-141)."""
+    adp = cfg.dataset.name == "ADP"
+    graphs = [make_crystal(g, None, cfg.radius, tuple(args.atoms), adp=adp) for g in range(args.synthetic)]
+    perm = torch.randperm(len(graphs), generator=torch.Generator().manual_seed(123)).tolist()
+    n_tr, n_va = int(0.8 * len(graphs)), int(0.1 * len(graphs))
+    tr = [graphs[i] for i in perm[:n_tr]]
+    va = [graphs[i] for i in perm[n_tr:n_tr + n_va]] or tr[:1]
+    te = [graphs[i] for i in perm[n_tr + n_va:]] or tr[:1]
+    gen = torch.Generator().manual_seed(cfg.seed + 1000 * rank)
+    aug = (lambda d: augment_data(d, gen)) if cfg.augment else None
+    return [DataLoader(tr, cfg.batch, shuffle=True, seed=cfg.seed, rank=rank, world_size=world, transform=aug),
+            DataLoader(va, cfg.batch), DataLoader(te, 1 if adp else cfg.batch)]
+
+
+def main(argv=None) -> dict:
+    args = build_parser().parse_args(argv)
+    fill_cfg(args)
+    torch.set_num_threads(args.threads)
+    rank, world, local = cdist.init_from_env()
+    if world > 1:
+        cfg.device = f"cuda:{local}"
+    torch.manual_seed(cfg.seed)
+    if args.inference or args.montecarlo:
+        raise SystemExit("--inference / --montecarlo write reports from the licensed ADP test set; not part of this build")
+    loaders = create_loaders(args, rank, world)
+    model = create_model()
+    n_params = sum(p.numel() for p in model.parameters())
+    opt = FlatAdam(model, lr=cfg.lr)
+    steps_per_epoch = len(loaders[0])
+    total_steps = cfg.optim.max_epoch * steps_per_epoch // cfg.batch_accumulation + cfg.optim.max_epoch   # train.py:59
+    sched_step = [0]
+
+    def scheduler():
+        sched_step[0] += 1
+        opt.set_lr(one_cycle_lr(min(sched_step[0], total_steps - 1), total_steps, cfg.lr, cfg.warmup))
+
+    opt.set_lr(one_cycle_lr(0, total_steps, cfg.lr, cfg.warmup))
+    ckpt_dir = os.path.join(cfg.run_dir, "ckpt")
+    best, history = float("inf"), []
+    for epoch in range(cfg.optim.max_epoch):
+        t0 = time.perf_counter()
+        tr = train_epoch(loaders[0], model, opt, cfg.batch_accumulation, scheduler, device=cfg.device)
+        va = eval_epoch(loaders[1], model, device=cfg.device)
+        history.append({"epoch": epoch, "train_mae": tr["mae"], "val_mae": va["mae"],
+                        "graphs_per_s": tr["graphs"] * world / tr["seconds"], "time_epoch": time.perf_counter() - t0})
+        if rank == 0:
+            print(json.dumps(history[-1]), flush=True)
+            if va["mae"] < best:                                          # train/train.py:91-102
+                best = va["mae"]
+                os.makedirs(ckpt_dir, exist_ok=True)
+                torch.save({"model_state": model.state_dict(), "optimizer_state": opt.state_dict()},
+                           os.path.join(ckpt_dir, "best.ckpt"))
+    cdist.barrier()
+    result = {"params": n_params, "history": history, "best_val_mae": best}
+    if rank == 0 and os.path.exists(os.path.join(ckpt_dir, "best.ckpt")):  # train/train.py:114-117
+        ck = torch.load(os.path.join(ckpt_dir, "best.ckpt"), map_location=cfg.device)
+        model.load_state_dict(ck["model_state"])
+        result["test_mae"] = eval_epoch(loaders[2], model, device=cfg.device)["mae"]
+        print(json.dumps({"params": n_params, "best_val_mae": best, "test_mae": result["test_mae"]}), flush=True)
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,32 @@
+"""BASELINE.json configs[0] plumbing: the main.py-equivalent trains CartNet (2 layers, dim 64) on 32 synthetic crystals
+of ~50 atoms through the reference's call order (loaders -> create_model -> Adam/OneCycle -> train -> best checkpoint ->
+reload -> test), on the GPU path."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_main_trains_and_checkpoints(tmp_path, monkeypatch):
+    import main as entry
+    monkeypatch.chdir(tmp_path)
+    res = entry.main(["--synthetic", "32", "--atoms", "30", "70", "--dim_in", "64", "--num_layers", "2", "--epochs", "4",
+                      "--batch", "4", "--batch_accumulation", "2", "--name", "plumbing", "--augment", "--lr", "2e-3"])
+    hist = res["history"]
+    assert len(hist) == 4 and all(torch.isfinite(torch.tensor(h["train_mae"])) for h in hist)
+    assert hist[-1]["train_mae"] < hist[0]["train_mae"]            # it learns
+    ck = torch.load(tmp_path / "results" / "plumbing" / "0" / "ckpt" / "best.ckpt")
+    assert set(ck) == {"model_state", "optimizer_state"}            # train/train.py:92-95
+    assert "encoder.embedding.weight" in ck["model_state"] and ck["optimizer_state"]["step"] > 0
+    assert "test_mae" in res and res["params"] == sum(v.numel() for k, v in ck["model_state"].items()
+                                                      if "running" not in k and "num_batches" not in k and "rbf" not in k)
+
+
+def test_main_runs_icomformer(tmp_path, monkeypatch):
+    import main as entry
+    monkeypatch.chdir(tmp_path)
+    res = entry.main(["--synthetic", "12", "--atoms", "10", "20", "--dim_in", "32", "--epochs", "2", "--batch", "3",
+                      "--batch_accumulation", "1", "--name", "icf", "--model", "icomformer"])
+    assert len(res["history"]) == 2 and res["history"][-1]["train_mae"] == res["history"][-1]["train_mae"]
