@@ -1,0 +1,134 @@
+// Periodic radius graph on the GPU (reference: dataset/utils.py:57-237 radius_graph_pbc, used by
+// dataset/figshare_dataset.py:65-68).  Emits edges in the reference's order -- target atom, then source atom, then
+// periodic image in cartesian_prod(a1, a2, a3) order -- so edge_index[1] comes out sorted and feeds cartnet_csr_build
+// directly.  Two passes (count, fill), one wavefront per target atom walking its candidates 64 at a time; the order
+// inside a row comes from ballot prefix counts, so there are no atomics and the output is deterministic.
+// Arithmetic mirrors the reference's fp32 operation order with explicitly rounded (non-fused) operations.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float sub(float a, float b) { return __fsub_rn(a, b); }
+
+// reps[g, d] = ceil(radius * |cross(a_{d+1}, a_{d+2}) / V|)   (dataset/utils.py:133-157)
+__global__ void cn_rg_reps_kernel(const float* __restrict__ cell, int Bg, float radius, int* __restrict__ reps) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= Bg) return;
+  const float* a = cell + (size_t)g * 9;
+  auto cross = [&](const float* u, const float* v, float* o) {
+    o[0] = sub(mul(u[1], v[2]), mul(u[2], v[1]));
+    o[1] = sub(mul(u[2], v[0]), mul(u[0], v[2]));
+    o[2] = sub(mul(u[0], v[1]), mul(u[1], v[0]));
+  };
+  float c23[3], c31[3], c12[3];
+  cross(a + 3, a + 6, c23);
+  cross(a + 6, a + 0, c31);
+  cross(a + 0, a + 3, c12);
+  const float vol = add(add(mul(a[0], c23[0]), mul(a[1], c23[1])), mul(a[2], c23[2]));
+  const float* cs[3] = {c23, c31, c12};
+  for (int d = 0; d < 3; ++d) {
+    const float x = cs[d][0] / vol, y = cs[d][1] / vol, z = cs[d][2] / vol;
+    const float nrm = sqrtf(add(add(mul(x, x), mul(y, y)), mul(z, z)));
+    reps[g * 3 + d] = (int)ceilf(mul(radius, nrm));
+  }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void cn_rg_kernel(const float* __restrict__ pos, const float* __restrict__ cell,
+                                                    const int64_t* __restrict__ graph_ptr,
+                                                    const int64_t* __restrict__ batch, const int* __restrict__ reps,
+                                                    int N, float r2, float eps2, int* __restrict__ deg,
+                                                    const int64_t* __restrict__ rowptr, int64_t* __restrict__ ei,
+                                                    long long E, float* __restrict__ dist, float* __restrict__ dir) {
+  const int lane = threadIdx.x & 63;
+  const int i1 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i1 >= N) return;
+  const int g = (int)batch[i1];
+  const int n0 = (int)graph_ptr[g], n = (int)graph_ptr[g + 1] - n0;
+  const int R1 = reps[g * 3], R2 = reps[g * 3 + 1], R3 = reps[g * 3 + 2];
+  const int m2 = 2 * R2 + 1, m3 = 2 * R3 + 1;
+  const int ncells = (2 * R1 + 1) * m2 * m3;
+  const float* a = cell + (size_t)g * 9;
+  const float px = pos[(size_t)i1 * 3], py = pos[(size_t)i1 * 3 + 1], pz = pos[(size_t)i1 * 3 + 2];
+  const long long total = (long long)n * ncells;
+  long long out = FILL ? rowptr[i1] : 0;
+  int count = 0;
+  for (long long base = 0; base < total; base += 64) {
+    const long long cand = base + lane;
+    bool valid = false;
+    float dx = 0.f, dy = 0.f, dz = 0.f, d2 = 0.f;
+    int i2 = 0;
+    if (cand < total) {
+      i2 = (int)(cand / ncells);
+      const int c = (int)(cand - (long long)i2 * ncells);
+      const float u3 = (float)(c % m3 - R3), u2 = (float)((c / m3) % m2 - R2), u1 = (float)(c / (m3 * m2) - R1);
+      // image offset = cell^T u, accumulated as (a1 u1 + a3 u3) + a2 u2 -- the order torch.bmm uses for this 3-term sum
+      const float ox = add(add(mul(a[0], u1), mul(a[6], u3)), mul(a[3], u2));
+      const float oy = add(add(mul(a[1], u1), mul(a[7], u3)), mul(a[4], u2));
+      const float oz = add(add(mul(a[2], u1), mul(a[8], u3)), mul(a[5], u2));
+      const float* q = pos + (size_t)(n0 + i2) * 3;
+      dx = sub(px, add(q[0], ox));
+      dy = sub(py, add(q[1], oy));
+      dz = sub(pz, add(q[2], oz));
+      d2 = add(add(mul(dx, dx), mul(dy, dy)), mul(dz, dz));
+      valid = (d2 <= r2) && (d2 > eps2);
+    }
+    const unsigned long long m = __ballot(valid);
+    if (FILL) {
+      if (valid) {
+        const long long p = out + __popcll(m & ((1ull << lane) - 1ull));
+        if (p < E) {
+          ei[p] = (int64_t)(n0 + i2);
+          ei[E + p] = (int64_t)i1;
+          const float d = sqrtf(d2);
+          const float dn = fmaxf(d, 1e-12f);      // F.normalize(vec, p=2, dim=-1, eps=1e-12)
+          dist[p] = d;
+          dir[p * 3] = dx / dn;
+          dir[p * 3 + 1] = dy / dn;
+          dir[p * 3 + 2] = dz / dn;
+        }
+      }
+      out += __popcll(m);
+    } else {
+      count += __popcll(m);
+    }
+  }
+  if (!FILL && lane == 0) deg[i1] = count;
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int cartnet_radius_graph_count(const float* pos, const float* cell, const int64_t* graph_ptr,
+                                          const int64_t* batch, int32_t N, int32_t Bg, float radius, int32_t* reps,
+                                          int32_t* deg, void* stream) {
+  CN_CHECK(N >= 0 && Bg >= 1 && radius > 0.f, "cartnet_radius_graph_count: bad sizes");
+  CN_CHECK(cell && graph_ptr && reps && (N == 0 || (pos && batch && deg)), "cartnet_radius_graph_count: null pointer");
+  hipLaunchKernelGGL(cn_rg_reps_kernel, dim3(cn_ceil_div(Bg, 64)), dim3(64), 0, ST(stream), cell, Bg, radius, reps);
+  CN_LAUNCH_CHECK("cartnet_radius_graph_count/reps");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(cn_rg_kernel<false>, dim3(cn_ceil_div(N, 4)), dim3(256), 0, ST(stream), pos, cell, graph_ptr, batch,
+                     reps, N, radius * radius, 0.0001f, deg, (const int64_t*)nullptr, (int64_t*)nullptr, 0LL,
+                     (float*)nullptr, (float*)nullptr);
+  CN_LAUNCH_CHECK("cartnet_radius_graph_count");
+  return 0;
+}
+
+extern "C" int cartnet_radius_graph_fill(const float* pos, const float* cell, const int64_t* graph_ptr,
+                                         const int64_t* batch, const int32_t* reps, const int64_t* rowptr, int32_t N,
+                                         int32_t Bg, float radius, int64_t E, int64_t* edge_index, float* cart_dist,
+                                         float* cart_dir, void* stream) {
+  CN_CHECK(N >= 0 && Bg >= 1 && radius > 0.f && E >= 0, "cartnet_radius_graph_fill: bad sizes");
+  if (N == 0 || E == 0) return 0;
+  CN_CHECK(pos && cell && graph_ptr && batch && reps && rowptr && edge_index && cart_dist && cart_dir,
+           "cartnet_radius_graph_fill: null pointer");
+  hipLaunchKernelGGL(cn_rg_kernel<true>, dim3(cn_ceil_div(N, 4)), dim3(256), 0, ST(stream), pos, cell, graph_ptr, batch,
+                     reps, N, radius * radius, 0.0001f, (int*)nullptr, rowptr, edge_index, (long long)E, cart_dist,
+                     cart_dir);
+  CN_LAUNCH_CHECK("cartnet_radius_graph_fill");
+  return 0;
+}

@@ -1,0 +1,48 @@
+"""Periodic radius graph on the GPU: the step right before the hot path.
+
+``radius_graph_pbc(pos, cell, ptr, radius)`` builds the edges of a whole batch of crystals on the device in the
+reference's edge order (reference: dataset/utils.py:57-237 as called by dataset/figshare_dataset.py:65-68), so the
+result can be fed straight to ``CartNet.forward``; integers match the reference bit for bit, distances / directions to
+fp32 rounding (tests/test_gpu_radius_graph.py)."""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+
+from . import lib as _l
+
+
+def radius_graph_pbc(pos: torch.Tensor, cell: torch.Tensor, ptr: torch.Tensor, radius: float = 5.0
+                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """pos [N,3] fp32, cell [Bg,3,3] fp32 (rows = lattice vectors), ptr [Bg+1] int64 atom offsets -- all on the GPU.
+    Returns (edge_index [2,E] int64 = (source, target), cart_dist [E], cart_dir [E,3])."""
+    if not (pos.is_cuda and pos.dtype == torch.float32 and pos.dim() == 2 and pos.shape[1] == 3):
+        raise ValueError("pos must be a CUDA fp32 tensor [N,3]")
+    if not (cell.is_cuda and cell.dtype == torch.float32 and cell.dim() == 3 and tuple(cell.shape[1:]) == (3, 3)):
+        raise ValueError("cell must be a CUDA fp32 tensor [Bg,3,3]")
+    if not (ptr.is_cuda and ptr.dtype == torch.int64 and ptr.dim() == 1 and ptr.numel() == cell.shape[0] + 1):
+        raise ValueError("ptr must be a CUDA int64 tensor [Bg+1]")
+    lib = _l.load()
+    dev = pos.device
+    pos, cell, ptr = pos.contiguous(), cell.contiguous(), ptr.contiguous()
+    N, Bg = int(pos.shape[0]), int(cell.shape[0])
+    batch = torch.repeat_interleave(torch.arange(Bg, device=dev), ptr[1:] - ptr[:-1]).contiguous()
+    if batch.numel() != N:
+        raise ValueError("ptr does not cover all atoms")
+    reps = torch.empty(Bg * 3, dtype=torch.int32, device=dev)
+    deg = torch.zeros(max(N, 1), dtype=torch.int32, device=dev)
+    _l.check(lib.cartnet_radius_graph_count(pos.data_ptr(), cell.data_ptr(), ptr.data_ptr(), batch.data_ptr(), N, Bg,
+                                            float(radius), reps.data_ptr(), deg.data_ptr(), _l.stream_ptr()),
+             "cartnet_radius_graph_count")
+    rowptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(deg[:N].long(), 0)
+    E = int(rowptr[-1].item())                       # one sync: the edge count sizes the outputs
+    edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
+    dist = torch.empty(E, dtype=torch.float32, device=dev)
+    dirs = torch.empty((E, 3), dtype=torch.float32, device=dev)
+    _l.check(lib.cartnet_radius_graph_fill(pos.data_ptr(), cell.data_ptr(), ptr.data_ptr(), batch.data_ptr(),
+                                           reps.data_ptr(), rowptr.data_ptr(), N, Bg, float(radius), E,
+                                           edge_index.data_ptr(), dist.data_ptr(), dirs.data_ptr(), _l.stream_ptr()),
+             "cartnet_radius_graph_fill")
+    return edge_index, dist, dirs

@@ -119,6 +119,20 @@ int cartnet_softplus_update_bwd_apply(const float* o, const float* x, const floa
  * cartnet_colsum_finalize (bias gradients of Linears whose output gradient is not produced by a GEMM epilogue). */
 int cartnet_colsum_partial(const float* x, int32_t ld, int32_t R, int32_t C, double* parts, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Periodic radius graph on the GPU (reference: dataset/utils.py:57-237 radius_graph_pbc as used by
+ * dataset/figshare_dataset.py:65-68; no neighbour cap, pairs with d^2 <= 1e-4 dropped).  Edges come out in the
+ * reference's order (target, source, periodic image), i.e. edge_index[1] ascending.
+ *   count: reps[Bg,3] = periodic repetitions per lattice direction, deg[N] = in-degree of every atom.
+ *   fill:  rowptr[N+1] = exclusive prefix sum of deg (int64), E = rowptr[N]; writes edge_index [2,E] (int64,
+ *          row 0 source, row 1 target), cart_dist [E], cart_dir [E,3] = (pos_target - (pos_source + offset)) / dist.
+ * ---------------------------------------------------------------------------------------------------- */
+int cartnet_radius_graph_count(const float* pos, const float* cell, const int64_t* graph_ptr, const int64_t* batch,
+                               int32_t N, int32_t Bg, float radius, int32_t* reps, int32_t* deg, void* stream);
+int cartnet_radius_graph_fill(const float* pos, const float* cell, const int64_t* graph_ptr, const int64_t* batch,
+                              const int32_t* reps, const int64_t* rowptr, int32_t N, int32_t Bg, float radius,
+                              int64_t E, int64_t* edge_index, float* cart_dist, float* cart_dir, void* stream);
+
 /* Opt-in timing of cartnet_gemm launches (the only process-global state in the library; used by bench.py):
  * while enabled, every cartnet_gemm call -- also those issued inside cartnet_model_forward/backward -- is bracketed
  * by HIP events on its launch stream.  cartnet_profile_gemm_read waits for the events and returns per-variant totals
