@@ -161,7 +161,7 @@ def main():
     # the chip with the weight-gradient stream.  Three extra single-stream steps (outside the timed region) give the
     # same launches undisturbed: kernel quality without the overlap.
     isolated = {}
-    if rank == 0 and not args.no_kernel_timer:
+    if world == 1 and not args.no_kernel_timer:   # single process only: the extra steps would need every rank
         model.overlap_weight_gradients = False
         extra = [fresh() for _ in range(3)]
         torch.cuda.synchronize()
