@@ -1,0 +1,132 @@
+"""Edge cases and host-integration properties of the GPU path that the golden fixtures do not cover."""
+import pytest
+import torch
+
+import golden_utils as gu
+from conftest import rel_err
+from test_gpu_model import PRED_TOL, _check_grads, _model
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh(b):
+    c = b.clone()
+    c.num_graphs = b.num_graphs
+    return c.to("cuda:0")
+
+
+def test_crystal_without_edges_and_isolated_atoms():
+    """A crystal whose atoms have no neighbour inside the cutoff (huge cell) next to normal ones: rows of the CSR are
+    empty, the aggregation is zero there, nothing divides by a zero degree; checked against the fp64 oracle."""
+    from cartnet_amd.data import Batch, Data
+    from cartnet_amd.model import make_state_dict
+    from cartnet_amd.synthetic import make_crystal
+    from oracle import cartnet_ref as orc
+    lonely = make_crystal(1, 3)
+    lonely.edge_index = torch.zeros(2, 0, dtype=torch.int64)
+    lonely.cart_dist, lonely.cart_dir = torch.zeros(0), torch.zeros(0, 3)
+    b = Batch.from_data_list([make_crystal(2, 9), lonely, make_crystal(3, 14)])
+    hp = dict(dim_in=32, dim_rbf=16, num_layers=2, radius=5.0, invariant=False, temperature=True, use_envelope=True,
+              atom_types=True, cholesky=True)
+    sd = make_state_dict(32, 16, 2, seed=4)
+    m = _model(hp, sd).train()
+    pred, true = m(_fresh(b))
+    (pred - true).abs().mean().backward()
+    sd64 = {k: (v.double().requires_grad_(k in dict(m.named_parameters())) if v.is_floating_point() else v)
+            for k, v in sd.items()}
+    b64 = gu.clone_batch(b)
+    for k, v in list(b64.__dict__.items()):
+        if torch.is_tensor(v) and v.is_floating_point():
+            setattr(b64, k, v.double())
+    ref = orc.cartnet_forward(sd64, b64, training=True, **gu.oracle_kwargs(hp))
+    assert rel_err(pred, ref) < PRED_TOL
+    (ref - b64.y).abs().mean().backward()
+    _check_grads({k: p.grad for k, p in m.named_parameters()}, {k: sd64[k].grad for k, _ in m.named_parameters()},
+                 "lonely")
+
+
+def test_gradient_accumulation_and_flat_adam_match_torch_adam():
+    """Two micro-batches accumulated (train/train.py:183-189: no rescaling) then one optimiser step: FlatAdam on the
+    flat buffers == torch.optim.Adam on autograd's per-parameter gradients."""
+    from cartnet_amd.optim import FlatAdam
+    z, hp, b, sd = gu.load("config1")
+    from cartnet_amd.data import Batch
+    ma, mb = _model(hp, sd).train(), _model(hp, sd).train()
+    opt_a = FlatAdam(ma, lr=1e-3)
+    opt_b = torch.optim.Adam(mb.parameters(), lr=1e-3)
+    opt_a.zero_grad()
+    opt_b.zero_grad()
+    for _ in range(2):
+        for m in (ma, mb):
+            m.load_state_dict({k: v for k, v in m.state_dict().items()})      # no-op, keeps buffers in place
+            pred, true = m(_fresh(b))
+            (pred - true).abs().mean().backward()
+    ga = torch.cat([p.grad.flatten() for p in ma.parameters()])
+    gb = torch.cat([p.grad.flatten() for p in mb.parameters()])
+    assert rel_err(ga, gb) < 1e-6                       # same kernels, same order: only the accumulation path differs
+    opt_a.step()
+    opt_b.step()
+    pa = torch.cat([p.detach().flatten() for p in ma.parameters()])
+    pb = torch.cat([p.detach().flatten() for p in mb.parameters()])
+    assert rel_err(pa, pb) < 1e-6
+
+
+def test_eval_mode_backward_and_second_backward_is_rejected():
+    z, hp, b, sd = gu.load("tiny_adp")
+    m = _model(hp, sd).eval()                              # running statistics, but gradients requested
+    pred, true = m(_fresh(b))
+    loss = (pred - true).abs().mean()
+    loss.backward(retain_graph=True)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    from oracle import cartnet_ref as orc
+    sd64 = {k: (v.double().requires_grad_(k in dict(m.named_parameters())) if v.is_floating_point() else v)
+            for k, v in sd.items()}
+    b64 = gu.clone_batch(b)
+    for k, v in list(b64.__dict__.items()):
+        if torch.is_tensor(v) and v.is_floating_point():
+            setattr(b64, k, v.double())
+    ref = orc.cartnet_forward(sd64, b64, training=False, **gu.oracle_kwargs(hp))
+    (ref - b64.y).abs().mean().backward()
+    _check_grads({k: p.grad for k, p in m.named_parameters()}, {k: sd64[k].grad for k, _ in m.named_parameters()},
+                 "eval-backward")
+    with pytest.raises(RuntimeError, match="called twice|without saved state"):
+        loss.backward()                                    # the saved activations were consumed in place
+
+
+def test_input_validation_errors_are_raised_on_the_host():
+    z, hp, b, sd = gu.load("tiny_adp")
+    m = _model(hp, sd).eval()
+    bad = _fresh(b)
+    bad.x = bad.x.float()
+    with pytest.raises(ValueError, match="int64 atomic numbers"):
+        m(bad)
+    bad = _fresh(b)
+    bad.cart_dist = bad.cart_dist[:-1]
+    with pytest.raises(ValueError, match="cart_dist"):
+        m(bad)
+    bad = gu.clone_batch(b)          # batch left on the CPU
+    with pytest.raises(ValueError, match="batch.to"):
+        m(bad)
+    unsorted = _fresh(b)
+    unsorted.edge_index = unsorted.edge_index.flip(1).contiguous()
+    with pytest.raises(ValueError, match="sorted"):
+        m(unsorted)
+
+
+def test_large_ragged_batch_is_finite_and_reproducible():
+    """48 crystals of 64..324 atoms (the ADP size distribution of SURVEY.md 8d): finite, bit-reproducible."""
+    from cartnet_amd.model import make_state_dict
+    from cartnet_amd.synthetic import make_regular_batch, make_batch
+    b = make_batch(12, None, first=2000)                  # variable sizes, real periodic graphs
+    hp = dict(dim_in=256, dim_rbf=64, num_layers=4, radius=5.0, invariant=False, temperature=True,
+              use_envelope=True, atom_types=True, cholesky=True)
+    m = _model(hp, make_state_dict(256, 64, 4, seed=8)).train()
+    outs = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        m.load_state_dict(make_state_dict(256, 64, 4, seed=8))
+        pred, true = m(_fresh(b))
+        (pred - true).abs().mean().backward()
+        outs.append((pred.detach().clone(), torch.cat([p.grad.flatten() for p in m.parameters()]).clone()))
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
