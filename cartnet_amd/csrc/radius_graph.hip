@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void cn_rg_kernel(const float* __restrict__ po
                                                     const int64_t* __restrict__ batch, const int* __restrict__ reps,
                                                     int N, float r2, float eps2, int* __restrict__ deg,
                                                     const int64_t* __restrict__ rowptr, int64_t* __restrict__ ei,
-                                                    long long E, float* __restrict__ dist, float* __restrict__ dir) {
+                                                    long long E, float* __restrict__ dist, float* __restrict__ dir,
+                                                    float* __restrict__ dist_sq) {
   const int lane = threadIdx.x & 63;
   const int i1 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i1 >= N) return;
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(256) void cn_rg_kernel(const float* __restrict__ po
           const float d = sqrtf(d2);
           const float dn = fmaxf(d, 1e-12f);      // F.normalize(vec, p=2, dim=-1, eps=1e-12)
           dist[p] = d;
+          if (dist_sq) dist_sq[p] = d2;
           dir[p * 3] = dx / dn;
           dir[p * 3 + 1] = dy / dn;
           dir[p * 3 + 2] = dz / dn;
@@ -97,6 +99,81 @@ __global__ __launch_bounds__(256) void cn_rg_kernel(const float* __restrict__ po
     }
   }
   if (!FILL && lane == 0) deg[i1] = count;
+}
+
+// Neighbour cap (dataset/utils.py:240-360 get_max_neighbors_mask, enforce_max_strictly = False): a target with more
+// than k candidate edges keeps those with d^2 <= (k+1)-th smallest d^2 of its row + tolerance, in their original
+// order; shorter rows are kept whole.  One wavefront per target.  The (k+1)-th smallest value is found by rank
+// counting (every lane ranks its own elements against the whole row), which needs no sort and no scratch.
+__global__ __launch_bounds__(256) void cn_cap_count_kernel(const int64_t* __restrict__ rowptr,
+                                                           const float* __restrict__ d2, int N, int k, float tol,
+                                                           float* __restrict__ cutoff, int* __restrict__ deg) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const long long b = rowptr[i];
+  const int n = (int)(rowptr[i + 1] - b);
+  if (n <= k) {
+    if (lane == 0) { cutoff[i] = INFINITY; deg[i] = n; }
+    return;
+  }
+  const float* row = d2 + b;
+  float kth = 0.f;
+  bool found = false;
+  for (int e = lane; e < n && !found; e += 64) {
+    const float v = row[e];
+    int lo = 0, eq = 0;
+    for (int j = 0; j < n; ++j) {
+      const float w = row[j];
+      lo += (w < v);
+      eq += (w == v);
+    }
+    if (lo <= k && k < lo + eq) { kth = v; found = true; }
+  }
+  // exactly the lanes holding the k-th value found it, and they all hold the same number
+  const unsigned long long m = __ballot(found);
+  const int owner = m ? __ffsll((long long)m) - 1 : 0;
+  kth = m ? __shfl(kth, owner, 64) : INFINITY;          // m == 0 only if the row holds NaNs: keep it whole
+  const float c = __fadd_rn(kth, tol);
+  int cnt = 0;
+  for (int e = lane; e < n; e += 64) cnt += (row[e] <= c);
+  for (int off = 32; off; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  if (lane == 0) { cutoff[i] = c; deg[i] = cnt; }
+}
+
+__global__ __launch_bounds__(256) void cn_cap_fill_kernel(const int64_t* __restrict__ rowptr,
+                                                          const int64_t* __restrict__ rowptr_out,
+                                                          const float* __restrict__ cutoff,
+                                                          const float* __restrict__ d2, const int64_t* __restrict__ ei,
+                                                          const float* __restrict__ dist, const float* __restrict__ dir,
+                                                          int N, long long E, long long E_out,
+                                                          int64_t* __restrict__ ei_out, float* __restrict__ dist_out,
+                                                          float* __restrict__ dir_out) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const long long b = rowptr[i];
+  const int n = (int)(rowptr[i + 1] - b);
+  const float c = cutoff[i];
+  long long out = rowptr_out[i];
+  for (int base = 0; base < n; base += 64) {
+    const int e = base + lane;
+    const bool keep = e < n && d2[b + e] <= c;
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+      const long long p = out + __popcll(m & ((1ull << lane) - 1ull));
+      if (p < E_out) {
+        const long long q = b + e;
+        ei_out[p] = ei[q];
+        ei_out[E_out + p] = ei[E + q];
+        dist_out[p] = dist[q];
+        dir_out[p * 3] = dir[q * 3];
+        dir_out[p * 3 + 1] = dir[q * 3 + 1];
+        dir_out[p * 3 + 2] = dir[q * 3 + 2];
+      }
+    }
+    out += __popcll(m);
+  }
 }
 
 }  // namespace
@@ -113,7 +190,7 @@ extern "C" int cartnet_radius_graph_count(const float* pos, const float* cell, c
   if (N == 0) return 0;
   hipLaunchKernelGGL(cn_rg_kernel<false>, dim3(cn_ceil_div(N, 4)), dim3(256), 0, ST(stream), pos, cell, graph_ptr, batch,
                      reps, N, radius * radius, 0.0001f, deg, (const int64_t*)nullptr, (int64_t*)nullptr, 0LL,
-                     (float*)nullptr, (float*)nullptr);
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr);
   CN_LAUNCH_CHECK("cartnet_radius_graph_count");
   return 0;
 }
@@ -121,14 +198,42 @@ extern "C" int cartnet_radius_graph_count(const float* pos, const float* cell, c
 extern "C" int cartnet_radius_graph_fill(const float* pos, const float* cell, const int64_t* graph_ptr,
                                          const int64_t* batch, const int32_t* reps, const int64_t* rowptr, int32_t N,
                                          int32_t Bg, float radius, int64_t E, int64_t* edge_index, float* cart_dist,
-                                         float* cart_dir, void* stream) {
+                                         float* cart_dir, float* cart_dist_sq, void* stream) {
   CN_CHECK(N >= 0 && Bg >= 1 && radius > 0.f && E >= 0, "cartnet_radius_graph_fill: bad sizes");
   if (N == 0 || E == 0) return 0;
   CN_CHECK(pos && cell && graph_ptr && batch && reps && rowptr && edge_index && cart_dist && cart_dir,
            "cartnet_radius_graph_fill: null pointer");
   hipLaunchKernelGGL(cn_rg_kernel<true>, dim3(cn_ceil_div(N, 4)), dim3(256), 0, ST(stream), pos, cell, graph_ptr, batch,
                      reps, N, radius * radius, 0.0001f, (int*)nullptr, rowptr, edge_index, (long long)E, cart_dist,
-                     cart_dir);
+                     cart_dir, cart_dist_sq);
   CN_LAUNCH_CHECK("cartnet_radius_graph_fill");
+  return 0;
+}
+
+extern "C" int cartnet_neighbor_cap_count(const int64_t* rowptr, const float* dist_sq, int32_t N, int32_t max_neighbors,
+                                          float tolerance, float* cutoff, int32_t* deg, void* stream) {
+  CN_CHECK(N >= 0 && max_neighbors >= 1 && tolerance >= 0.f, "cartnet_neighbor_cap_count: bad sizes");
+  if (N == 0) return 0;
+  CN_CHECK(rowptr && dist_sq && cutoff && deg, "cartnet_neighbor_cap_count: null pointer");
+  hipLaunchKernelGGL(cn_cap_count_kernel, dim3(cn_ceil_div(N, 4)), dim3(256), 0, ST(stream), rowptr, dist_sq, N,
+                     max_neighbors, tolerance, cutoff, deg);
+  CN_LAUNCH_CHECK("cartnet_neighbor_cap_count");
+  return 0;
+}
+
+extern "C" int cartnet_neighbor_cap_fill(const int64_t* rowptr, const int64_t* rowptr_out, const float* cutoff,
+                                         const float* dist_sq, const int64_t* edge_index, const float* cart_dist,
+                                         const float* cart_dir, int32_t N, int64_t E, int64_t E_out,
+                                         int64_t* edge_index_out, float* cart_dist_out, float* cart_dir_out,
+                                         void* stream) {
+  CN_CHECK(N >= 0 && E >= 0 && E_out >= 0 && E_out <= E, "cartnet_neighbor_cap_fill: bad sizes");
+  if (N == 0 || E_out == 0) return 0;
+  CN_CHECK(rowptr && rowptr_out && cutoff && dist_sq && edge_index && cart_dist && cart_dir && edge_index_out &&
+               cart_dist_out && cart_dir_out,
+           "cartnet_neighbor_cap_fill: null pointer");
+  hipLaunchKernelGGL(cn_cap_fill_kernel, dim3(cn_ceil_div(N, 4)), dim3(256), 0, ST(stream), rowptr, rowptr_out, cutoff,
+                     dist_sq, edge_index, cart_dist, cart_dir, N, (long long)E, (long long)E_out, edge_index_out,
+                     cart_dist_out, cart_dir_out);
+  CN_LAUNCH_CHECK("cartnet_neighbor_cap_fill");
   return 0;
 }

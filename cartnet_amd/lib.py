@@ -163,7 +163,12 @@ PROTOTYPES = {
     "cartnet_radius_graph_count": (C.c_int, [c_f32p, c_f32p, c_i64p, c_i64p, C.c_int32, C.c_int32, C.c_float, c_i32p,
                                              c_i32p, c_stream]),
     "cartnet_radius_graph_fill": (C.c_int, [c_f32p, c_f32p, c_i64p, c_i64p, c_i32p, c_i64p, C.c_int32, C.c_int32,
-                                            C.c_float, C.c_int64, c_i64p, c_f32p, c_f32p, c_stream]),
+                                            C.c_float, C.c_int64, c_i64p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "cartnet_neighbor_cap_count": (C.c_int, [c_i64p, c_f32p, C.c_int32, C.c_int32, C.c_float, c_f32p, c_i32p,
+                                             c_stream]),
+    "cartnet_neighbor_cap_fill": (C.c_int, [c_i64p, c_i64p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, C.c_int32,
+                                            C.c_int64, C.c_int64, c_i64p, c_f32p, c_f32p, c_stream]),
+    "cartnet_adp_metrics": (C.c_int, [c_f32p, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, c_f32p, c_f32p, c_stream]),
     "cartnet_profile_gemm": (C.c_int, [C.c_int32]),
     "cartnet_profile_gemm_read": (C.c_int, [C.POINTER(GemmProfile), C.c_int32]),
     "cartnet_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),

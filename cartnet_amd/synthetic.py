@@ -26,8 +26,23 @@ TEMP_STD = 81.2135    # reference: dataset/datasetADP.py:18
 VOLUME_PER_ATOM = 36.36
 
 
-def radius_graph_pbc_single(pos: torch.Tensor, cell: torch.Tensor, radius: float = 5.0,
-                            chunk: int = 64) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+def neighbor_cap_mask(tgt: torch.Tensor, d2: torch.Tensor, n: int, max_neighbors: int,
+                      tolerance: float = 0.01) -> torch.Tensor:
+    """Boolean keep-mask of the reference's neighbour cap (dataset/utils.py:240-360, enforce_max_strictly False):
+    a target with more than ``max_neighbors`` edges keeps those with d^2 <= (max_neighbors+1)-th smallest d^2 of its
+    row + tolerance.  ``tgt`` sorted ascending, ``d2`` fp32 squared distances."""
+    keep = torch.ones_like(tgt, dtype=torch.bool)
+    deg = torch.bincount(tgt, minlength=n)
+    start = torch.cumsum(deg, 0) - deg
+    for i in torch.nonzero(deg > max_neighbors).flatten().tolist():
+        row = d2[start[i]:start[i] + deg[i]]
+        cutoff = torch.sort(row).values[max_neighbors] + tolerance        # fp32 add, as the reference's tensor + float
+        keep[start[i]:start[i] + deg[i]] = torch.le(row, cutoff)
+    return keep
+
+
+def radius_graph_pbc_single(pos: torch.Tensor, cell: torch.Tensor, radius: float = 5.0, chunk: int = 64,
+                            max_neighbors: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Periodic radius graph of ONE crystal on the CPU.
 
     pos [n,3] float32 Cartesian, cell [3,3] float32 (rows are lattice vectors).
@@ -73,6 +88,9 @@ def radius_graph_pbc_single(pos: torch.Tensor, cell: torch.Tensor, radius: float
     src = torch.cat(src_l)
     tgt = torch.cat(tgt_l)
     vec = torch.cat(dir_l)
+    if max_neighbors is not None and max_neighbors > 0:                  # dataset/utils.py:216-233
+        keep = neighbor_cap_mask(tgt, torch.cat(d2_l), n, max_neighbors)
+        src, tgt, vec = src[keep], tgt[keep], vec[keep]
     edge_index = torch.stack((src, tgt))
     cart_dist = torch.norm(vec, p=2, dim=-1)
     cart_dir = torch.nn.functional.normalize(vec, p=2, dim=-1)

@@ -55,16 +55,27 @@ def train_epoch(loader, model, optimizer, batch_accumulation: int, scheduler: Op
     return {"mae": float(tot_mae.item()) / max(n_iter, 1), "graphs": graphs, "seconds": dt}
 
 
-def eval_epoch(loader, model, device="cuda:0"):
-    """train/train.py:202-243: eval mode, no grad."""
+def eval_epoch(loader, model, device="cuda:0", adp_metrics=False, test_metrics=False):
+    """train/train.py:202-243: eval mode, no grad.  ``adp_metrics`` adds the per-batch means the reference logs for
+    the ADP dataset (train/metrics.py:201-225): volume error and similarity index always, the voxel IoU only for the
+    test pass (``test_metrics``); all on the GPU (cartnet_amd/metrics.py)."""
+    from .metrics import adp_metrics as _adp_metrics
     model.eval()
-    tot_mae = torch.zeros((), device=device)
+    names = ["mae"] + (["volume_percentage_error", "similarity_index"] + (["iou"] if test_metrics else [])
+                       if adp_metrics else [])
+    tot = {k: torch.zeros((), device=device) for k in names}
     n = 0
     with torch.no_grad():
         for batch in loader:
             batch.to(device)
             pred, true = model(batch)
             mae, _ = compute_loss(pred, true)
-            tot_mae += mae
+            tot["mae"] += mae
+            if adp_metrics:
+                vol, sim, iou = _adp_metrics(pred, true, True, True, test_metrics)
+                tot["volume_percentage_error"] += vol.mean()
+                tot["similarity_index"] += sim.mean()
+                if test_metrics:
+                    tot["iou"] += iou.mean()
             n += 1
-    return {"mae": float(tot_mae.item()) / max(n, 1)}
+    return {k: float(v.item()) / max(n, 1) for k, v in tot.items()}

@@ -121,17 +121,44 @@ int cartnet_colsum_partial(const float* x, int32_t ld, int32_t R, int32_t C, dou
 
 /* ------------------------------------------------------------------------------------------------------
  * Periodic radius graph on the GPU (reference: dataset/utils.py:57-237 radius_graph_pbc as used by
- * dataset/figshare_dataset.py:65-68; no neighbour cap, pairs with d^2 <= 1e-4 dropped).  Edges come out in the
+ * dataset/figshare_dataset.py:65-68; pairs with d^2 <= 1e-4 dropped).  Edges come out in the
  * reference's order (target, source, periodic image), i.e. edge_index[1] ascending.
  *   count: reps[Bg,3] = periodic repetitions per lattice direction, deg[N] = in-degree of every atom.
  *   fill:  rowptr[N+1] = exclusive prefix sum of deg (int64), E = rowptr[N]; writes edge_index [2,E] (int64,
- *          row 0 source, row 1 target), cart_dist [E], cart_dir [E,3] = (pos_target - (pos_source + offset)) / dist.
+ *          row 0 source, row 1 target), cart_dist [E], cart_dir [E,3] = (pos_target - (pos_source + offset)) / dist,
+ *          and, if cart_dist_sq is not NULL, the squared distances [E] the neighbour cap ranks by.
+ * Neighbour cap (dataset/utils.py:240-360 get_max_neighbors_mask with enforce_max_strictly = False, as applied at
+ * dataset/utils.py:216-233 when figshare_dataset.py passes max_neigh): a target atom with more than max_neighbors
+ * edges keeps those with d^2 <= (max_neighbors+1)-th smallest d^2 of its row + tolerance (0.01 in the reference), in
+ * their original order; rows with <= max_neighbors edges are kept whole.
+ *   cap_count: rowptr[N+1] of the uncapped graph, dist_sq[E] -> cutoff[N] (fp32, +inf for whole rows), deg[N].
+ *   cap_fill:  rowptr_out[N+1] = exclusive prefix sum of deg, E_out = rowptr_out[N]; compacts edge_index [2,E] ->
+ *              [2,E_out], cart_dist, cart_dir.
  * ---------------------------------------------------------------------------------------------------- */
 int cartnet_radius_graph_count(const float* pos, const float* cell, const int64_t* graph_ptr, const int64_t* batch,
                                int32_t N, int32_t Bg, float radius, int32_t* reps, int32_t* deg, void* stream);
 int cartnet_radius_graph_fill(const float* pos, const float* cell, const int64_t* graph_ptr, const int64_t* batch,
                               const int32_t* reps, const int64_t* rowptr, int32_t N, int32_t Bg, float radius,
-                              int64_t E, int64_t* edge_index, float* cart_dist, float* cart_dir, void* stream);
+                              int64_t E, int64_t* edge_index, float* cart_dist, float* cart_dir, float* cart_dist_sq,
+                              void* stream);
+int cartnet_neighbor_cap_count(const int64_t* rowptr, const float* dist_sq, int32_t N, int32_t max_neighbors,
+                               float tolerance, float* cutoff, int32_t* deg, void* stream);
+int cartnet_neighbor_cap_fill(const int64_t* rowptr, const int64_t* rowptr_out, const float* cutoff,
+                              const float* dist_sq, const int64_t* edge_index, const float* cart_dist,
+                              const float* cart_dir, int32_t N, int64_t E, int64_t E_out, int64_t* edge_index_out,
+                              float* cart_dist_out, float* cart_dir_out, void* stream);
+
+/* ----------------------------------------------------------------------------------------------------
+ * ADP evaluation metrics (reference: train/metrics.py, called per test batch from
+ * train/metrics.py:201-214 and main.py:47-49,101-102).  pred, truth: [M,3,3] fp32 symmetric positive definite.
+ *   volume_error[M]     = |V(pred) - V(truth)| / (V(pred) + 1e-8), V = 4/3 pi sqrt(det)      (metrics.py:30-58)
+ *   similarity_index[M] = 100 (1 - 2^(3/2) det(T^-1 P^-1)^(1/4) / det(T^-1 + P^-1)^(1/2))    (metrics.py:76-94)
+ *   iou[M]              = voxel IoU of the two ellipsoids {x : x^T S^-1 x < 1}, S = matrix / max(|P|_F, |T|_F),
+ *                         over the grid[num_points]^3 lattice (the reference: linspace(-1, 1, 64)) (metrics.py:96-180)
+ * Any of the three outputs may be NULL (skipped); grid / num_points are only read for the IoU.
+ * ---------------------------------------------------------------------------------------------------- */
+int cartnet_adp_metrics(const float* pred, const float* truth, int32_t M, const float* grid, int32_t num_points,
+                        float* volume_error, float* similarity_index, float* iou, void* stream);
 
 /* Opt-in timing of cartnet_gemm launches (the only process-global state in the library; used by bench.py):
  * while enabled, every cartnet_gemm call -- also those issued inside cartnet_model_forward/backward -- is bracketed

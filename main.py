@@ -149,8 +149,11 @@ def main(argv=None) -> dict:
     if rank == 0 and os.path.exists(os.path.join(ckpt_dir, "best.ckpt")):  # train/train.py:114-117
         ck = torch.load(os.path.join(ckpt_dir, "best.ckpt"), map_location=cfg.device)
         model.load_state_dict(ck["model_state"])
-        result["test_mae"] = eval_epoch(loaders[2], model, device=cfg.device)["mae"]
-        print(json.dumps({"params": n_params, "best_val_mae": best, "test_mae": result["test_mae"]}), flush=True)
+        adp = cfg.dataset.name == "ADP"
+        test = eval_epoch(loaders[2], model, device=cfg.device, adp_metrics=adp, test_metrics=adp)
+        result["test_mae"] = test["mae"]
+        result["test_metrics"] = test                                      # train/metrics.py:201-214
+        print(json.dumps({"params": n_params, "best_val_mae": best, "test": test}), flush=True)
     return result
 
 

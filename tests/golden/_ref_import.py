@@ -10,6 +10,8 @@ restate the published semantics the reference relies on:
         ``<name>_i`` = ``<name>.index_select(0, edge_index[1])``, ``<name>_j`` = ``...(0, edge_index[0])``,
         ``index`` = ``edge_index[1]``; message -> aggregate -> update, arguments matched by parameter name
   * ``torch_scatter.scatter(src, index, dim, out, dim_size, reduce)`` -> ``zeros.scatter_add_`` (sum / mean)
+  * ``torch_scatter.segment_coo(src, index, dim_size=)`` / ``segment_csr(src, indptr)`` -> per-segment sums (only
+        ``get_max_neighbors_mask`` uses them)
   * default ``aggregate`` (aggr='add') = scatter-sum of the messages over ``index``; default ``update`` = identity
   * ``e3nn.o3`` -> empty module (only the eComformer classes, which are out of scope, touch it)
   * ``torch_geometric.graphgym.config.cfg``      -> attribute bag (only ``invariant`` and ``radius`` are read)
@@ -127,9 +129,16 @@ def install_standins():
     tg_data.Batch = type("Batch", (), {})
     ts.scatter = _scatter
 
-    def _segment_unavailable(*a, **k):
-        raise NotImplementedError("segment_coo/csr are only reached with a neighbour cap, which CartNet disables")
-    ts.segment_coo = ts.segment_csr = _segment_unavailable
+    # torch_scatter 2.1.1 published semantics (default reduce="sum"); only the neighbour cap reaches these
+    def _segment_coo(src, index, out=None, dim_size=None, reduce="sum"):
+        assert out is None and reduce == "sum" and src.dim() == 1
+        return torch.zeros(int(dim_size), dtype=src.dtype, device=src.device).scatter_add_(0, index, src)
+
+    def _segment_csr(src, indptr, out=None, reduce="sum"):
+        assert out is None and reduce == "sum" and src.dim() == 1
+        c = torch.cat([src.new_zeros(1), torch.cumsum(src, 0)])
+        return c[indptr[1:]] - c[indptr[:-1]]
+    ts.segment_coo, ts.segment_csr = _segment_coo, _segment_csr
     return _Cfg
 
 

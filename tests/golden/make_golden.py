@@ -227,12 +227,74 @@ def radius_graph_fixture():
         arrays[f"pos{i}"], arrays[f"cell{i}"] = to_np(d.pos), to_np(d.cell[0])
         arrays[f"edge_index{i}"], arrays[f"dist{i}"], arrays[f"dir{i}"] = to_np(ei), to_np(dist), to_np(dirn)
         print(f"radius_graph[{i}]: n={n} E={ei.shape[1]} identical to reference")
+        # neighbour cap as figshare_dataset.py:65 passes it for iComformer (main.py:141 uses 25; these sparse synthetic
+        # crystals have ~14 neighbours per atom, so 8 is what actually drops edges here)
+        ei_c, _, _, vec_c = ref_dutils.radius_graph_pbc(data, 5.0, 8)
+        mine_ei, mine_dist, mine_dir = radius_graph_pbc_single(d.pos, d.cell[0], 5.0, max_neighbors=8)
+        assert torch.equal(ei_c, mine_ei), "capped edge_index differs from the reference"
+        assert torch.equal(torch.norm(vec_c, p=2, dim=-1), mine_dist)
+        assert ei_c.shape[1] < ei.shape[1]
+        arrays[f"cap8_edge_index{i}"], arrays[f"cap8_dist{i}"] = to_np(ei_c), to_np(mine_dist)
+        arrays[f"cap8_dir{i}"] = to_np(mine_dir)
+        print(f"radius_graph[{i}]: cap 8 -> E={ei_c.shape[1]} identical to reference")
+    # degenerate shells: simple cubic, one atom, a = 2.5 -> 6 + 12 + 8 + 6 neighbours inside 5 A; the tolerance keeps
+    # whole shells (26 edges for a cap of 25, 18 for a cap of 10)
+    data = type("D", (), {})()
+    data.pos, data.cell = torch.tensor([[0.3, 0.4, 0.5]]), (2.5 * torch.eye(3)).view(1, 3, 3)
+    data.natoms, data.pbc = torch.tensor([1]), torch.tensor([[True, True, True]])
+    arrays["cubic_pos"], arrays["cubic_cell"] = to_np(data.pos), to_np(data.cell[0])
+    for k in (10, 25):
+        ei_c, _, _, vec_c = ref_dutils.radius_graph_pbc(data, 5.0, k)
+        mine_ei, mine_dist, mine_dir = radius_graph_pbc_single(data.pos, data.cell[0], 5.0, max_neighbors=k)
+        assert torch.equal(ei_c, mine_ei) and torch.equal(torch.norm(vec_c, p=2, dim=-1), mine_dist)
+        arrays[f"cubic_cap{k}_edge_index"], arrays[f"cubic_cap{k}_dist"] = to_np(ei_c), to_np(mine_dist)
+        arrays[f"cubic_cap{k}_dir"] = to_np(mine_dir)
+        print(f"radius_graph[cubic]: cap {k} -> E={ei_c.shape[1]} identical to reference")
     np.savez_compressed(os.path.join(HERE, "radius_graph.npz"), **arrays)
+
+
+def random_adp(m, seed, spread):
+    """[m,3,3] fp32 SPD matrices in the range of real ADPs (eigenvalues ~0.005..0.1 A^2) and a perturbed copy."""
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(m, 3, 3, generator=g, dtype=torch.float64)
+    q, _ = torch.linalg.qr(a)
+    ev = 0.005 + 0.1 * torch.rand(m, 3, generator=g, dtype=torch.float64) ** 2
+    true = q @ torch.diag_embed(ev) @ q.transpose(1, 2)
+    b = torch.randn(m, 3, 3, generator=g, dtype=torch.float64) * spread
+    l = torch.linalg.cholesky(true) @ (torch.eye(3, dtype=torch.float64) + torch.tril(b))
+    pred = l @ l.transpose(1, 2)
+    sym = lambda x: (0.5 * (x + x.transpose(1, 2))).float()
+    return sym(pred), sym(true)
+
+
+def metrics_fixture():
+    """train/metrics.py run as is (its only third-party import is the GraphGym cfg stand-in)."""
+    import importlib
+    ref_metrics = importlib.import_module("train.metrics")
+    from oracle import metrics_ref as om
+    arrays = {}
+    for name, m, seed, spread in (("close", 48, 31, 0.05), ("far", 48, 32, 0.6)):
+        pred, true = random_adp(m, seed, spread)
+        vol = ref_metrics.get_error_volume(pred, true)
+        sim = ref_metrics.get_similarity_index(pred, true)
+        iou = ref_metrics.compute_3D_IoU(pred, true)
+        vol64 = ref_metrics.get_error_volume(pred.double(), true.double())
+        sim64 = ref_metrics.get_similarity_index(pred.double(), true.double())
+        assert torch.allclose(om.get_error_volume(pred, true), vol, rtol=1e-5, atol=1e-7)
+        assert torch.allclose(om.get_similarity_index(pred, true), sim, rtol=1e-4, atol=1e-3)
+        assert torch.allclose(om.compute_3d_iou(pred, true), iou, rtol=0, atol=1e-4)
+        arrays.update({f"{name}_pred": to_np(pred), f"{name}_true": to_np(true), f"{name}_volume_error": to_np(vol),
+                       f"{name}_similarity_index": to_np(sim), f"{name}_iou": to_np(iou),
+                       f"{name}_volume_error64": to_np(vol64), f"{name}_similarity_index64": to_np(sim64)})
+        print(f"adp_metrics[{name}]: vol {vol.mean():.4f} S12 {sim.mean():.4f} IoU {iou.mean():.4f} | fp32-vs-fp64 "
+              f"vol {(vol - vol64).abs().max():.2e} S12 {(sim - sim64).abs().max():.2e}")
+    np.savez_compressed(os.path.join(HERE, "adp_metrics.npz"), **arrays)
 
 
 def main():
     torch.set_num_threads(4)
     radius_graph_fixture()
+    metrics_fixture()
     save_model_fixture("tiny_adp", hp_dict(16, 8, 2), tiny_batch(), seed=11, store_weights=True, full_grads=True,
                        trace=True)
     save_model_fixture("tiny_scalar", hp_dict(16, 8, 2, temperature=False, cholesky=False), tiny_batch(adp=False),

@@ -22,6 +22,9 @@ def test_main_trains_and_checkpoints(tmp_path, monkeypatch):
     assert "encoder.embedding.weight" in ck["model_state"] and ck["optimizer_state"]["step"] > 0
     assert "test_mae" in res and res["params"] == sum(v.numel() for k, v in ck["model_state"].items()
                                                       if "running" not in k and "num_batches" not in k and "rbf" not in k)
+    tm = res["test_metrics"]                                         # train/metrics.py:201-214 on the GPU
+    assert set(tm) == {"mae", "volume_percentage_error", "similarity_index", "iou"}
+    assert 0.0 < tm["iou"] <= 1.0 and tm["similarity_index"] >= 0.0 and tm["volume_percentage_error"] >= 0.0
 
 
 def test_main_runs_icomformer(tmp_path, monkeypatch):

@@ -25,6 +25,46 @@ def test_matches_reference_golden_fixture():
                torch.from_numpy(z[f"dir{i}"]))
 
 
+def test_neighbour_cap_matches_reference_golden_fixture():
+    from cartnet_amd.graph import radius_graph_pbc
+    z = np.load(gu.GOLDEN + "/radius_graph.npz")
+    cases = [(f"pos{i}", f"cell{i}", 8, f"cap8_edge_index{i}", f"cap8_dist{i}", f"cap8_dir{i}") for i in range(3)]
+    cases += [("cubic_pos", "cubic_cell", k, f"cubic_cap{k}_edge_index", f"cubic_cap{k}_dist", f"cubic_cap{k}_dir")
+              for k in (10, 25)]
+    for pk, ck, k, ek, dk, vk in cases:
+        pos, cell = torch.from_numpy(z[pk]), torch.from_numpy(z[ck])
+        ptr = torch.tensor([0, pos.shape[0]])
+        ei, dist, dirs = radius_graph_pbc(pos.cuda(), cell.view(1, 3, 3).cuda(), ptr.cuda(), 5.0, max_neighbors=k)
+        _check(ei, dist, dirs, torch.from_numpy(z[ek]), torch.from_numpy(z[dk]), torch.from_numpy(z[vk]))
+
+
+def test_neighbour_cap_on_a_batch_matches_cpu_builder():
+    """Dense crystals (up to ~60 neighbours), the iComformer cap of 25, several crystals per call; a cap nobody
+    reaches returns the uncapped graph."""
+    from cartnet_amd.graph import radius_graph_pbc
+    from cartnet_amd.synthetic import radius_graph_pbc_single
+    gen = torch.Generator().manual_seed(5)
+    pos_l, cell_l, ref = [], [], []
+    for n, a in ((40, 7.0), (150, 11.0), (3, 3.1), (64, 8.0)):
+        cell = a * torch.eye(3) + 0.3 * torch.randn(3, 3, generator=gen)
+        pos = torch.rand(n, 3, generator=gen) @ cell
+        pos_l.append(pos); cell_l.append(cell)
+        ref.append(radius_graph_pbc_single(pos, cell, 5.0, max_neighbors=25))
+    off = 0
+    ref_ei, ref_d, ref_v = [], [], []
+    for (ei, d, v), p in zip(ref, pos_l):
+        ref_ei.append(ei + off); ref_d.append(d); ref_v.append(v); off += p.shape[0]
+    ptr = torch.tensor([0] + list(np.cumsum([p.shape[0] for p in pos_l])))
+    pos, cell = torch.cat(pos_l).cuda(), torch.stack(cell_l).cuda()
+    ei, dist, dirs = radius_graph_pbc(pos, cell, ptr.cuda(), 5.0, max_neighbors=25)
+    _check(ei, dist, dirs, torch.cat(ref_ei, 1), torch.cat(ref_d), torch.cat(ref_v))
+    deg = torch.bincount(ei[1].cpu(), minlength=pos.shape[0])
+    assert int(deg.max()) >= 25 and int(deg.max()) < 40
+    full = radius_graph_pbc(pos, cell, ptr.cuda(), 5.0)
+    big = radius_graph_pbc(pos, cell, ptr.cuda(), 5.0, max_neighbors=10_000)
+    assert all(torch.equal(a, b) for a, b in zip(full, big)) and full[0].shape[1] > ei.shape[1]
+
+
 def test_batch_of_crystals_matches_cpu_builder_and_feeds_the_model():
     from cartnet_amd.data import Batch
     from cartnet_amd.graph import radius_graph_pbc

@@ -89,6 +89,20 @@ def test_radius_graph_matches_reference_bit_exact():
         assert bool((ei[1][1:] >= ei[1][:-1]).all())      # target index sorted: CSR is a bincount + cumsum
 
 
+def test_neighbour_cap_matches_reference_bit_exact():
+    """dataset/utils.py:240-360 through figshare_dataset.py:65: the cap keeps whole degenerate shells."""
+    from cartnet_amd.synthetic import radius_graph_pbc_single
+    z = np.load(gu.GOLDEN + "/radius_graph.npz")
+    cases = [(f"pos{i}", f"cell{i}", 8, f"cap8_edge_index{i}", f"cap8_dist{i}", f"cap8_dir{i}") for i in range(3)]
+    cases += [("cubic_pos", "cubic_cell", k, f"cubic_cap{k}_edge_index", f"cubic_cap{k}_dist", f"cubic_cap{k}_dir")
+              for k in (10, 25)]
+    for pk, ck, k, ek, dk, vk in cases:
+        ei, dist, dirn = radius_graph_pbc_single(torch.from_numpy(z[pk]), torch.from_numpy(z[ck]), 5.0, max_neighbors=k)
+        assert torch.equal(ei, torch.from_numpy(z[ek])), ek
+        assert torch.equal(dist, torch.from_numpy(z[dk])) and torch.equal(dirn, torch.from_numpy(z[vk]))
+    assert z["cubic_cap10_edge_index"].shape[1] == 18 and z["cubic_cap25_edge_index"].shape[1] == 26
+
+
 def test_equivariance_of_the_oracle():
     """Rotating cart_dir by R rotates the predicted ADP tensors: pred' = R^T pred R (reference main.py:96-97)."""
     from cartnet_amd.synthetic import random_rotation
