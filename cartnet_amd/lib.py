@@ -94,6 +94,17 @@ class BatchDesc(C.Structure):
                [("N", C.c_int32), ("Bg", C.c_int32), ("M", C.c_int32), ("E", C.c_int64)]
 
 
+class Shard(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("atom_ptr", "edge_ptr", "y_ptr", "z", "pos", "non_h_mask", "edge_src",
+                                          "edge_tgt", "cart_dist", "cart_dir", "cell", "temperature", "y")] + \
+               [("y_width", C.c_int32)]
+
+
+class Collated(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "pos", "non_h_mask", "batch", "ptr", "edge_index", "cart_dist",
+                                          "cart_dir", "cell", "temperature", "y")]
+
+
 # name -> (restype, argtypes); every symbol include/cartnet_hip.h declares
 PROTOTYPES = {
     "cartnet_last_error": (C.c_char_p, []),
@@ -169,6 +180,8 @@ PROTOTYPES = {
     "cartnet_neighbor_cap_fill": (C.c_int, [c_i64p, c_i64p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, C.c_int32,
                                             C.c_int64, C.c_int64, c_i64p, c_f32p, c_f32p, c_stream]),
     "cartnet_adp_metrics": (C.c_int, [c_f32p, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, c_f32p, c_f32p, c_stream]),
+    "cartnet_collate": (C.c_int, [C.POINTER(Shard), c_i64p, c_i64p, c_i64p, c_i64p, C.c_int32, C.c_int64, C.c_int64,
+                                  C.c_int64, c_f32p, C.c_float, C.c_float, C.POINTER(Collated), c_stream]),
     "cartnet_profile_gemm": (C.c_int, [C.c_int32]),
     "cartnet_profile_gemm_read": (C.c_int, [C.POINTER(GemmProfile), C.c_int32]),
     "cartnet_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),

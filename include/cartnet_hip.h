@@ -160,6 +160,58 @@ int cartnet_neighbor_cap_fill(const int64_t* rowptr, const int64_t* rowptr_out, 
 int cartnet_adp_metrics(const float* pred, const float* truth, int32_t M, const float* grid, int32_t num_points,
                         float* volume_error, float* similarity_index, float* iou, void* stream);
 
+/* ----------------------------------------------------------------------------------------------------
+ * Device-side batching from a packed shard resident in HBM (replaces torch.load of one pickled
+ * Data per structure, dataset/datasetADP.py:41-42, PyG's collate in loader/loader.py:114-124, and the per-sample
+ * CPU augmentation / temperature standardisation of dataset/datasetADP.py:33-39,43-45,76-77).
+ * A shard is the concatenation of G crystals in CSR form; all pointers are device pointers:
+ *   atom_ptr, edge_ptr, y_ptr [G+1] int64;  z [N] int32;  pos [N,3];  non_h_mask [N] u8;
+ *   edge_src, edge_tgt [E] int32 (atom index INSIDE its crystal, edge_tgt ascending per crystal);
+ *   cart_dist [E];  cart_dir [E,3];  cell [G,9];  temperature [G] (raw kelvin or pre-standardised);
+ *   y [Y, y_width]: y_width = 9 -> one 3x3 ADP tensor per non-hydrogen atom, otherwise per-crystal targets.
+ * pos, non_h_mask, cell, temperature may be NULL when the matching output is NULL.
+ * cartnet_collate gathers crystals sel[0..B) into one batch: out_*_ptr [B+1] are the exclusive prefix sums of the
+ * selected crystals' atom / edge / target counts (N, E, M = their last entries).  Outputs: x [N] int64, pos [N,3],
+ * non_h_mask [N] u8 (0/1), batch [N] int64, ptr [B+1] int64, edge_index [2,E] int64 (batch numbering), cart_dist
+ * [E], cart_dir [E,3], cell [B,9], temperature [B] = (T - temp_mean) / temp_std, y [M, y_width].
+ * rot: NULL, or [B,9] one rotation per crystal: cart_dir <- cart_dir R, cell <- cell R, y <- R^T y R (y_width 9).
+ * Without rot every output is a bit-exact copy (integers rebased); one launch, no host synchronisation.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct CartnetShard {
+  const int64_t* atom_ptr;
+  const int64_t* edge_ptr;
+  const int64_t* y_ptr;
+  const int32_t* z;
+  const float* pos;
+  const uint8_t* non_h_mask;
+  const int32_t* edge_src;
+  const int32_t* edge_tgt;
+  const float* cart_dist;
+  const float* cart_dir;
+  const float* cell;
+  const float* temperature;
+  const float* y;
+  int32_t y_width;
+} CartnetShard;
+
+typedef struct CartnetCollated {
+  int64_t* x;
+  float* pos;
+  uint8_t* non_h_mask;
+  int64_t* batch;
+  int64_t* ptr;
+  int64_t* edge_index;
+  float* cart_dist;
+  float* cart_dir;
+  float* cell;
+  float* temperature;
+  float* y;
+} CartnetCollated;
+
+int cartnet_collate(const CartnetShard* shard, const int64_t* sel, const int64_t* out_atom_ptr,
+                    const int64_t* out_edge_ptr, const int64_t* out_y_ptr, int32_t B, int64_t N, int64_t E, int64_t M,
+                    const float* rot, float temp_mean, float temp_std, const CartnetCollated* out, void* stream);
+
 /* Opt-in timing of cartnet_gemm launches (the only process-global state in the library; used by bench.py):
  * while enabled, every cartnet_gemm call -- also those issued inside cartnet_model_forward/backward -- is bracketed
  * by HIP events on its launch stream.  cartnet_profile_gemm_read waits for the events and returns per-variant totals

@@ -67,6 +67,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--device", type=str, default="cuda:0")
     p.add_argument("--synthetic", type=int, default=32, help="number of synthetic crystals (80/10/10 split)")
     p.add_argument("--atoms", type=int, nargs=2, default=(30, 70), help="atoms per synthetic crystal: lo hi")
+    p.add_argument("--resident_dataset", action="store_true",
+                   help="keep the splits as packed shards in HBM and build every batch (and its augmentation) on the GPU")
     return p
 
 
@@ -100,6 +102,12 @@ def create_loaders(args, rank: int, world: int):
     tr = [graphs[i] for i in perm[:n_tr]]
     va = [graphs[i] for i in perm[n_tr:n_tr + n_va]] or tr[:1]
     te = [graphs[i] for i in perm[n_tr + n_va:]] or tr[:1]
+    if args.resident_dataset:                                             # cartnet_amd/shard.py
+        from cartnet_amd.shard import DeviceShard, ShardLoader
+        shards = [DeviceShard.from_data_list(part, cfg.device) for part in (tr, va, te)]
+        return [ShardLoader(shards[0], cfg.batch, shuffle=True, seed=cfg.seed, rank=rank, world_size=world,
+                            augment=cfg.augment),
+                ShardLoader(shards[1], cfg.batch), ShardLoader(shards[2], 1 if adp else cfg.batch)]
     gen = torch.Generator().manual_seed(cfg.seed + 1000 * rank)
     aug = (lambda d: augment_data(d, gen)) if cfg.augment else None
     return [DataLoader(tr, cfg.batch, shuffle=True, seed=cfg.seed, rank=rank, world_size=world, transform=aug),

@@ -27,6 +27,20 @@ def test_main_trains_and_checkpoints(tmp_path, monkeypatch):
     assert 0.0 < tm["iou"] <= 1.0 and tm["similarity_index"] >= 0.0 and tm["volume_percentage_error"] >= 0.0
 
 
+def test_main_with_resident_dataset_matches_host_loader(tmp_path, monkeypatch):
+    """--resident_dataset builds the same batches on the GPU (cartnet_collate), so training is reproduced exactly."""
+    import main as entry
+    monkeypatch.chdir(tmp_path)
+    common = ["--synthetic", "20", "--atoms", "10", "30", "--dim_in", "32", "--num_layers", "2", "--epochs", "2",
+              "--batch", "4", "--batch_accumulation", "2"]
+    a = entry.main(common + ["--name", "host"])
+    b = entry.main(common + ["--name", "resident", "--resident_dataset"])
+    assert [h["train_mae"] for h in a["history"]] == [h["train_mae"] for h in b["history"]]
+    assert a["test_metrics"] == b["test_metrics"]
+    c = entry.main(common + ["--name", "resident_aug", "--resident_dataset", "--augment"])
+    assert all(torch.isfinite(torch.tensor(h["train_mae"])) for h in c["history"])
+
+
 def test_main_runs_icomformer(tmp_path, monkeypatch):
     import main as entry
     monkeypatch.chdir(tmp_path)

@@ -1,0 +1,133 @@
+"""Device-side batching (cartnet_collate through cartnet_amd.shard) against the host collation rules
+(cartnet_amd/data.py: PyG's contract), bit for bit; the fused SO(3) augmentation against the host augmentation."""
+import numpy as np
+import pytest
+import torch
+
+from cartnet_amd import shard
+from cartnet_amd.data import Batch
+from cartnet_amd.synthetic import make_crystal
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("x", "pos", "non_H_mask", "batch", "ptr", "edge_index", "cart_dist", "cart_dir", "cell", "temperature", "y")
+
+
+def _items(adp=True, sizes=(5, 9, 1, 14, 3, 64, 2)):
+    return [make_crystal(300 + g, n, adp=adp) for g, n in enumerate(sizes)]
+
+
+def _assert_same(b, ref, keys=KEYS):
+    for k in keys:
+        if not hasattr(ref, k):
+            assert not hasattr(b, k), k
+            continue
+        got, want = getattr(b, k).cpu(), getattr(ref, k)
+        assert got.dtype == want.dtype and got.shape == want.shape, (k, got.dtype, got.shape, want.dtype, want.shape)
+        assert torch.equal(got, want), k
+
+
+def test_collate_is_bit_exact_for_any_selection(tmp_path):
+    items = _items()
+    path = str(tmp_path / "s.cnshard")
+    shard.write_shard(path, items)
+    ds = shard.DeviceShard.from_file(path)
+    assert ds.num_graphs == len(items) and ds.per_atom_target
+    for sel in ([0, 1, 2, 3, 4, 5, 6], [5], [2], [6, 0, 5, 5, 3], [2, 2, 2]):
+        b = ds.collate(sel)
+        ref = Batch.from_data_list([items[i] for i in sel])
+        _assert_same(b, ref)
+        assert b.num_graphs == len(sel)
+    with pytest.raises(IndexError):
+        ds.collate([0, 7])
+    with pytest.raises(ValueError):
+        ds.collate([])
+
+
+def test_scalar_target_shard():
+    items = _items(adp=False)
+    ds = shard.DeviceShard.from_data_list(items)
+    b = ds.collate([3, 1, 6])
+    _assert_same(b, Batch.from_data_list([items[i] for i in (3, 1, 6)]))
+    assert b.y.shape == (3,) and not hasattr(b, "non_H_mask") and not hasattr(b, "temperature")
+
+
+def test_temperature_standardisation_matches_the_reference_formula():
+    items = _items()
+    for d in items:
+        d.temperature = d.temperature * 81.2135 + 192.1785               # raw kelvin in the shard
+    ds = shard.DeviceShard.from_data_list(items)
+    b = ds.collate([0, 4, 5], temp_mean=192.1785, temp_std=81.2135)
+    raw = torch.cat([items[i].temperature for i in (0, 4, 5)])
+    want = (raw - torch.tensor(192.1785)) / torch.tensor(81.2135)         # dataset/datasetADP.py:43-45
+    assert torch.equal(b.temperature.cpu(), want)
+
+
+def test_fused_augmentation_matches_host_augmentation():
+    """dataset/datasetADP.py:33-39: y <- R^T y R, cart_dir <- cart_dir R, cell <- cell R; everything else untouched."""
+    items = _items()
+    ds = shard.DeviceShard.from_data_list(items)
+    sel = [5, 1, 3, 0]
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    R = shard.random_rotations(len(sel), gen, "cuda")
+    eye = torch.eye(3, device="cuda")
+    assert (R @ R.transpose(1, 2) - eye).abs().max().item() < 1e-6 and (torch.linalg.det(R) - 1).abs().max() < 1e-6
+    b = ds.collate(sel, rot=R)
+    ref_items = []
+    for i, r in zip(sel, R.cpu()):
+        d = items[i].clone()
+        d.y = r.t() @ d.y @ r
+        d.cart_dir = d.cart_dir @ r
+        d.cell = d.cell @ r
+        ref_items.append(d)
+    ref = Batch.from_data_list(ref_items)
+    _assert_same(b, ref, keys=("x", "pos", "non_H_mask", "batch", "ptr", "edge_index", "cart_dist", "temperature"))
+    assert (b.cart_dir.cpu() - ref.cart_dir).abs().max().item() <= 1e-6
+    assert (b.cell.cpu() - ref.cell).abs().max().item() <= 1e-5 * ref.cell.abs().max().item()
+    assert (b.y.cpu() - ref.y).abs().max().item() <= 1e-6 * ref.y.abs().max().item() + 1e-8
+    plain = ds.collate(sel)
+    assert not torch.equal(plain.cart_dir, b.cart_dir)
+    # an identity rotation is an exact copy
+    ident = ds.collate(sel, rot=eye.expand(len(sel), 3, 3).contiguous())
+    _assert_same(ident, Batch.from_data_list([items[i] for i in sel]))
+
+
+def test_loader_feeds_the_model_and_shards_across_ranks():
+    from cartnet_amd.data import DataLoader
+    from cartnet_amd.model import CartNet, make_state_dict
+    items = _items(sizes=(5, 9, 7, 14, 3, 30, 2, 11))
+    ds = shard.DeviceShard.from_data_list(items)
+    m = CartNet(32, 16, 2)
+    m.load_state_dict(make_state_dict(32, 16, 2, seed=4))
+    m = m.cuda().eval()
+    host = DataLoader(items, 3, shuffle=True, seed=9)
+    dev = shard.ShardLoader(ds, 3, shuffle=True, seed=9)
+    assert len(host) == len(dev) == 3
+    with torch.no_grad():
+        for hb, db in zip(host, dev):
+            hb.to("cuda:0")
+            ph, _ = m(hb)
+            pd, td = m(db)
+            assert torch.equal(ph, pd) and td is db.y                      # same batch -> same bits
+    seen = []
+    for rank in range(2):
+        for b in shard.ShardLoader(ds, 2, shuffle=True, seed=1, rank=rank, world_size=2):
+            seen.append(int(b.num_graphs))
+    assert sum(seen) == 8
+    r0 = shard.ShardLoader(ds, 8, shuffle=True, seed=1, rank=0, world_size=2)._order()
+    r1 = shard.ShardLoader(ds, 8, shuffle=True, seed=1, rank=1, world_size=2)._order()
+    assert set(r0).isdisjoint(r1) and len(r0) == len(r1) == 4
+    aug = shard.ShardLoader(ds, 4, augment=True, seed=2)
+    b1 = next(iter(aug))
+    assert not torch.equal(b1.cart_dir, ds.collate([0, 1, 2, 3]).cart_dir)
+    assert torch.allclose(b1.cart_dir.norm(dim=1), torch.ones_like(b1.cart_dist), atol=1e-5)
+
+
+def test_full_size_batch_round_trip_and_throughput_sanity():
+    """64 crystals x 194 atoms (the bench workload's shape): collate == host collate, bit for bit."""
+    items = [make_crystal(900 + g, 194) for g in range(16)]
+    ds = shard.DeviceShard.from_data_list(items)
+    sel = list(np.random.default_rng(0).integers(0, 16, size=64))
+    b = ds.collate(sel)
+    _assert_same(b, Batch.from_data_list([items[i] for i in sel]))
+    assert bool((b.edge_index[1][1:] >= b.edge_index[1][:-1]).all())
