@@ -1,6 +1,6 @@
 // Host side of the GEMM entry points + the small deterministic reduction kernels (split-K slabs, partial sums).
 // The MFMA kernel itself is in gemm_kernel.h, instantiated per tile width in gemm_bn{256,128,64}.hip.
-#include "gemm_kernel.h"
+#include "gemm_x3.h"
 #include <vector>
 
 namespace cn_gemm {
@@ -167,6 +167,19 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
     fl.wide = w ? 1 : 0;
   }
   CN_CHECK(a.precision == 0 || a.precision == 1, "cartnet_gemm: precision=%d (0 = fp32 MFMA, 1 = bf16x3 split)", a.precision);
+  if (a.precision == 1 && a.nsegs > 1 && a.b_split_folded && a.N == cn_gemm::X3_BN && !a.a_kstrided && a.b_kstrided &&
+      a.splitk == 1 && a.ngroups == 1 && a.M > 0) {
+    // K-segments that are adjacent column blocks of one matrix: one product over the concatenated K.  Folded only when
+    // the pre-split kernel is certain to take the launch (B[0] alone does not describe the folded operand).
+    bool fold = fl.wide && vecA && vecB && a.K % cn_gemm::BK == 0 && (long long)a.K * a.nsegs <= a.lda &&
+                (double)a.M * a.lda * 4.0 < 4294967296.0;
+    for (int s = 1; s < a.nsegs; ++s) fold = fold && a.A[s] == a.A[0] + (size_t)s * a.K;
+    if (fold) {
+      a.K *= a.nsegs;
+      a.nsegs = 1;
+      a.b_split[0] = a.b_split_folded;
+    }
+  }
   fl.x3 = a.precision;
   fl.vecA = vecA ? 1 : 0;
   fl.vecB = vecB ? 1 : 0;

@@ -634,6 +634,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_kernel(const CartnetGemmA
 #undef CN_EPI
 }
 
+// gemm_x3.hip
+void launch_x3nn(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
+void launch_x3tn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
+
 template <bool A_KS, bool B_KS, int BN, bool A_ACT, bool B_ACT>
 void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
   const int tiles_n = cn_ceil_div(a.N, BN);
@@ -652,8 +656,23 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
     constexpr bool X3_OK = FAST && BN == 256 && B_KS && !A_KS;
     if constexpr (X3_OK) {
       if (fl.x3) {
+        // second-generation kernel (gemm_x3.h) when the weight operand comes pre-split and the epilogue is vectorisable
+        bool presplit = fl.wide && a.splitk == 1 && m0 == 0 && a.nsegs == 1 && (double)a.M * a.lda * 4.0 < 4294967296.0;
+        const int nptr = a.ngroups > 1 ? a.ngroups : a.nsegs;
+        for (int i = 0; i < nptr; ++i) presplit = presplit && a.b_split[i] != nullptr;
+        if (presplit) {
+          launch_x3nn(A_ACT, a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
+          return;
+        }
         hipLaunchKernelGGL((cn_gemm_kernel<A_KS, B_KS, BN, A_ACT, B_ACT, true, 1>), dim3(nm * tiles_n, ns, a.ngroups),
                            dim3(NTHREADS), 0, st, a, fl);
+        return;
+      }
+    }
+    // weight gradients (both operands k-strided): transposing-read bf16x3 kernel over whole 128-row tiles
+    if constexpr (FAST && BN == 256 && B_KS && A_KS && !A_ACT) {
+      if (fl.x3 && a.M % BM == 0 && a.nsegs == 1) {
+        launch_x3tn(B_ACT, a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
         return;
       }
     }

@@ -1,0 +1,357 @@
+// Second-generation bf16x3 split-operand GEMM kernels (CartnetGemmArgs.precision == 1) for gfx950.
+//
+// The arithmetic is the one described in gemm_kernel.h ("bf16x3"): every fp32 operand element is split exactly into
+// three bf16 pieces and each fp32 product is rebuilt from six v_mfma_f32_32x32x16_bf16 products accumulated in fp32.
+// What changes is where the splitting work goes, because in the first kernel the vector ALU (splitting BOTH operand
+// tiles every K-step in every workgroup) cost as many issue cycles as the matrix pipe had work:
+//
+//  * NN kernel (activations x weights, cn_gemm_x3nn_kernel): the weight operand arrives PRE-SPLIT
+//    (cartnet_gemm_split_b, once per step per matrix -- weights are a few hundred KB) as an exact image of the LDS
+//    tile, so its staging is a lane-linear direct-to-LDS copy (global_load_lds_dwordx4: no VGPRs, no VALU, no
+//    ds_write); only the activation tile (one float4 per thread per K-step) is split in flight.
+//  * TN kernel (weight gradients dW = dY^T X, both operands k-strided activations, cn_gemm_x3tn_kernel): the tiles
+//    are staged as [k][m] bf16 planes -- the layout the fp32 rows convert to without a transpose -- and the MFMA
+//    operands (8 consecutive k per lane) are fetched with the transposing LDS read ds_read_b64_tr_b16.
+//
+// Tile shape, wave grid, accumulator layout and therefore the epilogues are those of gemm_kernel.h.
+#pragma once
+#include "gemm_kernel.h"
+
+namespace cn_gemm {
+
+constexpr int X3_BN = 256;
+constexpr int X3_A_PLANE = BM * 32;                       // [128 rows][16 k] bf16
+constexpr int X3_A_BYTES = 3 * X3_A_PLANE;                // 12 KB
+constexpr int X3_B_PLANE = X3_BN * 32;                    // [256 rows][16 k] bf16
+constexpr int X3_B_BYTES = 3 * X3_B_PLANE;                // 24 KB per K-step per 256-column tile
+constexpr int X3_BUF_BYTES = X3_A_BYTES + X3_B_BYTES;     // 36 KB; two buffers per workgroup, two workgroups per CU
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+template <int KIND_RT>
+__device__ __forceinline__ void x3_epilogue(const CartnetGemmArgs& p, f32x16 (&acc)[2][2], int g, int row0, int col0,
+                                            int tile_m, int wm, int wn, int lane, int tid, float* smem) {
+  const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
+                   (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);
+#define CN_EPIW(K) epilogue_wide<X3_BN, K>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem, kind)
+  switch (kind) {
+    case 0: CN_EPIW(0); break;
+    case 1: CN_EPIW(1); break;
+    case 16: CN_EPIW(16); break;
+    case 96: CN_EPIW(96); break;
+    case 2: CN_EPIW(2); break;
+    case 4: CN_EPIW(4); break;
+    case 12: CN_EPIW(12); break;
+    case 14: CN_EPIW(14); break;
+    default: CN_EPIW(-1); break;
+  }
+#undef CN_EPIW
+}
+
+// C[g] = epilogue(sum_s (silu?)(A[s]) @ B[s]), A fp32 [M, K] row-major (k-contiguous), B given pre-split
+// (p.b_split[s]: image written by cartnet_gemm_split_b for the [K, N] operand).  Requirements (checked on the host):
+// nsegs == 1, K % 16 == 0, N % 256 == 0, A rows 16-byte aligned and M * lda * 4 < 2^32, every epilogue operand
+// 16-byte aligned.
+//
+// Pipeline (one barrier per 16-deep K-step, two LDS buffers, two workgroups per CU):
+//   K-step u multiplies buffer u&1.  Each wave issues its A-fragment reads, and while they fly splits the A tile of
+//   step u+1 (in registers since step u-2) into the other buffer, starts the DMA of the B tile of step u+1 into it and
+//   the register load of the A tile of step u+3, then runs the 24 MFMAs.  Memory operations retire in issue order, so
+//   "all but the youngest one" (s_waitcnt vmcnt(1)) before the barrier means: the DMA has landed, the A load issued
+//   after it stays in flight across the barrier -- every A load (HBM) gets two K-steps to arrive, every DMA (L2) one.
+//   The A loads are inline asm so that the compiler's own counter bookkeeping (which drains everything whenever a DMA
+//   is outstanding) stays out of the loop; all waits in the loop are written by hand.
+template <bool A_ACT>
+__global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const CartnetGemmArgs p, const GemmFlags fl) {
+  using S = Shape<X3_BN>;
+  static_assert(S::TM == 2 && S::TN == 2, "wave tile is 64 x 64");
+  __shared__ __attribute__((aligned(16))) float smem[2 * X3_BUF_BYTES / 4];
+  char* lds = reinterpret_cast<char*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / S::WGN, wn = wid % S::WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tiles_n = p.N / X3_BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int row0 = tile_m * BM, col0 = tile_n * X3_BN;
+  const int g = blockIdx.z;
+  const int nk = p.K / BK;
+  const int nsteps = nk;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // this thread's share of the A tile: row tid/4, k-quad tid%4 (rows past M are clamped; the epilogue drops them)
+  const int arow = tid >> 2, akq = tid & 3;
+  const unsigned a_voff = ((unsigned)min(row0 + arow, p.M - 1) * (unsigned)p.lda + akq * 4) * 4u;   // bytes
+  const int a_lds = x3_offset(arow, akq >> 1) + (akq & 1) * 8;
+  const unsigned b_voff = lane * 16;
+  const size_t b_tile = (size_t)tile_n * nk * X3_B_BYTES;
+
+  // one K range per launch (the host folds K-segments that are adjacent column blocks of one matrix into one K)
+  const float* a0 = p.A[g];
+  const char* b0 = reinterpret_cast<const char*>(p.b_split[g]) + b_tile;
+  auto a_base = [&](int v) -> const float* { return a0 + v * BK; };
+  auto b_base = [&](int v) -> const char* { return b0 + (size_t)v * X3_B_BYTES; };
+  // register load of this thread's float4 of K-step v, outside the compiler's memory-counter bookkeeping
+  auto a_issue = [&](f32x4& dst, int v) {
+    const float* base = a_base(v);
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(a_voff), "s"(base) : "memory");
+  };
+  auto a_store = [&](f32x4 v, int buf) {
+    if (A_ACT) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = fast_silu(v[c]);
+    }
+    const Split3 s = split3(v);
+    char* dst = lds + buf * X3_BUF_BYTES + a_lds;
+    *reinterpret_cast<bf16x4*>(dst) = s.h;
+    *reinterpret_cast<bf16x4*>(dst + X3_A_PLANE) = s.m;
+    *reinterpret_cast<bf16x4*>(dst + 2 * X3_A_PLANE) = s.l;
+  };
+  // B tile of K-step v: 24 KB, a lane-linear copy; wave w moves the 1 KB pieces w, w+8, w+16
+  auto b_issue = [&](int v, int buf) {
+    const char* src = b_base(v);
+    char* dst = lds + buf * X3_BUF_BYTES + X3_A_BYTES;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int c = (j * 8 + wid) * 1024;
+      __builtin_amdgcn_global_load_lds((glb_void_ptr)(src + c + b_voff), (lds_void_ptr)(dst + c), 16, 0, 0);
+    }
+  };
+  bf16x8 ah[2], am[2], al[2], bh, bm, bl;
+  auto frag_a = [&](int buf) {
+    const char* cA = lds + buf * X3_BUF_BYTES;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const char* q = cA + x3_offset(wm * S::WM + a * 32 + li, lh);
+      ah[a] = *reinterpret_cast<const bf16x8*>(q);
+      am[a] = *reinterpret_cast<const bf16x8*>(q + X3_A_PLANE);
+      al[a] = *reinterpret_cast<const bf16x8*>(q + 2 * X3_A_PLANE);
+    }
+  };
+  auto frag_b = [&](int buf, int b) {
+    const char* q = lds + buf * X3_BUF_BYTES + X3_A_BYTES + x3_offset(wn * S::WN + b * 32 + li, lh);
+    bh = *reinterpret_cast<const bf16x8*>(q);
+    bm = *reinterpret_cast<const bf16x8*>(q + X3_B_PLANE);
+    bl = *reinterpret_cast<const bf16x8*>(q + 2 * X3_B_PLANE);
+  };
+  auto mma = [&](int b) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {   // small terms first
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bm, acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bh, acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bm, acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][b], 0, 0, 0);
+    }
+  };
+  // one K-step; r holds the A tile of step u+1 on entry and receives the load of step u+3
+  auto step = [&](auto cur_c, int u, f32x4& r) {
+    constexpr int CUR = decltype(cur_c)::value;
+    frag_a(CUR);
+    __builtin_amdgcn_sched_barrier(0);
+    if (u + 1 < nsteps) {
+      a_store(r, CUR ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      b_issue(u + 1, CUR ^ 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (u + 3 < nsteps) a_issue(r, u + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    frag_b(CUR, 0);
+    mma(0);
+    frag_b(CUR, 1);
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (u + 3 < nsteps) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (nsteps > 0) {
+    f32x4 r0, r1;
+    a_issue(r0, 0);
+    b_issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(3)" : "+v"(r0) :: "memory");   // the A load is older than the three DMA pieces
+    a_store(r0, 0);
+    if (nsteps > 1) a_issue(r1, 1);
+    if (nsteps > 2) a_issue(r0, 2);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(r0), "+v"(r1) :: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int u = 0; u < nsteps; u += 2) {
+      step(std::integral_constant<int, 0>{}, u, r1);
+      if (u + 1 < nsteps) step(std::integral_constant<int, 1>{}, u + 1, r0);
+    }
+  }
+  x3_epilogue<0>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients: C[g] (+ split-K slabs) = A[g]^T @ (silu?)(B[g]), A fp32 [K, M] and B fp32 [K, N] row-major
+// (k-strided), reduction over the K rows (edges / atoms).  M % 128 == 0 handled per row tile, N == 256 per column
+// tile.  LDS tile: 3 planes of [16 k][ROWS] bf16 (k-major, exactly how the fp32 rows convert), the 64-byte chunks of
+// row k XOR-ed with k & 3 so that the four k-rows a transposing read touches fall on different banks.
+template <int ROWS>
+__device__ __forceinline__ int x3t_offset(int k, int col) {   // byte offset of element (k, col) in a plane
+  const int byte = col * 2;
+  return k * (ROWS * 2) + ((((byte >> 6) ^ (k & 3)) << 6) | (byte & 63));
+}
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// 8 consecutive k (k0 .. k0+7) of column `col` as one MFMA operand register: two transposing reads of 4 k each.
+// Lane 4q+p of a 16-lane group addresses row k0+q (k0+4+q), columns cbase + 4p .. 4p+3 of the group's 16 columns.
+template <int ROWS>
+__device__ __forceinline__ bf16x8 x3t_read(const char* plane, int k0, int cbase, int lane) {
+  const int q = (lane >> 2) & 3, pp = lane & 3;
+  const int col = cbase + pp * 4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(plane + x3t_offset<ROWS>(k0 + q, col)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(plane + x3t_offset<ROWS>(k0 + 4 + q, col)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+constexpr int X3T_A_PLANE = BK * BM * 2;        // [16 k][128 m] bf16 = 4 KB
+constexpr int X3T_B_PLANE = BK * X3_BN * 2;     // [16 k][256 n] bf16 = 8 KB
+constexpr int X3T_A_BYTES = 3 * X3T_A_PLANE;
+constexpr int X3T_BUF_BYTES = 3 * (X3T_A_PLANE + X3T_B_PLANE);   // 36 KB
+
+template <bool B_ACT>
+__global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3tn_kernel(const CartnetGemmArgs p, const GemmFlags fl) {
+  using S = Shape<X3_BN>;
+  __shared__ __attribute__((aligned(16))) float smem[2 * X3T_BUF_BYTES / 4];
+  char* lds = reinterpret_cast<char*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / S::WGN, wn = wid % S::WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tiles_n = p.N / X3_BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int row0 = tile_m * BM, col0 = tile_n * X3_BN;
+  const int g = blockIdx.z;
+  const int split = fl.split0 + blockIdx.y;
+  const int kbeg = fl.k_lo + blockIdx.y * fl.kchunk;
+  const int kend = min(fl.k_hi, kbeg + fl.kchunk);
+  const int nsteps = (kend - kbeg) / BK;          // whole K-steps only (the host gives the tail to the fp32 kernel)
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // staging units: (k, 4 consecutive columns).  A: 16 x 32 = 512 units (one per thread); B: 16 x 64 = 1024 (two).
+  const float* __restrict__ Ab = p.A[g];
+  const float* __restrict__ Bb = p.B[g];
+  const int ak = tid >> 5, ac = (tid & 31) * 4;
+  const int bk0 = tid >> 6, bc = (tid & 63) * 4;          // second unit: k + 8
+  const float* a_ptr = Ab + (size_t)(kbeg + ak) * p.lda + row0 + ac;
+  const float* b_ptr = Bb + (size_t)(kbeg + bk0) * p.ldb + col0 + bc;
+  const size_t a_step = (size_t)BK * p.lda, b_step = (size_t)BK * p.ldb, b_half = (size_t)8 * p.ldb;
+  const int a_lds = x3t_offset<BM>(ak, ac);
+  const int b_lds0 = X3T_A_BYTES + x3t_offset<X3_BN>(bk0, bc);
+  const int b_lds1 = X3T_A_BYTES + x3t_offset<X3_BN>(bk0 + 8, bc);
+
+  f32x4 ra, rb0, rb1;
+  auto load = [&](int u) {
+    ra = *reinterpret_cast<const f32x4*>(a_ptr + u * a_step);
+    rb0 = *reinterpret_cast<const f32x4*>(b_ptr + u * b_step);
+    rb1 = *reinterpret_cast<const f32x4*>(b_ptr + u * b_step + b_half);
+  };
+  auto put = [&](f32x4 v, char* dst, int plane_bytes, bool act) {
+    if (act) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = fast_silu(v[c]);
+    }
+    const Split3 s = split3(v);
+    *reinterpret_cast<bf16x4*>(dst) = s.h;
+    *reinterpret_cast<bf16x4*>(dst + plane_bytes) = s.m;
+    *reinterpret_cast<bf16x4*>(dst + 2 * plane_bytes) = s.l;
+  };
+  auto store = [&](int buf) {
+    char* base = lds + buf * X3T_BUF_BYTES;
+    put(ra, base + a_lds, X3T_A_PLANE, false);
+    put(rb0, base + b_lds0, X3T_B_PLANE, B_ACT);
+    put(rb1, base + b_lds1, X3T_B_PLANE, B_ACT);
+  };
+  auto compute = [&](int buf) {
+    const char* cA = lds + buf * X3T_BUF_BYTES;
+    const char* cB = cA + X3T_A_BYTES;
+    const int grp16 = ((lane >> 4) & 1) * 16;     // which 16 columns of the 32-wide MFMA tile this lane group holds
+    bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int cb = wm * S::WM + a * 32 + grp16;
+      ah[a] = x3t_read<BM>(cA, 8 * lh, cb, lane);
+      am[a] = x3t_read<BM>(cA + X3T_A_PLANE, 8 * lh, cb, lane);
+      al[a] = x3t_read<BM>(cA + 2 * X3T_A_PLANE, 8 * lh, cb, lane);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int cb = wn * S::WN + b * 32 + grp16;
+      const bf16x8 bh = x3t_read<X3_BN>(cB, 8 * lh, cb, lane);
+      const bf16x8 bm = x3t_read<X3_BN>(cB + X3T_B_PLANE, 8 * lh, cb, lane);
+      const bf16x8 bl = x3t_read<X3_BN>(cB + 2 * X3T_B_PLANE, 8 * lh, cb, lane);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bm, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bh, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bm, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][b], 0, 0, 0);
+      }
+    }
+  };
+
+  if (nsteps > 0) {
+    load(0);
+    store(0);
+    if (nsteps > 1) load(1);
+    __syncthreads();
+    for (int u = 0; u < nsteps; ++u) {
+      const int cur = u & 1;
+      if (u + 1 < nsteps) store(cur ^ 1);
+      if (u + 2 < nsteps) load(u + 2);
+      compute(cur);
+      __syncthreads();
+    }
+  }
+
+  if (p.splitk > 1) {   // raw partial slab
+    float* __restrict__ C = p.C[g] + (size_t)split * p.M * p.ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int grow = row0 + wm * S::WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int gcol = col0 + wn * S::WN + b * 32 + li;
+          C[(size_t)grow * p.ldc + gcol] = acc[a][b][r];
+        }
+      }
+    return;
+  }
+  x3_epilogue<0>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem);
+}
+
+}  // namespace cn_gemm

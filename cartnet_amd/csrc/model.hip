@@ -51,6 +51,10 @@ struct Work {
   float *edge0T, *edge2T, *atomT, *head0T;
   float *gate0T[CARTNET_MAX_LAYERS], *aggr0T[CARTNET_MAX_LAYERS], *gate2T[CARTNET_MAX_LAYERS],
       *aggr2T[CARTNET_MAX_LAYERS];
+  // bf16x3 pre-split weight images (gemm_precision == 1 and D % 256 == 0; else all null)
+  char *i_edge2, *i_atom, *i_edge2_b, *i_atom_b, *i_head0_b;
+  char *i_pn[CARTNET_MAX_LAYERS], *i_pre[CARTNET_MAX_LAYERS], *i_gs[CARTNET_MAX_LAYERS], *i_dpre[CARTNET_MAX_LAYERS],
+      *i_de[CARTNET_MAX_LAYERS], *i_dx[CARTNET_MAX_LAYERS];
   // forward transients
   float* Pn;
   double *cs, *cq, *ps, *pq;
@@ -127,6 +131,26 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
     w.aggr0T[l] = c.take<float>((size_t)3 * D * D);
     w.gate2T[l] = c.take<float>((size_t)D * D);
     w.aggr2T[l] = c.take<float>((size_t)D * D);
+  }
+  if (m.gemm_precision == 1 && D % 256 == 0) {
+    const size_t blk = cartnet_gemm_split_b_bytes(D, D);          // one D x D block
+    w.i_edge2 = c.take<char>(cartnet_gemm_split_b_bytes(2 * D, D));
+    w.i_atom = c.take<char>(cartnet_gemm_split_b_bytes(2 * D, D));
+    for (int l = 0; l < L; ++l) {
+      w.i_pn[l] = c.take<char>(4 * blk);     // gate_i, aggr_i, gate_j, aggr_j
+      w.i_pre[l] = c.take<char>(2 * blk);    // gate_e, aggr_e
+      w.i_gs[l] = c.take<char>(2 * blk);     // gate2, aggr2
+    }
+    if (need_bwd) {
+      w.i_edge2_b = c.take<char>(cartnet_gemm_split_b_bytes(D, 2 * D));
+      w.i_atom_b = c.take<char>(cartnet_gemm_split_b_bytes(D, 2 * D));
+      if (H % 16 == 0) w.i_head0_b = c.take<char>(cartnet_gemm_split_b_bytes(H, D));
+      for (int l = 0; l < L; ++l) {
+        w.i_dpre[l] = c.take<char>(2 * blk);   // gate2, aggr2 as [out, in]
+        w.i_de[l] = c.take<char>(2 * blk);     // folded: gate0[:, 2D:], aggr0[:, 2D:]
+        w.i_dx[l] = c.take<char>(4 * blk);     // folded: gate0[:, :D], aggr0[:, :D], gate0[:, D:2D], aggr0[:, D:2D]
+      }
+    }
   }
   w.Pn = c.take<float>(Nn * 4 * D);
   const size_t big = (size_t)(w.tiles_e > w.gparts ? w.tiles_e : w.gparts);
@@ -315,6 +339,49 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     RUN(flush());
   }
 
+  // bf16x3: split every weight operand once (forward operands B = W^T: stride_k 1, stride_n ld; backward operands
+  // B = W: stride_k ld, stride_n 1)
+  if (w.i_edge2) {
+    std::vector<const float*> src; std::vector<void*> dst; std::vector<int32_t> Ks, Ns, sk, sn;
+    const size_t blk = cartnet_gemm_split_b_bytes(D, D);
+    auto fwd = [&](const float* W, int ld, int K_, int N_, char* img) {
+      src.push_back(W); dst.push_back(img); Ks.push_back(K_); Ns.push_back(N_); sk.push_back(1); sn.push_back(ld);
+    };
+    auto bwd = [&](const float* W, int ld, int K_, int N_, char* img) {
+      src.push_back(W); dst.push_back(img); Ks.push_back(K_); Ns.push_back(N_); sk.push_back(ld); sn.push_back(1);
+    };
+    fwd(P.edge2_w, 2 * D, 2 * D, D, w.i_edge2);
+    fwd(P.atom_w, 2 * D, 2 * D, D, w.i_atom);
+    for (int l = 0; l < L; ++l) {
+      const CartnetLayerParams& q = P.layer[l];
+      fwd(q.gate0_w, 3 * D, D, D, w.i_pn[l]);
+      fwd(q.aggr0_w, 3 * D, D, D, w.i_pn[l] + blk);
+      fwd(q.gate0_w + D, 3 * D, D, D, w.i_pn[l] + 2 * blk);
+      fwd(q.aggr0_w + D, 3 * D, D, D, w.i_pn[l] + 3 * blk);
+      fwd(q.gate0_w + 2 * D, 3 * D, D, D, w.i_pre[l]);
+      fwd(q.aggr0_w + 2 * D, 3 * D, D, D, w.i_pre[l] + blk);
+      fwd(q.gate2_w, D, D, D, w.i_gs[l]);
+      fwd(q.aggr2_w, D, D, D, w.i_gs[l] + blk);
+    }
+    if (need_backward) {
+      bwd(P.edge2_w, 2 * D, D, 2 * D, w.i_edge2_b);
+      bwd(P.atom_w, 2 * D, D, 2 * D, w.i_atom_b);
+      if (w.i_head0_b) bwd(P.head0_w, D, H, D, w.i_head0_b);
+      for (int l = 0; l < L; ++l) {
+        const CartnetLayerParams& q = P.layer[l];
+        bwd(q.gate2_w, D, D, D, w.i_dpre[l]);
+        bwd(q.aggr2_w, D, D, D, w.i_dpre[l] + blk);
+        bwd(q.gate0_w + 2 * D, 3 * D, D, D, w.i_de[l]);
+        bwd(q.aggr0_w + 2 * D, 3 * D, D, D, w.i_de[l] + blk);
+        bwd(q.gate0_w, 3 * D, D, D, w.i_dx[l]);
+        bwd(q.aggr0_w, 3 * D, D, D, w.i_dx[l] + blk);
+        bwd(q.gate0_w + D, 3 * D, D, D, w.i_dx[l] + 2 * blk);
+        bwd(q.aggr0_w + D, 3 * D, D, D, w.i_dx[l] + 3 * blk);
+      }
+    }
+    RUN(cartnet_gemm_split_b(src.data(), dst.data(), Ks.data(), Ns.data(), sk.data(), sn.data(), (int32_t)src.size(), st));
+  }
+
   // ---- encoder, edges (cartnet.py:159)
   RUN(cartnet_edge_features(b.cart_dist, b.cart_dir, m.rbf_means, m.rbf_betas, b.E, m.R, m.invariant, m.radius,
                             m.env_radius, w.feat, w.ldf, w.env, st));
@@ -326,7 +393,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
   {
     CartnetGemmArgs a = gemm_args(E, D, 2 * D, 2 * D, D, D);
     a.A[0] = w.he_pre; a.B[0] = w.edge2T; a.C[0] = w.e0; a.cpre[0] = w.e0_pre; a.bias[0] = P.edge2_b;
-    a.b_kstrided = 1; a.a_act = 1; a.out_act = 1;
+    a.b_kstrided = 1; a.a_act = 1; a.out_act = 1; a.b_split[0] = w.i_edge2;
     RUN(cartnet_gemm(&a, st));
   }
   // ---- encoder, atoms (cartnet.py:145-154)
@@ -337,7 +404,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
   {
     CartnetGemmArgs a = gemm_args(N, D, 2 * D, 2 * D, D, D);
     a.A[0] = w.x0; a.B[0] = w.atomT; a.C[0] = w.xenc; a.cpre[0] = w.xa_pre; a.bias[0] = P.atom_b;
-    a.b_kstrided = 1; a.a_act = 1; a.out_act = 1;
+    a.b_kstrided = 1; a.a_act = 1; a.out_act = 1; a.b_split[0] = w.i_atom;
     RUN(cartnet_gemm(&a, st));
   }
   if (need_backward && m.atom_types)
@@ -354,7 +421,11 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       CartnetGemmArgs a = gemm_args(N, D, D, D, D, 4 * D);
       a.ngroups = 4; a.b_kstrided = 1;
       const float* Bt[4] = {w.gate0T[l], w.aggr0T[l], w.gate0T[l] + (size_t)D * D, w.aggr0T[l] + (size_t)D * D};
-      for (int g = 0; g < 4; ++g) { a.A[g] = x; a.B[g] = Bt[g]; a.C[g] = w.Pn + (size_t)g * D; }
+      const size_t blk = cartnet_gemm_split_b_bytes(D, D);
+      for (int g = 0; g < 4; ++g) {
+        a.A[g] = x; a.B[g] = Bt[g]; a.C[g] = w.Pn + (size_t)g * D;
+        if (w.i_pn[l]) a.b_split[g] = w.i_pn[l] + g * blk;
+      }
       a.bias[0] = q.gate0_b; a.bias[1] = q.aggr0_b;
       RUN(cartnet_gemm(&a, st));
     }
@@ -366,6 +437,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       a.C[0] = w.pre[l]; a.C[1] = w.pre[l] + D;
       a.gather_i[0] = w.Pn; a.gather_i[1] = w.Pn + D; a.gather_j[0] = w.Pn + 2 * D; a.gather_j[1] = w.Pn + 3 * D;
       a.ldg = 4 * D; a.tgt = w.tgt32; a.src = w.src32;
+      if (w.i_pre[l]) { a.b_split[0] = w.i_pre[l]; a.b_split[1] = w.i_pre[l] + cartnet_gemm_split_b_bytes(D, D); }
       RUN(cartnet_gemm(&a, st));
     }
     {  // gs = silu(pre) W2^T + b2, BatchNorm statistics of the gate half
@@ -374,6 +446,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       a.A[0] = w.pre[l]; a.A[1] = w.pre[l] + D; a.B[0] = w.gate2T[l]; a.B[1] = w.aggr2T[l];
       a.C[0] = w.gs[l]; a.C[1] = w.gs[l] + D; a.bias[0] = q.gate2_b; a.bias[1] = q.aggr2_b;
       a.colsum[0] = w.cs; a.colsq[0] = w.cq;
+      if (w.i_gs[l]) { a.b_split[0] = w.i_gs[l]; a.b_split[1] = w.i_gs[l] + cartnet_gemm_split_b_bytes(D, D); }
       RUN(cartnet_gemm(&a, st));
     }
     RUN(cartnet_bn_finalize(w.cs, w.cq, w.tiles_e, b.E, D, m.bn_eps, m.bn_momentum, training, m.buf[l].norm_mean,
@@ -493,7 +566,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     float* o[1] = {G.head0_w};
     RUN(wgrad(dY, H, X, D, o, D, N, H, D, 1, false, w, sw));
     CartnetGemmArgs a = gemm_args(N, D, H, H, D, D);
-    a.A[0] = w.dhid; a.B[0] = P.head0_w; a.C[0] = w.dx[0]; a.b_kstrided = 1;
+    a.A[0] = w.dhid; a.B[0] = P.head0_w; a.C[0] = w.dx[0]; a.b_kstrided = 1; a.b_split[0] = w.i_head0_b;
     RUN(cartnet_gemm(&a, st));
   }
   float* dx = w.dx[0];
@@ -565,6 +638,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       a.A[0] = gs; a.A[1] = gs + D; a.B[0] = q.gate2_w; a.B[1] = q.aggr2_w;
       a.C[0] = dpre; a.C[1] = dpre + D; a.dact[0] = pre; a.dact[1] = pre + D; a.ldd = 2 * D;
       a.colsum[0] = w.csg[par]; a.colsum[1] = w.csa[par];
+      if (w.i_dpre[l]) { a.b_split[0] = w.i_dpre[l]; a.b_split[1] = w.i_dpre[l] + cartnet_gemm_split_b_bytes(D, D); }
       RUN(cartnet_gemm(&a, st));
     }
     FORK();
@@ -584,6 +658,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       a.nsegs = 2; a.b_kstrided = 1;
       a.A[0] = dpre; a.A[1] = dpre + D; a.B[0] = q.gate0_w + 2 * D; a.B[1] = q.aggr0_w + 2 * D;
       a.C[0] = de_in; a.resid[0] = de; a.ldr = D;
+      a.b_split_folded = w.i_de[l];
       if (l == 0) { a.dact[0] = w.e0_pre; a.ldd = D; a.colsum[0] = w.cs_misc[0]; }
       RUN(cartnet_gemm(&a, st));
       if (l == 0) {
@@ -609,6 +684,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       a.A[0] = dPn; a.A[1] = dPn + D; a.A[2] = dPn + 2 * D; a.A[3] = dPn + 3 * D;
       a.B[0] = q.gate0_w; a.B[1] = q.aggr0_w; a.B[2] = q.gate0_w + D; a.B[3] = q.aggr0_w + D;
       a.C[0] = dx_other; a.resid[0] = dx; a.ldr = D;
+      a.b_split_folded = w.i_dx[l];
       if (l == 0) { a.dact[0] = w.xa_pre; a.ldd = D; a.colsum[0] = w.cs_misc[1]; }
       RUN(cartnet_gemm(&a, st));
       if (l == 0) {
@@ -631,6 +707,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     RUN(wgrad(dY, D, X, 2 * D, o, 2 * D, b.E, D, 2 * D, 1, true, w, sw));
     CartnetGemmArgs a = gemm_args(E, 2 * D, D, D, 2 * D, 2 * D);
     a.A[0] = de; a.B[0] = P.edge2_w; a.C[0] = w.dhe; a.dact[0] = w.he_pre; a.ldd = 2 * D; a.b_kstrided = 1;
+    a.b_split[0] = w.i_edge2_b;
     a.colsum[0] = w.cs_misc[2];
     RUN(cartnet_gemm(&a, st));       // dhe = d(he_pre)
     FORK();
@@ -649,6 +726,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     RUN(wgrad(dY, D, X, 2 * D, o, 2 * D, N, D, 2 * D, 1, true, w, sw));
     CartnetGemmArgs a = gemm_args(N, 2 * D, D, D, 2 * D, 2 * D);
     a.A[0] = dx; a.B[0] = P.atom_w; a.C[0] = w.dx0; a.dact[0] = w.x0; a.ldd = 2 * D; a.b_kstrided = 1;
+    a.b_split[0] = w.i_atom_b;
     RUN(cartnet_gemm(&a, st));
     RUN(cartnet_node_embed_bwd(m.use_temperature ? b.batch : nullptr, m.use_temperature ? b.temperature : nullptr, w.dx0,
                                N, 2 * D, w.pa, w.pb, st));

@@ -38,6 +38,7 @@ class GemmArgs(C.Structure):
         ("ngroups", C.c_int32), ("nsegs", C.c_int32), ("splitk", C.c_int32),
         ("a_kstrided", C.c_int32), ("b_kstrided", C.c_int32), ("a_act", C.c_int32), ("b_act", C.c_int32),
         ("out_act", C.c_int32), ("precision", C.c_int32),
+        ("b_split", C.c_void_p * MAX_GROUPS), ("b_split_folded", C.c_void_p),
     ]
 
 
@@ -110,6 +111,10 @@ PROTOTYPES = {
     "cartnet_last_error": (C.c_char_p, []),
     "cartnet_abi_version": (C.c_int, []),
     "cartnet_gemm": (C.c_int, [C.POINTER(GemmArgs), c_stream]),
+    "cartnet_gemm_split_b_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "cartnet_gemm_split_b": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32,
+                                       c_stream]),
     "cartnet_splitk_reduce": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, c_stream]),
     "cartnet_colsum_finalize": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32,

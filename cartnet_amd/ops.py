@@ -70,7 +70,8 @@ def _aslist(x, n):
 def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequence[Tensor] | Tensor, *,
          a_kstrided: bool = False, b_kstrided: bool = False, a_act: bool = False, b_act: bool = False,
          out_act: bool = False, segments: bool = False, bias=None, gather_i=None, gather_j=None, tgt=None, src=None,
-         resid=None, dact=None, cpre=None, colsum=None, colsq=None, splitk: int = 1, precision: int = 0) -> None:
+         resid=None, dact=None, cpre=None, colsum=None, colsq=None, splitk: int = 1, precision: int = 0,
+         b_split=None) -> None:
     """C[g] = epilogue(sum_s opA(A[s]) @ opB(B[s])) on the fp32 matrix cores (see include/cartnet_hip.h).
 
     A / B / C_out: one tensor or a list.  With ``segments=False`` the lists are independent problems (groups) of
@@ -116,6 +117,17 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
     for i in range(nptr):
         args.A[i] = A[i].data_ptr()
         args.B[i] = B[i].data_ptr()
+    if b_split is not None:
+        b_split = _aslist(b_split, nptr)
+        if len(b_split) != nptr or not b_kstrided or a_kstrided:
+            raise ValueError("gemm: b_split needs one image per B operand, b_kstrided=True and a_kstrided=False")
+        need = int(lib.cartnet_gemm_split_b_bytes(int(K), int(N)))
+        for i, t in enumerate(b_split):
+            if t is None:
+                continue
+            if need == 0 or t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous() or t.numel() < need:
+                raise ValueError(f"gemm b_split[{i}]: expected a contiguous uint8 CUDA tensor of {need} bytes")
+            args.b_split[i] = t.data_ptr()
     for g in range(ngroups):
         if _ld(C_out[g]) != ldc:
             raise ValueError("gemm: outputs must share a leading dimension")
@@ -173,6 +185,32 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
             _vec(t, tiles_m * N, f"gemm {name}[{g}]", torch.float64)
             getattr(args, field)[g] = t.data_ptr()
     _l.check(lib.cartnet_gemm(C.byref(args), _l.stream_ptr()), "cartnet_gemm")
+
+
+def split_b(mats: Sequence[Tensor]) -> list:
+    """bf16x3 pre-split images (cartnet_gemm_split_b) of k-strided GEMM operands: each entry is a 2-D fp32 view
+    B [K, N] with arbitrary strides (``W.t()`` of a weight W [out, in] gives the forward operand)."""
+    lib = _l.load()
+    mats = list(mats)
+    outs = []
+    n = len(mats)
+    src = (C.c_void_p * n)()
+    dst = (C.c_void_p * n)()
+    Ks, Ns, sk, sn = (C.c_int32 * n)(), (C.c_int32 * n)(), (C.c_int32 * n)(), (C.c_int32 * n)()
+    for i, m in enumerate(mats):
+        if m.dim() != 2 or m.dtype != torch.float32 or not m.is_cuda:
+            raise ValueError(f"split_b[{i}]: expected a 2-D fp32 CUDA tensor")
+        K, N = int(m.shape[0]), int(m.shape[1])
+        nbytes = int(lib.cartnet_gemm_split_b_bytes(K, N))
+        if nbytes == 0:
+            raise ValueError(f"split_b[{i}]: K={K} must be a multiple of 16 and N={N} of 256")
+        out = torch.empty(nbytes, dtype=torch.uint8, device=m.device)
+        outs.append(out)
+        src[i], dst[i] = m.data_ptr(), out.data_ptr()
+        Ks[i], Ns[i], sk[i], sn[i] = K, N, int(m.stride(0)), int(m.stride(1))
+    if n:
+        _l.check(lib.cartnet_gemm_split_b(src, dst, Ks, Ns, sk, sn, n, _l.stream_ptr()), "cartnet_gemm_split_b")
+    return outs
 
 
 def gemm_tiles_m(M: int) -> int:

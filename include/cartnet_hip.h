@@ -75,9 +75,26 @@ typedef struct CartnetGemmArgs {
   int32_t precision;   /* 0: fp32 MFMA (exact fp32 products).  1: bf16x3 split operands, 6 bf16 MFMAs per product,
                           fp32 accumulate (fp32-level accuracy, see gemm_kernel.h); falls back to 0 where no
                           such kernel exists (narrow tiles, ragged K tail, unaligned operands). */
+  const void* b_split[CARTNET_MAX_GROUPS];
+                       /* optional, precision 1 with b_kstrided = 1 and a_kstrided = 0: B[i] pre-split into bf16 planes
+                          by cartnet_gemm_split_b (the weight operand, split once per step instead of once per
+                          tile); B[i] must still be given (fallback paths read it). */
+  const void* b_split_folded;
+                       /* optional, nsegs > 1 and N == 256: the segments' images one after the other (segment order).
+                          Used when the A segments are adjacent column blocks of one matrix (A[s] == A[0] + s*K):
+                          the sum over segments is then one product over K*nsegs. */
 } CartnetGemmArgs;
 
 int cartnet_gemm(const CartnetGemmArgs* args, void* stream);
+
+/* bf16x3 pre-split of a k-strided GEMM operand B [K, N] (element (k, n) = src[k*stride_k + n*stride_n]; a weight
+ * W [out, in] used as B = W^T has stride_k = 1, stride_n = ld) into the image cartnet_gemm reads through
+ * CartnetGemmArgs.b_split: per 256-column tile and 16-deep K-step, three planes (high / middle / low bf16 piece) of
+ * [256][16] bf16 in the kernel's LDS order.  K % 16 == 0 and N % 256 == 0; dst: cartnet_gemm_split_b_bytes(K, N)
+ * = 6*K*N bytes (0 when the shape has no such image), 16-byte aligned.  njobs matrices per call (host arrays). */
+size_t cartnet_gemm_split_b_bytes(int32_t K, int32_t N);
+int cartnet_gemm_split_b(const float* const* src, void* const* dst, const int32_t* K, const int32_t* N,
+                         const int32_t* stride_k, const int32_t* stride_n, int32_t njobs, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * iComformer-only pieces (models/comformer.py:75-132, models/comformer_conv.py:21-193); the dense work of that
