@@ -85,3 +85,9 @@ __device__ __forceinline__ double cn_block_colsum(const double* __restrict__ par
 }
 
 static inline int cn_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Long partial-sum matrices ([nparts][N] fp64, nparts in the thousands) are folded to CN_FOLD_ROWS rows first
+// (cn_fold_parts, gemm.hip: row r <- sum of rows r, r+R, r+2R, ... in that order, in place), so that the finalising
+// kernels -- a handful of blocks -- only have CN_FOLD_ROWS rows left to add.  Returns the row count to finalise.
+constexpr int CN_FOLD_ROWS = 32;
+int cn_fold_parts(double* const* parts, int njobs, int nparts, int N, hipStream_t st);

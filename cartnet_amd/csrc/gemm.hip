@@ -28,6 +28,61 @@ __global__ void cn_splitk_reduce_kernel(const ReduceJobs jobs, int splitk, int M
   }
 }
 
+// N % 4 == 0, 16-byte aligned slabs / rows: 64 float4 elements per block, the slabs dealt round-robin to four
+// 64-thread groups (eight independent 16-byte loads in flight per thread), group sums added in group order.
+__global__ __launch_bounds__(256) void cn_splitk_reduce4_kernel(const ReduceJobs jobs, int splitk, int M, int N,
+                                                                int ldo) {
+  __shared__ f32x4 red[4][64];
+  const float* __restrict__ slabs = jobs.slabs[blockIdx.y];
+  float* __restrict__ out = jobs.out[blockIdx.y];
+  const size_t total4 = (size_t)M * N / 4;
+  const int sg = threadIdx.x >> 6, el = threadIdx.x & 63;
+  const size_t i = (size_t)blockIdx.x * 64 + el;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (i < total4) {
+    const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(slabs) + i;
+    int s = sg;
+    for (; s + 28 < splitk; s += 32) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(s + 4 * u) * total4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; s < splitk; s += 4) acc += p[(size_t)s * total4];
+  }
+  red[sg][el] = acc;
+  __syncthreads();
+  if (sg == 0 && i < total4) {
+    f32x4 t = red[0][el];
+    t += red[1][el];
+    t += red[2][el];
+    t += red[3][el];
+    const size_t e0 = i * 4, m = e0 / N, n = e0 % N;
+    *reinterpret_cast<f32x4*>(out + m * ldo + n) = t;
+  }
+}
+
+struct FoldJobs {
+  double* parts[8];
+};
+
+// parts[r][c] <- sum_i parts[r + i*R][c] for r < R = CN_FOLD_ROWS, in place.  grid (ceil(N/64), R, njobs), 256 threads:
+// four row groups take i = g, g+4, ...; group sums are added in group order.  Row r (and every row r + i*R) is
+// touched by this block only, so the in-place update does not race.
+__global__ __launch_bounds__(256) void cn_fold_parts_kernel(const FoldJobs jobs, int nparts, int N) {
+  __shared__ double red[4][64];
+  double* __restrict__ parts = jobs.parts[blockIdx.z];
+  const int gq = threadIdx.x >> 6, cl = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + cl, r = blockIdx.y;
+  double acc = 0.0;
+  if (c < N)
+    for (int row = r + gq * CN_FOLD_ROWS; row < nparts; row += 4 * CN_FOLD_ROWS) acc += parts[(size_t)row * N + c];
+  red[gq][cl] = acc;
+  __syncthreads();
+  if (gq == 0 && c < N && r < nparts) parts[(size_t)r * N + c] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+}
+
 struct FinalizeJobs {
   const double* parts[8];
   float* out[8];
@@ -198,6 +253,15 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
   return 0;
 }
 
+int cn_fold_parts(double* const* parts, int njobs, int nparts, int N, hipStream_t st) {
+  if (nparts <= 2 * CN_FOLD_ROWS || N <= 0 || njobs <= 0 || njobs > 8) return nparts;
+  FoldJobs jobs;
+  for (int j = 0; j < 8; ++j) jobs.parts[j] = j < njobs ? parts[j] : nullptr;
+  hipLaunchKernelGGL(cn_fold_parts_kernel, dim3(cn_ceil_div(N, 64), CN_FOLD_ROWS, njobs), dim3(256), 0, st, jobs, nparts,
+                     N);
+  return CN_FOLD_ROWS;
+}
+
 extern "C" int cartnet_splitk_reduce(const float* const* slabs, float* const* outs, int32_t njobs, int32_t splitk,
                                      int32_t M, int32_t N, int32_t ldo, void* stream) {
   CN_CHECK(slabs && outs && njobs >= 1 && njobs <= CARTNET_MAX_GROUPS, "cartnet_splitk_reduce: njobs=%d out of range",
@@ -211,6 +275,14 @@ extern "C" int cartnet_splitk_reduce(const float* const* slabs, float* const* ou
     if (j < njobs) CN_CHECK(slabs[j] && outs[j], "cartnet_splitk_reduce: null pointer in job %d", j);
   }
   const size_t total = (size_t)M * N;
+  bool vec4 = (N % 4 == 0) && (ldo % 4 == 0);
+  for (int j = 0; j < njobs; ++j) vec4 = vec4 && aligned16(slabs[j]) && aligned16(outs[j]);
+  if (vec4) {
+    hipLaunchKernelGGL(cn_splitk_reduce4_kernel, dim3((unsigned)((total / 4 + 63) / 64), njobs), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), jobs, splitk, M, N, ldo);
+    CN_LAUNCH_CHECK("cartnet_splitk_reduce");
+    return 0;
+  }
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(cn_splitk_reduce_kernel, dim3(blocks, njobs), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
@@ -219,7 +291,7 @@ extern "C" int cartnet_splitk_reduce(const float* const* slabs, float* const* ou
   return 0;
 }
 
-extern "C" int cartnet_colsum_finalize(const double* const* parts, float* const* outs, int32_t njobs, int32_t nparts,
+extern "C" int cartnet_colsum_finalize(double* const* parts, float* const* outs, int32_t njobs, int32_t nparts,
                                        int32_t N, void* stream) {
   CN_CHECK(parts && outs && njobs >= 1 && njobs <= 8, "cartnet_colsum_finalize: njobs=%d out of range (1..8)", njobs);
   CN_CHECK(nparts >= 0 && N >= 0, "cartnet_colsum_finalize: bad shape");
@@ -230,6 +302,7 @@ extern "C" int cartnet_colsum_finalize(const double* const* parts, float* const*
     jobs.out[j] = j < njobs ? outs[j] : nullptr;
     if (j < njobs) CN_CHECK(parts[j] && outs[j], "cartnet_colsum_finalize: null pointer in job %d", j);
   }
+  nparts = cn_fold_parts(parts, njobs, nparts, N, reinterpret_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(cn_colsum_finalize_kernel, dim3(cn_ceil_div(N, 64), njobs), dim3(1024), 0,
                      reinterpret_cast<hipStream_t>(stream), jobs, nparts, N);
   CN_LAUNCH_CHECK("cartnet_colsum_finalize");

@@ -596,7 +596,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     // node update: x_out = silu(bn2(aggr)) + x_in
     RUN(cartnet_node_update_bwd_stats(w.aggr[l], dx, w.mr2[l], q.norm2_w, q.norm2_b, N, D, w.pa, w.pb, st));
     {
-      const double* parts[2] = {w.pa, w.pb};
+      double* parts[2] = {w.pa, w.pb};
       float* outs[2] = {w.sums2, w.sums2 + D};
       RUN(cartnet_colsum_finalize(parts, outs, 2, w.nparts_n, D, st));
     }
@@ -611,7 +611,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     RUN(cartnet_gate_scatter_bwd_stats(gs, de, w.daggr, env, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, N, D, w.pa, w.pb,
                                        st));
     {
-      const double* parts[2] = {w.pa, w.pb};
+      double* parts[2] = {w.pa, w.pb};
       float* outs[2] = {w.sums1, w.sums1 + D};
       RUN(cartnet_colsum_finalize(parts, outs, 2, w.gparts, D, st));
     }
@@ -624,7 +624,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
                                        training, N, D, w.pc[par], w.pd[par], st));   // gs = [dg | ds]
     FORK();
     {  // side: bias gradients of the second Linears, then their weight gradients (need silu(pre), which stays intact)
-      const double* parts[2] = {w.pc[par], w.pd[par]};
+      double* parts[2] = {w.pc[par], w.pd[par]};
       float* outs[2] = {gq.gate2_b, gq.aggr2_b};
       RUN(cartnet_colsum_finalize(parts, outs, 2, w.gparts, D, sw));
       const float* dY[2] = {gs, gs + D};
@@ -643,7 +643,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     }
     FORK();
     {  // side: bias and edge-block weight gradients of the first Linears
-      const double* parts[2] = {w.csg[par], w.csa[par]};
+      double* parts[2] = {w.csg[par], w.csa[par]};
       float* outs[2] = {gq.gate0_b, gq.aggr0_b};
       RUN(cartnet_colsum_finalize(parts, outs, 2, w.tiles_e, D, sw));
       const float* dY[2] = {dpre, dpre + D};
@@ -662,7 +662,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       if (l == 0) { a.dact[0] = w.e0_pre; a.ldd = D; a.colsum[0] = w.cs_misc[0]; }
       RUN(cartnet_gemm(&a, st));
       if (l == 0) {
-        const double* parts[1] = {w.cs_misc[0]};
+        double* parts[1] = {w.cs_misc[0]};
         float* outs[1] = {G.edge2_b};
         RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_e, D, st));
       }
@@ -688,7 +688,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       if (l == 0) { a.dact[0] = w.xa_pre; a.ldd = D; a.colsum[0] = w.cs_misc[1]; }
       RUN(cartnet_gemm(&a, st));
       if (l == 0) {
-        const double* parts[1] = {w.cs_misc[1]};
+        double* parts[1] = {w.cs_misc[1]};
         float* outs[1] = {G.atom_b};
         RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_n, D, st));
       }
@@ -711,7 +711,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     a.colsum[0] = w.cs_misc[2];
     RUN(cartnet_gemm(&a, st));       // dhe = d(he_pre)
     FORK();
-    const double* parts[1] = {w.cs_misc[2]};
+    double* parts[1] = {w.cs_misc[2]};
     float* outs[1] = {G.edge0_b};
     RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_e, 2 * D, sw));
     const float* dY2[1] = {w.dhe};
@@ -731,11 +731,11 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     RUN(cartnet_node_embed_bwd(m.use_temperature ? b.batch : nullptr, m.use_temperature ? b.temperature : nullptr, w.dx0,
                                N, 2 * D, w.pa, w.pb, st));
     if (m.use_temperature) {
-      const double* parts[2] = {w.pa, w.pb};
+      double* parts[2] = {w.pa, w.pb};
       float* outs[2] = {G.temp_w, G.temp_b};
       RUN(cartnet_colsum_finalize(parts, outs, 2, w.nparts_n, 2 * D, st));
     } else {
-      const double* parts[1] = {w.pb};
+      double* parts[1] = {w.pb};
       float* outs[1] = {G.enc_bias};
       RUN(cartnet_colsum_finalize(parts, outs, 1, w.nparts_n, 2 * D, st));
     }

@@ -439,13 +439,17 @@ extern "C" int cartnet_node_embed_bwd(const int64_t* batch, const float* tempera
   return 0;
 }
 
-extern "C" int cartnet_bn_finalize(const double* parts_sum, const double* parts_sq, int32_t nparts, int64_t count,
+extern "C" int cartnet_bn_finalize(double* parts_sum, double* parts_sq, int32_t nparts, int64_t count,
                                    int32_t C, float eps, float momentum, int32_t training, float* running_mean,
                                    float* running_var, int64_t* num_batches_tracked, float* mean_rstd, void* stream) {
   CN_CHECK(C >= 1 && mean_rstd, "cartnet_bn_finalize: bad arguments");
   if (training) CN_CHECK(parts_sum && parts_sq && nparts >= 0 && count >= 0, "cartnet_bn_finalize: missing partial sums");
   else CN_CHECK(running_mean && running_var, "cartnet_bn_finalize: eval mode needs running statistics");
   CN_CHECK((running_mean == nullptr) == (running_var == nullptr), "cartnet_bn_finalize: running stats must pair");
+  if (training) {
+    double* fp[2] = {parts_sum, parts_sq};
+    nparts = cn_fold_parts(fp, 2, nparts, C, ST(stream));
+  }
   hipLaunchKernelGGL(cn_bn_finalize_kernel, dim3(cn_ceil_div(C, 64)), dim3(1024), 0, ST(stream), parts_sum, parts_sq,
                      nparts, (long long)count, C, eps, momentum, training, running_mean, running_var,
                      num_batches_tracked, mean_rstd);
