@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void cn_segment_sum_kernel(const float* __rest
 // Long-segment variant (few, very uneven segments, e.g. atoms grouped by element): pass 1 cuts the sorted positions
 // into chunks of LONG_CHUNK rows, one wave per (chunk, 256-column slab), and writes one partial row per run of equal
 // segment id at tmp[first position of the run]; pass 2 adds each segment's partial rows in position order.
-constexpr int LONG_CHUNK = 128;
+constexpr int LONG_CHUNK = 32;
+constexpr int LONG_BATCH = 8;    // independent row loads in flight per wave
 
 __global__ __launch_bounds__(256) void cn_segment_long_pass1_kernel(const float* __restrict__ rows, int ld,
                                                                     const int* __restrict__ ptr,
@@ -208,14 +209,26 @@ __global__ __launch_bounds__(256) void cn_segment_long_pass1_kernel(const float*
     while (seg + 1 < nseg && ptr[seg + 1] <= p0) ++seg;
     int run_start = p0;
     f32x4 acc = {0, 0, 0, 0};
-    for (int p = p0; p < p1; ++p) {
-      while (seg + 1 <= nseg && p >= ptr[seg + 1]) {   // p starts a new segment: flush the finished run
-        if (p > run_start && c < W) st4(tmp + (size_t)run_start * W + c, acc);
-        acc = f32x4{0, 0, 0, 0};
-        run_start = p;
-        ++seg;
+    for (int pb = p0; pb < p1; pb += LONG_BATCH) {
+      f32x4 v[LONG_BATCH];
+#pragma unroll
+      for (int u = 0; u < LONG_BATCH; ++u) {   // the loads of a batch are independent; the adds below keep position order
+        const int p = pb + u;
+        v[u] = f32x4{0, 0, 0, 0};
+        if (p < p1 && c < W) v[u] = ld4(rows + (size_t)(perm ? perm[p] : p) * ld + c);
       }
-      if (c < W) acc += ld4(rows + (size_t)(perm ? perm[p] : p) * ld + c);
+#pragma unroll
+      for (int u = 0; u < LONG_BATCH; ++u) {
+        const int p = pb + u;
+        if (p >= p1) break;
+        while (seg + 1 <= nseg && p >= ptr[seg + 1]) {   // p starts a new segment: flush the finished run
+          if (p > run_start && c < W) st4(tmp + (size_t)run_start * W + c, acc);
+          acc = f32x4{0, 0, 0, 0};
+          run_start = p;
+          ++seg;
+        }
+        acc += v[u];
+      }
     }
     if (p1 > run_start && c < W) st4(tmp + (size_t)run_start * W + c, acc);
   }
@@ -234,9 +247,22 @@ __global__ __launch_bounds__(256) void cn_segment_long_pass2_kernel(const float*
     const int b = ptr[s], e = ptr[s + 1];
     f32x4 acc = {0, 0, 0, 0};
     int p = b;
-    while (p < e) {
-      acc += ld4(tmp + (size_t)p * W + c);
-      p = (p / LONG_CHUNK + 1) * LONG_CHUNK;
+    while (p < e) {    // partial rows sit at b and at every chunk boundary inside (b, e); batches of independent loads
+      int pos[LONG_BATCH];
+      f32x4 v[LONG_BATCH];
+#pragma unroll
+      for (int u = 0; u < LONG_BATCH; ++u) {
+        pos[u] = p;
+        if (p < e) {
+          v[u] = ld4(tmp + (size_t)p * W + c);
+          p = (p / LONG_CHUNK + 1) * LONG_CHUNK;
+        } else {
+          v[u] = f32x4{0, 0, 0, 0};
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < LONG_BATCH; ++u)
+        if (pos[u] < e) acc += v[u];
     }
     st4(out + (size_t)s * ldo + c, acc);
   }

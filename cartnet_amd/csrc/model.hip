@@ -407,8 +407,6 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     a.b_kstrided = 1; a.a_act = 1; a.out_act = 1; a.b_split[0] = w.i_atom;
     RUN(cartnet_gemm(&a, st));
   }
-  if (need_backward && m.atom_types)
-    RUN(cartnet_sort_by_key(b.z, N, m.n_types, w.zperm, w.zptr, w.zstatus, st));
 
   // ---- message-passing layers (cartnet.py:204-274)
   const float* x = w.xenc;
@@ -545,6 +543,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
   hipStream_t hs = S.main;
 #define FORK() do { if (S.fork() != 0) { cartnet_set_error("cartnet_model_backward: stream fork failed"); return 2; } } while (0)
 
+  hipEvent_t sort_done = nullptr;
   // ---- head
   {
     const int row = m.cholesky ? 7 * H + 8 : 2 * H + 8;
@@ -553,6 +552,10 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     else
       RUN(cartnet_scalar_head_bwd(w.hid, P.head2_w, b.graph_ptr, b.batch, dpred, N, b.Bg, H, w.dhid, w.head_parts, st));
     FORK();
+    if (m.atom_types) {   // atoms grouped by element for the embedding gradient: off the critical path
+      RUN(cartnet_sort_by_key(b.z, N, m.n_types, w.zperm, w.zptr, w.zstatus, sw));
+      sort_done = S.mark_side();
+    }
     RUN(cartnet_colsum_finalize_f32(w.head_parts, w.nparts_n, row, w.head_tot, sw));
     const int nw2 = m.cholesky ? 6 * H : H, nb2 = m.cholesky ? 6 : 1;
     if (hipMemcpyAsync(G.head2_w, w.head_tot, sizeof(float) * nw2, hipMemcpyDeviceToDevice, S.side) != hipSuccess ||
@@ -739,6 +742,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       float* outs[1] = {G.enc_bias};
       RUN(cartnet_colsum_finalize(parts, outs, 1, w.nparts_n, 2 * D, st));
     }
+    if (m.atom_types && S.main_waits(sort_done) != 0) { cartnet_set_error("cartnet_model_backward: wait failed"); return 2; }
     if (m.atom_types)
       RUN(cartnet_segment_sum_long(w.dx0, 2 * D, w.zptr, w.zperm, m.n_types, N, 2 * D, w.seg_tmp, G.embedding, 2 * D,
                                    st));

@@ -58,12 +58,26 @@ __global__ __launch_bounds__(256) void cn_embed_bwd_cols_kernel(const int64_t* _
     const int c = c0 + lane * 4;
     const bool active = c < C;
     f64x4 pw = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
-    for (int n = blockIdx.x * NODES_PER_BLOCK + wid; n < N; n += gridDim.x * NODES_PER_BLOCK) {
+    const int stride = gridDim.x * NODES_PER_BLOCK;
+    for (int n0 = blockIdx.x * NODES_PER_BLOCK + wid; n0 < N; n0 += 4 * stride) {
       if (!active) continue;
-      const f32x4 d = ld4(dx0 + (size_t)n * C + c);
-      const float t = temperature ? temperature[batch[n]] : 0.f;
-      cn_acc4(pw, d * t);
-      cn_acc4(pb, d);
+      f32x4 d[4];
+      float t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {      // four independent rows in flight; accumulated in row order below
+        const int n = n0 + u * stride;
+        d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        t[u] = 0.f;
+        if (n < N) {
+          d[u] = ld4(dx0 + (size_t)n * C + c);
+          if (temperature) t[u] = temperature[batch[n]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        cn_acc4(pw, d[u] * t[u]);
+        cn_acc4(pb, d[u]);
+      }
     }
     cn_block_store_parts(pw, red, parts_w, C, c, active, wid, lane);
     cn_block_store_parts(pb, red, parts_b, C, c, active, wid, lane);
