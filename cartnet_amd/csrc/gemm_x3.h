@@ -117,15 +117,17 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
     *reinterpret_cast<bf16x4*>(dst + X3_A_PLANE) = s.m;
     *reinterpret_cast<bf16x4*>(dst + 2 * X3_A_PLANE) = s.l;
   };
-  // B tile of K-step v: 24 KB, a lane-linear copy; wave w moves the 1 KB pieces w, w+8, w+16
+  // B tile of K-step v: 24 KB, a lane-linear copy; wave w moves the 1 KB pieces w, w+8, w+16.  Issued as inline asm
+  // (scalar base + one lane-offset VGPR; the builtin keeps a 64-bit address pair per piece in VGPRs, which this
+  // kernel cannot afford at 128 registers).
+  const unsigned lds_b = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + X3_A_BYTES + wid * 1024;
   auto b_issue = [&](int v, int buf) {
-    const char* src = b_base(v);
-    char* dst = lds + buf * X3_BUF_BYTES + X3_A_BYTES;
+    const char* src = b_base(v) + wid * 1024;
+    const unsigned dst = lds_b + buf * X3_BUF_BYTES;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int c = (j * 8 + wid) * 1024;
-      __builtin_amdgcn_global_load_lds((glb_void_ptr)(src + c + b_voff), (lds_void_ptr)(dst + c), 16, 0, 0);
-    }
+    for (int j = 0; j < 3; ++j)
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   :: "s"(dst + j * 8192), "v"(b_voff), "s"(src + j * 8192) : "memory", "m0");
   };
   bf16x8 ah[2], am[2], al[2], bh, bm, bl;
   auto frag_a = [&](int buf) {
@@ -178,6 +180,83 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
+  // The same K-step for the steady state (u + 3 < nsteps: nothing conditional), scheduled by hand: the MFMA chain
+  // starts as soon as the first fragments are in, and everything else of the step -- the split of the next A tile
+  // (three slices), its LDS writes, the DMA issue, the A load, the second half's B fragments -- sits in the shadow of
+  // MFMAs (an MFMA holds the issue port 8 of its 32 cycles).  The B registers are reloaded with the second column
+  // half as soon as the last MFMA that reads them has issued: products are ordered by B plane (h, m, l) per half.
+#define CN_SB() __builtin_amdgcn_sched_barrier(0)
+#define CN_MMA(a, b, x, y) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[a][b], 0, 0, 0)
+  auto step_full = [&](auto cur_c, int u, f32x4& r) {
+    constexpr int CUR = decltype(cur_c)::value;
+    const char* qb = lds + CUR * X3_BUF_BYTES + X3_A_BYTES + x3_offset(wn * S::WN + li, lh);
+    char* wdst = lds + (CUR ^ 1) * X3_BUF_BYTES + a_lds;
+    frag_a(CUR);
+    bh = *reinterpret_cast<const bf16x8*>(qb);
+    bm = *reinterpret_cast<const bf16x8*>(qb + X3_B_PLANE);
+    bl = *reinterpret_cast<const bf16x8*>(qb + 2 * X3_B_PLANE);
+    CN_SB();
+    if (A_ACT) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) r[c] = fast_silu(r[c]);
+    }
+    const bf16x4 sh = __builtin_convertvector(r, bf16x4);                       // slice 1 (hides the LDS latency)
+    const f32x4 r1 = r - __builtin_convertvector(sh, f32x4);
+    CN_SB();
+    CN_MMA(0, 0, al[0], bh);
+    CN_MMA(1, 0, al[1], bh);
+    CN_SB();
+    const bf16x4 sm = __builtin_convertvector(r1, bf16x4);                      // slice 2
+    const f32x4 r2 = r1 - __builtin_convertvector(sm, f32x4);
+    CN_SB();
+    CN_MMA(0, 0, am[0], bh);
+    CN_MMA(1, 0, am[1], bh);
+    CN_SB();
+    const bf16x4 sl = __builtin_convertvector(r2, bf16x4);                      // slice 3 + the three LDS writes
+    *reinterpret_cast<bf16x4*>(wdst) = sh;
+    *reinterpret_cast<bf16x4*>(wdst + X3_A_PLANE) = sm;
+    *reinterpret_cast<bf16x4*>(wdst + 2 * X3_A_PLANE) = sl;
+    CN_SB();
+    CN_MMA(0, 0, ah[0], bh);
+    CN_MMA(1, 0, ah[1], bh);
+    CN_SB();
+    bh = *reinterpret_cast<const bf16x8*>(qb + 32 * 32);                        // second column half, high plane
+    b_issue(u + 1, CUR ^ 1);
+    CN_SB();
+    CN_MMA(0, 0, am[0], bm);
+    CN_MMA(1, 0, am[1], bm);
+    CN_SB();
+    a_issue(r, u + 3);
+    CN_SB();
+    CN_MMA(0, 0, ah[0], bm);
+    CN_MMA(1, 0, ah[1], bm);
+    CN_SB();
+    bm = *reinterpret_cast<const bf16x8*>(qb + 32 * 32 + X3_B_PLANE);
+    CN_SB();
+    CN_MMA(0, 0, ah[0], bl);
+    CN_MMA(1, 0, ah[1], bl);
+    CN_SB();
+    bl = *reinterpret_cast<const bf16x8*>(qb + 32 * 32 + 2 * X3_B_PLANE);
+    CN_SB();
+    CN_MMA(0, 1, al[0], bh);
+    CN_MMA(1, 1, al[1], bh);
+    CN_MMA(0, 1, am[0], bh);
+    CN_MMA(1, 1, am[1], bh);
+    CN_MMA(0, 1, ah[0], bh);
+    CN_MMA(1, 1, ah[1], bh);
+    CN_MMA(0, 1, am[0], bm);
+    CN_MMA(1, 1, am[1], bm);
+    CN_MMA(0, 1, ah[0], bm);
+    CN_MMA(1, 1, ah[1], bm);
+    CN_MMA(0, 1, ah[0], bl);
+    CN_MMA(1, 1, ah[1], bl);
+    CN_SB();
+    asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+#undef CN_MMA
+#undef CN_SB
 
   if (nsteps > 0) {
     f32x4 r0, r1;
@@ -190,7 +269,12 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(r0), "+v"(r1) :: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    for (int u = 0; u < nsteps; u += 2) {
+    int u = 0;
+    for (; u + 4 < nsteps; u += 2) {        // both steps satisfy u + 3 < nsteps
+      step_full(std::integral_constant<int, 0>{}, u, r1);
+      step_full(std::integral_constant<int, 1>{}, u + 1, r0);
+    }
+    for (; u < nsteps; u += 2) {
       step(std::integral_constant<int, 0>{}, u, r1);
       if (u + 1 < nsteps) step(std::integral_constant<int, 1>{}, u + 1, r0);
     }
@@ -327,7 +411,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3tn_kernel(const Cartnet
     store(0);
     if (nsteps > 1) load(1);
     __syncthreads();
-    for (int u = 0; u < nsteps; ++u) {
+    int u = 0;
+    for (; u < nsteps; ++u) {
       const int cur = u & 1;
       if (u + 1 < nsteps) store(cur ^ 1);
       if (u + 2 < nsteps) load(u + 2);
