@@ -664,9 +664,11 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
           launch_x3nn(A_ACT, a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
           return;
         }
-        hipLaunchKernelGGL((cn_gemm_kernel<A_KS, B_KS, BN, A_ACT, B_ACT, true, 1>), dim3(nm * tiles_n, ns, a.ngroups),
-                           dim3(NTHREADS), 0, st, a, fl);
-        return;
+        if (fl.x3 == 1) {   // first-generation kernel (both operands split in flight); precision 2 has no such form
+          hipLaunchKernelGGL((cn_gemm_kernel<A_KS, B_KS, BN, A_ACT, B_ACT, true, 1>), dim3(nm * tiles_n, ns, a.ngroups),
+                             dim3(NTHREADS), 0, st, a, fl);
+          return;
+        }
       }
     }
     // weight gradients (both operands k-strided): transposing-read bf16x3 kernel over whole 128-row tiles

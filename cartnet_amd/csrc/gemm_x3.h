@@ -62,7 +62,7 @@ __device__ __forceinline__ void x3_epilogue(const CartnetGemmArgs& p, f32x16 (&a
 //   after it stays in flight across the barrier -- every A load (HBM) gets two K-steps to arrive, every DMA (L2) one.
 //   The A loads are inline asm so that the compiler's own counter bookkeeping (which drains everything whenever a DMA
 //   is outstanding) stays out of the loop; all waits in the loop are written by hand.
-template <bool A_ACT>
+template <bool A_ACT, bool ONE>
 __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const CartnetGemmArgs p, const GemmFlags fl) {
   using S = Shape<X3_BN>;
   static_assert(S::TM == 2 && S::TN == 2, "wave tile is 64 x 64");
@@ -111,11 +111,15 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = fast_silu(v[c]);
     }
-    const Split3 s = split3(v);
     char* dst = lds + buf * X3_BUF_BYTES + a_lds;
-    *reinterpret_cast<bf16x4*>(dst) = s.h;
-    *reinterpret_cast<bf16x4*>(dst + X3_A_PLANE) = s.m;
-    *reinterpret_cast<bf16x4*>(dst + 2 * X3_A_PLANE) = s.l;
+    if constexpr (ONE) {   // plain bf16 operands (precision 2): the high piece only
+      *reinterpret_cast<bf16x4*>(dst) = __builtin_convertvector(v, bf16x4);
+    } else {
+      const Split3 s = split3(v);
+      *reinterpret_cast<bf16x4*>(dst) = s.h;
+      *reinterpret_cast<bf16x4*>(dst + X3_A_PLANE) = s.m;
+      *reinterpret_cast<bf16x4*>(dst + 2 * X3_A_PLANE) = s.l;
+    }
   };
   // B tile of K-step v: 24 KB, a lane-linear copy; wave w moves the 1 KB pieces w, w+8, w+16.  Issued as inline asm
   // (scalar base + one lane-offset VGPR; the builtin keeps a 64-bit address pair per piece in VGPRs, which this
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
     const char* src = b_base(v) + wid * 1024;
     const unsigned dst = lds_b + buf * X3_BUF_BYTES;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < (ONE ? 1 : 3); ++j)   // piece j of every wave belongs to plane j (h, m, l)
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                    :: "s"(dst + j * 8192), "v"(b_voff), "s"(src + j * 8192) : "memory", "m0");
   };
@@ -136,19 +140,27 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
     for (int a = 0; a < 2; ++a) {
       const char* q = cA + x3_offset(wm * S::WM + a * 32 + li, lh);
       ah[a] = *reinterpret_cast<const bf16x8*>(q);
-      am[a] = *reinterpret_cast<const bf16x8*>(q + X3_A_PLANE);
-      al[a] = *reinterpret_cast<const bf16x8*>(q + 2 * X3_A_PLANE);
+      if constexpr (!ONE) {
+        am[a] = *reinterpret_cast<const bf16x8*>(q + X3_A_PLANE);
+        al[a] = *reinterpret_cast<const bf16x8*>(q + 2 * X3_A_PLANE);
+      }
     }
   };
   auto frag_b = [&](int buf, int b) {
     const char* q = lds + buf * X3_BUF_BYTES + X3_A_BYTES + x3_offset(wn * S::WN + b * 32 + li, lh);
     bh = *reinterpret_cast<const bf16x8*>(q);
-    bm = *reinterpret_cast<const bf16x8*>(q + X3_B_PLANE);
-    bl = *reinterpret_cast<const bf16x8*>(q + 2 * X3_B_PLANE);
+    if constexpr (!ONE) {
+      bm = *reinterpret_cast<const bf16x8*>(q + X3_B_PLANE);
+      bl = *reinterpret_cast<const bf16x8*>(q + 2 * X3_B_PLANE);
+    }
   };
   auto mma = [&](int b) {
 #pragma unroll
     for (int a = 0; a < 2; ++a) {   // small terms first
+      if constexpr (ONE) {
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][b], 0, 0, 0);
+        continue;
+      }
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][b], 0, 0, 0);
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a][b], 0, 0, 0);
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bm, acc[a][b], 0, 0, 0);
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
     f32x4 r0, r1;
     a_issue(r0, 0);
     b_issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(3)" : "+v"(r0) :: "memory");   // the A load is older than the three DMA pieces
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0) :: "memory");
     a_store(r0, 0);
     if (nsteps > 1) a_issue(r1, 1);
     if (nsteps > 2) a_issue(r0, 2);
@@ -270,9 +282,11 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     int u = 0;
-    for (; u + 4 < nsteps; u += 2) {        // both steps satisfy u + 3 < nsteps
-      step_full(std::integral_constant<int, 0>{}, u, r1);
-      step_full(std::integral_constant<int, 1>{}, u + 1, r0);
+    if constexpr (!ONE) {
+      for (; u + 4 < nsteps; u += 2) {        // both steps satisfy u + 3 < nsteps
+        step_full(std::integral_constant<int, 0>{}, u, r1);
+        step_full(std::integral_constant<int, 1>{}, u + 1, r0);
+      }
     }
     for (; u < nsteps; u += 2) {
       step(std::integral_constant<int, 0>{}, u, r1);
@@ -315,7 +329,7 @@ constexpr int X3T_B_PLANE = BK * X3_BN * 2;     // [16 k][256 n] bf16 = 8 KB
 constexpr int X3T_A_BYTES = 3 * X3T_A_PLANE;
 constexpr int X3T_BUF_BYTES = 3 * (X3T_A_PLANE + X3T_B_PLANE);   // 36 KB
 
-template <bool B_ACT>
+template <bool B_ACT, bool ONE>
 __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3tn_kernel(const CartnetGemmArgs p, const GemmFlags fl) {
   using S = Shape<X3_BN>;
   __shared__ __attribute__((aligned(16))) float smem[2 * X3T_BUF_BYTES / 4];
@@ -365,10 +379,14 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3tn_kernel(const Cartnet
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = fast_silu(v[c]);
     }
-    const Split3 s = split3(v);
-    *reinterpret_cast<bf16x4*>(dst) = s.h;
-    *reinterpret_cast<bf16x4*>(dst + plane_bytes) = s.m;
-    *reinterpret_cast<bf16x4*>(dst + 2 * plane_bytes) = s.l;
+    if constexpr (ONE) {
+      *reinterpret_cast<bf16x4*>(dst) = __builtin_convertvector(v, bf16x4);
+    } else {
+      const Split3 s = split3(v);
+      *reinterpret_cast<bf16x4*>(dst) = s.h;
+      *reinterpret_cast<bf16x4*>(dst + plane_bytes) = s.m;
+      *reinterpret_cast<bf16x4*>(dst + 2 * plane_bytes) = s.l;
+    }
   };
   auto store = [&](int buf) {
     char* base = lds + buf * X3T_BUF_BYTES;
@@ -385,13 +403,20 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3tn_kernel(const Cartnet
     for (int a = 0; a < 2; ++a) {
       const int cb = wm * S::WM + a * 32 + grp16;
       ah[a] = x3t_read<BM>(cA, 8 * lh, cb, lane);
-      am[a] = x3t_read<BM>(cA + X3T_A_PLANE, 8 * lh, cb, lane);
-      al[a] = x3t_read<BM>(cA + 2 * X3T_A_PLANE, 8 * lh, cb, lane);
+      if constexpr (!ONE) {
+        am[a] = x3t_read<BM>(cA + X3T_A_PLANE, 8 * lh, cb, lane);
+        al[a] = x3t_read<BM>(cA + 2 * X3T_A_PLANE, 8 * lh, cb, lane);
+      }
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int cb = wn * S::WN + b * 32 + grp16;
       const bf16x8 bh = x3t_read<X3_BN>(cB, 8 * lh, cb, lane);
+      if constexpr (ONE) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][b], 0, 0, 0);
+        continue;
+      }
       const bf16x8 bm = x3t_read<X3_BN>(cB + X3T_B_PLANE, 8 * lh, cb, lane);
       const bf16x8 bl = x3t_read<X3_BN>(cB + 2 * X3T_B_PLANE, 8 * lh, cb, lane);
 #pragma unroll

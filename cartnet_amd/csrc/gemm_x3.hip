@@ -3,15 +3,26 @@
 
 namespace cn_gemm {
 
-int g_x3_diag = 0;
 void launch_x3nn(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st) {
-  if (a_act) hipLaunchKernelGGL((cn_gemm_x3nn_kernel<true>), grid, dim3(NTHREADS), 0, st, a, fl);
-  else hipLaunchKernelGGL((cn_gemm_x3nn_kernel<false>), grid, dim3(NTHREADS), 0, st, a, fl);
+  const bool one = fl.x3 == 2;   // precision 2: plain bf16 operands, one MFMA product
+  if (a_act) {
+    if (one) hipLaunchKernelGGL((cn_gemm_x3nn_kernel<true, true>), grid, dim3(NTHREADS), 0, st, a, fl);
+    else hipLaunchKernelGGL((cn_gemm_x3nn_kernel<true, false>), grid, dim3(NTHREADS), 0, st, a, fl);
+  } else {
+    if (one) hipLaunchKernelGGL((cn_gemm_x3nn_kernel<false, true>), grid, dim3(NTHREADS), 0, st, a, fl);
+    else hipLaunchKernelGGL((cn_gemm_x3nn_kernel<false, false>), grid, dim3(NTHREADS), 0, st, a, fl);
+  }
 }
 
 void launch_x3tn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st) {
-  if (b_act) hipLaunchKernelGGL((cn_gemm_x3tn_kernel<true>), grid, dim3(NTHREADS), 0, st, a, fl);
-  else hipLaunchKernelGGL((cn_gemm_x3tn_kernel<false>), grid, dim3(NTHREADS), 0, st, a, fl);
+  const bool one = fl.x3 == 2;
+  if (b_act) {
+    if (one) hipLaunchKernelGGL((cn_gemm_x3tn_kernel<true, true>), grid, dim3(NTHREADS), 0, st, a, fl);
+    else hipLaunchKernelGGL((cn_gemm_x3tn_kernel<true, false>), grid, dim3(NTHREADS), 0, st, a, fl);
+  } else {
+    if (one) hipLaunchKernelGGL((cn_gemm_x3tn_kernel<false, true>), grid, dim3(NTHREADS), 0, st, a, fl);
+    else hipLaunchKernelGGL((cn_gemm_x3tn_kernel<false, false>), grid, dim3(NTHREADS), 0, st, a, fl);
+  }
 }
 
 }  // namespace cn_gemm
@@ -54,8 +65,6 @@ __global__ __launch_bounds__(256) void cn_split_b_kernel(const SplitJobs jobs) {
 }
 
 }  // namespace
-
-extern "C" void cartnet_debug_x3_diag(int v) { cn_gemm::g_x3_diag = v; }
 
 extern "C" size_t cartnet_gemm_split_b_bytes(int32_t K, int32_t N) {
   if (K <= 0 || N <= 0 || K % cn_gemm::BK != 0 || N % cn_gemm::X3_BN != 0) return 0;

@@ -132,7 +132,7 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
     w.gate2T[l] = c.take<float>((size_t)D * D);
     w.aggr2T[l] = c.take<float>((size_t)D * D);
   }
-  if (m.gemm_precision == 1 && D % 256 == 0) {
+  if (m.gemm_precision >= 1 && D % 256 == 0) {
     const size_t blk = cartnet_gemm_split_b_bytes(D, D);          // one D x D block
     w.i_edge2 = c.take<char>(cartnet_gemm_split_b_bytes(2 * D, D));
     w.i_atom = c.take<char>(cartnet_gemm_split_b_bytes(2 * D, D));
@@ -254,7 +254,7 @@ int check_model(const CartnetModel* m, const CartnetBatch* b, const char* who) {
   CN_CHECK(m->L >= 1 && m->L <= CARTNET_MAX_LAYERS, "%s: num_layers=%d out of range (1..%d)", who, m->L,
            CARTNET_MAX_LAYERS);
   CN_CHECK(m->R >= 1, "%s: dim_rbf=%d", who, m->R);
-  CN_CHECK(m->gemm_precision == 0 || m->gemm_precision == 1, "%s: gemm_precision=%d", who, m->gemm_precision);
+  CN_CHECK(m->gemm_precision >= 0 && m->gemm_precision <= 2, "%s: gemm_precision=%d", who, m->gemm_precision);
   CN_CHECK(m->use_temperature || m->atom_types, "%s: a model without atom types and without temperature is not built",
            who);
   CN_CHECK(b->N >= 0 && b->E >= 0 && b->Bg >= 1 && b->M >= 0, "%s: bad batch sizes", who);

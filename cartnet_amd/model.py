@@ -251,7 +251,7 @@ class CartNet(nn.Module):
         self.cholesky = cholesky
         self.head = Cholesky_head(dim_in) if cholesky else Scalar_head(dim_in)
         self.validate_graph = False     # set True to sync-check edge_index ordering / ranges once per batch
-        self.gemm_precision = 0         # 0: fp32 MFMA.  1: bf16x3 split-operand MFMA (see csrc/gemm_kernel.h)
+        self.gemm_precision = 0         # 0: fp32 MFMA.  1: bf16x3 split-operand MFMA.  2: plain bf16 operands (csrc/gemm_x3.h)
         self.overlap_weight_gradients = True   # run weight-gradient GEMMs on a second stream during backward
         self._aux_stream = None
         self._param_names = [n for n, _ in self.named_parameters()]

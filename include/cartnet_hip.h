@@ -74,7 +74,10 @@ typedef struct CartnetGemmArgs {
   int32_t a_kstrided, b_kstrided, a_act, b_act, out_act;
   int32_t precision;   /* 0: fp32 MFMA (exact fp32 products).  1: bf16x3 split operands, 6 bf16 MFMAs per product,
                           fp32 accumulate (fp32-level accuracy, see gemm_kernel.h); falls back to 0 where no
-                          such kernel exists (narrow tiles, ragged K tail, unaligned operands). */
+                          such kernel exists (narrow tiles, ragged K tail, unaligned operands).
+                          2: plain bf16 operands (round-to-nearest), ONE bf16 MFMA per product, fp32 accumulate and
+                          fp32 storage -- the reduced-precision mode of BASELINE configs[2]; only the pre-split /
+                          transposing-read kernels implement it (256-wide tiles), every other shape runs precision 0. */
   const void* b_split[CARTNET_MAX_GROUPS];
                        /* optional, precision 1 with b_kstrided = 1 and a_kstrided = 0: B[i] pre-split into bf16 planes
                           by cartnet_gemm_split_b (the weight operand, split once per step instead of once per
