@@ -229,9 +229,10 @@ def main():
             # FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate passes); null if never profiled
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath) and args.precision == 0:
+            if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_launch")
+                    tv = json.load(open(tpath)).get("variants", {}).get("fp32" if args.precision == 0 else "x3", {})
+                    traffic = tv.get(key, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             # bf16x3 kernels retire an fp32 product with six bf16 MFMAs: their ceiling is the dense bf16 peak / 6

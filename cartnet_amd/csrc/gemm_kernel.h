@@ -442,6 +442,30 @@ __device__ __forceinline__ void epilogue_wide(const CartnetGemmArgs& p, f32x16 (
   }
 }
 
+// Block -> (tile, group) map for grouped launches without split-K.  Workgroups go to the 8 XCDs round-robin in
+// dispatch order (x fastest, then z), and groups of one row tile read the same A rows (layer GEMM1: both MLPs read e;
+// node projections: four products of x): the groups of a tile are placed 8 dispatch slots apart -- same XCD, same
+// L2, a few microseconds apart -- instead of a whole grid apart.
+__device__ __forceinline__ void cn_block_map(int& bx, int& g) {
+  const int X = gridDim.x, G = gridDim.z;
+  if (G == 1 || gridDim.y != 1) {
+    bx = blockIdx.x;
+    g = blockIdx.z;
+    return;
+  }
+  const int L = blockIdx.x + X * blockIdx.z;
+  const int X8 = X & ~7;
+  if (L < X8 * G) {
+    const int chunk = L / (8 * G), w = L - chunk * 8 * G;
+    g = w >> 3;
+    bx = chunk * 8 + (w & 7);
+  } else {
+    const int r = L - X8 * G, rem = X - X8;
+    g = r / rem;
+    bx = X8 + r % rem;
+  }
+}
+
 // FAST: every tile of the launch is full, K is a whole number of K-steps and rows are 16-byte aligned -> the operand
 // loads carry no predicates.  The checked variant is a separate kernel so its register needs do not leak into this one.
 template <bool A_KS, bool B_KS, int BN, bool A_ACT, bool B_ACT, bool FAST, int PREC>
@@ -459,9 +483,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_kernel(const CartnetGemmA
   const int li = lane & 31, lh = lane >> 5;
 
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile_m = fl.tile_m0 + blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  int bx, g;
+  cn_block_map(bx, g);
+  const int tile_m = fl.tile_m0 + bx / tiles_n, tile_n = bx % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
-  const int g = blockIdx.z;
   const int split = fl.split0 + blockIdx.y;
 
   f32x16 acc[S::TM][S::TN];

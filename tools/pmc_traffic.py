@@ -1,0 +1,78 @@
+"""HBM bytes per kernel launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; tools/collect_profiles.sh).
+
+FETCH_SIZE (KB) is doubled for gfx950 (wide coalesced 128-B reads are tallied at 64 B, MI355X_MICROARCH.md "HBM");
+WRITE_SIZE (KB) is taken as is.  Output: JSON keyed by kernel name, averages over all launches of that kernel in the
+profiled process (2 fp32 steps + the bf16x3 pass of bench.py, warm-ups included).
+Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+"""
+import csv, json, sys, collections
+
+
+def per_kernel(path, counter):
+    tot = collections.defaultdict(float)
+    cnt = collections.defaultdict(int)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        tot[r["Kernel_Name"]] += float(r["Counter_Value"])
+        cnt[r["Kernel_Name"]] += 1
+    return tot, cnt
+
+
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+def main():
+    f, fc = per_kernel(sys.argv[1], "FETCH_SIZE")
+    w, wc = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {"_about": __doc__.strip()}
+    rows = []
+    for k in f:
+        n = fc[k]
+        fetch = 2.0 * 1024.0 * f[k] / n
+        write = 1024.0 * w.get(k, 0.0) / max(wc.get(k, 1), 1)
+        rows.append((fetch * n + write * n, k, n, fetch, write))
+    rows.sort(reverse=True)
+    for _, k, n, fetch, write in rows:
+        out[short(k)] = {"launches_profiled": n, "fetch_bytes_per_launch": int(fetch), "write_bytes_per_launch": int(write),
+                         "hbm_bytes_per_launch": int(fetch + write)}
+    # the same numbers under bench.py's variant keys (nn/tn + tile width + fused SiLU), launch-weighted
+    import re
+    variants = {"fp32": {}, "x3": {}}
+    for _, k, n, fetch, write in rows:
+        name = short(k)
+        m = re.match(r"cn_gemm::cn_gemm_kernel<(\w+), (\w+), (\d+), (\w+), (\w+), (\w+), (\d)>", name)
+        mode = "fp32"
+        if m:
+            a_ks, b_ks, bn, a_act, b_act, _fast, prec = m.groups()
+            if prec != "0":
+                mode = "x3"
+        else:
+            m2 = re.match(r"cn_gemm::cn_gemm_x3(nn|tn)_kernel<(\w+), (\w+)>", name)
+            if not m2 or m2.group(3) == "true":
+                continue
+            mode = "x3"
+            a_ks, bn = ("true" if m2.group(1) == "tn" else "false"), "256"
+            a_act = m2.group(2) if m2.group(1) == "nn" else "false"
+            b_act = m2.group(2) if m2.group(1) == "tn" else "false"
+        key = ("tn" if a_ks == "true" else "nn") + bn + ("+silu(A)" if a_act == "true" else "") + \
+              ("+silu(B)" if b_act == "true" else "")
+        v = variants[mode].setdefault(key, {"launches_profiled": 0, "fetch": 0.0, "write": 0.0})
+        v["launches_profiled"] += n
+        v["fetch"] += fetch * n
+        v["write"] += write * n
+    for mode in variants:
+        for key, v in variants[mode].items():
+            n = v["launches_profiled"]
+            variants[mode][key] = {"launches_profiled": n, "fetch_bytes_per_launch": int(v["fetch"] / n),
+                                   "write_bytes_per_launch": int(v["write"] / n),
+                                   "hbm_bytes_per_launch": int((v["fetch"] + v["write"]) / n)}
+    out["variants"] = variants
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for _, k, n, fetch, write in rows[:16]:
+        print(f"{short(k)[:70]:70s} n={n:4d} fetch {fetch/1e6:8.1f} MB write {write/1e6:8.1f} MB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+"""Copy the outputs of tools/collect_profiles.sh (gpurun_out/prof_<tag>/) into profiles/ and write the summary.
+Usage: python tools/publish_profiles.py gpurun_out/prof_r01b r01"""
+import glob, json, os, shutil, subprocess, sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+fetch = glob.glob(os.path.join(src, "fetch", "*", "*_counter_collection.csv"))[0]
+write = glob.glob(os.path.join(src, "write", "*", "*_counter_collection.csv"))[0]
+shutil.copy(stats, os.path.join(dst, f"{tag}_bench_n1_kernel_stats.csv"))
+shutil.copy(fetch, os.path.join(dst, f"{tag}_pmc_fetch_size.csv"))
+shutil.copy(write, os.path.join(dst, f"{tag}_pmc_write_size.csv"))
+shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, f"{tag}_bench_n1_under_rocprof.json"))
+shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, f"{tag}_bench_n1.json"))
+subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), fetch, write,
+                os.path.join(dst, "traffic.json")], check=True, stdout=subprocess.DEVNULL)
+table = subprocess.run([sys.executable, os.path.join(root, "tools", "summarize_stats.py"), stats, "36"],
+                       check=True, capture_output=True, text=True).stdout
+under = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+plain = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
+rf = plain["roofline"]
+traffic = json.load(open(os.path.join(dst, "traffic.json")))
+import csv
+rows = list(csv.DictReader(open(stats)))
+dom = next(r for r in rows if "cn_gemm_kernel<false, true, 256, false, false, true, 0>" in r["Name"])
+md = f"""# Round 1 — rocprofv3 `--kernel-trace --stats` of the default bench command (1x MI355X)
+
+Command (on the GPU box, `tools/collect_profiles.sh`): `cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d <out> -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline`
+
+Files: `{tag}_bench_n1_kernel_stats.csv` (raw per-kernel stats), `{tag}_bench_n1_under_rocprof.json` (the bench line printed under the profiler),
+`{tag}_bench_n1.json` (un-profiled default run incl. `cpu_baseline`), `{tag}_pmc_fetch_size.csv` / `{tag}_pmc_write_size.csv` (separate `--pmc FETCH_SIZE` /
+`--pmc WRITE_SIZE` passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer`) and `traffic.json` (HBM bytes per launch per kernel derived from them by
+`tools/pmc_traffic.py`: FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is).
+
+The profiled process runs, in this order: 13 fp32-MFMA training steps on two streams (3 warm-up + 10 timed), 3 single-stream fp32 steps (the `roofline.isolated` pass) and
+12 bf16x3 steps (2 + 10, the `bf16x3` object of the bench line); kernel names tell the two GEMM families apart (`cn_gemm_kernel<..., 0>` = fp32 MFMA, `cn_gemm_x3nn/x3tn_kernel` = bf16x3).
+
+Bench line under the profiler: {under['value']} graphs/s, {under['ms_per_step']} ms/step (bf16x3 pass: {under['bf16x3']['value']} graphs/s, {under['bf16x3']['ms_per_step']} ms/step).
+Un-profiled: {plain['value']} graphs/s, {plain['ms_per_step']} ms/step; bf16x3 pass {plain['bf16x3']['value']} graphs/s, {plain['bf16x3']['ms_per_step']} ms/step; cpu_baseline {plain['cpu_baseline']['value']} graphs/s on {plain['cpu_baseline']['cores']} threads.
+
+Dominant kernel `cn_gemm_kernel variant nn256` = `cn_gemm_kernel<false, true, 256, false, false, true, 0>`: HIP events inside bench.py give {rf['avg_launch_us']} us per launch over the
+overlapped timed steps ({rf['achieved']} TFLOP/s, {rf['frac']} of the fp32 matrix peak) and {rf['isolated']['avg_launch_us']} us isolated ({rf['isolated']['achieved']} TFLOP/s, {rf['isolated']['frac']});
+rocprofv3 reports {float(dom['AverageNs'])/1e3:.1f} us averaged over all {dom['Calls']} launches of the process (timed + warm-up + isolated steps).  HBM traffic of that variant from the
+PMC passes: {traffic['variants']['fp32']['nn256']['hbm_bytes_per_launch']/1e6:.0f} MB per launch (bf16x3 kernel on the same launches: {traffic['variants']['x3']['nn256']['hbm_bytes_per_launch']/1e6:.0f} MB).
+
+Backward runs on two streams, so kernel durations of the two streams overlap in wall time (their sum exceeds the step time).
+
+{table}
+"""
+open(os.path.join(dst, f"{tag}_bench_n1_summary.md"), "w").write(md)
+print(md[:1500])
