@@ -223,7 +223,7 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
   }
   CN_CHECK(a.precision >= 0 && a.precision <= 2, "cartnet_gemm: precision=%d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = bf16)",
            a.precision);
-  if (a.precision >= 1 && a.nsegs > 1 && a.b_split_folded && a.N == cn_gemm::X3_BN && !a.a_kstrided && a.b_kstrided &&
+  if (a.nsegs > 1 && a.b_split_folded && a.N == cn_gemm::X3_BN && !a.a_kstrided && a.b_kstrided &&
       a.splitk == 1 && a.ngroups == 1 && a.M > 0) {
     // K-segments that are adjacent column blocks of one matrix: one product over the concatenated K.  Folded only when
     // the pre-split kernel is certain to take the launch (B[0] alone does not describe the folded operand).

@@ -662,6 +662,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_kernel(const CartnetGemmA
 // gemm_x3.hip
 void launch_x3nn(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
 void launch_x3tn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
+// gemm_f32.hip
+void launch_f32nn(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
 
 template <bool A_KS, bool B_KS, int BN, bool A_ACT, bool B_ACT>
 void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
@@ -692,6 +694,18 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
         if (fl.x3 == 1) {   // first-generation kernel (both operands split in flight); precision 2 has no such form
           hipLaunchKernelGGL((cn_gemm_kernel<A_KS, B_KS, BN, A_ACT, B_ACT, true, 1>), dim3(nm * tiles_n, ns, a.ngroups),
                              dim3(NTHREADS), 0, st, a, fl);
+          return;
+        }
+      }
+    }
+    // fp32 MFMA with a pre-packed weight operand: second-generation kernel (gemm_f32.h)
+    if constexpr (FAST && BN == 256 && B_KS && !A_KS) {
+      if (!fl.x3) {
+        bool prepacked = fl.wide && a.splitk == 1 && m0 == 0 && a.nsegs == 1 && (double)a.M * a.lda * 4.0 < 4294967296.0;
+        const int nptr = a.ngroups > 1 ? a.ngroups : a.nsegs;
+        for (int i = 0; i < nptr; ++i) prepacked = prepacked && a.b_split[i] != nullptr;
+        if (prepacked) {
+          launch_f32nn(A_ACT, a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
           return;
         }
       }

@@ -132,7 +132,7 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
     w.gate2T[l] = c.take<float>((size_t)D * D);
     w.aggr2T[l] = c.take<float>((size_t)D * D);
   }
-  if (m.gemm_precision >= 1 && D % 256 == 0) {
+  if (D % 256 == 0) {   // pre-arranged weight images (bf16 planes at precision 1 / 2, fp32 rows at precision 0; sized for the larger)
     const size_t blk = cartnet_gemm_split_b_bytes(D, D);          // one D x D block
     w.i_edge2 = c.take<char>(cartnet_gemm_split_b_bytes(2 * D, D));
     w.i_atom = c.take<char>(cartnet_gemm_split_b_bytes(2 * D, D));
@@ -200,6 +200,11 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
   }
   *total = align_up(c.off);
   return w;
+}
+
+// bytes of one D x D weight image at the model's GEMM precision (images of a folded operand sit back to back)
+inline size_t img_blk(const CartnetModel& m) {
+  return m.gemm_precision == 0 ? cartnet_gemm_pack_b_bytes(m.D, m.D) : cartnet_gemm_split_b_bytes(m.D, m.D);
 }
 
 thread_local int g_precision = 0;   // set per call from CartnetModel.gemm_precision
@@ -343,7 +348,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
   // B = W: stride_k ld, stride_n 1)
   if (w.i_edge2) {
     std::vector<const float*> src; std::vector<void*> dst; std::vector<int32_t> Ks, Ns, sk, sn;
-    const size_t blk = cartnet_gemm_split_b_bytes(D, D);
+    const size_t blk = img_blk(m);
     auto fwd = [&](const float* W, int ld, int K_, int N_, char* img) {
       src.push_back(W); dst.push_back(img); Ks.push_back(K_); Ns.push_back(N_); sk.push_back(1); sn.push_back(ld);
     };
@@ -379,7 +384,10 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
         bwd(q.aggr0_w + D, 3 * D, D, D, w.i_dx[l] + 3 * blk);
       }
     }
-    RUN(cartnet_gemm_split_b(src.data(), dst.data(), Ks.data(), Ns.data(), sk.data(), sn.data(), (int32_t)src.size(), st));
+    if (m.gemm_precision == 0)
+      RUN(cartnet_gemm_pack_b(src.data(), dst.data(), Ks.data(), Ns.data(), sk.data(), sn.data(), (int32_t)src.size(), st));
+    else
+      RUN(cartnet_gemm_split_b(src.data(), dst.data(), Ks.data(), Ns.data(), sk.data(), sn.data(), (int32_t)src.size(), st));
   }
 
   // ---- encoder, edges (cartnet.py:159)
@@ -419,7 +427,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       CartnetGemmArgs a = gemm_args(N, D, D, D, D, 4 * D);
       a.ngroups = 4; a.b_kstrided = 1;
       const float* Bt[4] = {w.gate0T[l], w.aggr0T[l], w.gate0T[l] + (size_t)D * D, w.aggr0T[l] + (size_t)D * D};
-      const size_t blk = cartnet_gemm_split_b_bytes(D, D);
+      const size_t blk = img_blk(m);
       for (int g = 0; g < 4; ++g) {
         a.A[g] = x; a.B[g] = Bt[g]; a.C[g] = w.Pn + (size_t)g * D;
         if (w.i_pn[l]) a.b_split[g] = w.i_pn[l] + g * blk;
@@ -435,7 +443,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       a.C[0] = w.pre[l]; a.C[1] = w.pre[l] + D;
       a.gather_i[0] = w.Pn; a.gather_i[1] = w.Pn + D; a.gather_j[0] = w.Pn + 2 * D; a.gather_j[1] = w.Pn + 3 * D;
       a.ldg = 4 * D; a.tgt = w.tgt32; a.src = w.src32;
-      if (w.i_pre[l]) { a.b_split[0] = w.i_pre[l]; a.b_split[1] = w.i_pre[l] + cartnet_gemm_split_b_bytes(D, D); }
+      if (w.i_pre[l]) { a.b_split[0] = w.i_pre[l]; a.b_split[1] = w.i_pre[l] + img_blk(m); }
       RUN(cartnet_gemm(&a, st));
     }
     {  // gs = silu(pre) W2^T + b2, BatchNorm statistics of the gate half
@@ -444,7 +452,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       a.A[0] = w.pre[l]; a.A[1] = w.pre[l] + D; a.B[0] = w.gate2T[l]; a.B[1] = w.aggr2T[l];
       a.C[0] = w.gs[l]; a.C[1] = w.gs[l] + D; a.bias[0] = q.gate2_b; a.bias[1] = q.aggr2_b;
       a.colsum[0] = w.cs; a.colsq[0] = w.cq;
-      if (w.i_gs[l]) { a.b_split[0] = w.i_gs[l]; a.b_split[1] = w.i_gs[l] + cartnet_gemm_split_b_bytes(D, D); }
+      if (w.i_gs[l]) { a.b_split[0] = w.i_gs[l]; a.b_split[1] = w.i_gs[l] + img_blk(m); }
       RUN(cartnet_gemm(&a, st));
     }
     RUN(cartnet_bn_finalize(w.cs, w.cq, w.tiles_e, b.E, D, m.bn_eps, m.bn_momentum, training, m.buf[l].norm_mean,
@@ -641,7 +649,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       a.A[0] = gs; a.A[1] = gs + D; a.B[0] = q.gate2_w; a.B[1] = q.aggr2_w;
       a.C[0] = dpre; a.C[1] = dpre + D; a.dact[0] = pre; a.dact[1] = pre + D; a.ldd = 2 * D;
       a.colsum[0] = w.csg[par]; a.colsum[1] = w.csa[par];
-      if (w.i_dpre[l]) { a.b_split[0] = w.i_dpre[l]; a.b_split[1] = w.i_dpre[l] + cartnet_gemm_split_b_bytes(D, D); }
+      if (w.i_dpre[l]) { a.b_split[0] = w.i_dpre[l]; a.b_split[1] = w.i_dpre[l] + img_blk(m); }
       RUN(cartnet_gemm(&a, st));
     }
     FORK();

@@ -115,6 +115,10 @@ PROTOTYPES = {
     "cartnet_gemm_split_b": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32,
                                        c_stream]),
+    "cartnet_gemm_pack_b_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "cartnet_gemm_pack_b": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32,
+                                      c_stream]),
     "cartnet_splitk_reduce": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, c_stream]),
     "cartnet_colsum_finalize": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32,

@@ -121,7 +121,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
         b_split = _aslist(b_split, nptr)
         if len(b_split) != nptr or not b_kstrided or a_kstrided:
             raise ValueError("gemm: b_split needs one image per B operand, b_kstrided=True and a_kstrided=False")
-        need = int(lib.cartnet_gemm_split_b_bytes(int(K), int(N)))
+        need = int((lib.cartnet_gemm_pack_b_bytes if precision == 0 else lib.cartnet_gemm_split_b_bytes)(int(K), int(N)))
         for i, t in enumerate(b_split):
             if t is None:
                 continue
@@ -187,10 +187,17 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
     _l.check(lib.cartnet_gemm(C.byref(args), _l.stream_ptr()), "cartnet_gemm")
 
 
-def split_b(mats: Sequence[Tensor]) -> list:
+def pack_b(mats: Sequence[Tensor]) -> list:
+    """fp32 images (cartnet_gemm_pack_b) of k-strided GEMM operands for precision-0 calls; see split_b."""
+    return split_b(mats, _fp32=True)
+
+
+def split_b(mats: Sequence[Tensor], _fp32: bool = False) -> list:
     """bf16x3 pre-split images (cartnet_gemm_split_b) of k-strided GEMM operands: each entry is a 2-D fp32 view
     B [K, N] with arbitrary strides (``W.t()`` of a weight W [out, in] gives the forward operand)."""
     lib = _l.load()
+    fn_bytes = lib.cartnet_gemm_pack_b_bytes if _fp32 else lib.cartnet_gemm_split_b_bytes
+    fn = lib.cartnet_gemm_pack_b if _fp32 else lib.cartnet_gemm_split_b
     mats = list(mats)
     outs = []
     n = len(mats)
@@ -201,7 +208,7 @@ def split_b(mats: Sequence[Tensor]) -> list:
         if m.dim() != 2 or m.dtype != torch.float32 or not m.is_cuda:
             raise ValueError(f"split_b[{i}]: expected a 2-D fp32 CUDA tensor")
         K, N = int(m.shape[0]), int(m.shape[1])
-        nbytes = int(lib.cartnet_gemm_split_b_bytes(K, N))
+        nbytes = int(fn_bytes(K, N))
         if nbytes == 0:
             raise ValueError(f"split_b[{i}]: K={K} must be a multiple of 16 and N={N} of 256")
         out = torch.empty(nbytes, dtype=torch.uint8, device=m.device)
@@ -209,7 +216,7 @@ def split_b(mats: Sequence[Tensor]) -> list:
         src[i], dst[i] = m.data_ptr(), out.data_ptr()
         Ks[i], Ns[i], sk[i], sn[i] = K, N, int(m.stride(0)), int(m.stride(1))
     if n:
-        _l.check(lib.cartnet_gemm_split_b(src, dst, Ks, Ns, sk, sn, n, _l.stream_ptr()), "cartnet_gemm_split_b")
+        _l.check(fn(src, dst, Ks, Ns, sk, sn, n, _l.stream_ptr()), "cartnet_gemm_split_b / pack_b")
     return outs
 
 

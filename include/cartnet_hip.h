@@ -79,9 +79,11 @@ typedef struct CartnetGemmArgs {
                           fp32 storage -- the reduced-precision mode of BASELINE configs[2]; only the pre-split /
                           transposing-read kernels implement it (256-wide tiles), every other shape runs precision 0. */
   const void* b_split[CARTNET_MAX_GROUPS];
-                       /* optional, precision 1 with b_kstrided = 1 and a_kstrided = 0: B[i] pre-split into bf16 planes
-                          by cartnet_gemm_split_b (the weight operand, split once per step instead of once per
-                          tile); B[i] must still be given (fallback paths read it). */
+                       /* optional, b_kstrided = 1 and a_kstrided = 0: B[i] pre-arranged as the kernel's LDS image --
+                          by cartnet_gemm_split_b for precision 1 / 2 (bf16 planes; the weight operand is split once
+                          per step instead of once per tile), by cartnet_gemm_pack_b for precision 0 (fp32 rows of
+                          16 k + pad).  The image must match the precision of the call.  B[i] must still be given
+                          (fallback paths read it). */
   const void* b_split_folded;
                        /* optional, nsegs > 1 and N == 256: the segments' images one after the other (segment order).
                           Used when the A segments are adjacent column blocks of one matrix (A[s] == A[0] + s*K):
@@ -96,6 +98,10 @@ int cartnet_gemm(const CartnetGemmArgs* args, void* stream);
  * [256][16] bf16 in the kernel's LDS order.  K % 16 == 0 and N % 256 == 0; dst: cartnet_gemm_split_b_bytes(K, N)
  * = 6*K*N bytes (0 when the shape has no such image), 16-byte aligned.  njobs matrices per call (host arrays). */
 size_t cartnet_gemm_split_b_bytes(int32_t K, int32_t N);
+/* The precision-0 counterpart: fp32 image (per 256-column tile and K-step [256][16 + 4 pad] floats), 5*K*N bytes. */
+size_t cartnet_gemm_pack_b_bytes(int32_t K, int32_t N);
+int cartnet_gemm_pack_b(const float* const* src, void* const* dst, const int32_t* K, const int32_t* N,
+                        const int32_t* stride_k, const int32_t* stride_n, int32_t njobs, void* stream);
 int cartnet_gemm_split_b(const float* const* src, void* const* dst, const int32_t* K, const int32_t* N,
                          const int32_t* stride_k, const int32_t* stride_n, int32_t njobs, void* stream);
 

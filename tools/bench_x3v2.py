@@ -37,7 +37,9 @@ W = rnd(N, K) * 0.1               # weight [out, in]; forward operand B = W^T
 ref = A.double() @ W.double().t()
 Bt = W.t().contiguous()
 img = ops.split_b([W.t()])[0]
-for name, kw in (("fp32", dict(precision=0)), ("x3 v1", dict(precision=1)), ("x3 v2", dict(precision=1, b_split=img))):
+pimg = ops.pack_b([W.t()])[0]
+for name, kw in (("fp32", dict(precision=0)), ("fp32v2", dict(precision=0, b_split=pimg)), ("x3 v1", dict(precision=1)),
+                 ("x3 v2", dict(precision=1, b_split=img))):
     C = torch.zeros(M, N, device=dev)
     ops.gemm(A, Bt, C, b_kstrided=True, **kw)
     print(f"NN {name:6s} rel err vs fp64: {err(C, ref):.3e}")
@@ -45,6 +47,9 @@ ref2 = torch.nn.functional.silu(A.double()) @ W.double().t()
 C = torch.zeros(M, N, device=dev)
 ops.gemm(A, Bt, C, b_kstrided=True, a_act=True, precision=1, b_split=img)
 print(f"NN silu(A) x3 v2 rel err: {err(C, ref2):.3e}")
+C = torch.zeros(M, N, device=dev)
+ops.gemm(A, Bt, C, b_kstrided=True, a_act=True, precision=0, b_split=pimg)
+print(f"NN silu(A) fp32v2 rel err: {err(C, ref2):.3e}")
 # two K-segments, N = 512 (two column tiles), backward-style operand (B = W as [K=out, N=in])
 W2 = [rnd(256, 512) * 0.1 for _ in range(2)]
 A2 = [rnd(M, 256) for _ in range(2)]
@@ -83,13 +88,16 @@ gs = rnd(E, 2 * D)
 Wl = [rnd(D, D) * 0.05 for _ in range(4)]
 Wt = [w.t().contiguous() for w in Wl]
 im = ops.split_b([w.t() for w in Wl])
+pim = ops.pack_b([w.t() for w in Wl])
 out2 = torch.empty(E, 2 * D, device=dev)
 Nn = 12416
 Pn = rnd(Nn, 4 * D)
 tgt = torch.sort(torch.randint(0, Nn, (E,), generator=g)).values.to(torch.int32).to(dev)
 src = torch.randint(0, Nn, (E,), generator=g).to(torch.int32).to(dev)
 F2 = 2.0 * E * D * D * 2
-for name, kw0, kw1 in (("fp32", dict(precision=0), dict(precision=0)), ("x3v1", dict(precision=1), dict(precision=1)),
+for name, kw0, kw1 in (("fp32", dict(precision=0), dict(precision=0)),
+                       ("fp32v2", dict(precision=0, b_split=pim[:2]), dict(precision=0, b_split=pim[2:])),
+                       ("x3v1", dict(precision=1), dict(precision=1)),
                        ("x3v2", dict(precision=1, b_split=im[:2]), dict(precision=1, b_split=im[2:]))):
     timeit(lambda: ops.gemm([e, e], Wt[:2], [out2[:, :D], out2[:, D:]], b_kstrided=True, **kw0), F2, f"NN x2 plain {name}")
     timeit(lambda: ops.gemm([e, e], Wt[:2], [out2[:, :D], out2[:, D:]], b_kstrided=True,
