@@ -73,6 +73,14 @@ class ComformerConv_edge(nn.Module):
         self.bn_att, self.bn = nn.BatchNorm1d(c), nn.BatchNorm1d(c)
 
 
+_GEMM_PRECISION = [0]     # CartnetGemmArgs.precision of the running forward / backward (set from model.gemm_precision)
+
+
+def _gemm(*args, **kw):
+    """ops.gemm at the model's GEMM precision (0 fp32 MFMA, 1 bf16x3, 2 bf16; shapes without such a kernel run fp32)."""
+    return ops.gemm(*args, precision=_GEMM_PRECISION[0], **kw)
+
+
 def _e(shape, dev, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=dev)
 
@@ -96,10 +104,10 @@ def _wgrad(dY: List[torch.Tensor], X: List[torch.Tensor], outs: List[torch.Tenso
     tiles = len(dY) * ((M + 127) // 128) * ((N + 255) // 256 if N > 128 else 1)
     S = _split_k(K, tiles)
     if S == 1:
-        ops.gemm(dY, X, outs, a_kstrided=True, b_kstrided=True, b_act=b_act)
+        _gemm(dY, X, outs, a_kstrided=True, b_kstrided=True, b_act=b_act)
         return
     slabs = [_e((S * M, N), dY[0].device) for _ in dY]
-    ops.gemm(dY, X, slabs, a_kstrided=True, b_kstrided=True, b_act=b_act, splitk=S)
+    _gemm(dY, X, slabs, a_kstrided=True, b_kstrided=True, b_act=b_act, splitk=S)
     ops.splitk_reduce(slabs, S, outs)
 
 
@@ -119,11 +127,11 @@ class _Attention:
         S = seg_layout.N
         W1k, W1m = P[pre + ".key_update.0.weight"], P[pre + ".lin_msg_update.0.weight"]
         pr = _e((R, 2 * C), dev)
-        ops.gemm([ea, ea], [W1k[:, 2 * C:], W1m[:, 2 * C:]], [pr[:, :C], pr[:, C:]],
+        _gemm([ea, ea], [W1k[:, 2 * C:], W1m[:, 2 * C:]], [pr[:, :C], pr[:, C:]],
                  gather_i=[term_i[:, :C], term_i[:, C:]], gather_j=[term_j[:, :C], term_j[:, C:]], tgt=idx_i, src=idx_j)
         keyb = _e((R, 2 * C), dev)      # key' in the first half (second half unused: groups share a leading dim)
         gs = _e((R, 2 * C), dev)        # [alpha | msg]
-        ops.gemm([pr[:, :C], pr[:, C:]], [P[pre + ".key_update.2.weight"], P[pre + ".lin_msg_update.2.weight"]],
+        _gemm([pr[:, :C], pr[:, C:]], [P[pre + ".key_update.2.weight"], P[pre + ".lin_msg_update.2.weight"]],
                  [keyb[:, :C], gs[:, C:]], a_act=True,
                  bias=[P[pre + ".key_update.2.bias"], P[pre + ".lin_msg_update.2.bias"]])
         npart = ops.segment_nparts(S)
@@ -167,7 +175,7 @@ class _Attention:
                [G[pre + ".key_update.2.weight"], G[pre + ".lin_msg_update.2.weight"]], b_act=True)
         tiles = ops.gemm_tiles_m(R)
         csk, csm = _parts(tiles * C, dev), _parts(tiles * C, dev)
-        ops.gemm([gs[:, :C], gs[:, C:]], [P[pre + ".key_update.2.weight"], P[pre + ".lin_msg_update.2.weight"]],
+        _gemm([gs[:, :C], gs[:, C:]], [P[pre + ".key_update.2.weight"], P[pre + ".lin_msg_update.2.weight"]],
                  [pr[:, :C], pr[:, C:]], b_kstrided=True, dact=[pr[:, :C], pr[:, C:]], colsum=[csk, csm])   # pr = dpre
         G[pre + ".key_update.0.bias"], G[pre + ".lin_msg_update.0.bias"] = _e((C,), dev), _e((C,), dev)
         ops.colsum_finalize([csk, csm], tiles, [G[pre + ".key_update.0.bias"], G[pre + ".lin_msg_update.0.bias"]])
@@ -183,6 +191,8 @@ class _IComformerFunction(torch.autograd.Function):
         P: Dict[str, torch.Tensor] = dict(zip(model._param_names, params))
         B: Dict[str, torch.Tensor] = dict(model.named_buffers())
         need_grad = any(ctx.needs_input_grad)
+        ctx.gemm_precision = int(model.gemm_precision)
+        _GEMM_PRECISION[0] = ctx.gemm_precision
         C = model.dim_in
         dev = params[0].device
         z = batch.x
@@ -209,7 +219,7 @@ class _IComformerFunction(torch.autograd.Function):
             r = _e((n, C), dev)
             ops.rbf_expand(vals, B[cbuf], rbf_mod.gamma, r)
             pre = _e((n, C), dev)
-            ops.gemm(r, P[lin + ".weight"], pre, bias=P[lin + ".bias"])
+            _gemm(r, P[lin + ".weight"], pre, bias=P[lin + ".bias"])
             out = _e((n, C), dev)
             ops.eltwise(0, pre, None, out)
             sv[tag] = (r, pre)
@@ -232,22 +242,22 @@ class _IComformerFunction(torch.autograd.Function):
             p = f"att_layers.{l}"
             s = {}
             QKV = _e((N, 3 * C), dev)
-            ops.gemm([x, x, x], [P[p + ".lin_query.weight"], P[p + ".lin_key.weight"], P[p + ".lin_value.weight"]],
+            _gemm([x, x, x], [P[p + ".lin_query.weight"], P[p + ".lin_key.weight"], P[p + ".lin_value.weight"]],
                      [QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:]],
                      bias=[P[p + ".lin_query.bias"], P[p + ".lin_key.bias"], P[p + ".lin_value.bias"]])
             ea = _e((E, C), dev)
-            ops.gemm(e, P[p + ".lin_edge.weight"], ea, bias=P[p + ".lin_edge.bias"])
+            _gemm(e, P[p + ".lin_edge.weight"], ea, bias=P[p + ".lin_edge.bias"])
             W1k, W1m = P[p + ".key_update.0.weight"], P[p + ".lin_msg_update.0.weight"]
             k, v = QKV[:, C:2 * C], QKV[:, 2 * C:]
             KPi, KPj = _e((N, 2 * C), dev), _e((N, 2 * C), dev)      # [key | msg] node terms for target / source
-            ops.gemm([k, v, k, v], [W1k[:, :C], W1m[:, :C], W1k[:, C:2 * C], W1m[:, C:2 * C]],
+            _gemm([k, v, k, v], [W1k[:, :C], W1m[:, :C], W1k[:, C:2 * C], W1m[:, C:2 * C]],
                      [KPi[:, :C], KPi[:, C:], KPj[:, :C], KPj[:, C:]],
                      bias=[P[p + ".key_update.0.bias"], P[p + ".lin_msg_update.0.bias"], None, None])
             aggr = _Attention.forward(P, B, p, QKV[:, :C], KPi, KPj, lay.tgt, lay.src, ea, lay, E, training, s)
             tiles = ops.gemm_tiles_m(N)
             cs, cq = _parts(tiles * C, dev), _parts(tiles * C, dev)
             o = _e((N, C), dev)
-            ops.gemm(aggr, P[p + ".lin_concate.weight"], o, bias=P[p + ".lin_concate.bias"], colsum=cs, colsq=cq)
+            _gemm(aggr, P[p + ".lin_concate.weight"], o, bias=P[p + ".lin_concate.bias"], colsum=cs, colsq=cq)
             mr2 = _e((2 * C,), dev)
             ops.bn_finalize(cs, cq, tiles, N, C, BN_EPS, BN_MOMENTUM, training, B[p + ".bn.running_mean"],
                             B[p + ".bn.running_var"], B[p + ".bn.num_batches_tracked"], mr2)
@@ -261,24 +271,24 @@ class _IComformerFunction(torch.autograd.Function):
             p = "edge_update_layer"
             s = {}
             QKV = _e((E, 3 * C), dev)
-            ops.gemm([e, e, e], [P[p + ".lin_query.weight"], P[p + ".lin_key.weight"], P[p + ".lin_value.weight"]],
+            _gemm([e, e, e], [P[p + ".lin_query.weight"], P[p + ".lin_key.weight"], P[p + ".lin_value.weight"]],
                      [QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:]],
                      bias=[P[p + ".lin_query.bias"], P[p + ".lin_key.bias"], P[p + ".lin_value.bias"]])
             NL3 = NLt.view(Bg, 3 * C)
             KY, VY = _e((Bg, 3 * C), dev), _e((Bg, 3 * C), dev)
             for out, kind in ((KY, "key"), (VY, "value")):
-                ops.gemm([NL3[:, i * C:(i + 1) * C] for i in range(3)],
+                _gemm([NL3[:, i * C:(i + 1) * C] for i in range(3)],
                          [P[p + f".lin_{kind}_e{i + 1}.weight"] for i in range(3)],
                          [out[:, i * C:(i + 1) * C] for i in range(3)],
                          bias=[P[p + f".lin_{kind}_e{i + 1}.bias"] for i in range(3)])
             exy = _e((3 * E, C), dev)
-            ops.gemm(NA, P[p + ".lin_edge.weight"], exy)
+            _gemm(NA, P[p + ".lin_edge.weight"], exy)
             W1k, W1m = P[p + ".key_update.0.weight"], P[p + ".lin_msg_update.0.weight"]
             Ka = _e((E, 2 * C), dev)            # per-edge term   [key | msg]
-            ops.gemm([QKV[:, C:2 * C], QKV[:, 2 * C:]], [W1k[:, :C], W1m[:, :C]], [Ka[:, :C], Ka[:, C:]],
+            _gemm([QKV[:, C:2 * C], QKV[:, 2 * C:]], [W1k[:, :C], W1m[:, :C]], [Ka[:, :C], Ka[:, C:]],
                      bias=[P[p + ".key_update.0.bias"], P[p + ".lin_msg_update.0.bias"]])
             KYb = _e((Bg * 3, 2 * C), dev)      # per (crystal, lattice vector) term
-            ops.gemm([KY.view(Bg * 3, C), VY.view(Bg * 3, C)], [W1k[:, C:2 * C], W1m[:, C:2 * C]],
+            _gemm([KY.view(Bg * 3, C), VY.view(Bg * 3, C)], [W1k[:, C:2 * C], W1m[:, C:2 * C]],
                      [KYb[:, :C], KYb[:, C:]])
             aggr = _Attention.forward(P, B, p, QKV[:, :C], Ka, KYb, idx_edge, idx_gl, exy, seg3, 3 * E, training, s)
             bias3 = _e((1, C), dev)
@@ -286,7 +296,7 @@ class _IComformerFunction(torch.autograd.Function):
             tiles = ops.gemm_tiles_m(E)
             cs, cq = _parts(tiles * C, dev), _parts(tiles * C, dev)
             o = _e((E, C), dev)
-            ops.gemm(aggr, P[p + ".lin_concate.weight"], o, bias=bias3.view(C), colsum=cs, colsq=cq)
+            _gemm(aggr, P[p + ".lin_concate.weight"], o, bias=bias3.view(C), colsum=cs, colsq=cq)
             mr2 = _e((2 * C,), dev)
             ops.bn_finalize(cs, cq, tiles, E, C, BN_EPS, BN_MOMENTUM, training, B[p + ".bn.running_mean"],
                             B[p + ".bn.running_var"], B[p + ".bn.num_batches_tracked"], mr2)
@@ -305,7 +315,7 @@ class _IComformerFunction(torch.autograd.Function):
         # ---- Cholesky head (shared with CartNet)
         H = C // 2
         hid = _e((N, H), dev)
-        ops.gemm(x, P["cholesky.MLP.0.weight"], hid, bias=P["cholesky.MLP.0.bias"])
+        _gemm(x, P["cholesky.MLP.0.weight"], hid, bias=P["cholesky.MLP.0.bias"])
         M = int(batch.y.shape[0])
         idx = torch.empty(N, dtype=torch.int32, device=dev)
         ops.mask_index(batch.non_H_mask.contiguous(), idx, None)
@@ -321,6 +331,7 @@ class _IComformerFunction(torch.autograd.Function):
         sv = ctx.sv
         if sv is None:
             raise RuntimeError("iComformer backward called without saved state")
+        _GEMM_PRECISION[0] = ctx.gemm_precision
         ctx.sv = None
         P, model, lay = sv["P"], sv["model"], sv["lay"]
         N, E, Bg, training = sv["N"], sv["E"], sv["Bg"], sv["training"]
@@ -342,7 +353,7 @@ class _IComformerFunction(torch.autograd.Function):
         G["cholesky.MLP.0.weight"] = _e((H, C), dev)
         _wgrad([dhid], [sv["x_final"]], [G["cholesky.MLP.0.weight"]])
         dx = _e((N, C), dev)
-        ops.gemm(dhid, P["cholesky.MLP.0.weight"], dx, b_kstrided=True)
+        _gemm(dhid, P["cholesky.MLP.0.weight"], dx, b_kstrided=True)
 
         def softplus_bwd(p, s, dy, rows, x_in):
             """Backward of y = softplus(x_in + bn(o)): returns (d_o, d_residual)."""
@@ -366,7 +377,7 @@ class _IComformerFunction(torch.autograd.Function):
             _wgrad([dQKV[:, :C], dQKV[:, C:2 * C], dQKV[:, 2 * C:]], [inp, inp, inp],
                    [G[p + ".lin_query.weight"], G[p + ".lin_key.weight"], G[p + ".lin_value.weight"]])
             d_in = _e(tuple(inp.shape), dev)
-            ops.gemm([dQKV[:, :C], dQKV[:, C:2 * C], dQKV[:, 2 * C:]],
+            _gemm([dQKV[:, :C], dQKV[:, C:2 * C], dQKV[:, 2 * C:]],
                      [P[p + ".lin_query.weight"], P[p + ".lin_key.weight"], P[p + ".lin_value.weight"]], d_in,
                      b_kstrided=True, segments=True, resid=resid)
             return d_in
@@ -382,7 +393,7 @@ class _IComformerFunction(torch.autograd.Function):
             G[p + ".lin_concate.weight"] = _e((C, C), dev)
             _wgrad([d_o], [s["aggr"]], [G[p + ".lin_concate.weight"]])
             daggr = _e((N, C), dev)
-            ops.gemm(d_o, P[p + ".lin_concate.weight"], daggr, b_kstrided=True)
+            _gemm(d_o, P[p + ".lin_concate.weight"], daggr, b_kstrided=True)
             dQKV = _e((N, 3 * C), dev)
             dpre, dW1k, dW1m = _Attention.backward(P, G, p, daggr, QKV[:, :C], ea, lay, E, training, s, dQKV[:, :C])
             W1k, W1m = P[p + ".key_update.0.weight"], P[p + ".lin_msg_update.0.weight"]
@@ -390,14 +401,14 @@ class _IComformerFunction(torch.autograd.Function):
             dea = _e((E, C), dev)
             tiles = ops.gemm_tiles_m(E)
             cs = _parts(tiles * C, dev)
-            ops.gemm([dpre[:, :C], dpre[:, C:]], [W1k[:, 2 * C:], W1m[:, 2 * C:]], dea, b_kstrided=True, segments=True,
+            _gemm([dpre[:, :C], dpre[:, C:]], [W1k[:, 2 * C:], W1m[:, 2 * C:]], dea, b_kstrided=True, segments=True,
                      colsum=cs)
             G[p + ".lin_edge.bias"] = _e((C,), dev)
             ops.colsum_finalize(cs, tiles, G[p + ".lin_edge.bias"])
             G[p + ".lin_edge.weight"] = _e((C, C), dev)
             _wgrad([dea], [e_in], [G[p + ".lin_edge.weight"]])
             de = _e((E, C), dev)
-            ops.gemm(dea, P[p + ".lin_edge.weight"], de, b_kstrided=True)
+            _gemm(dea, P[p + ".lin_edge.weight"], de, b_kstrided=True)
             # node terms: reduce dpre over incoming (target) / outgoing (source) edges
             dKPi, dKPj = _e((N, 2 * C), dev), _e((N, 2 * C), dev)
             ops.segment_sum(dpre, lay.rowptr, None, dKPi)
@@ -405,9 +416,9 @@ class _IComformerFunction(torch.autograd.Function):
             k, v = QKV[:, C:2 * C], QKV[:, 2 * C:]
             _wgrad([dKPi[:, :C], dKPi[:, C:], dKPj[:, :C], dKPj[:, C:]], [k, v, k, v],
                    [dW1k[:, :C], dW1m[:, :C], dW1k[:, C:2 * C], dW1m[:, C:2 * C]])
-            ops.gemm([dKPi[:, :C], dKPj[:, :C]], [W1k[:, :C], W1k[:, C:2 * C]], dQKV[:, C:2 * C], b_kstrided=True,
+            _gemm([dKPi[:, :C], dKPj[:, :C]], [W1k[:, :C], W1k[:, C:2 * C]], dQKV[:, C:2 * C], b_kstrided=True,
                      segments=True)
-            ops.gemm([dKPi[:, C:], dKPj[:, C:]], [W1m[:, :C], W1m[:, C:2 * C]], dQKV[:, 2 * C:], b_kstrided=True,
+            _gemm([dKPi[:, C:], dKPj[:, C:]], [W1m[:, :C], W1m[:, C:2 * C]], dQKV[:, 2 * C:], b_kstrided=True,
                      segments=True)
             dx_in = linear3_bwd(p, dQKV, x_in, dres)
             return dx_in, de
@@ -426,18 +437,18 @@ class _IComformerFunction(torch.autograd.Function):
             G[p + ".lin_concate.weight"] = _e((C, C), dev)
             _wgrad([d_o], [s["aggr"]], [G[p + ".lin_concate.weight"]])
             daggr = _e((E, C), dev)
-            ops.gemm(d_o, P[p + ".lin_concate.weight"], daggr, b_kstrided=True)
+            _gemm(d_o, P[p + ".lin_concate.weight"], daggr, b_kstrided=True)
             dQKV = _e((E, 3 * C), dev)
             dpre, dW1k, dW1m = _Attention.backward(P, G, p, daggr, QKV[:, :C], exy, seg3, 3 * E, training, s,
                                                    dQKV[:, :C])
             W1k, W1m = P[p + ".key_update.0.weight"], P[p + ".lin_msg_update.0.weight"]
             # angle branch: d(exy) -> lin_edge (no bias) -> dNA
             dexy = _e((3 * E, C), dev)
-            ops.gemm([dpre[:, :C], dpre[:, C:]], [W1k[:, 2 * C:], W1m[:, 2 * C:]], dexy, b_kstrided=True, segments=True)
+            _gemm([dpre[:, :C], dpre[:, C:]], [W1k[:, 2 * C:], W1m[:, 2 * C:]], dexy, b_kstrided=True, segments=True)
             G[p + ".lin_edge.weight"] = _e((C, C), dev)
             _wgrad([dexy], [sv["NA"]], [G[p + ".lin_edge.weight"]])
             dNA = _e((3 * E, C), dev)
-            ops.gemm(dexy, P[p + ".lin_edge.weight"], dNA, b_kstrided=True)
+            _gemm(dexy, P[p + ".lin_edge.weight"], dNA, b_kstrided=True)
             # per-edge term (sum over the three lattice vectors) and per-(crystal, lattice vector) term
             dKa = _e((E, 2 * C), dev)
             ops.segment_sum(dpre, seg3.rowptr, None, dKa)
@@ -450,11 +461,11 @@ class _IComformerFunction(torch.autograd.Function):
             KYf, VYf = KY.view(Bg * 3, C), VY.view(Bg * 3, C)
             _wgrad([dKa[:, :C], dKa[:, C:]], [kx, vx], [dW1k[:, :C], dW1m[:, :C]])
             _wgrad([dKYb[:, :C], dKYb[:, C:]], [KYf, VYf], [dW1k[:, C:2 * C], dW1m[:, C:2 * C]])
-            ops.gemm(dKa[:, :C], W1k[:, :C], dQKV[:, C:2 * C], b_kstrided=True)
-            ops.gemm(dKa[:, C:], W1m[:, :C], dQKV[:, 2 * C:], b_kstrided=True)
+            _gemm(dKa[:, :C], W1k[:, :C], dQKV[:, C:2 * C], b_kstrided=True)
+            _gemm(dKa[:, C:], W1m[:, :C], dQKV[:, 2 * C:], b_kstrided=True)
             dKY, dVY = _e((Bg, 3 * C), dev), _e((Bg, 3 * C), dev)
-            ops.gemm(dKYb[:, :C], W1k[:, C:2 * C], dKY.view(Bg * 3, C), b_kstrided=True)
-            ops.gemm(dKYb[:, C:], W1m[:, C:2 * C], dVY.view(Bg * 3, C), b_kstrided=True)
+            _gemm(dKYb[:, :C], W1k[:, C:2 * C], dKY.view(Bg * 3, C), b_kstrided=True)
+            _gemm(dKYb[:, C:], W1m[:, C:2 * C], dVY.view(Bg * 3, C), b_kstrided=True)
             # lin_key_e{i} / lin_value_e{i} on the lattice-length features
             NL3 = sv["NLt"].view(Bg, 3 * C)
             dNL3 = _e((Bg, 3 * C), dev)
@@ -466,7 +477,7 @@ class _IComformerFunction(torch.autograd.Function):
                     ops.colsum(dT[:, sl], G[nm + ".bias"])
                     G[nm + ".weight"] = _e((C, C), dev)
                     _wgrad([dT[:, sl]], [NL3[:, sl]], [G[nm + ".weight"]])
-                ops.gemm([dKY[:, sl], dVY[:, sl]], [P[p + f".lin_key_e{i + 1}.weight"], P[p + f".lin_value_e{i + 1}.weight"]],
+                _gemm([dKY[:, sl], dVY[:, sl]], [P[p + f".lin_key_e{i + 1}.weight"], P[p + f".lin_value_e{i + 1}.weight"]],
                          dNL3[:, sl], b_kstrided=True, segments=True)
             de = linear3_bwd(p, dQKV, e_in, dres)
             return de, dNL3.view(Bg * 3, C), dNA
@@ -534,6 +545,7 @@ class iComformer(nn.Module):
         self.edge_update_layer = ComformerConv_edge(c)
         self.cholesky = Cholesky_head(c)
         self.validate_graph = False
+        self.gemm_precision = 0         # 0: fp32 MFMA.  1: bf16x3 split-operand MFMA.  2: plain bf16 operands
         self._param_names = [n for n, _ in self.named_parameters()]
 
     def forward(self, data):

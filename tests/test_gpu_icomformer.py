@@ -69,8 +69,10 @@ def test_train_step_gradients_and_bn_state_against_reference_golden(name):
                 assert int(sd_new[k[6:]]) == int(r), k
 
 
-def test_against_oracle_at_width_256():
-    """configs[4] width (C=256) on two small crystals: HIP path vs the fp64 oracle (forward and gradients)."""
+@pytest.mark.parametrize("precision", [0, 1])
+def test_against_oracle_at_width_256(precision):
+    """configs[4] width (C=256) on two small crystals: HIP path vs the fp64 oracle (forward and gradients), with the
+    fp32-MFMA and the bf16x3 GEMMs (same budget)."""
     from cartnet_amd.comformer import iComformer, make_icomformer_state_dict
     from cartnet_amd.data import Batch
     from cartnet_amd.synthetic import make_crystal
@@ -79,6 +81,7 @@ def test_against_oracle_at_width_256():
     sd = make_icomformer_state_dict(256, seed=7)
     m = iComformer(256)
     m.load_state_dict(sd)
+    m.gemm_precision = precision
     m = m.to("cuda:0").train()
     bb = _clone(b).to("cuda:0")
     pred, true = m(bb)
