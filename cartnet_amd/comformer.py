@@ -76,9 +76,30 @@ class ComformerConv_edge(nn.Module):
 _GEMM_PRECISION = [0]     # CartnetGemmArgs.precision of the running forward / backward (set from model.gemm_precision)
 
 
-def _gemm(*args, **kw):
-    """ops.gemm at the model's GEMM precision (0 fp32 MFMA, 1 bf16x3, 2 bf16; shapes without such a kernel run fp32)."""
-    return ops.gemm(*args, precision=_GEMM_PRECISION[0], **kw)
+_IMAGE_CACHE: Dict[tuple, tuple] = {}     # weight view -> (transposed copy, pre-split image); cleared every forward
+
+
+def _gemm(A, B, C_out, **kw):
+    """ops.gemm at the model's GEMM precision (0 fp32 MFMA, 1 bf16x3, 2 bf16; shapes without such a kernel run fp32).
+
+    At precision 1 / 2 a product Y = X W^T with the weight given as W [out, in] is handed over as the k-strided operand
+    W^T with its pre-split image (cartnet_gemm_split_b, once per weight per step): that is the form the bf16 kernels
+    implement."""
+    prec = _GEMM_PRECISION[0]
+    if prec > 0 and not kw.get("b_kstrided", False) and not kw.get("a_kstrided", False) and kw.get("splitk", 1) == 1:
+        Bs = list(B) if isinstance(B, (list, tuple)) else [B]
+        if all(w.shape[0] % 256 == 0 and w.shape[1] % 16 == 0 for w in Bs):
+            Bt, imgs = [], []
+            for w in Bs:
+                key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), prec)
+                if key not in _IMAGE_CACHE:
+                    _IMAGE_CACHE[key] = (w.t().contiguous(), ops.split_b([w.t()])[0])
+                t, im = _IMAGE_CACHE[key]
+                Bt.append(t)
+                imgs.append(im)
+            kw = dict(kw, b_kstrided=True, b_split=imgs)
+            return ops.gemm(A, Bt if isinstance(B, (list, tuple)) else Bt[0], C_out, precision=prec, **kw)
+    return ops.gemm(A, B, C_out, precision=prec, **kw)
 
 
 def _e(shape, dev, dtype=torch.float32):
@@ -193,6 +214,7 @@ class _IComformerFunction(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         ctx.gemm_precision = int(model.gemm_precision)
         _GEMM_PRECISION[0] = ctx.gemm_precision
+        _IMAGE_CACHE.clear()
         C = model.dim_in
         dev = params[0].device
         z = batch.x
