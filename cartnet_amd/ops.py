@@ -71,7 +71,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
          a_kstrided: bool = False, b_kstrided: bool = False, a_act: bool = False, b_act: bool = False,
          out_act: bool = False, segments: bool = False, bias=None, gather_i=None, gather_j=None, tgt=None, src=None,
          resid=None, dact=None, cpre=None, colsum=None, colsq=None, splitk: int = 1, precision: int = 0,
-         b_split=None) -> None:
+         b_split=None, b_split_folded=None) -> None:
     """C[g] = epilogue(sum_s opA(A[s]) @ opB(B[s])) on the fp32 matrix cores (see include/cartnet_hip.h).
 
     A / B / C_out: one tensor or a list.  With ``segments=False`` the lists are independent problems (groups) of
@@ -128,6 +128,12 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
             if need == 0 or t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous() or t.numel() < need:
                 raise ValueError(f"gemm b_split[{i}]: expected a contiguous uint8 CUDA tensor of {need} bytes")
             args.b_split[i] = t.data_ptr()
+    if b_split_folded is not None:
+        need = nsegs * int((lib.cartnet_gemm_pack_b_bytes if precision == 0 else lib.cartnet_gemm_split_b_bytes)(int(K), int(N)))
+        t = b_split_folded
+        if nsegs < 2 or need == 0 or t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous() or t.numel() < need:
+            raise ValueError(f"gemm b_split_folded: needs segments and a contiguous uint8 CUDA tensor of {need} bytes")
+        args.b_split_folded = t.data_ptr()
     for g in range(ngroups):
         if _ld(C_out[g]) != ldc:
             raise ValueError("gemm: outputs must share a leading dimension")

@@ -160,6 +160,50 @@ def test_gemm_rejects_bad_shapes(ops):
         ops.gemm(A.cpu(), rnd(12, 16), torch.empty(10, 12, device=dev()))
 
 
+# ---- second-generation kernels: pre-arranged weight images (gemm_f32.h / gemm_x3.h), every pipeline length
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("M,K,N,groups,act", [(1, 16, 256, 1, False), (127, 32, 256, 2, True), (128, 48, 512, 1, False),
+                                              (300, 64, 256, 4, False), (1000, 80, 256, 1, True),
+                                              (129, 256, 512, 2, False), (513, 512, 256, 1, True)])
+def test_gemm_with_weight_images(ops, precision, M, K, N, groups, act):
+    """Y[g] = (silu?)(X[g]) W[g]^T + b[g] through the DMA-fed kernels: K from one K-step (pipeline head only) to 32
+    (steady-state loop), ragged and single-row M, one and two column tiles, grouped launches."""
+    Xs = [rnd(M, K, seed=10 + g) for g in range(groups)]
+    Ws = [rnd(N, K, seed=20 + g, scale=0.1) for g in range(groups)]
+    bs = [rnd(N, seed=30 + g) for g in range(groups)]
+    Bt = [w.t().contiguous() for w in Ws]
+    imgs = (ops.pack_b if precision == 0 else ops.split_b)([w.t() for w in Ws])
+    Cs = [torch.full((M, N), float("nan"), device=dev()) for _ in range(groups)]
+    ops.gemm(Xs, Bt, Cs, b_kstrided=True, a_act=act, bias=bs, precision=precision, b_split=imgs)
+    for g in range(groups):
+        x = Xs[g].double()
+        ref = (silu64(x) if act else x) @ Ws[g].double().t() + bs[g].double()
+        assert rel_err(Cs[g], ref) < TOL, g
+
+
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_gemm_folded_segments_with_images(ops, precision):
+    """sum_s X[:, sK:(s+1)K] W_s: K-segments that are adjacent column blocks run as one product (b_split_folded); the
+    same call without the folded image must give the same numbers (segment form)."""
+    M, K, N, S = 700, 256, 256, 4
+    X = rnd(M, S * K, seed=1)
+    Ws = [rnd(K, N, seed=2 + s, scale=0.1) for s in range(S)]         # operands as [K, N] (backward form)
+    segs = [X[:, s * K:(s + 1) * K] for s in range(S)]
+    resid = rnd(M, N, seed=9)
+    ref = sum(a.double() @ w.double() for a, w in zip(segs, Ws)) + resid.double()
+    make = ops.pack_b if precision == 0 else ops.split_b
+    folded = torch.cat(make(Ws))
+    C1 = torch.empty(M, N, device=dev())
+    ops.gemm(segs, Ws, C1, b_kstrided=True, segments=True, resid=resid, precision=precision, b_split_folded=folded)
+    tol = TOL if precision < 2 else 2e-2
+    assert rel_err(C1, ref) < tol
+    if precision == 2:
+        assert rel_err(C1, ref) > 1e-6          # the bf16 kernel really ran
+    C2 = torch.empty(M, N, device=dev())
+    ops.gemm(segs, Ws, C2, b_kstrided=True, segments=True, resid=resid, precision=min(precision, 1))
+    assert rel_err(C2, ref) < TOL
+
+
 def test_colsum_finalize(ops):
     parts = rnd(37, 100, seed=1).double()
     out = torch.empty(100, device=dev())
