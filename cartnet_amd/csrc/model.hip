@@ -52,7 +52,7 @@ struct Work {
   float *gate0T[CARTNET_MAX_LAYERS], *aggr0T[CARTNET_MAX_LAYERS], *gate2T[CARTNET_MAX_LAYERS],
       *aggr2T[CARTNET_MAX_LAYERS];
   // bf16x3 pre-split weight images (gemm_precision == 1 and D % 256 == 0; else all null)
-  char *i_edge2, *i_atom, *i_edge2_b, *i_atom_b, *i_head0_b;
+  char *i_edge0, *i_edge2, *i_atom, *i_edge2_b, *i_atom_b, *i_head0_b;
   char *i_pn[CARTNET_MAX_LAYERS], *i_pre[CARTNET_MAX_LAYERS], *i_gs[CARTNET_MAX_LAYERS], *i_dpre[CARTNET_MAX_LAYERS],
       *i_de[CARTNET_MAX_LAYERS], *i_dx[CARTNET_MAX_LAYERS];
   // forward transients
@@ -73,7 +73,7 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
   const int D = m.D, L = m.L, H = m.D / 2;
   const size_t En = (size_t)(E > 0 ? E : 1), Nn = (size_t)(N > 0 ? N : 1);
   w.kf = m.invariant ? m.R : m.R + 3;
-  w.ldf = (w.kf + 3) / 4 * 4;
+  w.ldf = (w.kf + 15) / 16 * 16;   // K of the first edge Linear padded to whole K-steps (pad columns are zero)
   w.gparts = cartnet_gate_scatter_nparts(N);
   w.nparts_n = cartnet_node_nparts(N);
   w.tiles_e = tiles_m(E);
@@ -122,7 +122,7 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
   }
   w.hid = c.take<float>(Nn * H);
   w.p6 = c.take<float>((size_t)(M > 0 ? M : 1) * 6);
-  w.edge0T = c.take<float>((size_t)w.kf * 2 * D);
+  w.edge0T = c.take<float>((size_t)w.ldf * 2 * D);   // [ldf, 2D]: rows kf.. are zero
   w.edge2T = c.take<float>((size_t)2 * D * D);
   w.atomT = c.take<float>((size_t)2 * D * D);
   w.head0T = c.take<float>((size_t)D * H);
@@ -134,6 +134,7 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
   }
   if (D % 256 == 0) {   // pre-arranged weight images (bf16 planes at precision 1 / 2, fp32 rows at precision 0; sized for the larger)
     const size_t blk = cartnet_gemm_split_b_bytes(D, D);          // one D x D block
+    w.i_edge0 = c.take<char>(cartnet_gemm_split_b_bytes(w.ldf, 2 * D));
     w.i_edge2 = c.take<char>(cartnet_gemm_split_b_bytes(2 * D, D));
     w.i_atom = c.take<char>(cartnet_gemm_split_b_bytes(2 * D, D));
     for (int l = 0; l < L; ++l) {
@@ -331,6 +332,12 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       if (++n == 8) return flush();
       return 0;
     };
+    if (w.ldf > w.kf &&
+        hipMemsetAsync(w.edge0T + (size_t)w.kf * 2 * D, 0, sizeof(float) * (size_t)(w.ldf - w.kf) * 2 * D,
+                       (hipStream_t)st) != hipSuccess) {
+      cartnet_set_error("cartnet_model_forward: memset failed");
+      return 2;
+    }
     RUN(add(P.edge0_w, w.edge0T, 2 * D, w.kf));
     RUN(add(P.edge2_w, w.edge2T, D, 2 * D));
     RUN(add(P.atom_w, w.atomT, D, 2 * D));
@@ -355,6 +362,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     auto bwd = [&](const float* W, int ld, int K_, int N_, char* img) {
       src.push_back(W); dst.push_back(img); Ks.push_back(K_); Ns.push_back(N_); sk.push_back(ld); sn.push_back(1);
     };
+    bwd(w.edge0T, 2 * D, w.ldf, 2 * D, w.i_edge0);     // the zero-padded transposed copy is already [K, N]
     fwd(P.edge2_w, 2 * D, 2 * D, D, w.i_edge2);
     fwd(P.atom_w, 2 * D, 2 * D, D, w.i_atom);
     for (int l = 0; l < L; ++l) {
@@ -394,8 +402,9 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
   RUN(cartnet_edge_features(b.cart_dist, b.cart_dir, m.rbf_means, m.rbf_betas, b.E, m.R, m.invariant, m.radius,
                             m.env_radius, w.feat, w.ldf, w.env, st));
   {
-    CartnetGemmArgs a = gemm_args(E, 2 * D, w.kf, w.ldf, 2 * D, 2 * D);
+    CartnetGemmArgs a = gemm_args(E, 2 * D, w.ldf, w.ldf, 2 * D, 2 * D);
     a.A[0] = w.feat; a.B[0] = w.edge0T; a.C[0] = w.he_pre; a.bias[0] = P.edge0_b; a.b_kstrided = 1;
+    a.b_split[0] = w.i_edge0;
     RUN(cartnet_gemm(&a, st));
   }
   {
