@@ -710,17 +710,31 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
         }
       }
     }
-    // weight gradients (both operands k-strided): transposing-read bf16x3 kernel over whole 128-row tiles
-    if constexpr (FAST && BN == 256 && B_KS && A_KS && !A_ACT) {
-      if (fl.x3 && a.M % BM == 0 && a.nsegs == 1) {
-        launch_x3tn(B_ACT, a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
-        return;
-      }
-    }
     hipLaunchKernelGGL((cn_gemm_kernel<A_KS, B_KS, BN, A_ACT, B_ACT, FAST, 0>), dim3(nm * tiles_n, ns, a.ngroups),
                        dim3(NTHREADS), 0, st, a, fl);
   };
   auto round_up = [](int v) { return ((v + BK - 1) / BK) * BK; };
+  // weight gradients at precision 1 / 2: the transposing-read kernel takes every row tile (also a ragged last one)
+  // over the whole K-steps; a K tail (< 16 rows) is one more slab from the checked fp32 kernel
+  if constexpr (A_KS && B_KS && BN == 256 && !A_ACT) {
+    if (fl.x3 && fl.vecA && fl.vecB && a.nsegs == 1 && a.N % BN == 0 && a.M % 4 == 0 && a.M > 0 && a.K >= BK) {
+      const int K16x = (a.K / BK) * BK, tailx = a.K - K16x;
+      const int tiles_mx = cn_ceil_div(a.M, BM);
+      if (a.splitk == 1 && tailx == 0 && fl.wide) {
+        fl.tile_m0 = 0; fl.split0 = 0; fl.k_lo = 0; fl.k_hi = a.K; fl.kchunk = K16x;
+        launch_x3tn(B_ACT, a, fl, dim3(tiles_mx * tiles_n, 1, a.ngroups), st);
+        return;
+      }
+      if (a.splitk > 1) {
+        const int nfastx = tailx ? a.splitk - 1 : a.splitk;
+        fl.tile_m0 = 0; fl.split0 = 0; fl.k_lo = 0; fl.k_hi = K16x;
+        fl.kchunk = round_up(cn_ceil_div(K16x, nfastx));
+        launch_x3tn(B_ACT, a, fl, dim3(tiles_mx * tiles_n, nfastx, a.ngroups), st);
+        if (tailx) launch(std::false_type{}, 0, tiles_mx, nfastx, 1, K16x, a.K, BK);
+        return;
+      }
+    }
+  }
   // the predicate-free kernel covers ragged row tiles too when A is k-contiguous (row clamp in Stager::load)
   const bool fast_ok = fl.vecA && fl.vecB && (a.N % BN == 0) && (full_m > 0 || !A_KS) && a.M > 0;
   const int fast_m = A_KS ? full_m : full_m + rag_m;      // row tiles the predicate-free kernel takes

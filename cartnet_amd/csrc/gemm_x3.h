@@ -299,8 +299,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients: C[g] (+ split-K slabs) = A[g]^T @ (silu?)(B[g]), A fp32 [K, M] and B fp32 [K, N] row-major
-// (k-strided), reduction over the K rows (edges / atoms).  M % 128 == 0 handled per row tile, N == 256 per column
-// tile.  LDS tile: 3 planes of [16 k][ROWS] bf16 (k-major, exactly how the fp32 rows convert), the 64-byte chunks of
+// (k-strided), reduction over the K rows (edges / atoms).  128-row tiles of M (M % 4 == 0; a ragged last tile is
+// computed whole and stored up to M), 256-column tiles of N.  LDS tile: 3 planes of [16 k][ROWS] bf16 (k-major, exactly how the fp32 rows convert), the 64-byte chunks of
 // row k XOR-ed with k & 3 so that the four k-rows a transposing read touches fall on different banks.
 template <int ROWS>
 __device__ __forceinline__ int x3t_offset(int k, int col) {   // byte offset of element (k, col) in a plane
@@ -362,7 +362,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3tn_kernel(const Cartnet
   const float* __restrict__ Bb = p.B[g];
   const int ak = tid >> 5, ac = (tid & 31) * 4;
   const int bk0 = tid >> 6, bc = (tid & 63) * 4;          // second unit: k + 8
-  const float* a_ptr = Ab + (size_t)(kbeg + ak) * p.lda + row0 + ac;
+  // ragged last row tile (M % 128 != 0, M % 4 == 0): columns past M re-read the last four valid ones; the output rows
+  // they feed are never stored
+  const float* a_ptr = Ab + (size_t)(kbeg + ak) * p.lda + min(row0 + ac, p.M - 4);
   const float* b_ptr = Bb + (size_t)(kbeg + bk0) * p.ldb + col0 + bc;
   const size_t a_step = (size_t)BK * p.lda, b_step = (size_t)BK * p.ldb, b_half = (size_t)8 * p.ldb;
   const int a_lds = x3t_offset<BM>(ak, ac);
@@ -454,6 +456,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3tn_kernel(const Cartnet
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int grow = row0 + wm * S::WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (grow >= p.M) continue;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const int gcol = col0 + wn * S::WN + b * 32 + li;

@@ -60,7 +60,7 @@ struct Work {
   double *cs, *cq, *ps, *pq;
   // backward transients
   float *dhid, *head_parts, *head_tot, *dx[2], *de[2], *daggr, *sums1, *sums2, *dPn[2], *dpre[2], *dhe, *dx0, *seg_tmp,
-      *slabs;
+      *slabs, *e0wT;
   double *pa, *pb, *pc[2], *pd[2], *csg[2], *csa[2], *cs_misc[4];
   size_t slab_floats;
   int gparts, nparts_n, tiles_e, tiles_n;
@@ -195,6 +195,8 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
     mx(wgrad_slab_floats(4, N, D, D));
     mx(wgrad_slab_floats(1, E, D, 2 * D));
     mx(wgrad_slab_floats(1, E, 2 * D, w.kf));
+    mx(wgrad_slab_floats(1, E, w.ldf, 2 * D));
+    w.e0wT = c.take<float>((size_t)w.ldf * 2 * D);
     mx(wgrad_slab_floats(1, N, D, 2 * D));
     w.slab_floats = sl;
     w.slabs = c.take<float>(sl > 0 ? sl : 1);
@@ -737,7 +739,20 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     const float* dY2[1] = {w.dhe};
     const float* X2[1] = {w.feat};
     float* o2[1] = {G.edge0_w};
-    RUN(wgrad(dY2, 2 * D, X2, w.ldf, o2, w.kf, b.E, 2 * D, w.kf, 1, false, w, sw));
+    if (m.gemm_precision >= 1 && w.i_edge0) {
+      // bf16 kernels want 256-wide column tiles: compute the transpose, featT . dhe = dW0^T [ldf, 2D] (rows kf.. are the
+      // zero pad columns of feat), and write its first kf rows transposed into the gradient
+      const float* fT[1] = {w.feat};
+      const float* dh[1] = {w.dhe};
+      float* oT[1] = {w.e0wT};
+      RUN(wgrad(fT, w.ldf, dh, 2 * D, oT, 2 * D, b.E, w.ldf, 2 * D, 1, false, w, sw));
+      const float* tsrc[1] = {w.e0wT};
+      float* tdst[1] = {G.edge0_w};
+      const int32_t trows[1] = {w.kf}, tcols[1] = {2 * D}, tlds[1] = {2 * D}, tldd[1] = {w.kf};
+      RUN(cartnet_transpose(tsrc, tdst, trows, tcols, tlds, tldd, 1, sw));
+    } else {
+      RUN(wgrad(dY2, 2 * D, X2, w.ldf, o2, w.kf, b.E, 2 * D, w.kf, 1, false, w, sw));
+    }
   }
   {
     const float* dY[1] = {dx};

@@ -204,6 +204,24 @@ def test_gemm_folded_segments_with_images(ops, precision):
     assert rel_err(C2, ref) < TOL
 
 
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("E,M,N,splitk,act", [(5000, 80, 512, 8, False), (3001, 128, 256, 5, True), (777, 300, 256, 3, False),
+                                              (4096, 256, 512, 1, False)])
+def test_gemm_weight_gradient_ragged_rows(ops, precision, E, M, N, splitk, act):
+    """dW = dY^T (silu?)(X) with a ragged last row tile (M % 128 != 0), two column tiles, a K tail (E % 16 != 0) and
+    the un-split form, at both precisions (the transposing-read kernel takes all of them at precision 1)."""
+    dY, X = rnd(E, M, seed=3), rnd(E, N, seed=4)
+    ref = dY.double().t() @ (silu64(X.double()) if act else X.double())
+    out = torch.full((M, N), float("nan"), device=dev())
+    if splitk > 1:
+        slabs = torch.full((splitk * M, N), float("nan"), device=dev())
+        ops.gemm(dY, X, slabs, a_kstrided=True, b_kstrided=True, b_act=act, splitk=splitk, precision=precision)
+        ops.splitk_reduce(slabs, splitk, out)
+    else:
+        ops.gemm(dY, X, out, a_kstrided=True, b_kstrided=True, b_act=act, precision=precision)
+    assert rel_err(out, ref) < TOL
+
+
 def test_colsum_finalize(ops):
     parts = rnd(37, 100, seed=1).double()
     out = torch.empty(100, device=dev())
