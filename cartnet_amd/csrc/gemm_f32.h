@@ -186,3 +186,127 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
 }
 
 }  // namespace cn_gemm
+
+namespace cn_gemm {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients on the fp32 MFMA: C[g] (+ split-K slabs) = A[g]^T @ (silu?)(B[g]), A fp32 [K, M], B fp32 [K, N]
+// row-major, reduction over the K rows.  Both operand tiles ([16 k][128 m] and [16 k][256 n] fp32) are exactly what
+// the rows look like in memory, so BOTH are staged by direct-to-LDS DMA: no VGPR staging, no VALU, three LDS stages
+// (24 KB each) so that every tile has two K-steps to land; one barrier per K-step:
+//     s_waitcnt vmcnt(3)   this wave's three DMA pieces of step u have landed (step u+1's three stay in flight)
+//     s_barrier            everybody's have, and everybody is done reading stage (u+2) % 3 (used by step u-1)
+//     issue the DMA of step u+2 into that stage; read the fragments of step u; 32 MFMAs.
+// SiLU on the B operand is applied to the fragments (v_exp / v_rcp in the shadow of the 64-cycle MFMAs).
+constexpr int F32T_A_BYTES = BK * BM * 4;          // 8 KB
+constexpr int F32T_B_BYTES = BK * F32_BN * 4;      // 16 KB
+constexpr int F32T_STAGE = F32T_A_BYTES + F32T_B_BYTES;
+constexpr int F32T_NSTAGE = 3;
+
+template <bool B_ACT>
+__global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const CartnetGemmArgs p, const GemmFlags fl) {
+  using S = Shape<F32_BN>;
+  __shared__ __attribute__((aligned(16))) float smem[F32T_NSTAGE * F32T_STAGE / 4];
+  char* lds = reinterpret_cast<char*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / S::WGN, wn = wid % S::WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tiles_n = p.N / F32_BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int row0 = tile_m * BM, col0 = tile_n * F32_BN;
+  const int g = blockIdx.z;
+  const int split = fl.split0 + blockIdx.y;
+  const int kbeg = fl.k_lo + blockIdx.y * fl.kchunk;
+  const int kend = min(fl.k_hi, kbeg + fl.kchunk);
+  const int nsteps = (kend - kbeg) / BK;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // DMA pieces of 1 KB: wave w moves A rows 2w, 2w+1 (one piece) and B rows w, w+8 (two pieces)
+  const float* a_base = p.A[g] + (size_t)(kbeg + 2 * wid) * p.lda + row0;
+  const float* b_base = p.B[g] + (size_t)(kbeg + wid) * p.ldb + col0;
+  const unsigned a_voff = ((unsigned)(lane >> 5) * (unsigned)p.lda + (lane & 31) * 4) * 4u;
+  const unsigned b_voff = lane * 16;
+  const size_t a_step = (size_t)BK * p.lda, b_step = (size_t)BK * p.ldb, b_half = (size_t)8 * p.ldb;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  auto issue = [&](int v) {
+    const unsigned st = lds0 + (v % F32T_NSTAGE) * F32T_STAGE;
+    const float* sa = a_base + v * a_step;
+    const float* sb = b_base + v * b_step;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(st + wid * 1024), "v"(a_voff), "s"(sa) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(st + F32T_A_BYTES + wid * 1024), "v"(b_voff), "s"(sb) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(st + F32T_A_BYTES + (wid + 8) * 1024), "v"(b_voff), "s"(sb + b_half) : "memory", "m0");
+  };
+
+  if (nsteps > 0) {
+    issue(0);
+    if (nsteps > 1) issue(1);
+    for (int u = 0; u < nsteps; ++u) {
+      if (u + 1 < nsteps) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (u + 2 < nsteps) issue(u + 2);
+      const float* sA = reinterpret_cast<const float*>(lds + (u % F32T_NSTAGE) * F32T_STAGE);
+      const float* sB = sA + F32T_A_BYTES / 4;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        float af[2][4], bf[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = kg * 8 + 2 * j + lh;
+#pragma unroll
+          for (int a = 0; a < 2; ++a) af[a][j] = sA[k * BM + wm * S::WM + a * 32 + li];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const float v = sB[k * F32_BN + wn * S::WN + b * 32 + li];
+            bf[b][j] = B_ACT ? fast_silu(v) : v;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // the epilogue reuses the LDS
+    asm volatile("" ::: "memory");
+  }
+
+  if (p.splitk > 1) {   // raw partial slab
+    float* __restrict__ C = p.C[g] + (size_t)split * p.M * p.ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int grow = row0 + wm * S::WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int gcol = col0 + wn * S::WN + b * 32 + li;
+          C[(size_t)grow * p.ldc + gcol] = acc[a][b][r];
+        }
+      }
+    return;
+  }
+  const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
+                   (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);
+  epilogue_wide<F32_BN, -1>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem, kind);
+}
+
+}  // namespace cn_gemm

@@ -8,6 +8,11 @@ void launch_f32nn(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim
   else hipLaunchKernelGGL((cn_gemm_f32nn_kernel<false>), grid, dim3(NTHREADS), 0, st, a, fl);
 }
 
+void launch_f32tn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st) {
+  if (b_act) hipLaunchKernelGGL((cn_gemm_f32tn_kernel<true>), grid, dim3(NTHREADS), 0, st, a, fl);
+  else hipLaunchKernelGGL((cn_gemm_f32tn_kernel<false>), grid, dim3(NTHREADS), 0, st, a, fl);
+}
+
 }  // namespace cn_gemm
 
 namespace {

@@ -664,6 +664,7 @@ void launch_x3nn(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3
 void launch_x3tn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
 // gemm_f32.hip
 void launch_f32nn(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
+void launch_f32tn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
 
 template <bool A_KS, bool B_KS, int BN, bool A_ACT, bool B_ACT>
 void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
@@ -717,19 +718,27 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
   // weight gradients at precision 1 / 2: the transposing-read kernel takes every row tile (also a ragged last one)
   // over the whole K-steps; a K tail (< 16 rows) is one more slab from the checked fp32 kernel
   if constexpr (A_KS && B_KS && BN == 256 && !A_ACT) {
-    if (fl.x3 && fl.vecA && fl.vecB && a.nsegs == 1 && a.N % BN == 0 && a.M % 4 == 0 && a.M > 0 && a.K >= BK) {
+    // precision 0: the all-DMA fp32 kernel (gemm_f32.h), whole 128-row tiles only
+    // (SiLU on the B operand stays on the register-staged kernel at precision 0: applying it to the DMA-fed
+    //  fragments costs every wave 32 transcendental pairs per K-step in front of its MFMAs -- measured 15 % slower)
+    const bool tn_ok = fl.x3 ? (a.M % 4 == 0) : (a.M % BM == 0 && !B_ACT);
+    auto launch_tn = [&](dim3 grid) {
+      if (fl.x3) launch_x3tn(B_ACT, a, fl, grid, st);
+      else launch_f32tn(B_ACT, a, fl, grid, st);
+    };
+    if (tn_ok && fl.vecA && fl.vecB && a.nsegs == 1 && a.N % BN == 0 && a.M > 0 && a.K >= BK) {
       const int K16x = (a.K / BK) * BK, tailx = a.K - K16x;
       const int tiles_mx = cn_ceil_div(a.M, BM);
       if (a.splitk == 1 && tailx == 0 && fl.wide) {
         fl.tile_m0 = 0; fl.split0 = 0; fl.k_lo = 0; fl.k_hi = a.K; fl.kchunk = K16x;
-        launch_x3tn(B_ACT, a, fl, dim3(tiles_mx * tiles_n, 1, a.ngroups), st);
+        launch_tn(dim3(tiles_mx * tiles_n, 1, a.ngroups));
         return;
       }
       if (a.splitk > 1) {
         const int nfastx = tailx ? a.splitk - 1 : a.splitk;
         fl.tile_m0 = 0; fl.split0 = 0; fl.k_lo = 0; fl.k_hi = K16x;
         fl.kchunk = round_up(cn_ceil_div(K16x, nfastx));
-        launch_x3tn(B_ACT, a, fl, dim3(tiles_mx * tiles_n, nfastx, a.ngroups), st);
+        launch_tn(dim3(tiles_mx * tiles_n, nfastx, a.ngroups));
         if (tailx) launch(std::false_type{}, 0, tiles_mx, nfastx, 1, K16x, a.K, BK);
         return;
       }
