@@ -232,18 +232,32 @@ def main():
             if os.path.exists(tpath):
                 try:
                     tv = json.load(open(tpath)).get("variants", {}).get("fp32" if args.precision == 0 else "x3", {})
-                    traffic = tv.get(key, {}).get("hbm_bytes_per_launch")
+                    traffic = tv.get(key.split("[")[0], {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             # bf16x3 kernels retire an fp32 product with six bf16 MFMAs: their ceiling is the dense bf16 peak / 6
             peak = PEAK_FP32_MFMA_TFLOPS if args.precision == 0 else 2500.0 / 6.0
+            fam = "f32" if args.precision == 0 else "x3"
+            kernel_name = f"cn_gemm_{fam}{'tn' if key.startswith('tn') else 'nn'}_kernel"
+            # traffic.json aggregates every launch of the kernel template (all shapes): a per-launch average
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
                                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                               "kernel": f"cn_gemm_kernel variant {key}", "launches": d["launches"],
+                               "kernel": f"cartnet_gemm variant {key} ({kernel_name})", "launches": d["launches"],
                                "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                                "share_of_step": round(d["ms"] / (1e3 * dt), 3),
                                "all_gemm_variants_ms_per_step": {k: round(v["ms"] / args.steps, 3)
-                                                                 for k, v in sorted(summ.items())}}
+                                                                 for k, v in sorted(summ.items())
+                                                                 if v["ms"] / args.steps >= 0.05}}
+            # all launches of the same kernel template (every shape), for comparison with rocprofv3's per-kernel average
+            base = key.split("[")[0]
+            same = [v for k, v in summ.items() if k.split("[")[0] == base]
+            out["roofline"]["kernel_avg_launch_us_all_shapes"] = round(
+                1e3 * sum(v["ms"] for v in same) / max(1, sum(v["launches"] for v in same)), 2)
+            if isolated:
+                same_i = [v for k, v in isolated.items() if k.split("[")[0] == base]
+                if same_i:
+                    out["roofline"]["kernel_avg_launch_us_all_shapes_isolated"] = round(
+                        1e3 * sum(v["ms"] for v in same_i) / max(1, sum(v["launches"] for v in same_i)), 2)
             if key in isolated:
                 di = isolated[key]
                 achi = di["flops"] / (di["ms"] * 1e-3) / 1e12

@@ -160,8 +160,12 @@ extern "C" int cartnet_gemm(const CartnetGemmArgs* args, void* stream) {
   if (!g_prof_on || !args) return cartnet_gemm_impl(args, stream);
   GemmRecord r;
   const int bn = args->N > 128 ? 4 : (args->N > 64 ? 2 : 1);
+  // bit 8: the streamed dimension (rows of an activation x weight product, reduction length of a weight gradient) is
+  // edge-sized; bits 10..: the other inner dimension / 16 (K of an NN product, M of a weight gradient), capped
+  const long long streamed = args->a_kstrided ? args->K : args->M;
+  const int inner = args->a_kstrided ? args->M : args->K;
   r.variant = (args->a_kstrided ? 1 : 0) | (args->b_kstrided ? 2 : 0) | (args->a_act ? 4 : 0) | (args->b_act ? 8 : 0) |
-              (bn << 4);
+              (bn << 4) | (streamed >= 32768 ? 256 : 0) | ((inner > 4080 ? 255 : inner / 16) << 10);
   const int nptr = args->ngroups > 1 ? args->ngroups : args->nsegs;
   r.flops = 2.0 * args->M * args->N * (double)args->K * nptr;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -49,10 +49,14 @@ def main():
             if prec != "0":
                 mode = "x3"
         else:
+            m3 = re.match(r"cn_gemm::cn_gemm_f32(nn|tn)_kernel<(\w+)>", name)
             m2 = re.match(r"cn_gemm::cn_gemm_x3(nn|tn)_kernel<(\w+), (\w+)>", name)
-            if not m2 or m2.group(3) == "true":
+            if m3:
+                m2 = m3
+            elif not m2 or m2.group(3) == "true":
                 continue
-            mode = "x3"
+            else:
+                mode = "x3"
             a_ks, bn = ("true" if m2.group(1) == "tn" else "false"), "256"
             a_act = m2.group(2) if m2.group(1) == "nn" else "false"
             b_act = m2.group(2) if m2.group(1) == "tn" else "false"

@@ -23,7 +23,7 @@ rf = plain["roofline"]
 traffic = json.load(open(os.path.join(dst, "traffic.json")))
 import csv
 rows = list(csv.DictReader(open(stats)))
-dom = next(r for r in rows if "cn_gemm_kernel<false, true, 256, false, false, true, 0>" in r["Name"])
+dom = next(r for r in rows if "cn_gemm_f32nn_kernel<false>" in r["Name"])
 md = f"""# Round 1 — rocprofv3 `--kernel-trace --stats` of the default bench command (1x MI355X)
 
 Command (on the GPU box, `tools/collect_profiles.sh`): `cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d <out> -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline`
@@ -34,14 +34,17 @@ Files: `{tag}_bench_n1_kernel_stats.csv` (raw per-kernel stats), `{tag}_bench_n1
 `tools/pmc_traffic.py`: FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is).
 
 The profiled process runs, in this order: 13 fp32-MFMA training steps on two streams (3 warm-up + 10 timed), 3 single-stream fp32 steps (the `roofline.isolated` pass) and
-12 bf16x3 steps (2 + 10, the `bf16x3` object of the bench line); kernel names tell the two GEMM families apart (`cn_gemm_kernel<..., 0>` = fp32 MFMA, `cn_gemm_x3nn/x3tn_kernel` = bf16x3).
+12 bf16x3 steps (2 + 10, the `bf16x3` object of the bench line); kernel names tell the GEMM families apart (`cn_gemm_f32nn/f32tn_kernel`, `cn_gemm_kernel<..., 0>` = fp32 MFMA; `cn_gemm_x3nn/x3tn_kernel` = bf16x3).
 
 Bench line under the profiler: {under['value']} graphs/s, {under['ms_per_step']} ms/step (bf16x3 pass: {under['bf16x3']['value']} graphs/s, {under['bf16x3']['ms_per_step']} ms/step).
 Un-profiled: {plain['value']} graphs/s, {plain['ms_per_step']} ms/step; bf16x3 pass {plain['bf16x3']['value']} graphs/s, {plain['bf16x3']['ms_per_step']} ms/step; cpu_baseline {plain['cpu_baseline']['value']} graphs/s on {plain['cpu_baseline']['cores']} threads.
 
-Dominant kernel `cn_gemm_kernel variant nn256` = `cn_gemm_kernel<false, true, 256, false, false, true, 0>`: HIP events inside bench.py give {rf['avg_launch_us']} us per launch over the
+Dominant launch group `{rf['kernel']}` = kernel `cn_gemm_f32nn_kernel<false>` (the DMA-fed fp32-MFMA kernel of `csrc/gemm_f32.h`; the few launches of that variant without a
+weight image -- none in this model at D = 256 -- would run `cn_gemm_kernel<false, true, 256, ...>`): HIP events inside bench.py give {rf['avg_launch_us']} us per launch over the
 overlapped timed steps ({rf['achieved']} TFLOP/s, {rf['frac']} of the fp32 matrix peak) and {rf['isolated']['avg_launch_us']} us isolated ({rf['isolated']['achieved']} TFLOP/s, {rf['isolated']['frac']});
-rocprofv3 reports {float(dom['AverageNs'])/1e3:.1f} us averaged over all {dom['Calls']} launches of the process (timed + warm-up + isolated steps).  HBM traffic of that variant from the
+rocprofv3 reports {float(dom['AverageNs'])/1e3:.1f} us averaged over all {dom['Calls']} launches of that kernel in the process -- every shape it runs (the E-row layer GEMMs above,
+the small N-row node projections, the K = 80 first edge Linear) in the overlapped, warm-up and isolated steps alike; bench.py's average over the same set of shapes is
+{rf.get('kernel_avg_launch_us_all_shapes', 'n/a')} us in the overlapped timed steps and {rf.get('kernel_avg_launch_us_all_shapes_isolated', 'n/a')} us isolated (the process mixes 13 overlapped with 3 isolated fp32 steps).  HBM traffic of that variant from the
 PMC passes: {traffic['variants']['fp32']['nn256']['hbm_bytes_per_launch']/1e6:.0f} MB per launch (bf16x3 kernel on the same launches: {traffic['variants']['x3']['nn256']['hbm_bytes_per_launch']/1e6:.0f} MB).
 
 Backward runs on two streams, so kernel durations of the two streams overlap in wall time (their sum exceeds the step time).
