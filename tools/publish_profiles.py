@@ -15,6 +15,12 @@ shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, f"{
 shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, f"{tag}_bench_n1.json"))
 subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), fetch, write,
                 os.path.join(dst, "traffic.json")], check=True, stdout=subprocess.DEVNULL)
+mfma_csv = glob.glob(os.path.join(src, "mfma", "*", "*_counter_collection.csv"))
+mfma_table = ""
+if mfma_csv:
+    shutil.copy(mfma_csv[0], os.path.join(dst, f"{tag}_pmc_mfma_busy.csv"))
+    mfma_table = subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_mfma.py"), mfma_csv[0], "10"],
+                                check=True, capture_output=True, text=True).stdout
 table = subprocess.run([sys.executable, os.path.join(root, "tools", "summarize_stats.py"), stats, "36"],
                        check=True, capture_output=True, text=True).stdout
 under = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
@@ -50,6 +56,13 @@ PMC passes: {traffic['variants']['fp32']['nn256']['hbm_bytes_per_launch']/1e6:.0
 Backward runs on two streams, so kernel durations of the two streams overlap in wall time (their sum exceeds the step time).
 
 {table}
+
+## Matrix-pipe utilisation (`{tag}_pmc_mfma_busy.csv`: `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`, same command as the other PMC passes)
+
+Kernels run one at a time under the counter pass (no overlap between streams), so these are isolated figures; the clock column shows the chip
+sustaining ~2.3 GHz under the fp32 MFMA and ~2.0 GHz under the bf16 MFMA (the peaks in MI355X_MICROARCH.md are quoted at 2.4 GHz).
+
+{mfma_table}
 """
 open(os.path.join(dst, f"{tag}_bench_n1_summary.md"), "w").write(md)
 print(md[:1500])
