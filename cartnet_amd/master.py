@@ -20,4 +20,5 @@ def create_model():
         model = iComformer(dim_in=cfg.dim_in).to(getattr(cfg, "device", "cuda:0"))
     else:
         raise Exception("Model not implemented")
+    model.gemm_precision = int(getattr(cfg, "gemm_precision", 0))
     return model

@@ -67,6 +67,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--device", type=str, default="cuda:0")
     p.add_argument("--synthetic", type=int, default=32, help="number of synthetic crystals (80/10/10 split)")
     p.add_argument("--atoms", type=int, nargs=2, default=(30, 70), help="atoms per synthetic crystal: lo hi")
+    p.add_argument("--gemm_precision", type=int, default=0, choices=(0, 1, 2),
+                   help="GEMM arithmetic: 0 exact fp32 products (fp32 MFMA), 1 bf16x3 split operands (fp32-level "
+                        "accuracy on the bf16 MFMA), 2 plain bf16 operands")
     p.add_argument("--resident_dataset", action="store_true",
                    help="keep the splits as packed shards in HBM and build every batch (and its augmentation) on the GPU")
     return p
@@ -91,6 +94,7 @@ def fill_cfg(args) -> None:
     cfg.envelope, cfg.use_H, cfg.use_atom_types = args.disable_envelope, args.disable_H, args.disable_atom_types
     cfg.workers = args.workers
     cfg.device = args.device
+    cfg.gemm_precision = args.gemm_precision
 
 
 def create_loaders(args, rank: int, world: int):

@@ -47,3 +47,16 @@ def test_main_runs_icomformer(tmp_path, monkeypatch):
     res = entry.main(["--synthetic", "12", "--atoms", "10", "20", "--dim_in", "32", "--epochs", "2", "--batch", "3",
                       "--batch_accumulation", "1", "--name", "icf", "--model", "icomformer"])
     assert len(res["history"]) == 2 and res["history"][-1]["train_mae"] == res["history"][-1]["train_mae"]
+
+
+def test_main_at_width_256_with_bf16x3_gemms(tmp_path, monkeypatch):
+    """dim_in = 256 takes the DMA-fed kernels; --gemm_precision 1 must train to the same loss curve as precision 0
+    within the parity budget amplified by a few optimiser steps."""
+    import main as entry
+    monkeypatch.chdir(tmp_path)
+    common = ["--synthetic", "16", "--atoms", "20", "40", "--dim_in", "256", "--num_layers", "2", "--epochs", "2",
+              "--batch", "4", "--batch_accumulation", "1", "--lr", "1e-3"]
+    a = entry.main(common + ["--name", "p0"])
+    b = entry.main(common + ["--name", "p1", "--gemm_precision", "1"])
+    for ha, hb in zip(a["history"], b["history"]):
+        assert abs(ha["train_mae"] - hb["train_mae"]) < 1e-3 * abs(ha["train_mae"])
