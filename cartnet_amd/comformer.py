@@ -232,8 +232,10 @@ class _IComformerFunction(torch.autograd.Function):
         T = batch.temperature.contiguous()
         ops.node_embed(z, batch.batch, T, P["embedding.weight"], P["temperature_proj_atom.weight"],
                        P["temperature_proj_atom.bias"], None, x)
-        cell = batch.cell.contiguous()
+        equi_model = getattr(model, "kind", "i") == "e"
         edge_feat, nl, nc = _e((max(E, 1),), dev), _e((Bg * 3,), dev), _e((max(E, 1) * 3,), dev)
+        # edge_feat = -0.75 / dist for both models (comformer.py:59,117); the lattice terms are iComformer's only
+        cell = batch.cell.contiguous()
         ops.lattice_features(cell, batch.batch, lay.src, batch.cart_dist.contiguous(), batch.cart_dir.contiguous(),
                              edge_feat, nl, nc)
 
@@ -248,17 +250,19 @@ class _IComformerFunction(torch.autograd.Function):
             return out
 
         e = rbf_branch(edge_feat[:E], E, model.rbf[0], "rbf.0.centers", "rbf.1", "rbf_e")
-        NLt = rbf_branch(nl, Bg * 3, model.rbf[0], "rbf.0.centers", "rbf.1", "rbf_nl")           # [Bg*3, C]
-        NA = rbf_branch(nc[:3 * E], 3 * E, model.rbf_angle[0], "rbf_angle.0.centers", "rbf_angle.1", "rbf_na")  # [3E,C]
-        # index helpers for the edge layer: row r = 3*edge + lattice vector
-        ar3 = torch.arange(3 * E, device=dev, dtype=torch.int32)
-        idx_edge = torch.div(ar3, 3, rounding_mode="floor").to(torch.int32).contiguous()
-        g_of_e = batch.batch[batch.edge_index[0]].to(torch.int32)
-        idx_gl = (g_of_e.repeat_interleave(3) * 3 + ar3 % 3).to(torch.int32).contiguous()
-        ptr3 = (3 * torch.arange(E + 1, device=dev, dtype=torch.int32)).contiguous()
-        seg3 = ops.SegmentLayout(ptr3, 3 * E)
-        gedge_ptr = lay.rowptr[gptr.long()].contiguous()          # edge range of every crystal
-        sv.update(idx_edge=idx_edge, idx_gl=idx_gl, seg3=seg3, gedge_ptr=gedge_ptr, z=z, gid=batch.batch, T=T)
+        sv.update(z=z, gid=batch.batch, T=T, equi_model=equi_model)
+        if not equi_model:
+            NLt = rbf_branch(nl, Bg * 3, model.rbf[0], "rbf.0.centers", "rbf.1", "rbf_nl")           # [Bg*3, C]
+            NA = rbf_branch(nc[:3 * E], 3 * E, model.rbf_angle[0], "rbf_angle.0.centers", "rbf_angle.1", "rbf_na")
+            # index helpers for the edge layer: row r = 3*edge + lattice vector
+            ar3 = torch.arange(3 * E, device=dev, dtype=torch.int32)
+            idx_edge = torch.div(ar3, 3, rounding_mode="floor").to(torch.int32).contiguous()
+            g_of_e = batch.batch[batch.edge_index[0]].to(torch.int32)
+            idx_gl = (g_of_e.repeat_interleave(3) * 3 + ar3 % 3).to(torch.int32).contiguous()
+            ptr3 = (3 * torch.arange(E + 1, device=dev, dtype=torch.int32)).contiguous()
+            seg3 = ops.SegmentLayout(ptr3, 3 * E)
+            gedge_ptr = lay.rowptr[gptr.long()].contiguous()          # edge range of every crystal
+            sv.update(idx_edge=idx_edge, idx_gl=idx_gl, seg3=seg3, gedge_ptr=gedge_ptr)
 
         def conv(l, x, e):
             p = f"att_layers.{l}"
@@ -328,11 +332,52 @@ class _IComformerFunction(torch.autograd.Function):
             sv[p] = s
             return y
 
+        def equi(x, e):
+            """ComformerConvEqui (comformer_conv.py:266-279) on the tensor-product kernels of csrc/equi_ops.hip."""
+            p = "equi_update"
+            s = {}
+            ns = ops.EQUI_NS
+            x0 = _e((N, ns), dev)
+            _gemm(x, P[p + ".node_linear.weight"], x0, bias=P[p + ".node_linear.bias"])
+            cdir = batch.cart_dir.contiguous()
+            for li in (1, 2):       # the two edge MLPs: Linear, Softplus, Linear -> per-edge weights [E, 5120]
+                q = f"{p}.nlayer_{li}"
+                hpre, hact, w = _e((E, C), dev), _e((E, C), dev), _e((E, ops.EQUI_NW), dev)
+                _gemm(e, P[q + ".fc.0.weight"], hpre, bias=P[q + ".fc.0.bias"])
+                ops.eltwise(0, hpre, None, hact)
+                _gemm(hact, P[q + ".fc.2.weight"], w, bias=P[q + ".fc.2.bias"])
+                s[f"hpre{li}"], s[f"hact{li}"], s[f"w{li}"] = hpre, hact, w
+            h1 = _e((N, ops.EQUI_H1), dev)
+            ops.equi_tp1_fwd(x0, s["w1"], cdir, lay, h1)
+            o2 = _e((N, ns), dev)
+            ops.equi_tp2_fwd(h1, s["w2"], cdir, lay, o2)
+            np_ = ops.colstats_nparts(N)
+            ps, pq = _parts(np_ * ns, dev), _parts(np_ * ns, dev)
+            ops.colstats_partial(o2, ps, pq)
+            mr = _e((2 * ns,), dev)
+            ops.bn_finalize(ps, pq, np_, N, ns, BN_EPS, BN_MOMENTUM, training, B[p + ".bn.running_mean"],
+                            B[p + ".bn.running_var"], B[p + ".bn.num_batches_tracked"], mr)
+            zero = torch.zeros(N, ns, device=dev)
+            y1 = _e((N, ns), dev)
+            ops.softplus_update_fwd(o2, zero, mr, P[p + ".bn.weight"], P[p + ".bn.bias"], y1)   # softplus(bn(o2))
+            y2pre, y2, out = _e((N, C), dev), _e((N, C), dev), _e((N, C), dev)
+            _gemm(y1, P[p + ".node_linear_2.weight"], y2pre, bias=P[p + ".node_linear_2.bias"])
+            ops.eltwise(0, y2pre, None, y2)
+            _gemm(x, P[p + ".skip_linear.weight"], out, bias=P[p + ".skip_linear.bias"], resid=y2)
+            s.update(x=x, e=e, x0=x0, h1=h1, o2=o2, mr=mr, zero=zero, y1=y1, y2pre=y2pre, cdir=cdir)
+            sv[p] = s
+            return out
+
         x = conv(0, x, e)
-        sv["NLt"], sv["NA"] = NLt, NA
-        e = conv_edge(e)
-        for l in (1, 2, 3):
-            x = conv(l, x, e)
+        if equi_model:              # models/comformer.py:64-67
+            x = equi(x, e)
+            for l in (1, 2):
+                x = conv(l, x, e)
+        else:
+            sv["NLt"], sv["NA"] = NLt, NA
+            e = conv_edge(e)
+            for l in (1, 2, 3):
+                x = conv(l, x, e)
 
         # ---- Cholesky head (shared with CartNet)
         H = C // 2
@@ -504,20 +549,89 @@ class _IComformerFunction(torch.autograd.Function):
             de = linear3_bwd(p, dQKV, e_in, dres)
             return de, dNL3.view(Bg * 3, C), dNA
 
-        # ---- layers in reverse: att 3, 2, 1 (all read the updated edge features), edge layer, att 0
-        de_new = None
-        for l in (3, 2, 1):
-            dx, de_l = conv_bwd(l, dx)
-            if de_new is None:
-                de_new = de_l
-            else:
-                acc = _e((E, C), dev)
-                ops.eltwise(2, de_new, de_l, acc)
-                de_new = acc
-        de_old, dNLt, dNA = conv_edge_bwd(de_new)
-        dx, de0 = conv_bwd(0, dx)
-        de_tot = _e((E, C), dev)
-        ops.eltwise(2, de_old, de0, de_tot)
+        def lin_bwd(wname, dY, X, d_in=None, resid=None):
+            """Backward of Y = X W^T + b: bias / weight gradients into G, returns dX (+ resid) if ``d_in`` is given."""
+            W = P[wname + ".weight"]
+            G[wname + ".bias"] = _e((W.shape[0],), dev)
+            ops.colsum(dY, G[wname + ".bias"])
+            G[wname + ".weight"] = _e(tuple(W.shape), dev)
+            _wgrad([dY], [X], [G[wname + ".weight"]])
+            if d_in is not None:
+                _gemm(dY, W, d_in, b_kstrided=True, resid=resid)
+            return d_in
+
+        def equi_bwd(dy):
+            """Returns (dx, de) of equi_update."""
+            p = "equi_update"
+            s = sv.pop(p)
+            ns = ops.EQUI_NS
+            x_in, e_in, cdir = s["x"], s["e"], s["cdir"]
+            dx = lin_bwd(p + ".skip_linear", dy, x_in, _e((N, C), dev))
+            dy2pre = _e((N, C), dev)
+            ops.eltwise(1, dy, s["y2pre"], dy2pre)
+            dy1 = lin_bwd(p + ".node_linear_2", dy2pre, s["y1"], _e((N, ns), dev))
+            # y1 = softplus(bn(o2)): the shared two-pass BatchNorm backward with a zero residual
+            np_ = ops.segment_nparts(N)
+            pa, pb = _parts(np_ * ns, dev), _parts(np_ * ns, dev)
+            ops.softplus_update_bwd_stats(s["o2"], s["zero"], dy1, s["mr"], P[p + ".bn.weight"], P[p + ".bn.bias"], pa, pb)
+            sums = _e((2 * ns,), dev)
+            ops.colsum_finalize([pa, pb], np_, [sums[:ns], sums[ns:]])
+            G[p + ".bn.bias"], G[p + ".bn.weight"] = sums[:ns], sums[ns:]
+            do2, dres = _e((N, ns), dev), _e((N, ns), dev)
+            ops.softplus_update_bwd_apply(s["o2"], s["zero"], dy1, s["mr"], P[p + ".bn.weight"], P[p + ".bn.bias"], sums,
+                                          training, do2, None, dres)
+
+            def edge_mlp_bwd(li, dw):
+                q = f"{p}.nlayer_{li}"
+                dhact = lin_bwd(q + ".fc.2", dw, s[f"hact{li}"], _e((E, C), dev))
+                dhpre = _e((E, C), dev)
+                ops.eltwise(1, dhact, s[f"hpre{li}"], dhpre)
+                return lin_bwd(q + ".fc.0", dhpre, e_in, _e((E, C), dev))
+
+            dw2, dhe = _e((E, ops.EQUI_NW), dev), _e((E, ops.EQUI_H1), dev)
+            ops.equi_tp2_bwd(s["h1"], s["w2"], cdir, lay, do2, dw2, dhe)
+            dh1 = _e((N, ops.EQUI_H1), dev)
+            ops.segment_sum(dhe, lay.rowptr, None, dh1)
+            de2 = edge_mlp_bwd(2, dw2)
+            del dw2, dhe
+            dw1, dxe = _e((E, ops.EQUI_NW), dev), _e((E, ns), dev)
+            ops.equi_tp1_bwd(s["x0"], s["w1"], cdir, lay, dh1, dw1, dxe)
+            dx0s, dx0 = _e((N, ns), dev), _e((N, ns), dev)
+            ops.segment_sum(dxe, lay.rowptr, None, dx0s)
+            ops.eltwise(2, dx0s, dh1[:, :ns], dx0)                  # + the residual pad(x0)
+            de1 = edge_mlp_bwd(1, dw1)
+            de = _e((E, C), dev)
+            ops.eltwise(2, de1, de2, de)
+            dx_tot = lin_bwd(p + ".node_linear", dx0, x_in, _e((N, C), dev), resid=dx)
+            return dx_tot, de
+
+        def add_e(a, b):
+            if a is None:
+                return b
+            acc = _e((E, C), dev)
+            ops.eltwise(2, a, b, acc)
+            return acc
+
+        if sv["equi_model"]:
+            # ---- eComformer: att 2, att 1, equivariant update, att 0; the edge features are shared by all of them
+            de_tot = None
+            for l in (2, 1):
+                dx, de_l = conv_bwd(l, dx)
+                de_tot = add_e(de_tot, de_l)
+            dx, de_q = equi_bwd(dx)
+            de_tot = add_e(de_tot, de_q)
+            dx, de0 = conv_bwd(0, dx)
+            de_tot = add_e(de_tot, de0)
+        else:
+            # ---- layers in reverse: att 3, 2, 1 (all read the updated edge features), edge layer, att 0
+            de_new = None
+            for l in (3, 2, 1):
+                dx, de_l = conv_bwd(l, dx)
+                de_new = add_e(de_new, de_l)
+            de_old, dNLt, dNA = conv_edge_bwd(de_new)
+            dx, de0 = conv_bwd(0, dx)
+            de_tot = _e((E, C), dev)
+            ops.eltwise(2, de_old, de0, de_tot)
 
         # ---- RBF branches: out = softplus(pre), pre = rbf @ W^T + b ; rbf.1 is shared by the distance and the
         #      lattice-length features, so its gradients add up
@@ -531,11 +645,14 @@ class _IComformerFunction(torch.autograd.Function):
             return gw, gb
 
         gw1, gb1 = rbf_bwd("rbf_e", de_tot)
-        gw2, gb2 = rbf_bwd("rbf_nl", dNLt)
-        G["rbf.1.weight"], G["rbf.1.bias"] = _e((C, C), dev), _e((C,), dev)
-        ops.eltwise(2, gw1, gw2, G["rbf.1.weight"])
-        ops.eltwise(2, gb1.view(1, C), gb2.view(1, C), G["rbf.1.bias"].view(1, C))
-        G["rbf_angle.1.weight"], G["rbf_angle.1.bias"] = rbf_bwd("rbf_na", dNA)
+        if sv["equi_model"]:
+            G["rbf.1.weight"], G["rbf.1.bias"] = gw1, gb1
+        else:
+            gw2, gb2 = rbf_bwd("rbf_nl", dNLt)
+            G["rbf.1.weight"], G["rbf.1.bias"] = _e((C, C), dev), _e((C,), dev)
+            ops.eltwise(2, gw1, gw2, G["rbf.1.weight"])
+            ops.eltwise(2, gb1.view(1, C), gb2.view(1, C), G["rbf.1.bias"].view(1, C))
+            G["rbf_angle.1.weight"], G["rbf_angle.1.bias"] = rbf_bwd("rbf_na", dNA)
 
         # ---- atom embedding and temperature projection
         pw, pb = _parts(nparts_n * C, dev), _parts(nparts_n * C, dev)
@@ -577,6 +694,78 @@ class iComformer(nn.Module):
         pred, x = _IComformerFunction.apply(self, data, self.training, *params)
         data.x = x
         return pred, data.y
+
+
+class _EdgeMLP(nn.Module):
+    """TensorProductConvLayer (comformer_conv.py:197-213): only its edge MLP ``fc`` holds parameters (the e3nn tensor
+    product is weightless with shared_weights=False)."""
+
+    def __init__(self, c: int):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(c, c), nn.Softplus(), nn.Linear(c, ops.EQUI_NW))
+
+
+class ComformerConvEqui(nn.Module):
+    """Parameter container of the reference's ComformerConvEqui (comformer_conv.py:226-264; ns = 64, nv = 8)."""
+
+    def __init__(self, c: int):
+        super().__init__()
+        self.node_linear = nn.Linear(c, ops.EQUI_NS)
+        self.skip_linear = nn.Linear(c, c)
+        self.nlayer_1 = _EdgeMLP(c)
+        self.nlayer_2 = _EdgeMLP(c)
+        self.bn = nn.BatchNorm1d(ops.EQUI_NS)
+        self.node_linear_2 = nn.Linear(ops.EQUI_NS, c)
+
+
+class eComformer(nn.Module):
+    """eComformer (reference: models/comformer.py:25-70) on the gfx950 kernels: three attention layers around the
+    equivariant update.  The reference builds that update on e3nn, which is not available here; it is restated from
+    e3nn's published algorithm (csrc/equi_ops.hip, oracle/ecomformer_ref.py) and its parity with e3nn is unpinned."""
+
+    kind = "e"
+
+    def __init__(self, dim_in: int):
+        super().__init__()
+        if dim_in % 8 != 0 or dim_in // 2 > 512:
+            raise ValueError("dim_in must be a multiple of 8 and at most 1024")
+        c = dim_in
+        self.dim_in = c
+        self.embedding = nn.Embedding(N_ATOM_TYPES, c)
+        self.temperature_proj_atom = nn.Linear(1, c, bias=True)
+        self.rbf = nn.Sequential(_RBF(-4.0, 0.0, c), nn.Linear(c, c), nn.Softplus())
+        self.att_layers = nn.ModuleList([ComformerConv(c) for _ in range(3)])
+        self.equi_update = ComformerConvEqui(c)
+        self.cholesky = Cholesky_head(c)
+        self.validate_graph = False
+        self.gemm_precision = 0
+        self._param_names = [n for n, _ in self.named_parameters()]
+
+    def forward(self, data):
+        params = [p for _, p in self.named_parameters()]
+        if not params[0].is_cuda:
+            raise RuntimeError("cartnet_amd.eComformer runs only on an AMD GPU (HIP kernels); there is no CPU fallback")
+        pred, x = _IComformerFunction.apply(self, data, self.training, *params)
+        data.x = x
+        return pred, data.y
+
+
+def make_ecomformer_state_dict(dim_in: int, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Deterministic state_dict (CPU) for the eComformer tests; BatchNorm affine / running statistics randomised."""
+    torch.manual_seed(seed)
+    m = eComformer(dim_in)
+    g = torch.Generator().manual_seed(seed + 1)
+    sd = m.state_dict()
+    for k, v in sd.items():
+        if k.endswith("running_mean"):
+            v.copy_(0.1 * torch.randn(v.shape, generator=g))
+        elif k.endswith("running_var"):
+            v.copy_(0.5 + torch.rand(v.shape, generator=g))
+        elif (".bn." in k or ".bn_att." in k) and k.endswith(".weight"):
+            v.copy_(1.0 + 0.2 * torch.randn(v.shape, generator=g))
+        elif (".bn." in k or ".bn_att." in k) and k.endswith(".bias"):
+            v.copy_(0.2 * torch.randn(v.shape, generator=g))
+    return {k: v.clone() for k, v in sd.items()}
 
 
 def make_icomformer_state_dict(dim_in: int, seed: int = 0) -> Dict[str, torch.Tensor]:

@@ -119,6 +119,14 @@ PROTOTYPES = {
     "cartnet_gemm_pack_b": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32,
                                       c_stream]),
+    "cartnet_equi_tp1_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int32, c_f32p, c_stream]),
+    "cartnet_equi_tp1_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, c_f32p, C.c_int32, c_f32p, c_f32p,
+                                       c_stream]),
+    "cartnet_equi_tp2_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int32, c_f32p, c_stream]),
+    "cartnet_equi_tp2_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, c_f32p, C.c_int32, c_f32p, c_f32p,
+                                       c_stream]),
+    "cartnet_colstats_nparts": (C.c_int, [C.c_int32]),
+    "cartnet_colstats_partial": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_stream]),
     "cartnet_splitk_reduce": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, c_stream]),
     "cartnet_colsum_finalize": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32,

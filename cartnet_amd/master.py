@@ -7,8 +7,8 @@ from .config import cfg
 def create_model():
     """cfg.model == "CartNet" -> CartNet(dim_in, dim_rbf, num_layers, invariant, use_temp, envelope, use_atom_types,
     cholesky = (dataset == "ADP")) moved to ``cfg.device`` (the reference hard-codes "cuda:0").
-    cfg.model == "icomformer" -> iComformer(dim_in) (ADP only, models/master.py:40-43).  eComformer needs e3nn and is
-    outside this build."""
+    cfg.model == "icomformer" / "ecomformer" -> iComformer(dim_in) / eComformer(dim_in) (ADP only,
+    models/master.py:34-43); eComformer's equivariant block is restated without e3nn (parity with e3nn unpinned)."""
     if cfg.model == "CartNet":
         from .model import CartNet
         model = CartNet(dim_in=cfg.dim_in, dim_rbf=cfg.dim_rbf, num_layers=cfg.num_layers, invariant=cfg.invariant,
@@ -18,6 +18,10 @@ def create_model():
         from .comformer import iComformer
         assert cfg.dataset.name == "ADP", "iComformer only for ADP dataset"
         model = iComformer(dim_in=cfg.dim_in).to(getattr(cfg, "device", "cuda:0"))
+    elif cfg.model == "ecomformer":
+        from .comformer import eComformer
+        assert cfg.dataset.name == "ADP", "eComformer only for ADP dataset"
+        model = eComformer(dim_in=cfg.dim_in).to(getattr(cfg, "device", "cuda:0"))
     else:
         raise Exception("Model not implemented")
     model.gemm_precision = int(getattr(cfg, "gemm_precision", 0))

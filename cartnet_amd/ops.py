@@ -820,3 +820,78 @@ def colsum(x: Tensor, out: Tensor) -> None:
     _l.check(_l.load().cartnet_colsum_partial(x.data_ptr(), _ld(x), R, Cc, parts.data_ptr(), _l.stream_ptr()),
              "cartnet_colsum_partial")
     colsum_finalize(parts, npart, out)
+
+
+# ------------------------------------------------------------------------------------------------ eComformer (equi)
+EQUI_NS, EQUI_H1, EQUI_NW = 64, 128, 5120
+
+
+def _equi_common(feat: Tensor, width: int, w: Tensor, cart_dir: Tensor, layout: "GraphLayout", name: str):
+    _f32_2d(feat, f"{name} node features")
+    N = int(feat.shape[0])
+    if feat.shape[1] != width or not feat.is_contiguous():
+        raise ValueError(f"{name}: node features must be contiguous [N, {width}]")
+    E = int(layout.E)
+    if tuple(w.shape) != (E, EQUI_NW) or w.dtype != torch.float32 or not w.is_cuda or not w.is_contiguous():
+        raise ValueError(f"{name}: w must be a contiguous fp32 CUDA tensor [E={E}, {EQUI_NW}]")
+    if tuple(cart_dir.shape) != (E, 3) or cart_dir.dtype != torch.float32 or not cart_dir.is_contiguous():
+        raise ValueError(f"{name}: cart_dir must be contiguous fp32 [E, 3]")
+    if layout.N != N or layout.colptr is None:
+        raise ValueError(f"{name}: graph layout (with the by-source permutation) does not match the node count")
+    return N, E
+
+
+def _equi_out(t: Tensor, shape, name: str):
+    if tuple(t.shape) != tuple(shape) or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous fp32 CUDA tensor {tuple(shape)}")
+
+
+def equi_tp1_fwd(x0, w, cart_dir, layout: "GraphLayout", h1) -> None:
+    N, _ = _equi_common(x0, EQUI_NS, w, cart_dir, layout, "equi_tp1_fwd")
+    _equi_out(h1, (N, EQUI_H1), "equi_tp1_fwd h1")
+    _l.check(_l.load().cartnet_equi_tp1_fwd(x0.data_ptr(), w.data_ptr(), cart_dir.data_ptr(), layout.colptr.data_ptr(),
+                                            layout.perm.data_ptr(), layout.tgt.data_ptr(), N, h1.data_ptr(),
+                                            _l.stream_ptr()), "cartnet_equi_tp1_fwd")
+
+
+def equi_tp1_bwd(x0, w, cart_dir, layout: "GraphLayout", dh1, dw, dxe) -> None:
+    N, E = _equi_common(x0, EQUI_NS, w, cart_dir, layout, "equi_tp1_bwd")
+    _equi_out(dh1, (N, EQUI_H1), "equi_tp1_bwd dh1")
+    _equi_out(dw, (E, EQUI_NW), "equi_tp1_bwd dw")
+    _equi_out(dxe, (E, EQUI_NS), "equi_tp1_bwd dxe")
+    _l.check(_l.load().cartnet_equi_tp1_bwd(x0.data_ptr(), w.data_ptr(), cart_dir.data_ptr(), layout.colptr.data_ptr(),
+                                            layout.perm.data_ptr(), layout.tgt.data_ptr(), dh1.data_ptr(), N,
+                                            dw.data_ptr(), dxe.data_ptr(), _l.stream_ptr()), "cartnet_equi_tp1_bwd")
+
+
+def equi_tp2_fwd(h1, w, cart_dir, layout: "GraphLayout", o2) -> None:
+    N, _ = _equi_common(h1, EQUI_H1, w, cart_dir, layout, "equi_tp2_fwd")
+    _equi_out(o2, (N, EQUI_NS), "equi_tp2_fwd o2")
+    _l.check(_l.load().cartnet_equi_tp2_fwd(h1.data_ptr(), w.data_ptr(), cart_dir.data_ptr(), layout.colptr.data_ptr(),
+                                            layout.perm.data_ptr(), layout.tgt.data_ptr(), N, o2.data_ptr(),
+                                            _l.stream_ptr()), "cartnet_equi_tp2_fwd")
+
+
+def equi_tp2_bwd(h1, w, cart_dir, layout: "GraphLayout", do2, dw, dhe) -> None:
+    N, E = _equi_common(h1, EQUI_H1, w, cart_dir, layout, "equi_tp2_bwd")
+    _equi_out(do2, (N, EQUI_NS), "equi_tp2_bwd do2")
+    _equi_out(dw, (E, EQUI_NW), "equi_tp2_bwd dw")
+    _equi_out(dhe, (E, EQUI_H1), "equi_tp2_bwd dhe")
+    _l.check(_l.load().cartnet_equi_tp2_bwd(h1.data_ptr(), w.data_ptr(), cart_dir.data_ptr(), layout.colptr.data_ptr(),
+                                            layout.perm.data_ptr(), layout.tgt.data_ptr(), do2.data_ptr(), N,
+                                            dw.data_ptr(), dhe.data_ptr(), _l.stream_ptr()), "cartnet_equi_tp2_bwd")
+
+
+def colstats_nparts(R: int) -> int:
+    return int(_l.load().cartnet_colstats_nparts(int(R)))
+
+
+def colstats_partial(x: Tensor, parts_sum: Tensor, parts_sq: Tensor) -> None:
+    """fp64 partial column sums / sums of squares of x [R, C] (rows of parts: colstats_nparts(R))."""
+    _f32_2d(x, "colstats_partial x")
+    R, Cc = x.shape
+    n = colstats_nparts(R) * Cc
+    _vec(parts_sum, n, "colstats parts_sum", torch.float64)
+    _vec(parts_sq, n, "colstats parts_sq", torch.float64)
+    _l.check(_l.load().cartnet_colstats_partial(x.data_ptr(), _ld(x), R, Cc, parts_sum.data_ptr(), parts_sq.data_ptr(),
+                                                _l.stream_ptr()), "cartnet_colstats_partial")

@@ -141,6 +141,34 @@ int cartnet_softplus_update_bwd_apply(const float* o, const float* x, const floa
                                       const float* gamma, const float* beta, const float* sums, int32_t training,
                                       int32_t N, int32_t D, float* d_o, const float* dx_add, float* dx, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * eComformer's equivariant update (models/comformer_conv.py:197-280: ComformerConvEqui = two TensorProductConvLayer
+ * over e3nn's FullyConnectedTensorProduct with per-edge weights, irreps 64x0e -> 64x0e + 8x1o + 8x2e -> 64x0e,
+ * spherical harmonics 1x0e + 1x1o + 1x2e, "component" normalisation, scatter-mean over edge_index[0]).
+ * Restated without e3nn (oracle/ecomformer_ref.py has the derivation; parity with e3nn itself is unpinned).
+ *   w        [E, 5120] per-edge weights from the edge MLP (layer 1: [64x64 | 64x8 | 64x8], layer 2: [80 x 64])
+ *   colptr / perm   edges grouped by SOURCE atom (cartnet_csr_build); tgt [E] int32 target of every edge
+ *   tp1: x0 [N, 64] -> h1 [N, 128] = mean_{edges leaving j} [t0 | t1 (x) Y1 | t2 (x) Y2] + pad(x0),  t = x0[tgt] W / 8
+ *   tp2: h1 [N, 128] -> o2 [N, 64] = mean_{edges leaving j} [s | <v1,Y1>/sqrt3 | <v2,Y2>/sqrt5][tgt] W / sqrt(80)
+ * Backward: dw [E, 5120] and the per-edge gradient of the gathered rows (dxe [E, 64] / dhe [E, 128]), which the
+ * caller reduces over targets with cartnet_segment_sum (+ dh1[:, :64] for layer 1's residual).
+ * ---------------------------------------------------------------------------------------------------- */
+int cartnet_equi_tp1_fwd(const float* x0, const float* w, const float* cart_dir, const int32_t* colptr,
+                         const int32_t* perm, const int32_t* tgt, int32_t N, float* h1, void* stream);
+int cartnet_equi_tp1_bwd(const float* x0, const float* w, const float* cart_dir, const int32_t* colptr,
+                         const int32_t* perm, const int32_t* tgt, const float* dh1, int32_t N, float* dw, float* dxe,
+                         void* stream);
+int cartnet_equi_tp2_fwd(const float* h1, const float* w, const float* cart_dir, const int32_t* colptr,
+                         const int32_t* perm, const int32_t* tgt, int32_t N, float* o2, void* stream);
+int cartnet_equi_tp2_bwd(const float* h1, const float* w, const float* cart_dir, const int32_t* colptr,
+                         const int32_t* perm, const int32_t* tgt, const float* do2, int32_t N, float* dw, float* dhe,
+                         void* stream);
+/* fp64 partial column sums and sums of squares of x [R, C] -> parts [cartnet_colstats_nparts(R)][C] each (BatchNorm
+ * statistics of a tensor no GEMM epilogue produced); finalise with cartnet_bn_finalize. */
+int cartnet_colstats_nparts(int32_t R);
+int cartnet_colstats_partial(const float* x, int32_t ld, int32_t R, int32_t C, double* parts_sum, double* parts_sq,
+                             void* stream);
+
 /* parts[p][c] = partial column sums of the [R, C] view x (p < cartnet_segment_nparts(R)); finalise with
  * cartnet_colsum_finalize (bias gradients of Linears whose output gradient is not produced by a GEMM epilogue). */
 int cartnet_colsum_partial(const float* x, int32_t ld, int32_t R, int32_t C, double* parts, void* stream);

@@ -60,3 +60,11 @@ def test_main_at_width_256_with_bf16x3_gemms(tmp_path, monkeypatch):
     b = entry.main(common + ["--name", "p1", "--gemm_precision", "1"])
     for ha, hb in zip(a["history"], b["history"]):
         assert abs(ha["train_mae"] - hb["train_mae"]) < 1e-3 * abs(ha["train_mae"])
+
+
+def test_main_runs_ecomformer(tmp_path, monkeypatch):
+    import main as entry
+    monkeypatch.chdir(tmp_path)
+    res = entry.main(["--synthetic", "12", "--atoms", "10", "20", "--dim_in", "32", "--epochs", "2", "--batch", "3",
+                      "--batch_accumulation", "1", "--name", "ecf", "--model", "ecomformer"])
+    assert len(res["history"]) == 2 and res["history"][-1]["train_mae"] == res["history"][-1]["train_mae"]
