@@ -44,6 +44,27 @@ def test_host_side_argument_validation_without_gpu():
     assert l.cartnet_node_nparts(1) == 1
 
 
+def test_weight_image_sizes_and_gemm_precision_validation_without_gpu():
+    """Pure host functions of the GEMM ABI: image sizes (6 B per element for the three bf16 planes, 5 B for the padded
+    fp32 rows; 0 for shapes without an image) and the precision range check."""
+    from cartnet_amd import lib
+    l = lib.load()
+    assert l.cartnet_gemm_split_b_bytes(256, 256) == 6 * 256 * 256
+    assert l.cartnet_gemm_pack_b_bytes(256, 512) == 5 * 256 * 512
+    for K, N in ((250, 256), (256, 200), (0, 256), (16, 0)):
+        assert l.cartnet_gemm_split_b_bytes(K, N) == 0 and l.cartnet_gemm_pack_b_bytes(K, N) == 0
+    assert l.cartnet_colstats_nparts(1) == 1 and l.cartnet_colstats_nparts(10 ** 6) == 1024
+    args = lib.GemmArgs()
+    args.M = args.N = args.K = 16
+    args.lda = args.ldb = args.ldc = 16
+    args.ngroups = args.nsegs = args.splitk = 1
+    args.precision = 3
+    buf = ctypes.create_string_buffer(16 * 16 * 4 + 64)
+    base = (ctypes.addressof(buf) + 63) & ~63
+    args.A[0] = args.B[0] = args.C[0] = base
+    assert l.cartnet_gemm(ctypes.byref(args), None) != 0 and b"precision" in l.cartnet_last_error()
+
+
 def test_product_model_fails_loudly_off_gpu():
     from cartnet_amd.model import CartNet
     from cartnet_amd.synthetic import make_batch
