@@ -99,6 +99,18 @@ def _gemm(A, B, C_out, **kw):
                 imgs.append(im)
             kw = dict(kw, b_kstrided=True, b_split=imgs)
             return ops.gemm(A, Bt if isinstance(B, (list, tuple)) else Bt[0], C_out, precision=prec, **kw)
+    if prec > 0 and kw.get("b_kstrided", False) and not kw.get("a_kstrided", False) and kw.get("splitk", 1) == 1 and \
+            not kw.get("segments", False) and "b_split" not in kw:
+        # dX = dY W with the weight as the k-strided operand [K = out, N = in]: same kernels, image of that orientation
+        Bs = list(B) if isinstance(B, (list, tuple)) else [B]
+        if all(w.shape[1] % 256 == 0 and w.shape[0] % 16 == 0 for w in Bs):
+            imgs = []
+            for w in Bs:
+                key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), prec, "k")
+                if key not in _IMAGE_CACHE:
+                    _IMAGE_CACHE[key] = (None, ops.split_b([w])[0])
+                imgs.append(_IMAGE_CACHE[key][1])
+            kw = dict(kw, b_split=imgs)
     return ops.gemm(A, B, C_out, precision=prec, **kw)
 
 
