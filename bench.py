@@ -217,6 +217,21 @@ def main():
         "path_tflops_executed": round(value * FLOPS_EXEC_PER_GRAPH * (E / args.graphs / 2800.0) / 1e12 / world, 2),
         "path_tflops_reference_equiv": round(value * FLOPS_REF_PER_GRAPH * (E / args.graphs / 2800.0) / 1e12 / world, 2),
     }
+    # whole-path HBM figures (north_star asks for the fraction of the HBM roofline): compulsory bytes of the reference
+    # formulation (68 MB per 2800-edge crystal, fwd+bwd, perfect fusion) and the bytes the PMC passes
+    # counted for one step of this build (profiles/traffic.json), both over the measured step time, against 8 TB/s
+    try:
+        per_step = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("per_step", {})
+    except Exception:
+        per_step = {}
+    step_s = dt / args.steps
+    alg = 68.0e6 * (E / 2800.0)
+    out["path_hbm"] = {"peak_TBps": 8.0,
+                       "algorithmic_bytes_per_step": int(alg), "algorithmic_TBps": round(alg / step_s / 1e12, 3),
+                       "algorithmic_frac": round(alg / step_s / 8.0e12, 4),
+                       "counted_bytes_per_step": per_step.get("hbm_bytes"),
+                       "counted_TBps": round(per_step["hbm_bytes"] / step_s / 1e12, 3) if per_step.get("hbm_bytes") else None,
+                       "counted_frac": round(per_step["hbm_bytes"] / step_s / 8.0e12, 4) if per_step.get("hbm_bytes") else None}
     if x3 is not None:
         out["bf16x3"] = x3
     if rank == 0:

@@ -73,6 +73,14 @@ def main():
                                    "write_bytes_per_launch": int(v["write"] / n),
                                    "hbm_bytes_per_launch": int((v["fetch"] + v["write"]) / n)}
     out["variants"] = variants
+    # whole-step traffic: every dispatch of the profiled process / number of optimiser steps in it (cn_adam_kernel)
+    steps = max(1, max((fc[k] for k in f if "adam" in k), default=1))
+    tot_f = sum(2.0 * 1024.0 * f[k] for k in f)
+    tot_w = sum(1024.0 * w[k] for k in w)
+    out["per_step"] = {"steps_profiled": steps, "fetch_bytes": int(tot_f / steps), "write_bytes": int(tot_w / steps),
+                       "hbm_bytes": int((tot_f + tot_w) / steps),
+                       "note": "fabric-side bytes (Infinity-Cache hits included) averaged over the fp32 and bf16x3 steps "
+                               "of the profiled bench process"}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for _, k, n, fetch, write in rows[:16]:
         print(f"{short(k)[:70]:70s} n={n:4d} fetch {fetch/1e6:8.1f} MB write {write/1e6:8.1f} MB")
