@@ -309,7 +309,8 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
   const CartnetModel& m = *model;
   const CartnetBatch& b = *batch;
   const CartnetParams& P = m.p;
-  CN_CHECK(workspace && pred && x_out && e_out && status, "cartnet_model_forward: null output/workspace");
+  CN_CHECK(workspace && x_out && status && (e_out || b.E == 0) && (pred || (m.cholesky ? b.M == 0 : b.Bg == 0)),
+           "cartnet_model_forward: null output/workspace");
   CN_CHECK((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "cartnet_model_forward: workspace must be 256-byte aligned");
   size_t need = 0;
   const Work w = carve(m, b.N, b.E, b.Bg, b.M, need_backward != 0, static_cast<char*>(workspace), &need);

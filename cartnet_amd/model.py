@@ -184,10 +184,11 @@ class _CartNetFunction(torch.autograd.Function):
         nbytes = int(lib.cartnet_workspace_bytes(C.byref(md), N, E, Bg, M, int(need_grad)))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         x_out = torch.empty((N, D), dtype=torch.float32, device=dev)
-        e_out = torch.empty((E, D), dtype=torch.float32, device=dev)
+        e_store = torch.empty((max(E, 1), D), dtype=torch.float32, device=dev)   # never a null pointer, even for E = 0
+        e_out = e_store[:E]
         status = torch.empty(1, dtype=torch.int32, device=dev)
         _l.check(lib.cartnet_model_forward(C.byref(md), C.byref(bd), ws.data_ptr(), nbytes, int(training),
-                                           int(need_grad), pred.data_ptr(), x_out.data_ptr(), e_out.data_ptr(),
+                                           int(need_grad), pred.data_ptr(), x_out.data_ptr(), e_store.data_ptr(),
                                            status.data_ptr(), _l.stream_ptr()), "cartnet_model_forward")
         if model.validate_graph:
             ops.raise_on_graph_status(int(status.item()))

@@ -130,3 +130,37 @@ def test_large_ragged_batch_is_finite_and_reproducible():
         outs.append((pred.detach().clone(), torch.cat([p.grad.flatten() for p in m.parameters()]).clone()))
     assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_batch_without_any_edge_at_width_256(precision):
+    """E = 0 for the whole batch at the width that takes the DMA-fed kernels: every E-row GEMM is an empty launch, the
+    weight-gradient GEMMs reduce over zero rows (gradient 0), BatchNorm over zero edges must not divide by zero."""
+    from cartnet_amd.data import Batch
+    from cartnet_amd.model import make_state_dict
+    from cartnet_amd.synthetic import make_crystal
+    from oracle import cartnet_ref as orc
+    items = []
+    for i, n in enumerate((3, 1, 5)):
+        d = make_crystal(40 + i, n)
+        d.edge_index = torch.zeros(2, 0, dtype=torch.int64)
+        d.cart_dist, d.cart_dir = torch.zeros(0), torch.zeros(0, 3)
+        items.append(d)
+    b = Batch.from_data_list(items)
+    hp = dict(dim_in=256, dim_rbf=64, num_layers=2, radius=5.0, invariant=False, temperature=True, use_envelope=True,
+              atom_types=True, cholesky=True)
+    sd = make_state_dict(256, 64, 2, seed=6)
+    m = _model(hp, sd).train()
+    m.gemm_precision = precision
+    pred, true = m(_fresh(b))
+    (pred - true).abs().mean().backward()
+    sd64 = {k: (v.double().requires_grad_(k in dict(m.named_parameters())) if v.is_floating_point() else v)
+            for k, v in sd.items()}
+    b64 = gu.clone_batch(b)
+    for k, v in list(b64.__dict__.items()):
+        if torch.is_tensor(v) and v.is_floating_point():
+            setattr(b64, k, v.double())
+    ref = orc.cartnet_forward(sd64, b64, training=True, **gu.oracle_kwargs(hp))
+    assert torch.isfinite(pred).all() and rel_err(pred, ref) < PRED_TOL
+    for k, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
