@@ -271,3 +271,26 @@ def test_bf16_mode_on_adp_config2_fixture():
     (pred - true).abs().mean().backward()
     for k, p in m.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("variant", ["invariant", "no_temperature", "no_envelope"])
+def test_model_variants_at_width_256_against_oracle(variant, precision):
+    """The ablation switches of the reference (cartnet.py:41-46) at the width that takes the DMA-fed kernels: the
+    invariant encoder has K = 64 for the first edge Linear (no padding), the others K = 67 -> 80."""
+    from cartnet_amd.data import Batch
+    from cartnet_amd.model import make_state_dict
+    from cartnet_amd.synthetic import make_crystal
+    hp = dict(dim_in=256, dim_rbf=64, num_layers=2, radius=5.0, invariant=variant == "invariant",
+              temperature=variant != "no_temperature", use_envelope=variant != "no_envelope", atom_types=True,
+              cholesky=True)
+    b = Batch.from_data_list([make_crystal(300 + i, n) for i, n in enumerate((17, 40, 9))])
+    sd = make_state_dict(256, 64, 2, seed=11, invariant=hp["invariant"], temperature=hp["temperature"])
+    m = _model(hp, sd, precision).train()
+    bb = gu.clone_batch(b).to("cuda:0")
+    pred, true = m(bb)
+    (pred - true).abs().mean().backward()
+    names = set(k for k, _ in m.named_parameters())
+    ref, gref = _oracle_run(b, hp, sd, names)
+    assert rel_err(pred, ref) < PRED_TOL
+    _check_grads({k: p.grad for k, p in m.named_parameters()}, gref, variant)
