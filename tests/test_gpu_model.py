@@ -294,3 +294,24 @@ def test_model_variants_at_width_256_against_oracle(variant, precision):
     ref, gref = _oracle_run(b, hp, sd, names)
     assert rel_err(pred, ref) < PRED_TOL
     _check_grads({k: p.grad for k, p in m.named_parameters()}, gref, variant)
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_width_512_against_oracle(precision):
+    """dim_in = 512: two 256-column tiles per layer GEMM, K = 512 / 1024 pipelines, the folded K-segment form does not
+    apply (N != 256) and the segment form must take over."""
+    from cartnet_amd.data import Batch
+    from cartnet_amd.model import make_state_dict
+    from cartnet_amd.synthetic import make_crystal
+    hp = dict(dim_in=512, dim_rbf=64, num_layers=1, radius=5.0, invariant=False, temperature=True, use_envelope=True,
+              atom_types=True, cholesky=True)
+    b = Batch.from_data_list([make_crystal(330 + i, n) for i, n in enumerate((21, 33))])
+    sd = make_state_dict(512, 64, 1, seed=12)
+    m = _model(hp, sd, precision).train()
+    bb = gu.clone_batch(b).to("cuda:0")
+    pred, true = m(bb)
+    (pred - true).abs().mean().backward()
+    names = set(k for k, _ in m.named_parameters())
+    ref, gref = _oracle_run(b, hp, sd, names)
+    assert rel_err(pred, ref) < PRED_TOL
+    _check_grads({k: p.grad for k, p in m.named_parameters()}, gref, "width512")
