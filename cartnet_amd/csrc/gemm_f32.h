@@ -9,10 +9,13 @@
 namespace cn_gemm {
 
 constexpr int F32_BN = 256;
-constexpr int F32_A_BYTES = BM * KPAD * 4;              // [128 rows][20 floats]: 10 KB
-constexpr int F32_B_BYTES = F32_BN * KPAD * 4;          // [256 cols][20 floats]: 20 KB per K-step per 256-column tile
+constexpr int F32_A_BYTES = BM * KPAD * 4;              // [128 rows][20 floats]: 10 KB (register-staged, padded rows)
+// weight image (cartnet_gemm_pack_b): per 256-column tile and K-step [256 cols][16 k] fp32, rows of 64 bytes whose
+// four 16-byte slots are XOR-ed with (col >> 2) & 3 -- unpadded, so that it can be DMA'd lane-linearly, and
+// conflict-free for the ds_read_b128 fragment reads (16 consecutive rows hit 16 distinct (bank quadrant, slot) pairs)
+constexpr int F32_B_BYTES = F32_BN * BK * 4;            // 16 KB per K-step per 256-column tile
 constexpr int F32_BUF_BYTES = F32_A_BYTES + F32_B_BYTES;
-constexpr int F32_B_PIECES = F32_B_BYTES / 1024;        // 20 DMA pieces of 1 KB (64 lanes x 16 B)
+__device__ __host__ __forceinline__ int f32_swz(int row, int quad) { return row * 64 + ((quad ^ ((row >> 2) & 3)) << 4); }
 
 template <bool A_ACT>
 __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const CartnetGemmArgs p, const GemmFlags fl) {
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
     }
     *reinterpret_cast<f32x4*>(lds + buf * F32_BUF_BYTES + a_lds) = v;
   };
-  // B tile of K-step v: 20 pieces of 1 KB; wave w moves pieces w, w+8 and (w < 4) w+16
+  // B tile of K-step v: 16 pieces of 1 KB; wave w moves pieces w and w+8
   auto b_issue = [&](int v, int buf) {
     const char* src = b0 + (size_t)v * F32_B_BYTES + wid * 1024;
     const unsigned dst = lds_b + buf * F32_BUF_BYTES;
@@ -69,9 +72,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
     for (int j = 0; j < 2; ++j)
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                    :: "s"(dst + j * 8192), "v"(b_voff), "s"(src + j * 8192) : "memory", "m0");
-    if (wid < F32_B_PIECES - 16)
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                   :: "s"(dst + 16384), "v"(b_voff), "s"(src + 16384) : "memory", "m0");
   };
   f32x4 af[2][2], bf[2][2];     // [k-group of 8][tile]: k = kg*8 + lh*4 + j for element j
   auto frags = [&](int buf, int kg) {
@@ -82,7 +82,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
       af[kg][a] = *reinterpret_cast<const f32x4*>(&sA[(wm * S::WM + a * 32 + li) * KPAD + kg * 8 + lh * 4]);
 #pragma unroll
     for (int b = 0; b < 2; ++b)
-      bf[kg][b] = *reinterpret_cast<const f32x4*>(&sB[(wn * S::WN + b * 32 + li) * KPAD + kg * 8 + lh * 4]);
+      bf[kg][b] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sB) +
+                                                  f32_swz(wn * S::WN + b * 32 + li, kg * 2 + lh));
   };
   auto mma4 = [&](int kg, int j) {
 #pragma unroll

@@ -25,7 +25,8 @@ struct PackJobs {
   int K[PACK_MAX_JOBS], N[PACK_MAX_JOBS], sk[PACK_MAX_JOBS], sn[PACK_MAX_JOBS];
 };
 
-// One thread per (column n, 4 consecutive k): the LDS image of the fp32 kernel, rows of 16 k + 4 zero pad floats.
+// One thread per (column n, 4 consecutive k): the LDS image of the fp32 kernels (gemm_f32.h: 64-byte rows, swizzled
+// 16-byte slots).
 __global__ __launch_bounds__(256) void cn_pack_b_kernel(const PackJobs jobs) {
   const int j = blockIdx.y;
   const int K = jobs.K[j], N = jobs.N[j];
@@ -40,16 +41,15 @@ __global__ __launch_bounds__(256) void cn_pack_b_kernel(const PackJobs jobs) {
   const int t = k0 / cn_gemm::BK, kk = k0 % cn_gemm::BK;
   const int tile_n = n / cn_gemm::F32_BN, nl = n % cn_gemm::F32_BN;
   char* d = jobs.dst[j] + ((size_t)tile_n * (K / cn_gemm::BK) + t) * cn_gemm::F32_B_BYTES +
-            (nl * cn_gemm::KPAD + kk) * 4;
+            cn_gemm::f32_swz(nl, kk >> 2);
   *reinterpret_cast<f32x4*>(d) = v;
-  if (kk == 12) *reinterpret_cast<f32x4*>(d + 16) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 }  // namespace
 
 extern "C" size_t cartnet_gemm_pack_b_bytes(int32_t K, int32_t N) {
   if (K <= 0 || N <= 0 || K % cn_gemm::BK != 0 || N % cn_gemm::F32_BN != 0) return 0;
-  return (size_t)K * N * 5;
+  return (size_t)K * N * 4;
 }
 
 extern "C" int cartnet_gemm_pack_b(const float* const* src, void* const* dst, const int32_t* K, const int32_t* N,

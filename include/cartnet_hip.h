@@ -81,8 +81,8 @@ typedef struct CartnetGemmArgs {
   const void* b_split[CARTNET_MAX_GROUPS];
                        /* optional, b_kstrided = 1 and a_kstrided = 0: B[i] pre-arranged as the kernel's LDS image --
                           by cartnet_gemm_split_b for precision 1 / 2 (bf16 planes; the weight operand is split once
-                          per step instead of once per tile), by cartnet_gemm_pack_b for precision 0 (fp32 rows of
-                          16 k + pad).  The image must match the precision of the call.  B[i] must still be given
+                          per step instead of once per tile), by cartnet_gemm_pack_b for precision 0 (swizzled fp32
+                          rows of 16 k).  The image must match the precision of the call.  B[i] must still be given
                           (fallback paths read it). */
   const void* b_split_folded;
                        /* optional, nsegs > 1 and N == 256: the segments' images one after the other (segment order).
@@ -98,7 +98,8 @@ int cartnet_gemm(const CartnetGemmArgs* args, void* stream);
  * [256][16] bf16 in the kernel's LDS order.  K % 16 == 0 and N % 256 == 0; dst: cartnet_gemm_split_b_bytes(K, N)
  * = 6*K*N bytes (0 when the shape has no such image), 16-byte aligned.  njobs matrices per call (host arrays). */
 size_t cartnet_gemm_split_b_bytes(int32_t K, int32_t N);
-/* The precision-0 counterpart: fp32 image (per 256-column tile and K-step [256][16 + 4 pad] floats), 5*K*N bytes. */
+/* The precision-0 counterpart: fp32 image (per 256-column tile and K-step [256][16] floats, 16-byte slots of a row
+ * XOR-swizzled), 4*K*N bytes. */
 size_t cartnet_gemm_pack_b_bytes(int32_t K, int32_t N);
 int cartnet_gemm_pack_b(const float* const* src, void* const* dst, const int32_t* K, const int32_t* N,
                         const int32_t* stride_k, const int32_t* stride_n, int32_t njobs, void* stream);

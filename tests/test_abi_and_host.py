@@ -45,12 +45,12 @@ def test_host_side_argument_validation_without_gpu():
 
 
 def test_weight_image_sizes_and_gemm_precision_validation_without_gpu():
-    """Pure host functions of the GEMM ABI: image sizes (6 B per element for the three bf16 planes, 5 B for the padded
+    """Pure host functions of the GEMM ABI: image sizes (6 B per element for the three bf16 planes, 4 B for the swizzled
     fp32 rows; 0 for shapes without an image) and the precision range check."""
     from cartnet_amd import lib
     l = lib.load()
     assert l.cartnet_gemm_split_b_bytes(256, 256) == 6 * 256 * 256
-    assert l.cartnet_gemm_pack_b_bytes(256, 512) == 5 * 256 * 512
+    assert l.cartnet_gemm_pack_b_bytes(256, 512) == 4 * 256 * 512
     for K, N in ((250, 256), (256, 200), (0, 256), (16, 0)):
         assert l.cartnet_gemm_split_b_bytes(K, N) == 0 and l.cartnet_gemm_pack_b_bytes(K, N) == 0
     assert l.cartnet_colstats_nparts(1) == 1 and l.cartnet_colstats_nparts(10 ** 6) == 1024

@@ -181,6 +181,55 @@ def test_gemm_with_weight_images(ops, precision, M, K, N, groups, act):
         assert rel_err(Cs[g], ref) < TOL, g
 
 
+@pytest.mark.parametrize("case", ["plain", "gather", "dact_colsum", "resid_folded"])
+def test_gemm_edge_sized_rows_through_every_model_epilogue(ops, case):
+    """M > 32768 rows at precision 0 with a weight image (hundreds of row tiles, ragged last tile), through every
+    epilogue the model gives the DMA-fed kernel: bias, node-term gather, silu' with bias-gradient sums, residual with
+    folded K-segments."""
+    M = 32768 + (300 if case != "plain" else 77)
+    K, N, G = 256, 256, 2
+    Xs = [rnd(M, K, seed=40 + g) for g in range(G)]
+    Ws = [rnd(N, K, seed=50 + g, scale=0.1) for g in range(G)]
+    imgs = ops.pack_b([w.t() for w in Ws])
+    Bt = [w.t().contiguous() for w in Ws]
+    Cs = [torch.full((M, N), float("nan"), device=dev()) for _ in range(G)]
+    ref = [x.double() @ w.double().t() for x, w in zip(Xs, Ws)]
+    if case == "plain":
+        bs = [rnd(N, seed=60 + g) for g in range(G)]
+        ops.gemm(Xs, Bt, Cs, b_kstrided=True, bias=bs, b_split=imgs)
+        ref = [r + b.double() for r, b in zip(ref, bs)]
+    elif case == "gather":
+        nn = 999
+        P = rnd(nn, 4 * N, seed=7)
+        g_ = torch.Generator().manual_seed(3)
+        tgt = torch.sort(torch.randint(0, nn, (M,), generator=g_)).values.to(torch.int32).to(dev())
+        src = torch.randint(0, nn, (M,), generator=g_).to(torch.int32).to(dev())
+        ops.gemm(Xs, Bt, Cs, b_kstrided=True, gather_i=[P[:, :N], P[:, N:2 * N]], gather_j=[P[:, 2 * N:3 * N], P[:, 3 * N:]],
+                 tgt=tgt, src=src, b_split=imgs)
+        Pd = P.double()
+        ref = [ref[0] + Pd[tgt.long(), :N] + Pd[src.long(), 2 * N:3 * N], ref[1] + Pd[tgt.long(), N:2 * N] + Pd[src.long(), 3 * N:]]
+    elif case == "dact_colsum":
+        pre = [rnd(M, N, seed=70 + g) for g in range(G)]
+        tiles = ops.gemm_tiles_m(M)
+        cs = [torch.full((tiles * N,), float("nan"), dtype=torch.float64, device=dev()) for _ in range(G)]
+        ops.gemm(Xs, Bt, Cs, b_kstrided=True, dact=pre, colsum=cs, b_split=imgs)
+        ref = [r * dsilu64(p_.double()) for r, p_ in zip(ref, pre)]
+        for g in range(G):
+            assert rel_err(cs[g].view(tiles, N).sum(0), ref[g].sum(0)) < 1e-6
+    else:
+        resid = rnd(M, N, seed=80)
+        X2 = rnd(M, 2 * K, seed=81)
+        W2 = [rnd(K, N, seed=82 + s, scale=0.1) for s in range(2)]
+        C1 = torch.full((M, N), float("nan"), device=dev())
+        ops.gemm([X2[:, :K], X2[:, K:]], W2, C1, b_kstrided=True, segments=True, resid=resid,
+                 b_split_folded=torch.cat(ops.pack_b(W2)))
+        r2 = X2[:, :K].double() @ W2[0].double() + X2[:, K:].double() @ W2[1].double() + resid.double()
+        assert rel_err(C1, r2) < TOL
+        return
+    for g in range(G):
+        assert rel_err(Cs[g], ref[g]) < TOL, g
+
+
 @pytest.mark.parametrize("precision", [0, 1, 2])
 def test_gemm_folded_segments_with_images(ops, precision):
     """sum_s X[:, sK:(s+1)K] W_s: K-segments that are adjacent column blocks run as one product (b_split_folded); the
