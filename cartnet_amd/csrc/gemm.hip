@@ -259,7 +259,7 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
 }
 
 int cn_fold_parts(double* const* parts, int njobs, int nparts, int N, hipStream_t st) {
-  if (nparts <= 2 * CN_FOLD_ROWS || N <= 0 || njobs <= 0 || njobs > 8) return nparts;
+  if (nparts <= 8 * CN_FOLD_ROWS || N <= 0 || njobs <= 0 || njobs > 8) return nparts;
   FoldJobs jobs;
   for (int j = 0; j < 8; ++j) jobs.parts[j] = j < njobs ? parts[j] : nullptr;
   hipLaunchKernelGGL(cn_fold_parts_kernel, dim3(cn_ceil_div(N, 64), CN_FOLD_ROWS, njobs), dim3(256), 0, st, jobs, nparts,

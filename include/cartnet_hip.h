@@ -290,7 +290,7 @@ int cartnet_splitk_reduce(const float* const* slabs, float* const* outs, int32_t
  * digits), and a finalise kernel adds the rows in fixed order.
  * For each job j < njobs (<= 8; host arrays of device pointers, all with the same nparts and N):
  * outs[j][n] = (float) sum_{p<nparts} parts[j][p*N + n].
- * The partial rows are CONSUMED: when nparts > 64 they are first folded in place to 32 rows (row r <- rows r, r+32,
+ * The partial rows are CONSUMED: when nparts > 256 they are first folded in place to 32 rows (row r <- rows r, r+32,
  * r+64, ... in that order, one launch over many workgroups), so that the few finalising blocks have 32 rows left.
  * The _f32 form (single job) reads the fp32 partial rows of the head kernels. */
 int cartnet_colsum_finalize(double* const* parts, float* const* outs, int32_t njobs, int32_t nparts, int32_t N,
@@ -346,7 +346,7 @@ int cartnet_sort_by_key(const int64_t* keys, int32_t N, int32_t nkeys, int32_t* 
  * N rows).  parts_sum / parts_sq hold `nparts` per-column partial sums.  training != 0: batch mean and biased
  * variance -> mean_rstd[0:C] = mean, mean_rstd[C:2C] = 1/sqrt(var + eps); running stats updated in place with
  * `momentum` and the unbiased variance; num_batches_tracked += 1.  training == 0: mean_rstd from running stats.
- * The partial rows are consumed (folded in place when nparts > 64, see cartnet_colsum_finalize).
+ * The partial rows are consumed (folded in place when nparts > 256, see cartnet_colsum_finalize).
  * ---------------------------------------------------------------------------------------------------- */
 int cartnet_bn_finalize(double* parts_sum, double* parts_sq, int32_t nparts, int64_t count, int32_t C,
                         float eps, float momentum, int32_t training, float* running_mean, float* running_var,
