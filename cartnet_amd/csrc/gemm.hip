@@ -227,7 +227,17 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
   }
   CN_CHECK(a.precision >= 0 && a.precision <= 2, "cartnet_gemm: precision=%d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = bf16)",
            a.precision);
-  if (a.nsegs > 1 && a.b_split_folded && a.N == cn_gemm::X3_BN && !a.a_kstrided && a.b_kstrided &&
+  // Few row tiles (atom-sized M, small batches): 128 x 256 tiles would leave most of the 256 CUs idle and the launch
+  // would last one tile's latency (16+ K-steps of a full tile); narrower column tiles (the general kernel's 128- and
+  // 64-wide forms, exact fp32) spread the same work over 2-4x as many workgroups.  Precision 0 only: the bf16 kernels
+  // exist for 256-wide tiles, and their tiles are 3-6x shorter to begin with (measured: no gain at precision 1,
+  // a loss at precision 2).
+  int bn = a.N > 128 ? 256 : (a.N > 64 ? 128 : 64);
+  if (bn == 256 && a.precision == 0 && !a.a_kstrided && a.splitk == 1 && a.N % 64 == 0) {
+    const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 255) / 256) * a.ngroups;
+    if (tiles < 200) bn = (2 * tiles >= 200) ? 128 : 64;
+  }
+  if (bn == 256 && a.nsegs > 1 && a.b_split_folded && a.N == cn_gemm::X3_BN && !a.a_kstrided && a.b_kstrided &&
       a.splitk == 1 && a.ngroups == 1 && a.M > 0) {
     // K-segments that are adjacent column blocks of one matrix: one product over the concatenated K.  Folded only when
     // the pre-split kernel is certain to take the launch (B[0] alone does not describe the folded operand).
@@ -249,8 +259,8 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
   fl.kchunk = kchunk;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   bool ok;
-  if (a.N > 128) ok = cn_gemm::launch_bn<256>(a, fl, st);
-  else if (a.N > 64) ok = cn_gemm::launch_bn<128>(a, fl, st);
+  if (bn == 256) ok = cn_gemm::launch_bn<256>(a, fl, st);
+  else if (bn == 128) ok = cn_gemm::launch_bn<128>(a, fl, st);
   else ok = cn_gemm::launch_bn<64>(a, fl, st);
   CN_CHECK(ok, "cartnet_gemm: unsupported layout/activation combination (a_ks=%d b_ks=%d a_act=%d b_act=%d)",
            a.a_kstrided, a.b_kstrided, a.a_act, a.b_act);
