@@ -229,13 +229,14 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
            a.precision);
   // Few row tiles (atom-sized M, small batches): 128 x 256 tiles would leave most of the 256 CUs idle and the launch
   // would last one tile's latency (16+ K-steps of a full tile); narrower column tiles (the general kernel's 128- and
-  // 64-wide forms, exact fp32) spread the same work over 2-4x as many workgroups.  Precision 0 only: the bf16 kernels
-  // exist for 256-wide tiles, and their tiles are 3-6x shorter to begin with (measured: no gain at precision 1,
-  // a loss at precision 2).
+  // 64-wide forms, exact fp32) spread the same work over 2-4x as many workgroups.  Not at precision 2 (the bf16 kernels
+  // exist for 256-wide tiles only and their tiles are 6x shorter to begin with: measured a loss), and later at
+  // precision 1.
   int bn = a.N > 128 ? 256 : (a.N > 64 ? 128 : 64);
-  if (bn == 256 && a.precision == 0 && !a.a_kstrided && a.splitk == 1 && a.N % 64 == 0) {
+  if (bn == 256 && a.precision <= 1 && !a.a_kstrided && a.splitk == 1 && a.N % 64 == 0) {
     const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 255) / 256) * a.ngroups;
-    if (tiles < 200) bn = (2 * tiles >= 200) ? 128 : 64;
+    const long long few = a.precision == 0 ? 200 : 100;     // bf16x3 tiles are ~2x shorter: switch later
+    if (tiles < few) bn = (2 * tiles >= few) ? 128 : 64;
   }
   if (bn == 256 && a.nsegs > 1 && a.b_split_folded && a.N == cn_gemm::X3_BN && !a.a_kstrided && a.b_kstrided &&
       a.splitk == 1 && a.ngroups == 1 && a.M > 0) {
