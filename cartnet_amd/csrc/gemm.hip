@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void cn_fold_parts_kernel(const FoldJobs jobs,
 struct FinalizeJobs {
   const double* parts[8];
   float* out[8];
+  float* out2[8];     // optional second destination of the same sums (a gradient tensor next to a scratch copy)
 };
 
 __global__ __launch_bounds__(1024) void cn_colsum_finalize_kernel(const FinalizeJobs jobs, int nparts, int N) {
@@ -94,7 +95,10 @@ __global__ __launch_bounds__(1024) void cn_colsum_finalize_kernel(const Finalize
   float* __restrict__ out = jobs.out[blockIdx.y];
   const double tot = cn_block_colsum(parts, nparts, N, blockIdx.x * 64, red);
   const int c = blockIdx.x * 64 + threadIdx.x;
-  if (threadIdx.x < 64 && c < N) out[c] = (float)tot;
+  if (threadIdx.x < 64 && c < N) {
+    out[c] = (float)tot;
+    if (jobs.out2[blockIdx.y]) jobs.out2[blockIdx.y][c] = (float)tot;
+  }
 }
 
 __global__ void cn_colsum_finalize_f32_kernel(const float* __restrict__ parts, int nparts, int N,
@@ -309,6 +313,11 @@ extern "C" int cartnet_splitk_reduce(const float* const* slabs, float* const* ou
 
 extern "C" int cartnet_colsum_finalize(double* const* parts, float* const* outs, int32_t njobs, int32_t nparts,
                                        int32_t N, void* stream) {
+  return cartnet_colsum_finalize2(parts, outs, nullptr, njobs, nparts, N, stream);
+}
+
+extern "C" int cartnet_colsum_finalize2(double* const* parts, float* const* outs, float* const* outs2, int32_t njobs,
+                                        int32_t nparts, int32_t N, void* stream) {
   CN_CHECK(parts && outs && njobs >= 1 && njobs <= 8, "cartnet_colsum_finalize: njobs=%d out of range (1..8)", njobs);
   CN_CHECK(nparts >= 0 && N >= 0, "cartnet_colsum_finalize: bad shape");
   if (N == 0) return 0;
@@ -316,6 +325,7 @@ extern "C" int cartnet_colsum_finalize(double* const* parts, float* const* outs,
   for (int j = 0; j < 8; ++j) {
     jobs.parts[j] = j < njobs ? parts[j] : nullptr;
     jobs.out[j] = j < njobs ? outs[j] : nullptr;
+    jobs.out2[j] = (j < njobs && outs2) ? outs2[j] : nullptr;
     if (j < njobs) CN_CHECK(parts[j] && outs[j], "cartnet_colsum_finalize: null pointer in job %d", j);
   }
   nparts = cn_fold_parts(parts, njobs, nparts, N, reinterpret_cast<hipStream_t>(stream));

@@ -560,7 +560,6 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
             aux_stream != nullptr && aux_stream != stream};
   void* st = stream;            // main: activation-gradient chain
   void* sw = (void*)S.side;     // side: parameter gradients
-  hipStream_t hs = S.main;
 #define FORK() do { if (S.fork() != 0) { cartnet_set_error("cartnet_model_backward: stream fork failed"); return 2; } } while (0)
 
   hipEvent_t sort_done = nullptr;
@@ -621,12 +620,8 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     {
       double* parts[2] = {w.pa, w.pb};
       float* outs[2] = {w.sums2, w.sums2 + D};
-      RUN(cartnet_colsum_finalize(parts, outs, 2, w.nparts_n, D, st));
-    }
-    if (hipMemcpyAsync(gq.norm2_b, w.sums2, sizeof(float) * D, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
-        hipMemcpyAsync(gq.norm2_w, w.sums2 + D, sizeof(float) * D, hipMemcpyDeviceToDevice, hs) != hipSuccess) {
-      cartnet_set_error("cartnet_model_backward: norm2 gradient copy failed");
-      return 2;
+      float* grads2[2] = {gq.norm2_b, gq.norm2_w};      // the same sums are the BatchNorm affine gradients
+      RUN(cartnet_colsum_finalize2(parts, outs, grads2, 2, w.nparts_n, D, st));
     }
     RUN(cartnet_node_update_bwd_apply(w.aggr[l], dx, w.mr2[l], q.norm2_w, q.norm2_b, w.sums2, training, N, D, w.daggr,
                                       st));
@@ -636,12 +631,8 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     {
       double* parts[2] = {w.pa, w.pb};
       float* outs[2] = {w.sums1, w.sums1 + D};
-      RUN(cartnet_colsum_finalize(parts, outs, 2, w.gparts, D, st));
-    }
-    if (hipMemcpyAsync(gq.norm_b, w.sums1, sizeof(float) * D, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
-        hipMemcpyAsync(gq.norm_w, w.sums1 + D, sizeof(float) * D, hipMemcpyDeviceToDevice, hs) != hipSuccess) {
-      cartnet_set_error("cartnet_model_backward: norm gradient copy failed");
-      return 2;
+      float* grads1[2] = {gq.norm_b, gq.norm_w};
+      RUN(cartnet_colsum_finalize2(parts, outs, grads1, 2, w.gparts, D, st));
     }
     RUN(cartnet_gate_scatter_bwd_apply(gs, de, w.daggr, env, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, w.sums1, b.E,
                                        training, N, D, w.pc[par], w.pd[par], st));   // gs = [dg | ds]

@@ -131,6 +131,8 @@ PROTOTYPES = {
                                         C.c_int32, C.c_int32, c_stream]),
     "cartnet_colsum_finalize": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32,
                                           c_stream]),
+    "cartnet_colsum_finalize2": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
+                                           C.c_int32, C.c_int32, c_stream]),
     "cartnet_colsum_finalize_f32": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_stream]),
     "cartnet_csr_build": (C.c_int, [c_i64p, C.c_int64, C.c_int32, c_i64p, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p,
                                     c_i32p, c_i32p, c_stream]),

@@ -295,6 +295,10 @@ int cartnet_splitk_reduce(const float* const* slabs, float* const* outs, int32_t
  * The _f32 form (single job) reads the fp32 partial rows of the head kernels. */
 int cartnet_colsum_finalize(double* const* parts, float* const* outs, int32_t njobs, int32_t nparts, int32_t N,
                             void* stream);
+/* The same with an optional second destination per job (outs2, or outs2[j], may be NULL): the sums land in a scratch
+ * row a following kernel reads AND in the gradient tensor, without a device-to-device copy in between. */
+int cartnet_colsum_finalize2(double* const* parts, float* const* outs, float* const* outs2, int32_t njobs,
+                             int32_t nparts, int32_t N, void* stream);
 int cartnet_colsum_finalize_f32(const float* parts, int32_t nparts, int32_t N, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
