@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA GEMMs, 1: bf16x3 split-operand MFMA")
     ap.add_argument("--no-x3-pass", action="store_true", help="skip the extra bf16x3 timed pass")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: ranks beyond the visible GPUs share them (use with CARTNET_DIST_BACKEND=gloo)")
     args = ap.parse_args()
 
     from cartnet_amd import distributed as cdist
@@ -101,6 +103,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the CartNet hot path has no CPU fallback")
+    if args.share_gpu:
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

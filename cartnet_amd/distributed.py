@@ -26,7 +26,8 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+            # "nccl" is RCCL on ROCm; CARTNET_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs
+            backend = os.environ.get("CARTNET_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
