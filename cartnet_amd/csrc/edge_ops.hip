@@ -17,28 +17,39 @@ constexpr int GATE_BATCH = 4;     // edges whose row loads are in flight togethe
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-__global__ void cn_edge_features_kernel(const float* __restrict__ dist, const float* __restrict__ dir,
-                                        const float* __restrict__ means, const float* __restrict__ betas,
-                                        long long E, int R, int invariant, float radius, float env_radius,
-                                        float* __restrict__ feat, int ldf, float* __restrict__ env) {
-  const long long total = E * ldf;
+// One workgroup per FEAT_EDGES edges: the per-edge scalars (cutoff, exp(-alpha d), envelope) are computed once by
+// the first FEAT_EDGES threads and shared through LDS, so an output element costs one exp instead of two and a cos.
+constexpr int FEAT_EDGES = 64;
+
+__global__ __launch_bounds__(256) void cn_edge_features_kernel(
+    const float* __restrict__ dist, const float* __restrict__ dir, const float* __restrict__ means,
+    const float* __restrict__ betas, long long E, int R, int invariant, float radius, float env_radius,
+    float* __restrict__ feat, int ldf, float* __restrict__ env) {
+  __shared__ float s_cut[FEAT_EDGES], s_ex[FEAT_EDGES];
   const float alpha = 5.0f / radius;
   const float kPi = 3.14159265358979323846f;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const long long e = i / ldf;
-    const int c = (int)(i - e * ldf);
-    const float d = dist[e];
-    float v = 0.f;
-    if (c < R) {
-      const float cut = (d < radius) ? 0.5f * (cosf(d * kPi / radius) + 1.0f) : 0.f;
-      const float t = expf(alpha * (-d)) - means[c];
-      v = cut * expf(-betas[c] * t * t);
-    } else if (!invariant && c < R + 3) {
-      v = dir[e * 3 + (c - R)];
+  for (long long e0 = (long long)blockIdx.x * FEAT_EDGES; e0 < E; e0 += (long long)gridDim.x * FEAT_EDGES) {
+    const int ne = (int)min((long long)FEAT_EDGES, E - e0);
+    if ((int)threadIdx.x < ne) {
+      const float d = dist[e0 + threadIdx.x];
+      s_cut[threadIdx.x] = (d < radius) ? 0.5f * (cosf(d * kPi / radius) + 1.0f) : 0.f;
+      s_ex[threadIdx.x] = expf(alpha * (-d));
+      if (env) env[e0 + threadIdx.x] = (d < env_radius) ? 0.5f * (cosf(d * kPi / env_radius) + 1.0f) : 0.f;
     }
-    feat[i] = v;
-    if (c == 0 && env) env[e] = (d < env_radius) ? 0.5f * (cosf(d * kPi / env_radius) + 1.0f) : 0.f;
+    __syncthreads();
+    const int total = ne * ldf;
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const int el = i / ldf, c = i - el * ldf;
+      float v = 0.f;
+      if (c < R) {
+        const float t = s_ex[el] - means[c];
+        v = s_cut[el] * expf(-betas[c] * t * t);
+      } else if (!invariant && c < R + 3) {
+        v = dir[(e0 + el) * 3 + (c - R)];
+      }
+      feat[e0 * ldf + i] = v;
+    }
+    __syncthreads();
   }
 }
 
@@ -331,7 +342,7 @@ extern "C" int cartnet_edge_features(const float* cart_dist, const float* cart_d
   CN_CHECK(radius > 0.f && env_radius > 0.f, "cartnet_edge_features: radius must be positive");
   if (E == 0) return 0;
   CN_CHECK(cart_dist && means && betas && feat && (invariant || cart_dir), "cartnet_edge_features: null pointer");
-  long long blocks = (E * ldf + 255) / 256;
+  long long blocks = (E + FEAT_EDGES - 1) / FEAT_EDGES;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(cn_edge_features_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      cart_dist, cart_dir, means, betas, (long long)E, R, invariant, radius, env_radius, feat, ldf,

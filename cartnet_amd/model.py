@@ -197,6 +197,7 @@ class _CartNetFunction(torch.autograd.Function):
         else:
             ctx.saved = None
         ctx.mark_non_differentiable(x_out, e_out)
+        ctx.set_materialize_grads(False)   # no zero-filled [N, D] / [E, D] gradients for the two feature outputs
         return pred, x_out, e_out
 
     @staticmethod
@@ -207,6 +208,8 @@ class _CartNetFunction(torch.autograd.Function):
         model, md, bd, ws, nbytes, keep, x_out, training = ctx.saved
         ctx.saved = None
         lib = _l.load()
+        if dpred is None:
+            raise RuntimeError("CartNet backward: the loss does not depend on the prediction")
         dpred = dpred.contiguous()
         G = _GradBuffer(model, dpred.device)
         gd = _l.Params()
