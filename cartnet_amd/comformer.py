@@ -86,31 +86,40 @@ def _gemm(A, B, C_out, **kw):
     W^T with its pre-split image (cartnet_gemm_split_b, once per weight per step): that is the form the bf16 kernels
     implement."""
     prec = _GEMM_PRECISION[0]
-    if prec > 0 and not kw.get("b_kstrided", False) and not kw.get("a_kstrided", False) and kw.get("splitk", 1) == 1:
+    fp32_img = prec == 0      # precision 0: fp32 rows packed for the DMA-fed fp32-MFMA kernel (cartnet_gemm_pack_b)
+    if not kw.get("b_kstrided", False) and not kw.get("a_kstrided", False) and kw.get("splitk", 1) == 1:
         Bs = list(B) if isinstance(B, (list, tuple)) else [B]
         if all(w.shape[0] % 256 == 0 and w.shape[1] % 16 == 0 for w in Bs):
             Bt, imgs = [], []
             for w in Bs:
                 key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), prec)
                 if key not in _IMAGE_CACHE:
-                    _IMAGE_CACHE[key] = (w.t().contiguous(), ops.split_b([w.t()])[0])
+                    _IMAGE_CACHE[key] = (w.t().contiguous(), ops.split_b([w.t()], _fp32=fp32_img)[0])
                 t, im = _IMAGE_CACHE[key]
                 Bt.append(t)
                 imgs.append(im)
             kw = dict(kw, b_kstrided=True, b_split=imgs)
             return ops.gemm(A, Bt if isinstance(B, (list, tuple)) else Bt[0], C_out, precision=prec, **kw)
-    if prec > 0 and kw.get("b_kstrided", False) and not kw.get("a_kstrided", False) and kw.get("splitk", 1) == 1 and \
-            not kw.get("segments", False) and "b_split" not in kw:
+    if kw.get("b_kstrided", False) and not kw.get("a_kstrided", False) and kw.get("splitk", 1) == 1 and \
+            "b_split" not in kw and "b_split_folded" not in kw:
         # dX = dY W with the weight as the k-strided operand [K = out, N = in]: same kernels, image of that orientation
         Bs = list(B) if isinstance(B, (list, tuple)) else [B]
-        if all(w.shape[1] % 256 == 0 and w.shape[0] % 16 == 0 for w in Bs):
-            imgs = []
-            for w in Bs:
-                key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), prec, "k")
-                if key not in _IMAGE_CACHE:
-                    _IMAGE_CACHE[key] = (None, ops.split_b([w])[0])
-                imgs.append(_IMAGE_CACHE[key][1])
-            kw = dict(kw, b_split=imgs)
+        if not kw.get("segments", False):
+            if all(w.shape[1] % 256 == 0 and w.shape[0] % 16 == 0 for w in Bs):
+                imgs = []
+                for w in Bs:
+                    key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), prec, "k")
+                    if key not in _IMAGE_CACHE:
+                        _IMAGE_CACHE[key] = (None, ops.split_b([w], _fp32=fp32_img)[0])
+                    imgs.append(_IMAGE_CACHE[key][1])
+                kw = dict(kw, b_split=imgs)
+        elif len(Bs) > 1 and all(w.shape == Bs[0].shape and w.shape[1] == 256 and w.shape[0] % 16 == 0 for w in Bs):
+            # K-segments: the images of the segments back to back are the image of the product over the concatenated K
+            # (taken by the kernel when the A segments are adjacent column blocks of one matrix, csrc/gemm.hip)
+            key = (tuple((w.data_ptr(), tuple(w.stride())) for w in Bs), tuple(Bs[0].shape), prec, "fold")
+            if key not in _IMAGE_CACHE:
+                _IMAGE_CACHE[key] = (None, torch.cat(ops.split_b(Bs, _fp32=fp32_img)))
+            kw = dict(kw, b_split_folded=_IMAGE_CACHE[key][1])
     return ops.gemm(A, B, C_out, precision=prec, **kw)
 
 

@@ -122,6 +122,7 @@ struct GemmRecord {
   hipEvent_t e0, e1;
 };
 bool g_prof_on = false;
+int g_prof_only = -1;     // >= 0: only launches of this variant are timed
 std::vector<GemmRecord> g_prof;
 }  // namespace
 
@@ -133,6 +134,11 @@ extern "C" int cartnet_profile_gemm(int32_t enable) {
     g_prof.clear();
   }
   g_prof_on = enable != 0;
+  return 0;
+}
+
+extern "C" int cartnet_profile_gemm_only(int32_t variant) {
+  g_prof_only = variant;
   return 0;
 }
 
@@ -170,6 +176,7 @@ extern "C" int cartnet_gemm(const CartnetGemmArgs* args, void* stream) {
   const int inner = args->a_kstrided ? args->M : args->K;
   r.variant = (args->a_kstrided ? 1 : 0) | (args->b_kstrided ? 2 : 0) | (args->a_act ? 4 : 0) | (args->b_act ? 8 : 0) |
               (bn << 4) | (streamed >= 32768 ? 256 : 0) | ((inner > 4080 ? 255 : inner / 16) << 10);
+  if (g_prof_only >= 0 && r.variant != g_prof_only) return cartnet_gemm_impl(args, stream);
   const int nptr = args->ngroups > 1 ? args->ngroups : args->nsegs;
   r.flops = 2.0 * args->M * args->N * (double)args->K * nptr;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

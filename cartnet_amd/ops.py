@@ -17,8 +17,10 @@ from . import lib as _l
 Tensor = torch.Tensor
 
 
-def profile_gemm(enable: bool) -> None:
-    """Start / stop HIP-event timing of every cartnet_gemm launch (see include/cartnet_hip.h)."""
+def profile_gemm(enable: bool, only: Optional[int] = None) -> None:
+    """Start / stop HIP-event timing of cartnet_gemm launches (see include/cartnet_hip.h); ``only`` restricts it to
+    one variant (the ``variant`` number profile_gemm_read reports)."""
+    _l.check(_l.load().cartnet_profile_gemm_only(-1 if only is None else int(only)), "cartnet_profile_gemm_only")
     _l.check(_l.load().cartnet_profile_gemm(int(enable)), "cartnet_profile_gemm")
 
 
@@ -34,7 +36,8 @@ def profile_gemm_read() -> dict:
         name = ("tn" if v & 1 else ("nn" if v & 2 else "nt")) + str(64 * ((v >> 4) & 15)) + \
             ("+silu(A)" if v & 4 else "") + ("+silu(B)" if v & 8 else "") + \
             (f"[{'E' if v & 256 else 'N'}-rows,{'M' if v & 1 else 'K'}={16 * (v >> 10)}]")
-        out[name] = {"launches": int(buf[i].launches), "flops": float(buf[i].flops), "ms": float(buf[i].ms)}
+        out[name] = {"launches": int(buf[i].launches), "flops": float(buf[i].flops), "ms": float(buf[i].ms),
+                     "variant": int(v)}
     return out
 
 

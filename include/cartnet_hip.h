@@ -278,6 +278,10 @@ typedef struct CartnetGemmProfile {
   double ms;
 } CartnetGemmProfile;
 int cartnet_profile_gemm(int32_t enable);
+/* Restrict the timing to launches of one variant (the value CartnetGemmProfile.variant reports; < 0: all variants):
+ * bench.py prices every variant during its warm-up steps and only the dominant one inside the timed region, so the
+ * event pairs of the other ~50 launches per step do not sit in the measured steps. */
+int cartnet_profile_gemm_only(int32_t variant);
 int cartnet_profile_gemm_read(CartnetGemmProfile* out, int32_t max_entries);
 
 /* For each job j < njobs (<= 4; host arrays of device pointers):
