@@ -114,6 +114,18 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+// Column-tile width of a launch (see the comment in cartnet_gemm_impl): 256 / 128 / 64 by N, narrower for launches
+// with few tiles.  Shared with the launch timer so that its variant names the kernel family that really runs.
+static int choose_bn(const CartnetGemmArgs& a) {
+  int bn = a.N > 128 ? 256 : (a.N > 64 ? 128 : 64);
+  if (bn == 256 && a.precision <= 1 && !a.a_kstrided && a.splitk == 1 && a.N % 64 == 0) {
+    const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 255) / 256) * a.ngroups;
+    const long long few = a.precision == 0 ? 200 : 100;     // bf16x3 tiles are ~2x shorter: switch later
+    if (tiles < few) bn = (2 * tiles >= few) ? 128 : 64;
+  }
+  return bn;
+}
+
 // ---- opt-in launch timing (bench.py): HIP events on the launch stream around every cartnet_gemm call ------------
 namespace {
 struct GemmRecord {
@@ -169,7 +181,7 @@ extern "C" int cartnet_profile_gemm_read(CartnetGemmProfile* out, int32_t max_en
 extern "C" int cartnet_gemm(const CartnetGemmArgs* args, void* stream) {
   if (!g_prof_on || !args) return cartnet_gemm_impl(args, stream);
   GemmRecord r;
-  const int bn = args->N > 128 ? 4 : (args->N > 64 ? 2 : 1);
+  const int bn = choose_bn(*args) / 64;
   // bit 8: the streamed dimension (rows of an activation x weight product, reduction length of a weight gradient) is
   // edge-sized; bits 10..: the other inner dimension / 16 (K of an NN product, M of a weight gradient), capped
   const long long streamed = args->a_kstrided ? args->K : args->M;
@@ -243,12 +255,7 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
   // 64-wide forms, exact fp32) spread the same work over 2-4x as many workgroups.  Not at precision 2 (the bf16 kernels
   // exist for 256-wide tiles only and their tiles are 6x shorter to begin with: measured a loss), and later at
   // precision 1.
-  int bn = a.N > 128 ? 256 : (a.N > 64 ? 128 : 64);
-  if (bn == 256 && a.precision <= 1 && !a.a_kstrided && a.splitk == 1 && a.N % 64 == 0) {
-    const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 255) / 256) * a.ngroups;
-    const long long few = a.precision == 0 ? 200 : 100;     // bf16x3 tiles are ~2x shorter: switch later
-    if (tiles < few) bn = (2 * tiles >= few) ? 128 : 64;
-  }
+  int bn = choose_bn(a);
   if (bn == 256 && a.nsegs > 1 && a.b_split_folded && a.N == cn_gemm::X3_BN && !a.a_kstrided && a.b_kstrided &&
       a.splitk == 1 && a.ngroups == 1 && a.M > 0) {
     // K-segments that are adjacent column blocks of one matrix: one product over the concatenated K.  Folded only when

@@ -18,8 +18,10 @@ __global__ void cn_edge_convert_kernel(const int64_t* __restrict__ ei, long long
       tcur = ei[E + k];
       int bad = 0;
       if (s < 0 || s >= N || tcur < 0 || tcur >= N) bad |= 2;
-      src32[k] = (int)s;
-      tgt32[k] = (int)tcur;
+      // the int32 copies are what every later kernel gathers through: clamped, so that a malformed batch gives wrong
+      // numbers and a status bit, never an out-of-bounds access
+      src32[k] = (int)min(max(s, 0LL), (long long)max(N - 1, 0));
+      tgt32[k] = (int)min(max(tcur, 0LL), (long long)max(N - 1, 0));
       if (bad) atomicOr(status, bad);
     }
     long long tprev = -1;
@@ -187,6 +189,14 @@ extern "C" int cartnet_csr_build(const int64_t* edge_index, int64_t E, int32_t N
   CN_CHECK(graph_ptr == nullptr || Bg >= 1, "cartnet_csr_build: Bg=%d", Bg);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) {
+    cartnet_set_error("cartnet_csr_build: memset failed");
+    return 2;
+  }
+  // Defaults for entries a malformed batch (unsorted targets, edges across crystals, an oversized crystal) leaves
+  // unwritten: empty segments and row 0 instead of whatever the buffers held.
+  if (hipMemsetAsync(rowptr, 0, sizeof(int32_t) * ((size_t)N + 1), st) != hipSuccess ||
+      (colptr && hipMemsetAsync(colptr, 0, sizeof(int32_t) * ((size_t)N + 1), st) != hipSuccess) ||
+      (perm && E > 0 && hipMemsetAsync(perm, 0, sizeof(int32_t) * (size_t)E, st) != hipSuccess)) {
     cartnet_set_error("cartnet_csr_build: memset failed");
     return 2;
   }

@@ -113,6 +113,39 @@ def test_input_validation_errors_are_raised_on_the_host():
         m(unsorted)
 
 
+@pytest.mark.parametrize("damage", ["unsorted", "index_out_of_range", "edge_across_crystals"])
+def test_malformed_graph_without_validation_cannot_fault_and_is_reported_later(damage):
+    """validate_graph = False (the default, no host sync per batch): a malformed edge_index must neither fault the GPU
+    (gather indices are clamped, missing CSR/CSC entries default to empty segments) nor pass silently -- the status
+    word travels to pinned memory behind the kernels and the forward call two batches later raises."""
+    z, hp, b, sd = gu.load("tiny_adp")
+    m = _model(hp, sd).train()
+    m.validate_graph = False
+    bad = _fresh(b)
+    N = int(bad.x.shape[0])
+    ei = bad.edge_index.clone()
+    if damage == "unsorted":
+        ei = ei.flip(1).contiguous()
+    elif damage == "index_out_of_range":
+        ei[0, 0] = N + 12345
+        ei[0, 1] = -7
+    else:
+        ei[0, 0] = N - 1 if int(ei[1, 0]) == 0 else 0     # first edge now starts in another crystal
+        if int(bad.num_graphs) == 1:
+            pytest.skip("needs a batch of several crystals")
+    bad.edge_index = ei
+    pred, true = m(bad)                                   # enqueues; numbers are meaningless, nothing may fault
+    (pred - true).abs().mean().backward()
+    torch.cuda.synchronize()
+    m.zero_grad(set_to_none=True)
+    m(_fresh(b))                                          # a good batch in between
+    with pytest.raises(ValueError, match="two forward calls ago"):
+        m(_fresh(b))
+    torch.cuda.synchronize()
+    pred, _ = m(_fresh(b))                                # the model keeps working afterwards
+    assert torch.isfinite(pred).all()
+
+
 def test_large_ragged_batch_is_finite_and_reproducible():
     """48 crystals of 64..324 atoms (the ADP size distribution of SURVEY.md 8d): finite, bit-reproducible."""
     from cartnet_amd.model import make_state_dict
