@@ -50,7 +50,7 @@ weight image -- none in this model at D = 256 -- would run `cn_gemm_kernel<false
 overlapped timed steps ({rf['achieved']} TFLOP/s, {rf['frac']} of the fp32 matrix peak) and {rf['isolated']['avg_launch_us']} us isolated ({rf['isolated']['achieved']} TFLOP/s, {rf['isolated']['frac']});
 rocprofv3 reports {float(dom['AverageNs'])/1e3:.1f} us averaged over all {dom['Calls']} launches of that kernel in the process -- every shape it runs (the E-row layer GEMMs above,
 the small N-row node projections, the K = 80 first edge Linear) in the overlapped, warm-up and isolated steps alike; bench.py's average over the same set of shapes is
-{rf.get('kernel_avg_launch_us_all_shapes', 'n/a')} us in the overlapped timed steps and {rf.get('kernel_avg_launch_us_all_shapes_isolated', 'n/a')} us isolated (the process mixes 13 overlapped with 3 isolated fp32 steps).  HBM traffic of that variant from the
+{rf.get('kernel_avg_launch_us_all_shapes', 'n/a')} us in the overlapped steps (taken in warm-up steps 2-3: inside the timed steps only the dominant variant carries events) and {rf.get('kernel_avg_launch_us_all_shapes_isolated', 'n/a')} us isolated (the process mixes 13 overlapped with 3 isolated fp32 steps).  HBM traffic of that variant from the
 PMC passes: {traffic['variants']['fp32']['nn256']['hbm_bytes_per_launch']/1e6:.0f} MB per launch (bf16x3 kernel on the same launches: {traffic['variants']['x3']['nn256']['hbm_bytes_per_launch']/1e6:.0f} MB).
 
 Backward runs on two streams, so kernel durations of the two streams overlap in wall time (their sum exceeds the step time).
