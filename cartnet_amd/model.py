@@ -260,8 +260,7 @@ class CartNet(nn.Module):
         self.gemm_precision = 0         # 0: fp32 MFMA.  1: bf16x3 split-operand MFMA.  2: plain bf16 operands (csrc/gemm_x3.h)
         self.overlap_weight_gradients = True   # run weight-gradient GEMMs on a second stream during backward
         self._aux_stream = None
-        self._status_ring = None        # pinned copies of the last two batches' graph status words (_defer_graph_check)
-        self._status_turn = 0
+        self._status_ring = None        # in-flight pinned copies of the batches' graph status words (_defer_graph_check)
         self._param_names = [n for n, _ in self.named_parameters()]
         self._param_shapes = {n: tuple(p.shape) for n, p in self.named_parameters()}
         self._flat_grad = None          # set by cartnet_amd.optim.FlatAdam: gradients are accumulated here directly
@@ -291,28 +290,37 @@ class CartNet(nn.Module):
                 setattr(bl, field, B[f"layers.{l}.{key}"].data_ptr())
         return md
 
+    _STATUS_DEPTH = 64
+
     def _defer_graph_check(self, status: torch.Tensor) -> None:
         """Asynchronous check of the device status word of cartnet_csr_build (edge order / index range / crystal
-        membership): the word is copied to pinned host memory behind the forward's kernels and read two forward calls
-        later, when it has long arrived -- a malformed batch raises without a host sync on the hot path
-        (``validate_graph = True`` checks at once, with one sync per batch).  The kernels clamp what they gather
-        through, so a bad batch cannot fault in the meantime."""
-        if self._status_ring is None:
-            self._status_ring = [[torch.zeros(1, dtype=torch.int32).pin_memory(), None] for _ in range(2)]
-        slot = self._status_ring[self._status_turn & 1]
-        self._status_turn += 1
-        if slot[1] is not None:
-            slot[1].synchronize()
-            slot[1] = None
-            try:
-                ops.raise_on_graph_status(int(slot[0].item()))
-            except ValueError as exc:
-                raise ValueError(f"{exc} (reported for a batch passed two forward calls ago; set "
-                                 "model.validate_graph = True to check every batch at once)") from None
-        slot[0].copy_(status, non_blocking=True)
+        membership): the word is copied to pinned host memory behind the forward's kernels and read at a later forward
+        call, once its copy has arrived -- a malformed batch raises without a host sync on the hot path (the host
+        only ever waits when 64 forward calls are still in flight).  ``validate_graph = True`` checks every batch at
+        once, with one sync per batch.  The kernels clamp what they gather through, so a bad batch cannot fault in
+        the meantime."""
+        if self._status_ring is None:                # (in flight: [pinned word, event] oldest first, free pinned words)
+            pool = torch.zeros(self._STATUS_DEPTH + 1, dtype=torch.int32).pin_memory()    # one host allocation
+            self._status_ring = ([], [pool[i:i + 1] for i in range(self._STATUS_DEPTH + 1)])
+        pending, free = self._status_ring
+        bad = None
+        while pending and (len(pending) >= self._STATUS_DEPTH or pending[0][1].query()):
+            word, ev = pending.pop(0)
+            ev.synchronize()
+            if bad is None and int(word.item()) != 0:
+                bad = int(word.item())
+            free.append(word)
+        word = free.pop()
+        word.copy_(status, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        slot[1] = ev
+        pending.append([word, ev])
+        if bad is not None:
+            try:
+                ops.raise_on_graph_status(bad)
+            except ValueError as exc:
+                raise ValueError(f"{exc} (reported for a batch passed to an earlier forward call; set "
+                                 "model.validate_graph = True to check every batch at once)") from None
 
     def _aux_stream_ptr(self, dev):
         """Second HIP stream for the parameter-gradient work of backward (None -> single stream)."""

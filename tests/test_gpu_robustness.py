@@ -117,7 +117,7 @@ def test_input_validation_errors_are_raised_on_the_host():
 def test_malformed_graph_without_validation_cannot_fault_and_is_reported_later(damage):
     """validate_graph = False (the default, no host sync per batch): a malformed edge_index must neither fault the GPU
     (gather indices are clamped, missing CSR/CSC entries default to empty segments) nor pass silently -- the status
-    word travels to pinned memory behind the kernels and the forward call two batches later raises."""
+    word travels to pinned memory behind the kernels and a later forward call raises."""
     z, hp, b, sd = gu.load("tiny_adp")
     m = _model(hp, sd).train()
     m.validate_graph = False
@@ -138,9 +138,10 @@ def test_malformed_graph_without_validation_cannot_fault_and_is_reported_later(d
     (pred - true).abs().mean().backward()
     torch.cuda.synchronize()
     m.zero_grad(set_to_none=True)
-    m(_fresh(b))                                          # a good batch in between
-    with pytest.raises(ValueError, match="two forward calls ago"):
-        m(_fresh(b))
+    with pytest.raises(ValueError, match="earlier forward call"):
+        for _ in range(9):                                # good batches; the report arrives with one of them
+            m(_fresh(b))
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     pred, _ = m(_fresh(b))                                # the model keeps working afterwards
     assert torch.isfinite(pred).all()
