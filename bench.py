@@ -76,10 +76,25 @@ def cpu_baseline(seconds_budget: float = 12.0):
     torch.set_num_threads(cores)
     iters = max(5, min(60, int(seconds_budget / max(one, 1e-3))))
     med = median_time(iters)
+    torch.set_num_threads(1)          # scalar figure: one thread, two runs after one warm-up
+    step()
+    one_thread = min(median_time(1), median_time(1))
+    torch.set_num_threads(cores)
+    cpu_model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": round(n_graphs / med, 3), "unit": "graphs/s", "cores": cores, "kind": "port",
+            "one_thread_value": round(n_graphs / one_thread, 3), "cpu_model": cpu_model,
             "sample": f"oracle fwd+bwd (fp32, train-mode BN) on {n_graphs} crystals x 194 atoms "
                       f"(E={int(batch.edge_index.shape[1])}), median of {iters} runs after warm-up, best of 8/32/64 "
-                      f"torch CPU threads = {cores} (host has {ncpu} logical CPUs)"}
+                      f"torch CPU threads = {cores} (host: {cpu_model}, {ncpu} logical CPUs); one_thread_value: same "
+                      f"step on 1 thread"}
 
 
 def main():
