@@ -17,7 +17,7 @@ void launch_f32tn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim
 
 namespace {
 
-constexpr int PACK_MAX_JOBS = 16;
+constexpr int PACK_MAX_JOBS = 80;     // 2.5 KB of kernel arguments: the model's 66 images go in one launch
 
 struct PackJobs {
   const float* src[PACK_MAX_JOBS];

@@ -320,7 +320,8 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
                         st));
   // weights -> [in, out]
   {
-    const float* src[8]; float* dst[8]; int32_t rows[8], cols[8], lds[8], ldd[8];
+    constexpr int TB = 40;   // cartnet_transpose takes up to 40 matrices per launch
+    const float* src[TB]; float* dst[TB]; int32_t rows[TB], cols[TB], lds[TB], ldd[TB];
     int n = 0;
     auto flush = [&]() -> int {
       if (n == 0) return 0;
@@ -330,7 +331,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     };
     auto add = [&](const float* s, float* d, int r, int c) -> int {
       src[n] = s; dst[n] = d; rows[n] = r; cols[n] = c; lds[n] = c; ldd[n] = r;
-      if (++n == 8) return flush();
+      if (++n == TB) return flush();
       return 0;
     };
     if (w.ldf > w.kf &&

@@ -85,12 +85,13 @@ __global__ __launch_bounds__(256) void cn_embed_bwd_cols_kernel(const int64_t* _
 }
 
 // ------------------------------------------------------------------------------------------------ transpose
-// dst[c, r] = src[r, c] for up to 8 matrices per launch (weights -> [in, out] once per forward, so that every forward
+// dst[c, r] = src[r, c] for up to TRANSPOSE_MAX_JOBS matrices per launch (weights -> [in, out] once per forward, so that every forward
 // GEMM streams its weight tile with fully coalesced rows).
+constexpr int TRANSPOSE_MAX_JOBS = 40;     // 1280 B of kernel arguments: the model's 34 weights go in one launch
 struct TransposeJobs {
-  const float* src[8];
-  float* dst[8];
-  int rows[8], cols[8], lds[8], ldd[8];
+  const float* src[TRANSPOSE_MAX_JOBS];
+  float* dst[TRANSPOSE_MAX_JOBS];
+  int rows[TRANSPOSE_MAX_JOBS], cols[TRANSPOSE_MAX_JOBS], lds[TRANSPOSE_MAX_JOBS], ldd[TRANSPOSE_MAX_JOBS];
 };
 
 __global__ __launch_bounds__(256) void cn_transpose_kernel(const TransposeJobs jobs) {
@@ -562,11 +563,11 @@ extern "C" int cartnet_scalar_head_bwd(const float* hid, const float* w2, const 
 
 extern "C" int cartnet_transpose(const float* const* src, float* const* dst, const int32_t* rows, const int32_t* cols,
                                  const int32_t* lds, const int32_t* ldd, int32_t njobs, void* stream) {
-  CN_CHECK(src && dst && rows && cols && lds && ldd && njobs >= 1 && njobs <= 8,
-           "cartnet_transpose: njobs=%d out of range (1..8)", njobs);
+  CN_CHECK(src && dst && rows && cols && lds && ldd && njobs >= 1 && njobs <= TRANSPOSE_MAX_JOBS,
+           "cartnet_transpose: njobs=%d out of range (1..%d)", njobs, TRANSPOSE_MAX_JOBS);
   TransposeJobs jobs;
   int max_r = 0, max_c = 0;
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < TRANSPOSE_MAX_JOBS; ++j) {
     const bool on = j < njobs;
     jobs.src[j] = on ? src[j] : nullptr;
     jobs.dst[j] = on ? dst[j] : nullptr;

@@ -437,7 +437,7 @@ int cartnet_scalar_head_bwd(const float* hid, const float* w2, const int64_t* gr
                             const float* dout, int32_t N, int32_t Bg, int32_t H, float* dhid, float* parts,
                             void* stream);
 
-/* dst[j][c*ldd[j] + r] = src[j][r*lds[j] + c] for njobs <= 8 matrices (host arrays).  The model transposes its weights
+/* dst[j][c*ldd[j] + r] = src[j][r*lds[j] + c] for njobs <= 40 matrices (host arrays).  The model transposes its weights
  * once per forward so that forward GEMMs read them with b_kstrided = 1 (coalesced rows). */
 int cartnet_transpose(const float* const* src, float* const* dst, const int32_t* rows, const int32_t* cols,
                       const int32_t* lds, const int32_t* ldd, int32_t njobs, void* stream);
