@@ -282,7 +282,8 @@ def main():
             if os.path.exists(tpath):
                 try:
                     tv = json.load(open(tpath)).get("variants", {}).get("fp32" if args.precision == 0 else "x3", {})
-                    traffic = tv.get(key.split("[")[0], {}).get("hbm_bytes_per_launch")
+                    tv = tv.get(key.split("[")[0], {})
+                    traffic = tv.get("hbm_bytes_per_launch_edge_rows" if "[E-rows" in key else "", tv.get("hbm_bytes_per_launch"))
                 except Exception:
                     traffic = None
             # bf16x3 kernels retire an fp32 product with six bf16 MFMAs: their ceiling is the dense bf16 peak / 6

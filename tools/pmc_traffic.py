@@ -8,11 +8,14 @@ Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter
 import csv, json, sys, collections
 
 
-def per_kernel(path, counter):
+BIG_GRID = 500_000      # threads: the edge-sized (E-row) GEMM launches of the benchmark batch have >= 1384 x 512
+
+
+def per_kernel(path, counter, min_grid=0):
     tot = collections.defaultdict(float)
     cnt = collections.defaultdict(int)
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
+        if r["Counter_Name"] != counter or int(r["Grid_Size"]) < min_grid:
             continue
         tot[r["Kernel_Name"]] += float(r["Counter_Value"])
         cnt[r["Kernel_Name"]] += 1
@@ -72,6 +75,17 @@ def main():
             variants[mode][key] = {"launches_profiled": n, "fetch_bytes_per_launch": int(v["fetch"] / n),
                                    "write_bytes_per_launch": int(v["write"] / n),
                                    "hbm_bytes_per_launch": int((v["fetch"] + v["write"]) / n)}
+    # the activation x weight kernels again, edge-sized launches only (the N-row node projections share the kernel)
+    fb, fbc = per_kernel(sys.argv[1], "FETCH_SIZE", BIG_GRID)
+    wb, wbc = per_kernel(sys.argv[2], "WRITE_SIZE", BIG_GRID)
+    for k in fb:
+        name = short(k)
+        for pat, mode in ((r"cn_gemm::cn_gemm_f32nn_kernel<false>", "fp32"), (r"cn_gemm::cn_gemm_x3nn_kernel<false, false>", "x3")):
+            if name == pat and "nn256" in variants[mode]:
+                n = fbc[k]
+                variants[mode]["nn256"]["hbm_bytes_per_launch_edge_rows"] = int(
+                    (2.0 * 1024.0 * fb[k] + 1024.0 * wb.get(k, 0.0)) / n)
+                variants[mode]["nn256"]["launches_profiled_edge_rows"] = n
     out["variants"] = variants
     # whole-step traffic: every dispatch of the profiled process / number of optimiser steps in it (cn_adam_kernel)
     steps = max(1, max((fc[k] for k in f if "adam" in k), default=1))

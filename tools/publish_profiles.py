@@ -51,7 +51,7 @@ overlapped timed steps ({rf['achieved']} TFLOP/s, {rf['frac']} of the fp32 matri
 rocprofv3 reports {float(dom['AverageNs'])/1e3:.1f} us averaged over all {dom['Calls']} launches of that kernel in the process -- every shape it runs (the E-row layer GEMMs above,
 the small N-row node projections, the K = 80 first edge Linear) in the overlapped, warm-up and isolated steps alike; bench.py's average over the same set of shapes is
 {rf.get('kernel_avg_launch_us_all_shapes', 'n/a')} us in the overlapped steps (taken in warm-up steps 2-3: inside the timed steps only the dominant variant carries events) and {rf.get('kernel_avg_launch_us_all_shapes_isolated', 'n/a')} us isolated (the process mixes 13 overlapped with 3 isolated fp32 steps).  HBM traffic of that variant from the
-PMC passes: {traffic['variants']['fp32']['nn256']['hbm_bytes_per_launch']/1e6:.0f} MB per launch (bf16x3 kernel on the same launches: {traffic['variants']['x3']['nn256']['hbm_bytes_per_launch']/1e6:.0f} MB).
+PMC passes: {traffic['variants']['fp32']['nn256'].get('hbm_bytes_per_launch_edge_rows', traffic['variants']['fp32']['nn256']['hbm_bytes_per_launch'])/1e6:.0f} MB per edge-sized launch (the kernel's launches with a grid of >= 500k threads: 14 per step -- the 13 of the dominant variant and the K = 80 first edge Linear; bf16x3 kernel on the same launches: {traffic['variants']['x3']['nn256'].get('hbm_bytes_per_launch_edge_rows', traffic['variants']['x3']['nn256']['hbm_bytes_per_launch'])/1e6:.0f} MB; averaged over all launches of the kernel incl. the small node projections: {traffic['variants']['fp32']['nn256']['hbm_bytes_per_launch']/1e6:.0f} MB).  Algorithmic bytes of those launches (operands read once, outputs written once, node-term gathers at their nominal size): 543 + 724 MB (layer GEMM 1), 1086 MB (dpre), 724 MB (dE), 905 MB (encoder) -- the counted traffic is at or below it, i.e. no wasted re-reads.
 
 Backward runs on two streams, so kernel durations of the two streams overlap in wall time (their sum exceeds the step time).
 
