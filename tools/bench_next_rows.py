@@ -88,7 +88,8 @@ print(json.dumps({"row": "(f)2 ADP evaluation metrics", "workload": f"M = {M} no
                            "materialised: 2 x 13 GB of fp32 at this M)",
                   "algorithmic_flops": flops, "achieved_TFLOPs": round(flops / t_iou / 1e12, 2),
                   "peak_TFLOPs": VALU_FP32_PEAK / 1e12, "frac": round(flops / t_iou / VALU_FP32_PEAK, 3),
-                  "cpu": "oracle/metrics_ref.py timed in tests/test_gpu_metrics.py (tools may not import the oracle)"}),
+                  "cpu": "not timed here: tools may not import the oracle (tests/test_gpu_metrics.py checks the kernel against "
+                         "oracle/metrics_ref.py and the reference's golden outputs)"}),
       flush=True)
 
 # ---------------------------------------------------------------------------------------------- (f)3 collate

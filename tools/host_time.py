@@ -1,3 +1,4 @@
+"""Host-side cost of one training step at configs[2] shapes (cProfile of the Python / ctypes enqueue path; GPU box)."""
 import os, sys, time, cProfile, pstats
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
