@@ -57,6 +57,22 @@ def broadcast_buffers(model: torch.nn.Module, src: int = 0) -> None:
         dist.broadcast(b, src=src)
 
 
+def assert_replicas_in_sync(model: torch.nn.Module) -> None:
+    """Data-parallel invariant: every rank applied the same averaged gradients, so the parameters must be identical on
+    all ranks (BatchNorm running statistics are per rank and not compared).  One MAX and one MIN all-reduce of two
+    checksums; raises on every rank if they differ."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    params = [p.detach().double() for p in model.parameters()]
+    dev = params[0].device
+    chk = torch.stack([sum(p.sum() for p in params), sum((p * p).sum() for p in params)]).to(dev)
+    hi, lo = chk.clone(), chk.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    if not torch.equal(hi, lo):
+        raise RuntimeError(f"parameters diverged across ranks: checksums differ by {(hi - lo).tolist()}")
+
+
 def max_over_ranks(value: float, device) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value

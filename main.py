@@ -124,6 +124,8 @@ def main(argv=None) -> dict:
     torch.set_num_threads(args.threads)
     rank, world, local = cdist.init_from_env()
     if world > 1:
+        if os.environ.get("CARTNET_SHARE_GPU"):      # rehearsal on a box with fewer GPUs than ranks (gloo backend)
+            local %= max(1, torch.cuda.device_count())
         cfg.device = f"cuda:{local}"
     torch.manual_seed(cfg.seed)
     if args.inference or args.montecarlo:
@@ -156,6 +158,7 @@ def main(argv=None) -> dict:
                 os.makedirs(ckpt_dir, exist_ok=True)
                 torch.save({"model_state": model.state_dict(), "optimizer_state": opt.state_dict()},
                            os.path.join(ckpt_dir, "best.ckpt"))
+    cdist.assert_replicas_in_sync(model)
     cdist.barrier()
     result = {"params": n_params, "history": history, "best_val_mae": best}
     if rank == 0 and os.path.exists(os.path.join(ckpt_dir, "best.ckpt")):  # train/train.py:114-117

@@ -56,7 +56,21 @@ def _worker(rank, world, port, out_dir):
     cdist.barrier()
     tmax = cdist.max_over_ranks(float(rank), torch.device("cpu"))
     assert tmax == world - 1
-    torch.save({"flat": flat * scale, "loss": loss, "idx": list(mine)}, os.path.join(out_dir, f"r{rank}.pt"))
+    # replica check: identical parameters pass, a perturbed rank is reported on every rank
+    lin = torch.nn.Linear(3, 3)
+    with torch.no_grad():
+        for p_ in lin.parameters():
+            p_.fill_(0.5)
+    cdist.assert_replicas_in_sync(lin)
+    with torch.no_grad():
+        lin.weight[0, 0] += float(rank)
+    diverged = False
+    try:
+        cdist.assert_replicas_in_sync(lin)
+    except RuntimeError as exc:
+        diverged = "diverged" in str(exc)
+    torch.save({"flat": flat * scale, "loss": loss, "idx": list(mine), "diverged": diverged},
+               os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -67,6 +81,7 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
     res = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
     assert sorted(res[0]["idx"] + res[1]["idx"]) == [0, 1, 2, 3, 4]           # disjoint, exhaustive
     assert torch.equal(res[0]["flat"], res[1]["flat"])                         # every rank ends with the same gradient
+    assert res[0]["diverged"] and res[1]["diverged"]                            # replica check fires on both ranks
 
     # single-process reference: mean over ranks of the per-rank losses (each rank normalises BatchNorm and the MAE
     # over its own crystals -- standard data-parallel semantics)
