@@ -33,7 +33,7 @@ def pair():
     ops.segment_sum(dpre, lay.rowptr, None, dPn[:, :2 * D])
     ops.segment_sum(dpre, lay.colptr, lay.perm, dPn[:, 2 * D:])
 t = timeit(pair)
-print(f"segment_sum tgt+src pair: {t:7.1f} us  {2 * E * 2 * D * 4 / t / 1e3:7.1f} GB/s (CARTNET_SEG_REV={os.environ.get('CARTNET_SEG_REV')})")
+print(f"segment_sum tgt+src pair: {t:7.1f} us  {2 * E * 2 * D * 4 / t / 1e3:7.1f} GB/s")
 # gate kernels (forward after a GEMM-like ascending write of gs; backward statistics then apply)
 gs, e_in, env = rnd(E, 2 * D), rnd(E, D), torch.rand(E, generator=g).to(dev)
 e_out, aggr = torch.empty(E, D, device=dev), torch.empty(N, D, device=dev)
@@ -49,7 +49,7 @@ def write_only():
     gs.copy_(src_gs)
 tw = timeit(write_only)
 t = timeit(fwd_after_write) - tw
-print(f"gate_scatter_fwd after ascending write of gs: {t:7.1f} us  {E * D * 16 / t / 1e3:7.1f} GB/s (CARTNET_GATE_REV={os.environ.get('CARTNET_GATE_REV')})")
+print(f"gate_scatter_fwd after ascending write of gs: {t:7.1f} us  {E * D * 16 / t / 1e3:7.1f} GB/s")
 t = timeit(lambda: ops.gate_scatter_fwd(gs, e_in, env, lay, mr, gamma, beta, e_out, aggr, p1, p2))
 print(f"gate_scatter_fwd alone:                       {t:7.1f} us  {E * D * 16 / t / 1e3:7.1f} GB/s")
 de_out, daggr, sums = rnd(E, D), rnd(N, D), torch.zeros(2 * D, device=dev)
