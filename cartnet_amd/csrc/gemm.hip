@@ -120,7 +120,9 @@ static int choose_bn(const CartnetGemmArgs& a) {
   int bn = a.N > 128 ? 256 : (a.N > 64 ? 128 : 64);
   if (bn == 256 && a.precision <= 1 && !a.a_kstrided && a.splitk == 1 && a.N % 64 == 0) {
     const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 255) / 256) * a.ngroups;
-    const long long few = a.precision == 0 ? 200 : 100;     // bf16x3 tiles are ~2x shorter: switch later
+    // bf16x3 tiles are ~2x shorter: switch later (96: the benchmark batch's 97-row-tile dX product, K = 1024, stays on
+    // the DMA-fed bf16x3 kernel -- +0.4 % on the step in a same-box A/B)
+    const long long few = a.precision == 0 ? 200 : 96;
     if (tiles < few) bn = (2 * tiles >= few) ? 128 : 64;
   }
   return bn;
