@@ -423,6 +423,58 @@ def test_segment_sum(ops):
     assert rel_err(out_s[:, W:], ref_s) < TOL
 
 
+def _graph_with_degrees(degs, seed=0):
+    """One crystal whose node t has exactly degs[t] incoming edges (sources drawn at random), target-sorted."""
+    g = torch.Generator().manual_seed(seed)
+    n = len(degs)
+    tgt = torch.repeat_interleave(torch.arange(n), torch.tensor(degs))
+    src = torch.randint(0, n, (int(tgt.numel()),), generator=g)
+    return torch.stack([src, tgt]).to(torch.int64), torch.tensor([0, n], dtype=torch.int64)
+
+
+@pytest.mark.parametrize("W", [256, 512, 320])
+def test_segment_sum_every_batch_remainder_is_exact(ops, W):
+    """Segment lengths 0..17, 24, 40 (the kernel loads 8 rows per round and clamps the remainder round) with
+    integer-valued rows: sums are exact, so the comparison is bitwise, by target (ascending sweep) and by source
+    (permuted rows, descending sweep)."""
+    degs = list(range(18)) + [24, 40, 0, 8, 16, 1]
+    ei, ptr = _graph_with_degrees(degs, seed=W)
+    N, E = len(degs), ei.shape[1]
+    lay = ops.GraphLayout(ei.to(dev()), N, ptr.to(dev()))
+    g = torch.Generator().manual_seed(1)
+    rows = torch.randint(-8, 9, (E, W), generator=g).float().to(dev())
+    out_t, out_s = torch.full((N, W), 7.0, device=dev()), torch.full((N, W), 7.0, device=dev())
+    ops.segment_sum(rows, lay.rowptr, None, out_t)
+    ops.segment_sum(rows, lay.colptr, lay.perm, out_s)
+    ref_t = torch.zeros(N, W).index_add_(0, ei[1], rows.cpu())
+    ref_s = torch.zeros(N, W).index_add_(0, ei[0], rows.cpu())
+    assert torch.equal(out_t.cpu(), ref_t) and torch.equal(out_s.cpu(), ref_s)
+
+
+def test_gate_scatter_fwd_every_batch_remainder(ops):
+    """Forward gate with in-degrees 0..9 and 13 (rounds of 4 edges with a clamped remainder): against the fp64
+    formula, and the e_out rows of a clamped round are each written exactly once (checked through e_out itself)."""
+    D = 256
+    degs = list(range(10)) + [13, 0, 4, 8]
+    ei, ptr = _graph_with_degrees(degs, seed=3)
+    N, E = len(degs), ei.shape[1]
+    lay = ops.GraphLayout(ei.to(dev()), N, ptr.to(dev()))
+    gs, e_in = rnd(E, 2 * D, seed=1), rnd(E, D, seed=2)
+    env = torch.rand(E, generator=torch.Generator().manual_seed(3)).to(dev())
+    gamma, beta = rnd(D, seed=4) * 0.2 + 1.0, rnd(D, seed=5) * 0.1
+    mean, rstd = rnd(D, seed=6) * 0.1, torch.rand(D, generator=torch.Generator().manual_seed(7)).to(dev()) + 0.5
+    mr = torch.cat([mean, rstd]).contiguous()
+    nparts = ops.gate_nparts(N)
+    e_out, aggr = torch.full((E, D), float("nan"), device=dev()), torch.full((N, D), float("nan"), device=dev())
+    ps, pq = (torch.zeros(nparts * D, dtype=torch.float64, device=dev()) for _ in range(2))
+    ops.gate_scatter_fwd(gs, e_in, env, lay, mr, gamma, beta, e_out, aggr, ps, pq)
+    c = lambda t: t.detach().double().cpu()
+    eo_ref, ag_ref = _gate_reference(c(gs), c(e_in), c(env), ei[1], N, c(mean), c(rstd), c(gamma), c(beta))
+    assert torch.isfinite(e_out).all() and torch.isfinite(aggr).all()
+    assert rel_err(e_out, eo_ref) < TOL and rel_err(aggr, ag_ref) < TOL
+    assert rel_err(ps.view(nparts, D).sum(0), ag_ref.sum(0)) < 1e-6
+
+
 # --------------------------------------------------------------------------------------------------- node ops
 def test_bn_finalize_and_node_update(ops):
     N, D = 777, 64
