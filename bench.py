@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """graphs/sec of the CartNet hot path (forward + MAE loss + backward + gradient all-reduce + Adam step) on MI355X.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (N > 1 under torch.distributed.run, one rank per GPU,
-RCCL).  Rank 0 prints ONE JSON line.  Workload = BASELINE.json configs[1]: CartNet L=4, D=256, R=64, fp32,
+Contract: ``python bench.py --gpus N --steps K --warmup W``.  N > 1 runs one rank per GPU over RCCL: either the caller
+starts the ranks (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``, WORLD_SIZE must equal
+N) or -- when WORLD_SIZE is unset -- bench.py starts them itself as a child torch.distributed.run BEFORE anything
+touches the GPU, relays rank 0's JSON line and exits with the child's code.  Rank 0 prints ONE JSON line.  Workload = BASELINE.json configs[1]: CartNet L=4, D=256, R=64, fp32,
 ADP-shaped synthetic crystals of 194 atoms (periodic 5 A radius graph, ~2.8k edges each), ``--graphs`` crystals per
 rank per step (weak scaling: every rank owns its own crystals; one 10 MB gradient all-reduce per step).
 Inputs are resident in HBM before the timed region.
@@ -13,16 +15,20 @@ Extra objects on the line:
                 157.3 TFLOP/s
   cpu_baseline  the oracle (CPU restatement of the reference forward + autograd backward) timed on the host cores
                 on a bounded sample (rank 0, N = 1 only)
+  sustained     >= --sustain-seconds of the same steps after the timed region (graphs/s over the whole stretch and the
+                min / max ms per step over 100-step windows): clock / thermal steady state on the record
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import torch
+import torch            # importing torch does not initialise the GPU; nothing below touches it before self_launch()
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -97,6 +103,22 @@ def cpu_baseline(seconds_budget: float = 12.0):
                       f"step on 1 thread"}
 
 
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` without an outer launcher: start the N ranks as a CHILD torch.distributed.run (never
+    an exec, and before this process has made any GPU call), pass the child's output through and return its exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.share_gpu:
+        env.setdefault("CARTNET_DIST_BACKEND", "gloo")      # several ranks on one card: RCCL needs one device per rank
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,13 +131,20 @@ def main():
     ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA GEMMs, 1: bf16x3 split-operand MFMA")
     ap.add_argument("--no-x3-pass", action="store_true", help="skip the extra bf16x3 timed pass")
     ap.add_argument("--share-gpu", action="store_true",
-                    help="rehearsal only: ranks beyond the visible GPUs share them (use with CARTNET_DIST_BACKEND=gloo)")
+                    help="rehearsal only: ranks beyond the visible GPUs share them (gloo transport unless "
+                         "CARTNET_DIST_BACKEND says otherwise)")
+    ap.add_argument("--sustain-seconds", type=float, default=6.0,
+                    help="length of the sustained stretch after the timed region (0 disables; N = 1 only)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     from cartnet_amd import distributed as cdist
     rank, world, local = cdist.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, the two must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the CartNet hot path has no CPU fallback")
     if args.share_gpu:
@@ -191,6 +220,34 @@ def main():
     if not torch.isfinite(loss):
         raise SystemExit("non-finite loss")
 
+    # Sustained stretch (outside the timed region, same step, same batches re-armed): long enough for the clock and
+    # the power management to settle under the fp32 matrix load; windows of 100 steps are timed with one host sync each.
+    sustained = None
+    if world == 1 and args.sustain_seconds > 0:
+        win = 100
+        est = max(dt / args.steps, 1e-4)
+        n_win = max(1, int(args.sustain_seconds / (est * win) + 0.999))
+        pool = [fresh() for _ in range(4)]
+        ms = []
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        for wi in range(n_win):
+            tw = time.perf_counter()
+            for i in range(win):
+                bx = pool[i & 3]
+                bx.x, bx.edge_attr = base.x, None                 # forward replaced them: re-arm without a copy
+                bx._cartnet_layout = None
+                bx._cartnet_mask_index = None
+                step(bx)
+            torch.cuda.synchronize()
+            ms.append(1e3 * (time.perf_counter() - tw) / win)
+        tot = time.perf_counter() - ts0
+        sustained = {"seconds": round(tot, 2), "steps": n_win * win,
+                     "value": round(args.graphs * n_win * win / tot, 2), "unit": "graphs/s",
+                     "ms_per_step_min_window": round(min(ms), 3), "ms_per_step_max_window": round(max(ms), 3),
+                     "ms_per_step_first_window": round(ms[0], 3), "ms_per_step_last_window": round(ms[-1], 3),
+                     "window_steps": win}
+
     # The timed steps run backward on two streams, so a GEMM's event-bracketed duration includes the time it shares
     # the chip with the weight-gradient stream.  Three extra single-stream steps (outside the timed region) give the
     # same launches undisturbed: kernel quality without the overlap.
@@ -262,9 +319,13 @@ def main():
     out["path_hbm"] = {"peak_TBps": 8.0,
                        "algorithmic_bytes_per_step": int(alg), "algorithmic_TBps": round(alg / step_s / 1e12, 3),
                        "algorithmic_frac": round(alg / step_s / 8.0e12, 4),
+                       "counted_from": "profiles/traffic.json (committed rocprofv3 PMC passes of the fp32 step; a constant "
+                                       "of the build, NOT measured by this run)",
                        "counted_bytes_per_step": per_step.get("hbm_bytes"),
                        "counted_TBps": round(per_step["hbm_bytes"] / step_s / 1e12, 3) if per_step.get("hbm_bytes") else None,
                        "counted_frac": round(per_step["hbm_bytes"] / step_s / 8.0e12, 4) if per_step.get("hbm_bytes") else None}
+    if sustained is not None:
+        out["sustained"] = sustained
     if x3 is not None:
         out["bf16x3"] = x3
     if rank == 0:

@@ -33,28 +33,57 @@ def _deps():
     return hdr
 
 
+def _includes(src: str) -> list:
+    """Local headers a source pulls in, transitively (quote includes only; they all live in csrc/ or include/)."""
+    import re
+    seen, todo = [], [src]
+    roots = [CSRC, os.path.join(os.path.dirname(CSRC), "..", "include")]
+    while todo:
+        f = todo.pop()
+        try:
+            text = open(f).read()
+        except OSError:
+            continue
+        for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+            for r in roots:
+                cand = os.path.normpath(os.path.join(r, name))
+                if os.path.exists(cand) and cand not in seen:
+                    seen.append(cand)
+                    todo.append(cand)
+    return seen
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile what changed: every object carries the digest of its source + the headers it includes + the flags
+    (csrc/<name>.o.sha), so editing one kernel recompiles one translation unit; the link runs when any object did."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     stamp = os.path.join(CSRC, ".build_stamp")
     dig = _digest(srcs + _deps())
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
-    objs = []
 
     def cc(src):
         obj = src[:-4] + ".o"
+        sha = obj + ".sha"
+        d = _digest([src] + _includes(src))
+        if not force and os.path.exists(obj) and os.path.exists(sha) and open(sha).read() == d:
+            return obj, False
         cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        return obj
+        with open(sha, "w") as f:
+            f.write(d)
+        return obj, True
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(cc, srcs))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+        res = list(ex.map(cc, srcs))
+    objs = [o for o, _ in res]
+    if force or any(c for _, c in res) or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
     with open(stamp, "w") as f:
         f.write(dig)
     return LIB

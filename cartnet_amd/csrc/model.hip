@@ -261,8 +261,6 @@ int check_model(const CartnetModel* m, const CartnetBatch* b, const char* who) {
            CARTNET_MAX_LAYERS);
   CN_CHECK(m->R >= 1, "%s: dim_rbf=%d", who, m->R);
   CN_CHECK(m->gemm_precision >= 0 && m->gemm_precision <= 2, "%s: gemm_precision=%d", who, m->gemm_precision);
-  CN_CHECK(m->use_temperature || m->atom_types, "%s: a model without atom types and without temperature is not built",
-           who);
   CN_CHECK(b->N >= 0 && b->E >= 0 && b->Bg >= 1 && b->M >= 0, "%s: bad batch sizes", who);
   CN_CHECK(b->E < 2147483647LL, "%s: E does not fit int32", who);
   CN_CHECK((long long)b->E * 2 * m->D < 2147483647LL * 4, "%s: batch too large for 32-bit tile indexing", who);
@@ -272,12 +270,13 @@ int check_model(const CartnetModel* m, const CartnetBatch* b, const char* who) {
   CN_CHECK(!m->use_temperature || b->temperature, "%s: temperature missing", who);
   CN_CHECK(!m->cholesky || b->non_h_mask, "%s: non_H_mask missing", who);
   const CartnetParams& p = m->p;
-  CN_CHECK(m->rbf_means && m->rbf_betas && p.atom_w && p.atom_b && p.edge0_w && p.edge0_b && p.edge2_w && p.edge2_b &&
-               p.head0_w && p.head0_b && p.head2_w && p.head2_b,
+  const bool plain = !m->use_temperature && !m->atom_types;   // one learned row for every atom, no atom MLP (cartnet.py:150-151)
+  CN_CHECK(m->rbf_means && m->rbf_betas && (plain || (p.atom_w && p.atom_b)) && p.edge0_w && p.edge0_b && p.edge2_w &&
+               p.edge2_b && p.head0_w && p.head0_b && p.head2_w && p.head2_b,
            "%s: null parameter", who);
-  CN_CHECK(!m->atom_types || p.embedding, "%s: embedding missing", who);
+  CN_CHECK(!(m->atom_types || plain) || p.embedding, "%s: embedding missing", who);
   CN_CHECK(!m->use_temperature || (p.temp_w && p.temp_b), "%s: temperature projection missing", who);
-  CN_CHECK(m->use_temperature || p.enc_bias, "%s: encoder.bias missing", who);
+  CN_CHECK(m->use_temperature || !m->atom_types || p.enc_bias, "%s: encoder.bias missing", who);
   for (int l = 0; l < m->L; ++l) {
     const CartnetLayerParams& q = p.layer[l];
     CN_CHECK(q.gate0_w && q.gate0_b && q.gate2_w && q.gate2_b && q.aggr0_w && q.aggr0_b && q.aggr2_w && q.aggr2_b &&
@@ -315,6 +314,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
   CN_CHECK(workspace_bytes >= need, "cartnet_model_forward: workspace %zu < required %zu bytes", workspace_bytes, need);
   const int D = m.D, L = m.L, H = D / 2, N = b.N;
   const int E = (int)b.E;
+  const bool plain = !m.use_temperature && !m.atom_types;
 
   RUN(cartnet_csr_build(b.edge_index, b.E, N, b.graph_ptr, b.Bg, w.src32, w.tgt32, w.rowptr, w.colptr, w.perm, status,
                         st));
@@ -342,7 +342,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     }
     RUN(add(P.edge0_w, w.edge0T, 2 * D, w.kf));
     RUN(add(P.edge2_w, w.edge2T, D, 2 * D));
-    RUN(add(P.atom_w, w.atomT, D, 2 * D));
+    if (!plain) RUN(add(P.atom_w, w.atomT, D, 2 * D));
     RUN(add(P.head0_w, w.head0T, H, D));
     for (int l = 0; l < L; ++l) {
       RUN(add(P.layer[l].gate0_w, w.gate0T[l], D, 3 * D));
@@ -366,7 +366,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     };
     bwd(w.edge0T, 2 * D, w.ldf, 2 * D, w.i_edge0);     // the zero-padded transposed copy is already [K, N]
     fwd(P.edge2_w, 2 * D, 2 * D, D, w.i_edge2);
-    fwd(P.atom_w, 2 * D, 2 * D, D, w.i_atom);
+    if (!plain) fwd(P.atom_w, 2 * D, 2 * D, D, w.i_atom);
     for (int l = 0; l < L; ++l) {
       const CartnetLayerParams& q = P.layer[l];
       fwd(q.gate0_w, 3 * D, D, D, w.i_pn[l]);
@@ -380,7 +380,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     }
     if (need_backward) {
       bwd(P.edge2_w, 2 * D, D, 2 * D, w.i_edge2_b);
-      bwd(P.atom_w, 2 * D, D, 2 * D, w.i_atom_b);
+      if (!plain) bwd(P.atom_w, 2 * D, D, 2 * D, w.i_atom_b);
       if (w.i_head0_b) bwd(P.head0_w, D, H, D, w.i_head0_b);
       for (int l = 0; l < L; ++l) {
         const CartnetLayerParams& q = P.layer[l];
@@ -415,12 +415,15 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     a.b_kstrided = 1; a.a_act = 1; a.out_act = 1; a.b_split[0] = w.i_edge2;
     RUN(cartnet_gemm(&a, st));
   }
-  // ---- encoder, atoms (cartnet.py:145-154)
-  RUN(cartnet_node_embed(m.atom_types ? b.z : nullptr, m.use_temperature ? b.batch : nullptr,
-                         m.use_temperature ? b.temperature : nullptr, m.atom_types ? P.embedding : nullptr,
-                         m.use_temperature ? P.temp_w : nullptr, m.use_temperature ? P.temp_b : nullptr,
-                         m.use_temperature ? nullptr : P.enc_bias, N, 2 * D, w.x0, st));
-  {
+  // ---- encoder, atoms (cartnet.py:145-154); out-of-table atomic numbers / batch ids are clamped and reported in `status`
+  if (plain) {   // cartnet.py:150-151: the single row of Embedding(1, D) for every atom, no atom MLP
+    RUN(cartnet_node_embed(nullptr, nullptr, nullptr, P.embedding, nullptr, nullptr, nullptr, N, D, 1, b.Bg, status,
+                           w.xenc, st));
+  } else {
+    RUN(cartnet_node_embed(m.atom_types ? b.z : nullptr, m.use_temperature ? b.batch : nullptr,
+                           m.use_temperature ? b.temperature : nullptr, m.atom_types ? P.embedding : nullptr,
+                           m.use_temperature ? P.temp_w : nullptr, m.use_temperature ? P.temp_b : nullptr,
+                           m.use_temperature ? nullptr : P.enc_bias, N, 2 * D, m.n_types, b.Bg, status, w.x0, st));
     CartnetGemmArgs a = gemm_args(N, D, 2 * D, 2 * D, D, D);
     a.A[0] = w.x0; a.B[0] = w.atomT; a.C[0] = w.xenc; a.cpre[0] = w.xa_pre; a.bias[0] = P.atom_b;
     a.b_kstrided = 1; a.a_act = 1; a.out_act = 1; a.b_split[0] = w.i_atom;
@@ -545,9 +548,10 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
   const CartnetParams& P = m.p;
   CN_CHECK(workspace && dpred && x_out && grads, "cartnet_model_backward: null argument");
   const CartnetParams& G = *grads;
-  CN_CHECK(G.atom_w && G.atom_b && G.edge0_w && G.edge0_b && G.edge2_w && G.edge2_b && G.head0_w && G.head0_b &&
-               G.head2_w && G.head2_b && (!m.atom_types || G.embedding) &&
-               (!m.use_temperature || (G.temp_w && G.temp_b)) && (m.use_temperature || G.enc_bias),
+  const bool plain = !m.use_temperature && !m.atom_types;
+  CN_CHECK((plain || (G.atom_w && G.atom_b)) && G.edge0_w && G.edge0_b && G.edge2_w && G.edge2_b && G.head0_w &&
+               G.head0_b && G.head2_w && G.head2_b && (!(m.atom_types || plain) || G.embedding) &&
+               (!m.use_temperature || (G.temp_w && G.temp_b)) && (m.use_temperature || !m.atom_types || G.enc_bias),
            "cartnet_model_backward: a gradient destination is missing");
   size_t need = 0;
   const Work w = carve(m, b.N, b.E, b.Bg, b.M, true, static_cast<char*>(workspace), &need);
@@ -711,9 +715,9 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       a.B[0] = q.gate0_w; a.B[1] = q.aggr0_w; a.B[2] = q.gate0_w + D; a.B[3] = q.aggr0_w + D;
       a.C[0] = dx_other; a.resid[0] = dx; a.ldr = D;
       a.b_split_folded = w.i_dx[l];
-      if (l == 0) { a.dact[0] = w.xa_pre; a.ldd = D; a.colsum[0] = w.cs_misc[1]; }
+      if (l == 0 && !plain) { a.dact[0] = w.xa_pre; a.ldd = D; a.colsum[0] = w.cs_misc[1]; }
       RUN(cartnet_gemm(&a, st));
-      if (l == 0) {
+      if (l == 0 && !plain) {
         double* parts[1] = {w.cs_misc[1]};
         float* outs[1] = {G.atom_b};
         RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_n, D, st));
@@ -758,7 +762,12 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       RUN(wgrad(dY2, 2 * D, X2, w.ldf, o2, w.kf, b.E, 2 * D, w.kf, 1, false, w, sw));
     }
   }
-  {
+  if (plain) {   // every atom read the same learned row: its gradient is the column sum of dx over the atoms
+    double* parts[1] = {w.pa};
+    float* outs[1] = {G.embedding};
+    RUN(cartnet_colsum_partial(dx, D, N, D, parts[0], st));
+    RUN(cartnet_colsum_finalize(parts, outs, 1, cartnet_segment_nparts(N), D, st));
+  } else {
     const float* dY[1] = {dx};
     const float* X[1] = {w.x0};
     float* o[1] = {G.atom_w};
@@ -768,7 +777,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     a.b_split[0] = w.i_atom_b;
     RUN(cartnet_gemm(&a, st));
     RUN(cartnet_node_embed_bwd(m.use_temperature ? b.batch : nullptr, m.use_temperature ? b.temperature : nullptr, w.dx0,
-                               N, 2 * D, w.pa, w.pb, st));
+                               N, 2 * D, b.Bg, w.pa, w.pb, st));
     if (m.use_temperature) {
       double* parts[2] = {w.pa, w.pb};
       float* outs[2] = {G.temp_w, G.temp_b};

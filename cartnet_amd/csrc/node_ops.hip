@@ -26,30 +26,43 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ embedding
+// z / batch ids outside their tables are clamped (never an out-of-bounds read) and reported in the status word of the
+// forward pass: bit 16 = atomic number outside [0, n_types), bit 32 = batch id outside [0, Bg).  The reference's
+// nn.Embedding raises for the former; here the error surfaces through ops.raise_on_graph_status.
+// z == nullptr with a table: every atom takes row 0 (the "no atom types, no temperature" ablation, cartnet.py:150-151).
 __global__ void cn_node_embed_kernel(const int64_t* __restrict__ z, const int64_t* __restrict__ batch,
                                      const float* __restrict__ temperature, const float* __restrict__ emb,
                                      const float* __restrict__ wt, const float* __restrict__ bt,
-                                     const float* __restrict__ bias, int N, int C, float* __restrict__ x0) {
+                                     const float* __restrict__ bias, int N, int C, int n_types, int Bg,
+                                     int* __restrict__ status, float* __restrict__ x0) {
   const long long total = (long long)N * C;
+  int bad = 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int n = (int)(i / C), c = (int)(i % C);
     float v = 0.f;
-    if (emb) v = emb[(size_t)z[n] * C + c];
+    if (emb) {
+      long long a = z ? z[n] : 0;
+      if (a < 0 || a >= n_types) { bad |= 16; a = a < 0 ? 0 : n_types - 1; }
+      v = emb[(size_t)a * C + c];
+    }
     if (wt) {
       // Linear(1 -> C) on the crystal's temperature, then broadcast to its atoms (cartnet.py:145)
-      const float t = temperature[batch[n]] * wt[c] + bt[c];
+      long long g = batch[n];
+      if (g < 0 || g >= Bg) { bad |= 32; g = g < 0 ? 0 : Bg - 1; }
+      const float t = temperature[g] * wt[c] + bt[c];
       v = emb ? v + t : t;
     }
     if (bias) v += bias[c];
     x0[i] = v;
   }
+  if (bad && status) atomicOr(status, bad);
 }
 
 // Column sums of dx0 and of T[batch[n]] * dx0 (temperature projection gradients), per-block partials.
 __global__ __launch_bounds__(256) void cn_embed_bwd_cols_kernel(const int64_t* __restrict__ batch,
                                                                 const float* __restrict__ temperature,
-                                                                const float* __restrict__ dx0, int N, int C,
+                                                                const float* __restrict__ dx0, int N, int C, int Bg,
                                                                 double* __restrict__ parts_w,
                                                                 double* __restrict__ parts_b) {
   __shared__ double red[NODES_PER_BLOCK * 256];
@@ -70,7 +83,11 @@ __global__ __launch_bounds__(256) void cn_embed_bwd_cols_kernel(const int64_t* _
         t[u] = 0.f;
         if (n < N) {
           d[u] = ld4(dx0 + (size_t)n * C + c);
-          if (temperature) t[u] = temperature[batch[n]];
+          if (temperature) {
+            long long g = batch[n];                 // clamped like the forward (which reported it)
+            g = g < 0 ? 0 : (g >= Bg ? Bg - 1 : g);
+            t[u] = temperature[g];
+          }
         }
       }
 #pragma unroll
@@ -377,7 +394,7 @@ __global__ __launch_bounds__(256) void cn_scalar_head_bwd_kernel(const float* __
                                                                  const float* __restrict__ w2,
                                                                  const int64_t* __restrict__ graph_ptr,
                                                                  const int64_t* __restrict__ batch,
-                                                                 const float* __restrict__ dout, int N, int H,
+                                                                 const float* __restrict__ dout, int N, int Bg, int H,
                                                                  float* __restrict__ dhid,
                                                                  float* __restrict__ parts) {
   __shared__ float red[NODES_PER_BLOCK][2 * HEAD_MAX_H + 8];
@@ -386,7 +403,8 @@ __global__ __launch_bounds__(256) void cn_scalar_head_bwd_kernel(const float* __
   float hacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float bacc = 0.f;
   for (int n = blockIdx.x * NODES_PER_BLOCK + wid; n < N; n += gridDim.x * NODES_PER_BLOCK) {
-    const int g = (int)batch[n];
+    long long gl = batch[n];
+    const int g = (int)(gl < 0 ? 0 : (gl >= Bg ? Bg - 1 : gl));
     const int cnt = (int)(graph_ptr[g + 1] - graph_ptr[g]);
     const float dv = dout[g] / (float)(cnt > 0 ? cnt : 1);
     bacc += dv;
@@ -427,16 +445,17 @@ __global__ __launch_bounds__(256) void cn_scalar_head_bwd_kernel(const float* __
 
 extern "C" int cartnet_node_embed(const int64_t* z, const int64_t* batch, const float* temperature, const float* emb,
                                   const float* wt, const float* bt, const float* bias, int32_t N, int32_t C,
-                                  float* x0, void* stream) {
+                                  int32_t n_types, int32_t Bg, int32_t* status, float* x0, void* stream) {
   CN_CHECK(N >= 0 && C >= 1, "cartnet_node_embed: bad sizes");
   if (N == 0) return 0;
   CN_CHECK(x0 && (emb || wt), "cartnet_node_embed: need an embedding table or a temperature projection");
-  CN_CHECK(!emb || z, "cartnet_node_embed: embedding needs atomic numbers");
-  CN_CHECK(!wt || (bt && temperature && batch), "cartnet_node_embed: temperature projection needs wt, bt, T, batch");
+  CN_CHECK(!emb || n_types >= 1, "cartnet_node_embed: the embedding table needs n_types >= 1 rows");
+  CN_CHECK(!wt || (bt && temperature && batch && Bg >= 1),
+           "cartnet_node_embed: temperature projection needs wt, bt, T, batch and Bg >= 1");
   long long blocks = ((long long)N * C + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(cn_node_embed_kernel, dim3((int)blocks), dim3(256), 0, ST(stream), z, batch, temperature, emb,
-                     wt, bt, bias, N, C, x0);
+                     wt, bt, bias, N, C, n_types, Bg, status, x0);
   CN_LAUNCH_CHECK("cartnet_node_embed");
   return 0;
 }
@@ -444,12 +463,12 @@ extern "C" int cartnet_node_embed(const int64_t* z, const int64_t* batch, const 
 extern "C" int cartnet_node_nparts(int32_t N) { return node_parts(N); }
 
 extern "C" int cartnet_node_embed_bwd(const int64_t* batch, const float* temperature, const float* dx0, int32_t N,
-                                      int32_t C, double* parts_w, double* parts_b, void* stream) {
+                                      int32_t C, int32_t Bg, double* parts_w, double* parts_b, void* stream) {
   CN_CHECK(N >= 0 && C >= 4 && C % 4 == 0, "cartnet_node_embed_bwd: C=%d must be a multiple of 4", C);
   CN_CHECK((dx0 || N == 0) && parts_w && parts_b, "cartnet_node_embed_bwd: null pointer");
-  CN_CHECK(!temperature || batch, "cartnet_node_embed_bwd: temperature needs batch");
+  CN_CHECK(!temperature || (batch && Bg >= 1), "cartnet_node_embed_bwd: temperature needs batch and Bg >= 1");
   hipLaunchKernelGGL(cn_embed_bwd_cols_kernel, dim3(node_parts(N)), dim3(256), 0, ST(stream), batch, temperature, dx0,
-                     N, C, parts_w, parts_b);
+                     N, C, Bg, parts_w, parts_b);
   CN_LAUNCH_CHECK("cartnet_node_embed_bwd");
   return 0;
 }
@@ -556,7 +575,7 @@ extern "C" int cartnet_scalar_head_bwd(const float* hid, const float* w2, const 
   CN_CHECK(N >= 0 && Bg >= 0 && H >= 1 && H <= HEAD_MAX_H, "cartnet_scalar_head_bwd: H=%d out of range", H);
   CN_CHECK(hid && w2 && graph_ptr && batch && dout && dhid && parts, "cartnet_scalar_head_bwd: null pointer");
   hipLaunchKernelGGL(cn_scalar_head_bwd_kernel, dim3(node_parts(N)), dim3(256), 0, ST(stream), hid, w2, graph_ptr,
-                     batch, dout, N, H, dhid, parts);
+                     batch, dout, N, Bg, H, dhid, parts);
   CN_LAUNCH_CHECK("cartnet_scalar_head_bwd");
   return 0;
 }

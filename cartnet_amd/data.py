@@ -100,7 +100,8 @@ class DataLoader:
     graphs at a time (stand-in for ``torch_geometric.loader.DataLoader``; reference: loader/loader.py:114-124).
 
     ``rank`` / ``world_size`` give the batched-graph sharding mode: every rank walks the same permutation and
-    takes a contiguous, disjoint slice of it, so crystals are partitioned across GPUs with no data-path collective.
+    takes a contiguous, disjoint, edge-balanced slice of it (no crystal is dropped), so crystals are partitioned
+    across GPUs with no data-path collective.
     """
 
     def __init__(self, dataset: Sequence[Data], batch_size: int, shuffle: bool = False, seed: int = 0,
@@ -115,29 +116,37 @@ class DataLoader:
         self.transform = transform
         self.epoch = 0
 
-    def _indices(self) -> List[int]:
+    def _order(self) -> List[int]:
         n = len(self.dataset)
         if self.shuffle:
             g = torch.Generator().manual_seed(self.seed + self.epoch)
-            order = torch.randperm(n, generator=g).tolist()
-        else:
-            order = list(range(n))
-        per = n // self.world_size if self.world_size > 1 else n
+            return torch.randperm(n, generator=g).tolist()
+        return list(range(n))
+
+    def _batches(self) -> List[List[int]]:
+        """Crystal indices of this rank's batches for the current epoch.  One rank: consecutive chunks of
+        ``batch_size`` (PyG's DataLoader).  Several ranks: cartnet_amd.distributed.rank_batches -- contiguous
+        EDGE-balanced slices of the common permutation, nothing dropped, the same number of batches on every rank."""
+        order = self._order()
         if self.world_size > 1:
-            order = order[self.rank * per:(self.rank + 1) * per]
-        return order
+            from .distributed import rank_batches
+            weights = [int(self.dataset[j].edge_index.shape[1]) for j in order]
+            return [[order[i] for i in r] for r in rank_batches(weights, self.batch_size, self.rank, self.world_size)]
+        chunks = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+        if self.drop_last and chunks and len(chunks[-1]) < self.batch_size:
+            chunks.pop()
+        return chunks
 
     def __len__(self) -> int:
-        n = len(self._indices())
-        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+        return len(self._batches())
 
     def __iter__(self) -> Iterable[Batch]:
-        order = self._indices()
+        batches = self._batches()
         self.epoch += 1
-        for i in range(0, len(order), self.batch_size):
-            chunk = order[i:i + self.batch_size]
-            if self.drop_last and len(chunk) < self.batch_size:
-                break
+        for chunk in batches:
+            if not chunk:                 # fewer crystals than steps on this rank: a step with a zero gradient
+                yield None
+                continue
             items = [self.dataset[j] for j in chunk]
             if self.transform is not None:
                 items = [self.transform(d.clone()) for d in items]

@@ -12,25 +12,37 @@ statistics identical on every rank when a checkpoint is written.
 from __future__ import annotations
 
 import os
-from typing import Optional
+from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 
 
+def _forced() -> bool:
+    """CARTNET_DIST_FORCE=1: run every collective even in a world of ONE rank.  That is how the RCCL code path
+    (communicator init, the 10 MB all-reduce, barrier, MAX/MIN reductions) is exercised on a box with a single card:
+    ``backend="nccl"`` with world_size 1 goes through librccl exactly like a multi-rank job, only the ring is trivial."""
+    return os.environ.get("CARTNET_DIST_FORCE", "") not in ("", "0")
+
+
+def _active() -> bool:
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _forced())
+
+
 def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
     """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun's contract).
-    Returns (rank, world_size, local_rank); a no-op for single-process runs."""
+    Returns (rank, world_size, local_rank); a no-op for single-process runs (unless CARTNET_DIST_FORCE is set)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _forced()) and not dist.is_initialized():
         if backend is None:
             # "nccl" is RCCL on ROCm; CARTNET_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs
             backend = os.environ.get("CARTNET_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -42,16 +54,58 @@ def shard_range(n_items: int, rank: int, world: int) -> range:
     return range(start, start + base + (1 if rank < rem else 0))
 
 
+def balanced_partition(weights: Sequence[int], parts: int) -> List[range]:
+    """Contiguous, disjoint, exhaustive partition of ``len(weights)`` items into ``parts`` ranges whose weight sums
+    are as equal as a prefix-sum cut allows (shards balanced by EDGE count -- the step time of a rank is
+    proportional to its edges, and the job runs at the pace of the slowest rank).  Cut k sits where the running sum is
+    nearest to k/parts of the total; every range is non-empty whenever there are at least ``parts`` items."""
+    n = len(weights)
+    if parts <= 0:
+        raise ValueError("parts must be positive")
+    pre = [0]
+    for w in weights:
+        pre.append(pre[-1] + max(int(w), 0) + 1)     # +1: zero-weight items still count, cuts stay strictly ordered
+    total = pre[-1]
+    cuts = [0]
+    j = 0
+    for k in range(1, parts):
+        target = total * k / parts
+        while j < n and pre[j + 1] <= target:
+            j += 1
+        c = j + 1 if j < n and (pre[j + 1] - target) < (target - pre[j]) else j     # nearer of the two neighbours
+        lo = min(cuts[-1] + 1, n) if n >= parts else cuts[-1]                      # keep this part non-empty ...
+        hi = n - (parts - k) if n >= parts else n                                  # ... and leave one for each later part
+        cuts.append(max(lo, min(c, hi)))
+    cuts.append(n)
+    return [range(cuts[i], cuts[i + 1]) for i in range(parts)]
+
+
+def rank_batches(weights: Sequence[int], batch_size: int, rank: int, world: int) -> List[range]:
+    """The batches of ``rank`` for one epoch as index ranges into the (already permuted) crystal order.
+
+    Every rank gets a contiguous edge-balanced slice (no crystal is dropped) and cuts it into the SAME number of
+    batches -- ceil(n / (world * batch_size)) -- again balanced by edges, so that all ranks take the same number of
+    optimiser steps (one all-reduce each) and every step carries about the same number of edges on every rank.
+    ``batch_size`` is therefore nominal for world > 1: a rank holding small crystals packs a few more of them per
+    step.  A rank with fewer crystals than steps (tiny data sets only) gets empty ranges at the end: it contributes a
+    zero gradient to those steps."""
+    n = len(weights)
+    mine = balanced_partition(weights, world)[rank]
+    n_batches = max(1, -(-n // (world * max(int(batch_size), 1))))
+    w = [weights[i] for i in mine]
+    return [range(mine.start + r.start, mine.start + r.stop) for r in balanced_partition(w, n_batches)]
+
+
 def all_reduce_gradients(flat_grad: torch.Tensor) -> float:
     """SUM-all-reduce the flat gradient buffer in place; returns the scale (1/world) the optimiser should apply."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return 1.0
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return 1.0 / dist.get_world_size()
 
 
 def broadcast_buffers(model: torch.nn.Module, src: int = 0) -> None:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return
     for b in model.buffers():
         dist.broadcast(b, src=src)
@@ -61,7 +115,7 @@ def assert_replicas_in_sync(model: torch.nn.Module) -> None:
     """Data-parallel invariant: every rank applied the same averaged gradients, so the parameters must be identical on
     all ranks (BatchNorm running statistics are per rank and not compared).  One MAX and one MIN all-reduce of two
     checksums; raises on every rank if they differ."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return
     params = [p.detach().double() for p in model.parameters()]
     dev = params[0].device
@@ -74,7 +128,7 @@ def assert_replicas_in_sync(model: torch.nn.Module) -> None:
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -82,5 +136,5 @@ def max_over_ranks(value: float, device) -> float:
 
 
 def barrier() -> None:
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()

@@ -139,9 +139,10 @@ PROTOTYPES = {
     "cartnet_edge_features": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float,
                                         C.c_float, c_f32p, C.c_int32, c_f32p, c_stream]),
     "cartnet_node_embed": (C.c_int, [c_i64p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32,
-                                     c_f32p, c_stream]),
+                                     C.c_int32, C.c_int32, c_i32p, c_f32p, c_stream]),
     "cartnet_node_nparts": (C.c_int, [C.c_int32]),
-    "cartnet_node_embed_bwd": (C.c_int, [c_i64p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_stream]),
+    "cartnet_node_embed_bwd": (C.c_int, [c_i64p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p,
+                                         c_stream]),
     "cartnet_sort_by_key": (C.c_int, [c_i64p, C.c_int32, C.c_int32, c_i32p, c_i32p, c_i32p, c_stream]),
     "cartnet_segment_sum_long": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
                                            c_f32p, C.c_int32, c_stream]),

@@ -246,9 +246,6 @@ class CartNet(nn.Module):
             raise ValueError("dim_in up to 1024 is supported by the head kernels")
         if not (1 <= num_layers <= _l.MAX_LAYERS):
             raise ValueError(f"num_layers must be in 1..{_l.MAX_LAYERS}")
-        if not temperature and not atom_types:
-            raise NotImplementedError("the ablation without atom types AND without temperature (one learned row for "
-                                      "every atom, cartnet.py:150-151) is not built; no reference script uses it")
         self.encoder = Encoder(dim_in, dim_rbf=dim_rbf, radius=radius, invariant=invariant, temperature=temperature,
                                atom_types=atom_types)
         self.dim_in = dim_in
@@ -294,11 +291,12 @@ class CartNet(nn.Module):
 
     def _defer_graph_check(self, status: torch.Tensor) -> None:
         """Asynchronous check of the device status word of cartnet_csr_build (edge order / index range / crystal
-        membership): the word is copied to pinned host memory behind the forward's kernels and read at a later forward
+        membership) and of cartnet_node_embed (atomic numbers / batch ids inside their tables): the word is copied to pinned host memory behind the forward's kernels and read at a later forward
         call, once its copy has arrived -- a malformed batch raises without a host sync on the hot path (the host
         only ever waits when 64 forward calls are still in flight).  ``validate_graph = True`` checks every batch at
-        once, with one sync per batch.  The kernels clamp what they gather through, so a bad batch cannot fault in
-        the meantime."""
+        once, with one sync per batch; ``flush_graph_checks()`` drains what is in flight.  The kernels clamp every
+        index they gather through (edge endpoints, atomic numbers, batch ids), so a bad batch cannot fault in the
+        meantime."""
         if self._status_ring is None:                # (in flight: [pinned word, event] oldest first, free pinned words)
             pool = torch.zeros(self._STATUS_DEPTH + 1, dtype=torch.int32).pin_memory()    # one host allocation
             self._status_ring = ([], [pool[i:i + 1] for i in range(self._STATUS_DEPTH + 1)])
@@ -321,6 +319,23 @@ class CartNet(nn.Module):
             except ValueError as exc:
                 raise ValueError(f"{exc} (reported for a batch passed to an earlier forward call; set "
                                  "model.validate_graph = True to check every batch at once)") from None
+
+    def flush_graph_checks(self) -> None:
+        """Wait for every graph status word still in flight and raise if any batch was malformed.  The training /
+        evaluation loops call this before each optimiser step and at the end of a pass (one host sync per optimiser
+        step), so the last batches of an epoch are checked too and no gradient of a bad batch reaches the weights."""
+        if self._status_ring is None:
+            return
+        pending, free = self._status_ring
+        bad = None
+        while pending:
+            word, ev = pending.pop(0)
+            ev.synchronize()
+            if bad is None and int(word.item()) != 0:
+                bad = int(word.item())
+            free.append(word)
+        if bad is not None:
+            ops.raise_on_graph_status(bad)
 
     def _aux_stream_ptr(self, dev):
         """Second HIP stream for the parameter-gradient work of backward (None -> single stream)."""

@@ -327,6 +327,10 @@ def raise_on_graph_status(s: int) -> None:
             why.append("an edge connects two different crystals")
         if s & 8:
             why.append("a crystal has more than 8192 atoms")
+        if s & 16:
+            why.append("an atomic number is outside [0, 119) (the embedding table, cartnet.py:113)")
+        if s & 32:
+            why.append("a batch id is outside [0, num_graphs)")
         raise ValueError("invalid graph: " + "; ".join(why))
 
 
@@ -351,7 +355,9 @@ def edge_features(cart_dist: Tensor, cart_dir: Optional[Tensor], means: Tensor, 
         "cartnet_edge_features")
 
 
-def node_embed(z, batch, temperature, emb, wt, bt, bias, x0: Tensor) -> None:
+def node_embed(z, batch, temperature, emb, wt, bt, bias, x0: Tensor, status: Optional[Tensor] = None) -> None:
+    """x0 = emb[z] + temperature projection + bias (cartnet_node_embed).  Atomic numbers / batch ids outside their
+    tables are clamped and reported in ``status`` (int32 [1], bits 16 / 32; decode with raise_on_graph_status)."""
     _f32_2d(x0, "node_embed x0")
     N, Cc = x0.shape
     if not x0.is_contiguous():
@@ -367,10 +373,18 @@ def node_embed(z, batch, temperature, emb, wt, bt, bias, x0: Tensor) -> None:
     _vec(wt, Cc, "node_embed wt")
     _vec(bt, Cc, "node_embed bt")
     _vec(bias, Cc, "node_embed bias")
+    Bg = 0
     if temperature is not None:
-        _vec(temperature, 1, "node_embed temperature")
+        if not (temperature.is_cuda and temperature.dtype == torch.float32 and temperature.dim() == 1 and
+                temperature.is_contiguous() and temperature.numel() >= 1):
+            raise ValueError("node_embed: temperature must be a contiguous fp32 CUDA vector [Bg]")
+        Bg = int(temperature.numel())
+    if status is not None:
+        _vec(status, 1, "node_embed status", torch.int32)
+    n_types = int(emb.shape[0]) if emb is not None else 0
     _l.check(_l.load().cartnet_node_embed(_l.ptr(z), _l.ptr(batch), _l.ptr(temperature), _l.ptr(emb), _l.ptr(wt),
-                                          _l.ptr(bt), _l.ptr(bias), N, Cc, x0.data_ptr(), _l.stream_ptr()),
+                                          _l.ptr(bt), _l.ptr(bias), N, Cc, n_types, Bg, _l.ptr(status), x0.data_ptr(),
+                                          _l.stream_ptr()),
              "cartnet_node_embed")
 
 
@@ -394,7 +408,8 @@ def node_embed_bwd(batch, temperature, dx0: Tensor, parts_w, parts_b) -> None:
         _vec(batch, N, "node_embed_bwd batch", torch.int64)
     if temperature is not None and batch is None:
         raise ValueError("node_embed_bwd: temperature needs batch")
-    _l.check(_l.load().cartnet_node_embed_bwd(_l.ptr(batch), _l.ptr(temperature), dx0.data_ptr(), N, Cc,
+    Bg = int(temperature.numel()) if temperature is not None else 0
+    _l.check(_l.load().cartnet_node_embed_bwd(_l.ptr(batch), _l.ptr(temperature), dx0.data_ptr(), N, Cc, Bg,
                                               parts_w.data_ptr(), parts_b.data_ptr(), _l.stream_ptr()),
              "cartnet_node_embed_bwd")
 

@@ -67,14 +67,61 @@ class FlatAdam:
                       self.betas[1], self.eps, self.step_count, grad_scale)
 
     def state_dict(self):
-        return {"step": self.step_count, "lr": self.lr, "exp_avg": self.exp_avg.clone(),
-                "exp_avg_sq": self.exp_avg_sq.clone()}
+        """``torch.optim.Adam.state_dict()`` layout -- ``{"state": {i: {"step", "exp_avg", "exp_avg_sq"}},
+        "param_groups": [{"lr", "betas", "eps", ..., "params": [0..n-1]}]}`` with parameters numbered in
+        ``model.parameters()`` order -- so that ``best.ckpt["optimizer_state"]`` (train/train.py:92-95) is
+        interchangeable with the reference's: a torch Adam over the same model loads it, and
+        ``load_state_dict`` below reads a reference checkpoint.  Moments are copies of the flat buffers' slices."""
+        state, off = {}, 0
+        for i, p in enumerate(self.params):
+            k = p.numel()
+            if self.step_count > 0:           # torch creates a parameter's state at its first step
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[off:off + k].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + k].view(p.shape).clone()}
+            off += k
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd) -> None:
-        self.step_count = int(sd["step"])
-        self.set_lr(sd["lr"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        """Accepts torch.optim.Adam's layout (above; what the reference's checkpoints hold) and the flat layout
+        ``{"step", "lr", "exp_avg", "exp_avg_sq"}`` written by round-1 builds of this package."""
+        if "param_groups" not in sd:
+            self.step_count = int(sd["step"])
+            self.set_lr(sd["lr"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            return
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError(f"optimizer state holds {sum(len(g['params']) for g in groups)} parameters in "
+                             f"{len(groups)} group(s); this model has {len(self.params)} in one")
+        g = groups[0]
+        if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+            raise ValueError("FlatAdam implements plain Adam (weight_decay=0, amsgrad=False), as the reference uses it")
+        self.set_lr(float(g["lr"]))
+        self.betas = (float(g["betas"][0]), float(g["betas"][1]))
+        self.eps = float(g["eps"])
+        state = sd["state"]
+        steps = {int(float(st["step"])) for st in state.values()}
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not a state FlatAdam can hold")
+        self.step_count = steps.pop() if steps else 0
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        off = 0
+        for i, (pid, p) in enumerate(zip(g["params"], self.params)):
+            k = p.numel()
+            st = state.get(pid, state.get(str(pid)))
+            if st is not None:
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state of parameter {i}: shape {tuple(st['exp_avg'].shape)}, "
+                                     f"expected {tuple(p.shape)}")
+                self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+            off += k
 
 
 def one_cycle_lr(step: int, total_steps: int, max_lr: float, pct_start: float = 0.3, div_factor: float = 25.0,

@@ -220,7 +220,7 @@ def random_rotations(n: int, gen: torch.Generator, device) -> torch.Tensor:
 
 class ShardLoader:
     """Loader over a resident shard with the interface of cartnet_amd.data.DataLoader: seeded shuffling, ``rank`` /
-    ``world_size`` crystal sharding (every rank walks the same permutation and takes a disjoint slice), optional
+    ``world_size`` crystal sharding (every rank walks the same permutation and takes a disjoint edge-balanced slice), optional
     SO(3) augmentation.  Batches are born on the GPU; the host only draws the permutation."""
 
     def __init__(self, shard: DeviceShard, batch_size: int, shuffle: bool = False, seed: int = 0, rank: int = 0,
@@ -233,7 +233,10 @@ class ShardLoader:
         self.epoch = 0
         self._gen = torch.Generator(device=shard.device).manual_seed(seed + 7919 * rank)
 
-    def _order(self) -> List[int]:
+    def _batches(self) -> List[List[int]]:
+        """Crystal ids of this rank's batches for the current epoch (same rule as cartnet_amd.data.DataLoader: one
+        rank -> consecutive chunks of the permutation; several -> edge-balanced contiguous slices, nothing dropped,
+        equally many batches per rank; edge counts come from the shard's host copy of ``edge_ptr``)."""
         n = len(self.indices)
         if self.shuffle:
             g = torch.Generator().manual_seed(self.seed + self.epoch)
@@ -241,20 +244,24 @@ class ShardLoader:
         else:
             order = list(self.indices)
         if self.world_size > 1:
-            per = n // self.world_size
-            order = order[self.rank * per:(self.rank + 1) * per]
-        return order
+            from .distributed import rank_batches
+            ep = self.shard.edge_ptr
+            weights = [int(ep[j + 1] - ep[j]) for j in order]
+            return [[order[i] for i in r] for r in rank_batches(weights, self.batch_size, self.rank, self.world_size)]
+        chunks = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+        if self.drop_last and chunks and len(chunks[-1]) < self.batch_size:
+            chunks.pop()
+        return chunks
 
     def __len__(self) -> int:
-        n = len(self._order())
-        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+        return len(self._batches())
 
     def __iter__(self) -> Iterable[Batch]:
-        order = self._order()
+        batches = self._batches()
         self.epoch += 1
-        for i in range(0, len(order), self.batch_size):
-            chunk = order[i:i + self.batch_size]
-            if self.drop_last and len(chunk) < self.batch_size:
-                break
+        for chunk in batches:
+            if not chunk:
+                yield None
+                continue
             rot = random_rotations(len(chunk), self._gen, self.shard.device) if self.augment else None
             yield self.shard.collate(chunk, rot, self.temp_mean, self.temp_std)

@@ -36,20 +36,24 @@ def train_epoch(loader, model, optimizer, batch_accumulation: int, scheduler: Op
     tot_mae = torch.zeros((), device=device)
     graphs = 0
     t0 = time.perf_counter()
+    flush = getattr(model, "flush_graph_checks", None)
     for it, batch in enumerate(loader):
-        batch.to(device)
-        pred, true = model(batch)
-        mae, mse = compute_loss(pred, true)
-        loss = _pick_loss(mae, mse)
-        loss.mean().backward()                      # not divided by the accumulation count (train/train.py:183)
+        if batch is not None:                       # None: this rank has no crystals left for the step (sharded
+            batch.to(device)                        # loaders, tiny data sets) -- it adds a zero gradient
+            pred, true = model(batch)
+            mae, mse = compute_loss(pred, true)
+            loss = _pick_loss(mae, mse)
+            loss.mean().backward()                  # not divided by the accumulation count (train/train.py:183)
+            tot_mae += mae.detach()
+            graphs += int(batch.num_graphs)
         if ((it + 1) % batch_accumulation == 0) or (it + 1 == n_iter):
+            if flush is not None:
+                flush()                             # a malformed batch raises BEFORE its gradient reaches the weights
             scale = cdist.all_reduce_gradients(optimizer.flat_grad) if hasattr(optimizer, "flat_grad") else 1.0
             optimizer.step(scale) if hasattr(optimizer, "flat_grad") else optimizer.step()
             if scheduler is not None:
                 scheduler()
             optimizer.zero_grad()
-        tot_mae += mae.detach()
-        graphs += int(batch.num_graphs)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"mae": float(tot_mae.item()) / max(n_iter, 1), "graphs": graphs, "seconds": dt}
@@ -67,6 +71,8 @@ def eval_epoch(loader, model, device="cuda:0", adp_metrics=False, test_metrics=F
     n = 0
     with torch.no_grad():
         for batch in loader:
+            if batch is None:
+                continue
             batch.to(device)
             pred, true = model(batch)
             mae, _ = compute_loss(pred, true)
@@ -78,4 +84,6 @@ def eval_epoch(loader, model, device="cuda:0", adp_metrics=False, test_metrics=F
                 if test_metrics:
                     tot["iou"] += iou.mean()
             n += 1
+    if hasattr(model, "flush_graph_checks"):
+        model.flush_graph_checks()
     return {k: float(v.item()) / max(n, 1) for k, v in tot.items()}

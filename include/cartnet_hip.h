@@ -330,11 +330,15 @@ int cartnet_edge_features(const float* cart_dist, const float* cart_dir, const f
                           int64_t E, int32_t R, int32_t invariant, float radius, float env_radius,
                           float* feat, int32_t ldf, float* env, void* stream);
 
-/* Node embedding (models/cartnet.py:145-149):
- *   x0[n, c] = emb[z[n], c] (if emb) + (temperature[batch[n]] * wt[c] + bt[c]) (if wt) + bias[c] (if bias). */
+/* Node embedding (models/cartnet.py:145-151):
+ *   x0[n, c] = emb[z[n], c] (if emb) + (temperature[batch[n]] * wt[c] + bt[c]) (if wt) + bias[c] (if bias).
+ * emb has n_types rows; z == NULL with a table means row 0 for every atom (the single learned row of the ablation
+ * without atom types and temperature, cartnet.py:150-151).  nn.Embedding raises on an index outside the table
+ * (cartnet.py:145); here such an atomic number -- and a batch id outside [0, Bg) -- is clamped (no out-of-bounds read)
+ * and reported: status[0] |= 16 (atomic number) / 32 (batch id).  status may be NULL (clamp only). */
 int cartnet_node_embed(const int64_t* z, const int64_t* batch, const float* temperature, const float* emb,
-                       const float* wt, const float* bt, const float* bias, int32_t N, int32_t C, float* x0,
-                       void* stream);
+                       const float* wt, const float* bt, const float* bias, int32_t N, int32_t C, int32_t n_types,
+                       int32_t Bg, int32_t* status, float* x0, void* stream);
 /* Backward of the above, temperature projection / bias part: parts_w[p][c] / parts_b[p][c] = per-block partial sums
  * over atoms of T[batch[n]]*dx0[n,c] and dx0[n,c] (p < cartnet_node_nparts(N)); reduce with cartnet_colsum_finalize
  * into the gradients of temperature_proj_atom.weight and .bias (or encoder.bias).
@@ -342,7 +346,7 @@ int cartnet_node_embed(const int64_t* z, const int64_t* batch, const float* temp
  * cartnet_segment_sum_long (fixed order, no atomics). */
 int cartnet_node_nparts(int32_t N);
 int cartnet_node_embed_bwd(const int64_t* batch, const float* temperature, const float* dx0, int32_t N, int32_t C,
-                           double* parts_w, double* parts_b, void* stream);
+                           int32_t Bg, double* parts_w, double* parts_b, void* stream);
 
 /* Stable counting sort of N items by key in [0, nkeys), nkeys <= 1024: items with key k are
  * perm[ptr[k] .. ptr[k+1]) in ascending item order.  status[0] |= 16 if a key is out of range. */

@@ -9,7 +9,8 @@ never enters the repo; only tensors do.
     python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
 
 Fixtures (all fp32 unless suffixed _f64):
-  tiny_*      D=16, R=8, L=2, 2 crystals of 7/9 atoms, four model variants; weights stored in the fixture
+  tiny_*      D=16, R=8, L=2, 2 crystals of 7/9 atoms, five model variants (all four Encoder branches of
+              models/cartnet.py:111-121 + the scalar head); weights stored in the fixture
   config1     D=64, R=64, L=2, 4 crystals of 30..70 atoms (BASELINE.json configs[0] shape); weights from seed
   config2     D=256, R=64, L=4, 2 crystals of 194 atoms (configs[1] shape); weights from seed
   radius_graph  reference radius_graph_pbc output for 3 crystals (integers compared bit-exactly)
@@ -292,25 +293,46 @@ def metrics_fixture():
 
 
 def main():
+    """All fixtures, or only those named on the command line (``python tests/golden/make_golden.py tiny_nothing``)."""
     torch.set_num_threads(4)
-    radius_graph_fixture()
-    metrics_fixture()
-    save_model_fixture("tiny_adp", hp_dict(16, 8, 2), tiny_batch(), seed=11, store_weights=True, full_grads=True,
-                       trace=True)
-    save_model_fixture("tiny_scalar", hp_dict(16, 8, 2, temperature=False, cholesky=False), tiny_batch(adp=False),
-                       seed=12, store_weights=True, full_grads=True, trace=False)
-    save_model_fixture("tiny_invariant", hp_dict(16, 8, 2, invariant=True, use_envelope=False), tiny_batch(),
-                       seed=13, store_weights=True, full_grads=True, trace=False)
-    save_model_fixture("tiny_noatom", hp_dict(16, 8, 2, atom_types=False), tiny_batch(), seed=14,
-                       store_weights=True, full_grads=True, trace=False)
-    b1 = Batch.from_data_list([make_crystal(300 + g, None, n_range=(30, 70)) for g in range(4)])
-    save_model_fixture("config1", hp_dict(64, 64, 2), b1, seed=21, store_weights=False, full_grads=True, trace=False)
-    icomformer_fixture("icomformer_tiny", 16, tiny_batch(), seed=31, store_weights=True)
-    b5 = Batch.from_data_list([make_crystal(500 + g, None, n_range=(20, 40)) for g in range(3)])
-    icomformer_fixture("icomformer_c32", 32, b5, seed=32, store_weights=False)
-    b2 = Batch.from_data_list([make_crystal(400 + g, 194) for g in range(2)])
-    save_model_fixture("config2", hp_dict(256, 64, 4), b2, seed=22, store_weights=False, full_grads=False,
-                       trace=False)
+    b1 = lambda: Batch.from_data_list([make_crystal(300 + g, None, n_range=(30, 70)) for g in range(4)])
+    b5 = lambda: Batch.from_data_list([make_crystal(500 + g, None, n_range=(20, 40)) for g in range(3)])
+    b2 = lambda: Batch.from_data_list([make_crystal(400 + g, 194) for g in range(2)])
+    jobs = {
+        "radius_graph": radius_graph_fixture,
+        "adp_metrics": metrics_fixture,
+        "tiny_adp": lambda: save_model_fixture("tiny_adp", hp_dict(16, 8, 2), tiny_batch(), seed=11,
+                                               store_weights=True, full_grads=True, trace=True),
+        "tiny_scalar": lambda: save_model_fixture("tiny_scalar", hp_dict(16, 8, 2, temperature=False, cholesky=False),
+                                                  tiny_batch(adp=False), seed=12, store_weights=True, full_grads=True,
+                                                  trace=False),
+        "tiny_invariant": lambda: save_model_fixture("tiny_invariant",
+                                                     hp_dict(16, 8, 2, invariant=True, use_envelope=False),
+                                                     tiny_batch(), seed=13, store_weights=True, full_grads=True,
+                                                     trace=False),
+        "tiny_noatom": lambda: save_model_fixture("tiny_noatom", hp_dict(16, 8, 2, atom_types=False), tiny_batch(),
+                                                  seed=14, store_weights=True, full_grads=True, trace=False),
+        # scripts/run_no_atom_type.sh:16-27 ("CartNet_nothing"): --disable_atom_types --disable_temp, i.e. the fourth
+        # Encoder branch (models/cartnet.py:115-116,150-151): one learned row for every atom, no atom MLP
+        "tiny_nothing": lambda: save_model_fixture("tiny_nothing",
+                                                   hp_dict(16, 8, 2, atom_types=False, temperature=False),
+                                                   tiny_batch(), seed=15, store_weights=True, full_grads=True,
+                                                   trace=True),
+        "config1": lambda: save_model_fixture("config1", hp_dict(64, 64, 2), b1(), seed=21, store_weights=False,
+                                              full_grads=True, trace=False),
+        "icomformer_tiny": lambda: icomformer_fixture("icomformer_tiny", 16, tiny_batch(), seed=31,
+                                                      store_weights=True),
+        "icomformer_c32": lambda: icomformer_fixture("icomformer_c32", 32, b5(), seed=32, store_weights=False),
+        "config2": lambda: save_model_fixture("config2", hp_dict(256, 64, 4), b2(), seed=22, store_weights=False,
+                                              full_grads=False, trace=False),
+    }
+    only = sys.argv[1:]
+    for name in only:
+        if name not in jobs:
+            raise SystemExit(f"unknown fixture {name!r}; known: {', '.join(jobs)}")
+    for name, job in jobs.items():
+        if not only or name in only:
+            job()
 
 
 if __name__ == "__main__":

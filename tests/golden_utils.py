@@ -8,7 +8,7 @@ from cartnet_amd.data import Batch
 from cartnet_amd.model import make_state_dict
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-MODEL_FIXTURES = ["tiny_adp", "tiny_scalar", "tiny_invariant", "tiny_noatom", "config1", "config2"]
+MODEL_FIXTURES = ["tiny_adp", "tiny_scalar", "tiny_invariant", "tiny_noatom", "tiny_nothing", "config1", "config2"]
 
 
 def load(name):

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(cdll, name), f"{name} is declared in include/cartnet_hip.h but not exported"
     # the ctypes prototypes cover exactly the declared set
     assert sorted(lib.PROTOTYPES) == declared
-    assert lib.load().cartnet_abi_version() == 1
+    assert lib.load().cartnet_abi_version() == 2
 
 
 def test_host_side_argument_validation_without_gpu():
@@ -121,14 +121,49 @@ def test_batch_collation_follows_pyg_rules():
     assert bool((b.edge_index[1][1:] >= b.edge_index[1][:-1]).all())          # stays sorted by target
     assert b.temperature.shape == (3,) and b.cell.shape == (3, 3, 3)
     assert b.y.shape[0] == int(b.non_H_mask.sum())
-    # sharded loader: ranks see disjoint crystals, same count
-    ds = [make_crystal(i, 4) for i in range(10)]
-    seen = []
+    # sharded loader: ranks see disjoint crystals, together all of them (n = 11 is not a multiple of the world size:
+    # nothing is dropped), the same number of batches on every rank, per-rank edge totals balanced
+    ds = [make_crystal(i, 4 + (i % 5)) for i in range(11)]
+    seen, edges = [], []
     for r in range(2):
         dl = DataLoader(ds, batch_size=2, shuffle=True, seed=7, rank=r, world_size=2)
         assert len(dl) == 3
-        seen.append(sorted(int(bb.x.sum()) for bb in dl))
-    assert len(seen) == 2
+        mine = [j for chunk in dl._batches() for j in chunk]
+        seen.append(mine)
+        edges.append(sum(int(ds[j].edge_index.shape[1]) for j in mine))
+        assert sum(int(bb.num_graphs) for bb in dl if bb is not None) == len(mine)
+    assert sorted(seen[0] + seen[1]) == list(range(11))
+    assert abs(edges[0] - edges[1]) <= max(int(d.edge_index.shape[1]) for d in ds)
+
+
+def test_edge_balanced_partition_properties():
+    """cartnet_amd.distributed.balanced_partition / rank_batches (contiguous shards balanced by edge
+    count): exhaustive, disjoint, ordered, non-empty parts, near-equal weights; equal batch counts across ranks."""
+    import random
+    from cartnet_amd.distributed import balanced_partition, rank_batches
+    rnd = random.Random(3)
+    for n in (0, 1, 2, 7, 64, 1000):
+        for parts in (1, 2, 3, 8):
+            w = [rnd.randint(0, 5000) for _ in range(n)]
+            P = balanced_partition(w, parts)
+            assert len(P) == parts and [i for r in P for i in r] == list(range(n))
+            if n >= parts:
+                assert all(len(r) > 0 for r in P)
+            if n >= 1000:
+                sums = [sum(w[i] for i in r) for r in P]
+                assert max(sums) <= 1.02 * sum(w) / parts
+    # one rank's share of the ADP epoch (162,270 crystals of 64-324 atoms over 8 ranks, batch 64): every rank takes the
+    # same number of optimiser steps and no step carries more than a few percent above the mean number of edges
+    w = [int(14.3 * rnd.randint(64, 324)) for _ in range(162270 // 8)]
+    per_rank = [rank_batches(w, 64, r, 8) for r in range(8)]
+    assert len({len(b) for b in per_rank}) == 1 and len(per_rank[0]) == -(-len(w) // (8 * 64))
+    assert [i for b in per_rank for r in b for i in r] == list(range(len(w)))
+    step_edges = [[sum(w[i] for i in r) for r in b] for b in per_rank]
+    mean = sum(w) / (8 * len(per_rank[0]))
+    assert max(max(s) for s in step_edges) <= 1.03 * mean
+    # fewer crystals than ranks x steps: trailing empty ranges, still exhaustive
+    tiny = [rank_batches([5, 5, 5], 1, r, 2) for r in range(2)]
+    assert [i for b in tiny for r in b for i in r] == [0, 1, 2] and len(tiny[0]) == len(tiny[1]) == 2
 
 
 def test_one_cycle_schedule_matches_torch():

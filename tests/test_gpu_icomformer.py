@@ -93,3 +93,49 @@ def test_against_oracle_at_width_256(precision):
     (ref - b.y.double()).abs().mean().backward()
     _check_grads({k: p.grad for k, p in m.named_parameters() if p.grad is not None},
                  {k: sd64[k].grad for k in names}, "icomformer256")
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_properties_at_the_adp_shape(precision):
+    """BASELINE.json configs[4] at its real size -- 64 crystals x 194 atoms, E ~ 177k (3E ~ 531k rows in the
+    edge-update layer), C = 256 -- which the fp64 oracle cannot check element by element in seconds.  Size-independent
+    properties instead: (i) eval mode uses running BatchNorm statistics, so a crystal's prediction must not depend on
+    which crystals share its batch; (ii) two training steps from the same state agree bit for bit (no atomics);
+    (iii) every gradient the reference produces is finite and non-trivial."""
+    from cartnet_amd.comformer import iComformer, make_icomformer_state_dict
+    from cartnet_amd.data import Batch
+    from cartnet_amd.synthetic import make_crystal
+    items = [make_crystal(8000 + g, 194) for g in range(64)]
+    sd = make_icomformer_state_dict(256, seed=9)
+    m = iComformer(256)
+    m.load_state_dict(sd)
+    m.gemm_precision = precision
+    m = m.to("cuda:0")
+
+    def batch(idx):
+        return Batch.from_data_list([items[i] for i in idx]).to("cuda:0")
+
+    m.eval()
+    with torch.no_grad():
+        full, _ = m(batch(range(64)))
+        parts = torch.cat([m(batch(range(s, s + 16)))[0] for s in range(0, 64, 16)])
+        odd, _ = m(batch([63, 5, 17]))
+    assert torch.isfinite(full).all() and rel_err(full, parts) < 2e-6
+    per = torch.split(full, [int(it.non_H_mask.sum()) for it in items])
+    assert rel_err(odd, torch.cat([per[63], per[5], per[17]])) < 2e-6
+
+    outs = []
+    for _ in range(2):
+        m.load_state_dict(sd)
+        m.train()
+        m.zero_grad(set_to_none=True)
+        pred, true = m(batch(range(64)))
+        (pred - true).abs().mean().backward()
+        outs.append((pred.detach().clone(),
+                     {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1].keys() == outs[1][1].keys() and len(outs[0][1]) >= 40
+    for k, g in outs[0][1].items():
+        assert torch.isfinite(g).all(), k
+        assert torch.equal(g, outs[1][1][k]), k
+    assert sum(float(g.abs().sum()) for g in outs[0][1].values()) > 0

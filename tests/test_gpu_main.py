@@ -19,7 +19,8 @@ def test_main_trains_and_checkpoints(tmp_path, monkeypatch):
     assert hist[-1]["train_mae"] < hist[0]["train_mae"]            # it learns
     ck = torch.load(tmp_path / "results" / "plumbing" / "0" / "ckpt" / "best.ckpt")
     assert set(ck) == {"model_state", "optimizer_state"}            # train/train.py:92-95
-    assert "encoder.embedding.weight" in ck["model_state"] and ck["optimizer_state"]["step"] > 0
+    assert "encoder.embedding.weight" in ck["model_state"] and set(ck["optimizer_state"]) == {"state", "param_groups"}      # torch.optim.Adam's layout
+    assert float(ck["optimizer_state"]["state"][0]["step"]) > 0
     assert "test_mae" in res and res["params"] == sum(v.numel() for k, v in ck["model_state"].items()
                                                       if "running" not in k and "num_batches" not in k and "rbf" not in k)
     tm = res["test_metrics"]                                         # train/metrics.py:201-214 on the GPU

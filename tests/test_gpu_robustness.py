@@ -198,3 +198,95 @@ def test_batch_without_any_edge_at_width_256(precision):
     assert torch.isfinite(pred).all() and rel_err(pred, ref) < PRED_TOL
     for k, p in m.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+@pytest.mark.parametrize("what", ["z_high", "z_negative", "batch_id"])
+def test_atomic_number_or_batch_id_outside_its_table_is_reported_not_faulted(what):
+    """nn.Embedding raises for an index outside its 119 rows (cartnet.py:113,145); the HIP path clamps what it gathers
+    through (no out-of-bounds read of the embedding table / the temperature vector, forward or backward) and raises
+    through the graph status word -- immediately with validate_graph, otherwise at the next flush_graph_checks()."""
+    z, hp, b, sd = gu.load("tiny_adp")
+    for immediate in (True, False):
+        m = _model(hp, sd).train()
+        m.validate_graph = immediate
+        bad = _fresh(b)
+        if what == "z_high":
+            bad.x[1] = 119
+        elif what == "z_negative":
+            bad.x[0] = -1
+        else:
+            bad.batch[2] = 10 ** 6
+        needle = "batch id" if what == "batch_id" else "atomic number"
+        if immediate:
+            with pytest.raises(ValueError, match=needle):
+                m(bad)
+        else:
+            pred, true = m(bad)
+            (pred - true).abs().mean().backward()      # backward also reads the clamped ids: nothing may fault
+            torch.cuda.synchronize()
+            with pytest.raises(ValueError, match=needle):
+                m.flush_graph_checks()
+            m.flush_graph_checks()                      # drained: a second call is a no-op
+        pred, _ = m(_fresh(b))                          # the model keeps working afterwards
+        assert torch.isfinite(pred).all()
+
+
+def test_train_epoch_flushes_the_graph_checks_before_the_optimiser_step():
+    """A malformed LAST batch of an epoch used to go unreported (its status word was only read by a later forward);
+    train_epoch now drains the pending words before every optimiser step."""
+    from cartnet_amd.optim import FlatAdam
+    from cartnet_amd.train import train_epoch
+    z, hp, b, sd = gu.load("tiny_adp")
+    m = _model(hp, sd).train()
+    m.validate_graph = False
+    opt = FlatAdam(m, lr=1e-3)
+    before = opt.flat_param.clone()
+    bad = gu.clone_batch(b)
+    bad.edge_index = b.edge_index.flip(1)               # no longer sorted by target
+    with pytest.raises(ValueError, match="not sorted"):
+        train_epoch([gu.clone_batch(b), bad], m, opt, batch_accumulation=2)
+    assert torch.equal(opt.flat_param, before)          # the bad gradient never reached the weights
+
+
+def test_optimizer_state_is_interchangeable_with_torch_adam():
+    """best.ckpt["optimizer_state"] (train/train.py:92-95) in torch.optim.Adam's layout, both directions: a torch Adam
+    over the same model loads FlatAdam's state and continues identically; FlatAdam loads a torch Adam state."""
+    from cartnet_amd.optim import FlatAdam
+    z, hp, b, sd = gu.load("tiny_adp")
+
+    def grads(m):
+        pred, true = m(_fresh(b))
+        (pred - true).abs().mean().backward()
+
+    ma, mb = _model(hp, sd).train(), _model(hp, sd).train()
+    fa = FlatAdam(ma, lr=2e-3)
+    tb = torch.optim.Adam(mb.parameters(), lr=2e-3)
+    for _ in range(2):                                     # two steps on each: both hold a non-trivial state
+        fa.zero_grad(); tb.zero_grad()
+        grads(ma); grads(mb)
+        fa.step(); tb.step()
+    state = fa.state_dict()
+    assert set(state) == {"state", "param_groups"} and len(state["state"]) == len(list(ma.parameters()))
+    assert state["param_groups"][0]["params"] == list(range(len(fa.params)))
+    # FlatAdam -> torch: a fresh torch Adam on a copy of model A continues exactly like torch Adam on model B
+    mc = _model(hp, {k: v.detach().cpu() for k, v in ma.state_dict().items()}).train()
+    tc = torch.optim.Adam(mc.parameters(), lr=2e-3)
+    tc.load_state_dict(state)
+    tc.zero_grad(); tb.zero_grad()
+    grads(mc); grads(mb)
+    tc.step(); tb.step()
+    for (k, pc), (_, pb) in zip(mc.named_parameters(), mb.named_parameters()):
+        assert rel_err(pc, pb) < 1e-5, k
+    # torch -> FlatAdam: load torch's state (one step ahead now) into a fresh FlatAdam and take the same next step
+    md = _model(hp, {k: v.detach().cpu() for k, v in mb.state_dict().items()}).train()
+    fd = FlatAdam(md, lr=1e-3)
+    fd.load_state_dict(tb.state_dict())
+    assert fd.step_count == 3 and fd.lr == 2e-3
+    fd.zero_grad(); tb.zero_grad()
+    grads(md); grads(mb)
+    fd.step(); tb.step()
+    for (k, pd), (_, pb) in zip(md.named_parameters(), mb.named_parameters()):
+        assert rel_err(pd, pb) < 1e-5, k
+    # the flat layout of round-1 checkpoints still loads
+    fd.load_state_dict({"step": 7, "lr": 5e-4, "exp_avg": fd.exp_avg.clone(), "exp_avg_sq": fd.exp_avg_sq.clone()})
+    assert fd.step_count == 7 and fd.lr == 5e-4

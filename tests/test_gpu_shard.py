@@ -114,9 +114,9 @@ def test_loader_feeds_the_model_and_shards_across_ranks():
         for b in shard.ShardLoader(ds, 2, shuffle=True, seed=1, rank=rank, world_size=2):
             seen.append(int(b.num_graphs))
     assert sum(seen) == 8
-    r0 = shard.ShardLoader(ds, 8, shuffle=True, seed=1, rank=0, world_size=2)._order()
-    r1 = shard.ShardLoader(ds, 8, shuffle=True, seed=1, rank=1, world_size=2)._order()
-    assert set(r0).isdisjoint(r1) and len(r0) == len(r1) == 4
+    r0 = [j for c in shard.ShardLoader(ds, 8, shuffle=True, seed=1, rank=0, world_size=2)._batches() for j in c]
+    r1 = [j for c in shard.ShardLoader(ds, 8, shuffle=True, seed=1, rank=1, world_size=2)._batches() for j in c]
+    assert set(r0).isdisjoint(r1) and sorted(r0 + r1) == list(range(8))
     aug = shard.ShardLoader(ds, 4, augment=True, seed=2)
     b1 = next(iter(aug))
     assert not torch.equal(b1.cart_dir, ds.collate([0, 1, 2, 3]).cart_dir)

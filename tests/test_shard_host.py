@@ -55,11 +55,16 @@ def test_rejects_bad_input(tmp_path):
 def test_loader_order_matches_the_host_dataloader():
     class _FakeShard:
         num_graphs, device = 23, torch.device("cpu")
+        edge_ptr = np.concatenate([[0], np.cumsum([10 + (7 * i) % 13 for i in range(23)])]).astype(np.int64)
+
+    class _Item:
+        def __init__(self, i):
+            self.edge_index = torch.zeros((2, 10 + (7 * i) % 13), dtype=torch.int64)
     for world in (1, 2):
         for rank in range(world):
             a = shard.ShardLoader.__new__(shard.ShardLoader)
             a.shard, a.batch_size, a.shuffle, a.seed, a.rank, a.world_size = _FakeShard, 4, True, 5, rank, world
             a.drop_last, a.indices, a.epoch = False, list(range(23)), 3
-            b = DataLoader(list(range(23)), 4, shuffle=True, seed=5, rank=rank, world_size=world)
+            b = DataLoader([_Item(i) for i in range(23)], 4, shuffle=True, seed=5, rank=rank, world_size=world)
             b.epoch = 3
-            assert a._order() == b._indices() and len(a) == len(b)
+            assert a._batches() == b._batches() and len(a) == len(b)
