@@ -124,9 +124,12 @@ __global__ __launch_bounds__(1024) void cn_sort_by_key_kernel(const int64_t* __r
   for (int i = tid; i < nkeys; i += 1024) cnt[i] = 0;
   __syncthreads();
   for (int i = tid; i < N; i += 1024) {
-    const long long k = keys[i];
-    if (k < 0 || k >= nkeys) atomicOr(status, 16);
-    else atomicAdd(&cnt[(int)k], 1);
+    long long k = keys[i];
+    if (k < 0 || k >= nkeys) {     // clamped like the forward gather (cn_node_embed_kernel), so perm stays a full permutation
+      atomicOr(status, 16);
+      k = k < 0 ? 0 : nkeys - 1;
+    }
+    atomicAdd(&cnt[(int)k], 1);
   }
   __syncthreads();
   if (tid == 0) {
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(1024) void cn_sort_by_key_kernel(const int64_t* __r
     int key = -1;
     if (i < N) {
       const long long k = keys[i];
-      key = (k < 0 || k >= nkeys) ? -1 : (int)k;
+      key = k < 0 ? 0 : (k >= nkeys ? nkeys - 1 : (int)k);
     }
     skey[tid] = key;
     __syncthreads();

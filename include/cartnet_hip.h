@@ -349,7 +349,8 @@ int cartnet_node_embed_bwd(const int64_t* batch, const float* temperature, const
                            int32_t Bg, double* parts_w, double* parts_b, void* stream);
 
 /* Stable counting sort of N items by key in [0, nkeys), nkeys <= 1024: items with key k are
- * perm[ptr[k] .. ptr[k+1]) in ascending item order.  status[0] |= 16 if a key is out of range. */
+ * perm[ptr[k] .. ptr[k+1]) in ascending item order.  A key outside the range is clamped into it (perm is always a full
+ * permutation of 0..N-1) and reported: status[0] |= 16. */
 int cartnet_sort_by_key(const int64_t* keys, int32_t N, int32_t nkeys, int32_t* perm, int32_t* ptr, int32_t* status,
                         void* stream);
 

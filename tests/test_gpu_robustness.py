@@ -250,7 +250,9 @@ def test_train_epoch_flushes_the_graph_checks_before_the_optimiser_step():
 
 def test_optimizer_state_is_interchangeable_with_torch_adam():
     """best.ckpt["optimizer_state"] (train/train.py:92-95) in torch.optim.Adam's layout, both directions: a torch Adam
-    over the same model loads FlatAdam's state and continues identically; FlatAdam loads a torch Adam state."""
+    over the same model loads FlatAdam's state and takes the same next step; FlatAdam loads a torch Adam state.  Both
+    optimisers are fed the SAME gradient tensors (Adam divides by sqrt(v): for the biases in front of a training-mode
+    BatchNorm, whose true gradient is 0, two independent backward passes would hand it different rounding noise)."""
     from cartnet_amd.optim import FlatAdam
     z, hp, b, sd = gu.load("tiny_adp")
 
@@ -258,35 +260,44 @@ def test_optimizer_state_is_interchangeable_with_torch_adam():
         pred, true = m(_fresh(b))
         (pred - true).abs().mean().backward()
 
-    ma, mb = _model(hp, sd).train(), _model(hp, sd).train()
+    def copy_model(m):
+        return _model(hp, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}).train()
+
+    ma = _model(hp, sd).train()
     fa = FlatAdam(ma, lr=2e-3)
-    tb = torch.optim.Adam(mb.parameters(), lr=2e-3)
-    for _ in range(2):                                     # two steps on each: both hold a non-trivial state
-        fa.zero_grad(); tb.zero_grad()
-        grads(ma); grads(mb)
-        fa.step(); tb.step()
+    for _ in range(2):                                     # two real steps: a non-trivial state
+        fa.zero_grad()
+        grads(ma)
+        fa.step()
     state = fa.state_dict()
     assert set(state) == {"state", "param_groups"} and len(state["state"]) == len(list(ma.parameters()))
     assert state["param_groups"][0]["params"] == list(range(len(fa.params)))
-    # FlatAdam -> torch: a fresh torch Adam on a copy of model A continues exactly like torch Adam on model B
-    mc = _model(hp, {k: v.detach().cpu() for k, v in ma.state_dict().items()}).train()
+    # FlatAdam -> torch: same state, same gradients, same third step
+    mc = copy_model(ma)
     tc = torch.optim.Adam(mc.parameters(), lr=2e-3)
     tc.load_state_dict(state)
-    tc.zero_grad(); tb.zero_grad()
-    grads(mc); grads(mb)
-    tc.step(); tb.step()
-    for (k, pc), (_, pb) in zip(mc.named_parameters(), mb.named_parameters()):
-        assert rel_err(pc, pb) < 1e-5, k
-    # torch -> FlatAdam: load torch's state (one step ahead now) into a fresh FlatAdam and take the same next step
-    md = _model(hp, {k: v.detach().cpu() for k, v in mb.state_dict().items()}).train()
+    fa.zero_grad()
+    grads(ma)
+    for pa, pc in zip(ma.parameters(), mc.parameters()):
+        pc.grad = pa.grad.detach().clone()
+    fa.step()
+    tc.step()
+    for (k, pa), pc in zip(ma.named_parameters(), mc.parameters()):
+        assert rel_err(pa, pc) < 1e-6, k
+    # torch -> FlatAdam: load torch's state (three steps) into a fresh FlatAdam and take the same fourth step
+    md = copy_model(mc)
     fd = FlatAdam(md, lr=1e-3)
-    fd.load_state_dict(tb.state_dict())
+    fd.load_state_dict(tc.state_dict())
     assert fd.step_count == 3 and fd.lr == 2e-3
-    fd.zero_grad(); tb.zero_grad()
-    grads(md); grads(mb)
-    fd.step(); tb.step()
-    for (k, pd), (_, pb) in zip(md.named_parameters(), mb.named_parameters()):
-        assert rel_err(pd, pb) < 1e-5, k
+    tc.zero_grad(set_to_none=False)
+    grads(mc)
+    fd.zero_grad()
+    for pc, pd in zip(mc.parameters(), md.parameters()):
+        pd.grad.copy_(pc.grad)
+    fd.step()
+    tc.step()
+    for (k, pd), pc in zip(md.named_parameters(), mc.parameters()):
+        assert rel_err(pd, pc) < 1e-6, k
     # the flat layout of round-1 checkpoints still loads
     fd.load_state_dict({"step": 7, "lr": 5e-4, "exp_avg": fd.exp_avg.clone(), "exp_avg_sq": fd.exp_avg_sq.clone()})
     assert fd.step_count == 7 and fd.lr == 5e-4
