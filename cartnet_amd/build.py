@@ -15,6 +15,8 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcartnet_hip.so")
 SOURCES = ["abi.hip", "gemm.hip", "gemm_bn256.hip", "gemm_bn128.hip", "gemm_bn64.hip", "gemm_x3.hip", "gemm_f32.hip", "graph_ops.hip", "edge_ops.hip", "node_ops.hip", "optim.hip", "model.hip", "comformer_ops.hip", "equi_ops.hip", "radius_graph.hip", "metrics.hip", "collate.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# per-source additions (the reason is at the top of the source file)
+EXTRA_FLAGS = {"radius_graph.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
 
 
@@ -24,6 +26,7 @@ def _digest(paths) -> str:
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -65,10 +68,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def cc(src):
         obj = src[:-4] + ".o"
         sha = obj + ".sha"
-        d = _digest([src] + _includes(src))
+        extra = EXTRA_FLAGS.get(os.path.basename(src), [])
+        d = _digest([src] + _includes(src)) + " " + " ".join(extra)
         if not force and os.path.exists(obj) and os.path.exists(sha) and open(sha).read() == d:
             return obj, False
-        cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+        cmd = [HIPCC, *FLAGS, *extra, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -7,6 +7,12 @@
 #include "common.h"
 #include <math.h>
 
+// This file is compiled with -ffp-contract=off (cartnet_amd/build.py: EXTRA_FLAGS).  HIP's __fmul_rn / __fadd_rn are
+// plain * and +, and under hipcc's default -ffp-contract=fast-honor-pragmas the compiler fused them into FMAs --
+// differently in the count and the fill instantiation of the kernel below, which then disagreed about a pair whose d^2
+// lies within an ulp of radius^2 (2 of 49k atoms in one 256-crystal launch: two slots of the fill pass stayed unwritten
+// and every later crystal of the chunk was shifted).  With contraction off every product and sum is rounded on its own,
+// like the reference's torch ops, and both passes evaluate the same expression.
 namespace {
 
 __device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }

@@ -122,9 +122,11 @@ def augment_data(data: Data, gen: torch.Generator) -> Data:
     return data
 
 
-def make_crystal(g: int, n_atoms: Optional[int] = 194, radius: float = 5.0, n_range=(64, 324),
-                 adp: bool = True, base_seed: int = 1234) -> Data:
-    """One synthetic crystal graph with the attribute set CartNet reads (SURVEY.md §8a batch table)."""
+def make_geometry(g: int, n_atoms: Optional[int] = 194, n_range=(64, 324), adp: bool = True,
+                  base_seed: int = 1234) -> Data:
+    """Everything of synthetic crystal ``g`` except its edges (SURVEY.md §8d recipe): atoms, cell, positions, targets.
+    ``make_crystal`` adds the periodic radius graph on the host; tools/bench_config4.py builds it on the GPU instead
+    (cartnet_amd.graph.radius_graph_pbc) for tens of thousands of crystals."""
     gen = torch.Generator().manual_seed(base_seed + g)
     if n_atoms is None:
         n = int(torch.randint(n_range[0], n_range[1] + 1, (1,), generator=gen).item())
@@ -143,9 +145,7 @@ def make_crystal(g: int, n_atoms: Optional[int] = 194, radius: float = 5.0, n_ra
     z = torch.where(u < 0.45, torch.tensor(1), torch.where(u < 0.80, torch.tensor(6), torch.where(
         u < 0.87, torch.tensor(7), torch.where(u < 0.97, torch.tensor(8), other)))).to(torch.int64)
     temperature = ((90.0 + 210.0 * torch.rand(1, generator=gen)) - TEMP_MEAN) / TEMP_STD
-    edge_index, cart_dist, cart_dir = radius_graph_pbc_single(pos, cell, radius)
-    d = Data(x=z, pos=pos, cell=cell.unsqueeze(0), edge_index=edge_index, cart_dist=cart_dist,
-             cart_dir=cart_dir, natoms=torch.tensor([n]))
+    d = Data(x=z, pos=pos, cell=cell.unsqueeze(0), natoms=torch.tensor([n]))
     if adp:
         mask = z != 1
         m = int(mask.sum().item())
@@ -155,6 +155,20 @@ def make_crystal(g: int, n_atoms: Optional[int] = 194, radius: float = 5.0, n_ra
         d.temperature = temperature.to(torch.float32)
     else:
         d.y = torch.randn(1, generator=gen, dtype=torch.float32)
+    return d
+
+
+def make_crystal(g: int, n_atoms: Optional[int] = 194, radius: float = 5.0, n_range=(64, 324),
+                 adp: bool = True, base_seed: int = 1234) -> Data:
+    """One synthetic crystal graph with the attribute set CartNet reads (SURVEY.md §8a batch table)."""
+    geo = make_geometry(g, n_atoms, n_range, adp, base_seed)
+    edge_index, cart_dist, cart_dir = radius_graph_pbc_single(geo.pos, geo.cell[0], radius)
+    d = Data(x=geo.x, pos=geo.pos, cell=geo.cell, edge_index=edge_index, cart_dist=cart_dist, cart_dir=cart_dir,
+             natoms=geo.natoms)
+    d.y = geo.y
+    if adp:
+        d.non_H_mask = geo.non_H_mask
+        d.temperature = geo.temperature
     return d
 
 

@@ -86,3 +86,30 @@ def test_batch_of_crystals_matches_cpu_builder_and_feeds_the_model():
         p1, _ = m(b1)
         p2, _ = m(b2)
     assert (p1 - p2).abs().max().item() <= 1e-5 * p1.abs().max().item()
+
+
+def test_count_and_fill_passes_agree_on_pairs_at_the_cutoff():
+    """Regression (round 2): 256 ragged crystals in one launch, among them one (chunk index 180) with a pair whose d^2
+    lies within an ulp of radius^2.  The count and the fill pass used to round d^2 differently (compiler-chosen FMA
+    contraction), leaving two edge slots unwritten and shifting every later crystal; the translation unit is now built
+    with -ffp-contract=off.  Checks: targets sorted, every slot written, that crystal identical to the host builder
+    (which restates the reference's dataset/utils.py bit for bit, tests/test_oracle_golden.py)."""
+    from cartnet_amd.graph import radius_graph_pbc
+    from cartnet_amd.synthetic import make_geometry, radius_graph_pbc_single
+    part = [make_geometry(30000 + i, None) for i in range(2560, 2816)]
+    pos = torch.cat([d.pos for d in part]).cuda()
+    cell = torch.cat([d.cell for d in part]).cuda()
+    sizes = torch.tensor([int(d.x.shape[0]) for d in part], dtype=torch.int64)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(sizes, 0)]).cuda()
+    ei, dist, dirs = radius_graph_pbc(pos, cell, ptr, 5.0)
+    assert bool((ei[1][1:] >= ei[1][:-1]).all())
+    assert bool((dist > 0.01).all()) and bool((dist <= 5.0).all())
+    gid = torch.repeat_interleave(torch.arange(len(part), device="cuda"), ptr[1:] - ptr[:-1])
+    assert bool((gid[ei[0]] == gid[ei[1]]).all())
+    for k in (90, 180, 255):
+        sel = gid[ei[1]] == k
+        mine = (ei[:, sel] - ptr[k]).cpu()
+        ref_ei, ref_dist, ref_dir = radius_graph_pbc_single(part[k].pos, part[k].cell[0], 5.0)
+        assert torch.equal(mine, ref_ei), k
+        assert torch.allclose(dist[sel].cpu(), ref_dist, rtol=1e-6, atol=0)          # fp32 rounding of sqrt / division
+        assert torch.allclose(dirs[sel].cpu(), ref_dir, rtol=0, atol=1e-6), k

@@ -1,0 +1,105 @@
+"""One rank's share of BASELINE.json configs[3] on one MI355X: 162,270 / 8 = 20,284 ragged ADP-shaped crystals
+(64..324 atoms), edges built by the GPU radius-graph builder (cartnet_amd.graph), resident in HBM as a
+packed shard, every batch collated and SO(3)-augmented on the device, one training epoch per recipe:
+
+    batch 64 x accumulation 1          (the bench workload's batching)
+    batch 4 x accumulation 16          (the reference recipe, scripts/train_cartnet_adp.sh:4, train/train.py:183-189)
+    [batch 64 as 16 groups of 4]       (--grouped: reference-recipe BatchNorm / loss semantics in one pass per step)
+
+Each epoch lasts >= 5 s.  Prints one JSON object; profiles/r02_config4_share.json is a copy of it.
+usage: python tools/bench_config4.py [--crystals 20284] [--precision 0] [--grouped]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np
+import torch
+
+from cartnet_amd.config import cfg
+from cartnet_amd.graph import radius_graph_pbc
+from cartnet_amd.model import CartNet
+from cartnet_amd.optim import FlatAdam
+from cartnet_amd.shard import DeviceShard, ShardLoader
+from cartnet_amd.synthetic import make_geometry
+from cartnet_amd.train import train_epoch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--crystals", type=int, default=162270 // 8)
+ap.add_argument("--precision", type=int, default=0)
+ap.add_argument("--chunk", type=int, default=256, help="crystals per radius-graph launch")
+ap.add_argument("--grouped", action="store_true", help="also run batch 64 with BatchNorm / loss per group of 4")
+args = ap.parse_args()
+cfg.radius = 5.0
+dev = torch.device("cuda:0")
+n = args.crystals
+
+t0 = time.perf_counter()
+geo = [make_geometry(30000 + i, None) for i in range(n)]
+t_geo = time.perf_counter() - t0
+natoms = np.array([int(d.x.shape[0]) for d in geo], dtype=np.int64)
+atom_ptr = np.concatenate([[0], np.cumsum(natoms)])
+
+# ---- edges on the GPU, `chunk` crystals per launch pair; indices rebased to the crystal
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+src_l, tgt_l, dist_l, dir_l, ecount = [], [], [], [], []
+for c0 in range(0, n, args.chunk):
+    part = geo[c0:c0 + args.chunk]
+    pos = torch.cat([d.pos for d in part]).to(dev)
+    cell = torch.cat([d.cell for d in part]).to(dev)
+    sizes = torch.tensor([int(d.x.shape[0]) for d in part], dtype=torch.int64)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(sizes, 0)]).to(dev)
+    ei, dist, dirs = radius_graph_pbc(pos, cell, ptr, 5.0)
+    gid = torch.repeat_interleave(torch.arange(len(part), device=dev), ptr[1:] - ptr[:-1])
+    g_of_edge = gid[ei[1]]
+    off = ptr[g_of_edge]
+    src_l.append((ei[0] - off).to(torch.int32).cpu())
+    tgt_l.append((ei[1] - off).to(torch.int32).cpu())
+    dist_l.append(dist.cpu())
+    dir_l.append(dirs.cpu())
+    ecount.append(torch.bincount(g_of_edge, minlength=len(part)).cpu())
+torch.cuda.synchronize()
+t_graph = time.perf_counter() - t0
+ecount = torch.cat(ecount).numpy().astype(np.int64)
+ys = [d.y.reshape(-1, 9) for d in geo]
+arrays = {
+    "atom_ptr": atom_ptr.astype(np.int64),
+    "edge_ptr": np.concatenate([[0], np.cumsum(ecount)]).astype(np.int64),
+    "y_ptr": np.concatenate([[0], np.cumsum([y.shape[0] for y in ys])]).astype(np.int64),
+    "z": torch.cat([d.x for d in geo]).numpy().astype(np.int32),
+    "pos": torch.cat([d.pos for d in geo]).numpy().astype(np.float32),
+    "non_h_mask": torch.cat([d.non_H_mask for d in geo]).numpy().astype(np.uint8),
+    "edge_src": torch.cat(src_l).numpy(), "edge_tgt": torch.cat(tgt_l).numpy(),
+    "cart_dist": torch.cat(dist_l).numpy(), "cart_dir": torch.cat(dir_l).numpy().reshape(-1, 3),
+    "cell": torch.cat([d.cell.reshape(1, 9) for d in geo]).numpy().astype(np.float32),
+    "temperature": torch.cat([d.temperature.reshape(1) for d in geo]).numpy().astype(np.float32),
+    "y": torch.cat(ys).numpy().astype(np.float32),
+}
+del geo, src_l, tgt_l, dist_l, dir_l
+shard = DeviceShard(arrays, dev)
+out = {"workload": f"one rank's share of BASELINE configs[3]: {n} synthetic ADP crystals of 64..324 atoms "
+                   f"({int(atom_ptr[-1])} atoms, {int(arrays['edge_ptr'][-1])} edges), SO(3) augmentation on, CartNet L=4 "
+                   f"D=256 fp32 storage, gemm_precision={args.precision}, 1x MI355X",
+       "host_geometry_seconds": round(t_geo, 2), "gpu_radius_graph_seconds": round(t_graph, 2),
+       "shard_bytes_in_hbm": shard.nbytes(), "recipes": []}
+
+recipes = [("batch 64 x accumulation 1", 64, 1, 0), ("batch 4 x accumulation 16 (reference recipe)", 4, 16, 0)]
+if args.grouped:
+    recipes.append(("batch 64 as 16 BatchNorm/loss groups of 4 (reference-recipe semantics, one pass)", 64, 1, 4))
+for name, bs, accum, group in recipes:
+    torch.manual_seed(0)
+    model = CartNet(256, 64, 4).to(dev).train()
+    model.gemm_precision = args.precision
+    if group:
+        model.bn_group_size = group
+    opt = FlatAdam(model, lr=1e-3)
+    loader = ShardLoader(shard, bs, shuffle=True, seed=0, augment=True)
+    r = train_epoch(loader, model, opt, accum, None, device=dev)
+    out["recipes"].append({"recipe": name, "graphs": r["graphs"], "seconds": round(r["seconds"], 3),
+                           "graphs_per_s": round(r["graphs"] / r["seconds"], 1), "train_mae": round(r["mae"], 5),
+                           "epoch_of_162270_on_8_ranks_seconds": round(r["seconds"] * 162270 / 8 / r["graphs"], 2)})
+    print(json.dumps(out["recipes"][-1]), file=sys.stderr, flush=True)
+print(json.dumps(out))
