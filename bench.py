@@ -133,6 +133,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: ranks beyond the visible GPUs share them (gloo transport unless "
                          "CARTNET_DIST_BACKEND says otherwise)")
+    ap.add_argument("--bn-group-size", type=int, default=0,
+                    help="> 0: BatchNorm statistics and loss per group of this many crystals (the reference recipe's "
+                         "micro-batches of 4 inside one pass, CartnetGroups); 0: one BatchNorm batch (the headline)")
     ap.add_argument("--sustain-seconds", type=float, default=6.0,
                     help="length of the sustained stretch after the timed region (0 disables; N = 1 only)")
     args = ap.parse_args()
@@ -161,6 +164,7 @@ def main():
     torch.manual_seed(0)
     model = CartNet(dim_in=256, dim_rbf=64, num_layers=4).to(dev).train()
     model.gemm_precision = args.precision
+    model.bn_group_size = args.bn_group_size
     opt = FlatAdam(model, lr=1e-3)
     base = build_batch(args.graphs, 100_000 + rank * args.graphs, args.atoms).to(dev)
     N, E = int(base.x.shape[0]), int(base.edge_index.shape[1])
@@ -173,9 +177,14 @@ def main():
         b._cartnet_mask_index = getattr(base, "_cartnet_mask_index", None)
         return b
 
+    from cartnet_amd.train import grouped_loss
+
     def step(b):
         pred, true = model(b)
-        loss = (pred - true).abs().mean()
+        if args.bn_group_size > 0:
+            loss = grouped_loss(pred, true, b, args.bn_group_size)[0]
+        else:
+            loss = (pred - true).abs().mean()
         loss.backward()
         scale = cdist.all_reduce_gradients(opt.flat_grad)
         opt.step(scale)
@@ -301,6 +310,9 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: CartNet L=4 D=256 R=64 fp32 train step, {args.graphs} synthetic "
                                f"ADP crystals x {args.atoms} atoms per GPU per step (N={N} atoms, E={E} edges per GPU)",
                    "graphs_per_gpu_per_step": args.graphs, "parallelism": f"graph-sharded dp{world}",
+                   "batchnorm_groups": (f"{-(-args.graphs // args.bn_group_size)} groups of {args.bn_group_size} crystals "
+                                        "(reference-recipe micro-batches in one pass)") if args.bn_group_size > 0
+                   else "one (the whole per-GPU batch)",
                    "gemm_precision": "fp32 MFMA" if args.precision == 0 else
                    "bf16x3 split-operand MFMA (six bf16 MFMA products per fp32 product, fp32 accumulate) for all 256-wide GEMMs"},
         "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3),

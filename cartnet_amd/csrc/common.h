@@ -43,8 +43,8 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // Per-block partial column sums, kept in fp64 (see cartnet_hip.h "partial sums").  Four waves each hold the sums
 // of channels c..c+3 (lane l -> c = c0 + 4l); wave 0 adds them in wave order and writes parts[blockIdx.x][c..c+3].
 // lds: 4 * 256 doubles.
-__device__ __forceinline__ void cn_block_store_parts(f64x4 v, double* lds, double* parts, int D, int c, bool active,
-                                                     int wid, int lane) {
+__device__ __forceinline__ void cn_block_store_parts_row(f64x4 v, double* lds, double* parts, int D, int c, bool active,
+                                                         int wid, int lane, int row) {
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) lds[wid * 256 + lane * 4 + q] = v[q];
@@ -55,9 +55,20 @@ __device__ __forceinline__ void cn_block_store_parts(f64x4 v, double* lds, doubl
       double t = lds[lane * 4 + q];
 #pragma unroll
       for (int w = 1; w < 4; ++w) t += lds[w * 256 + lane * 4 + q];
-      parts[(size_t)blockIdx.x * D + c + q] = t;
+      parts[(size_t)row * D + c + q] = t;
     }
   }
+}
+__device__ __forceinline__ void cn_block_store_parts(f64x4 v, double* lds, double* parts, int D, int c, bool active,
+                                                     int wid, int lane) {
+  cn_block_store_parts_row(v, lds, parts, D, c, active, wid, lane, blockIdx.x);
+}
+
+// BatchNorm groups (CartnetGroups, cartnet_hip.h): group g = blockIdx.y of a per-node / per-edge kernel owns the nodes
+// [n0, n1) and the statistics row g.  node_gptr == nullptr: one group, the whole batch.
+__device__ __forceinline__ void cn_group_range(const int* __restrict__ node_gptr, int N, int& n0, int& n1) {
+  n0 = node_gptr ? node_gptr[blockIdx.y] : 0;
+  n1 = node_gptr ? node_gptr[blockIdx.y + 1] : N;
 }
 
 __device__ __forceinline__ void cn_acc4(f64x4& a, f32x4 v) {
@@ -85,6 +96,14 @@ __device__ __forceinline__ double cn_block_colsum(const double* __restrict__ par
 }
 
 static inline int cn_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// CartnetGroups on the host: NULL = one group with the kernel's own default number of workgroups.
+static inline bool cn_groups_ok(const CartnetGroups* g) {
+  return !g || (g->G >= 1 && g->G <= 65535 && g->node_gptr && g->edge_gptr && g->edge_parts >= 1 && g->node_parts >= 1);
+}
+static inline dim3 cn_group_grid(const CartnetGroups* g, int default_parts, bool per_edge) {
+  return g ? dim3(per_edge ? g->edge_parts : g->node_parts, g->G) : dim3(default_parts, 1);
+}
 
 // Long partial-sum matrices ([nparts][N] fp64, nparts in the thousands) are folded to CN_FOLD_ROWS rows first
 // (cn_fold_parts, gemm.hip: row r <- sum of rows r, r+R, r+2R, ... in that order, in place), so that the finalising

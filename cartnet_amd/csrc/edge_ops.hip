@@ -64,11 +64,15 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
     const float* __restrict__ gs, const float* __restrict__ e_in, const float* __restrict__ env,
     const int* __restrict__ rowptr, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, int N, int D, float* __restrict__ e_out, float* __restrict__ aggr,
-    double* __restrict__ parts_sum, double* __restrict__ parts_sq, int reverse) {
+    double* __restrict__ parts_sum, double* __restrict__ parts_sq, int reverse, const int* __restrict__ node_gptr) {
   __shared__ double red[NODES_PER_BLOCK * 256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int ld = 2 * D;
-  const int stride = gridDim.x * NODES_PER_BLOCK, nsweeps = (N + stride - 1) / stride;
+  int n0, n1;
+  cn_group_range(node_gptr, N, n0, n1);
+  mean_rstd += (size_t)blockIdx.y * 2 * D;
+  const int prow = blockIdx.y * gridDim.x + blockIdx.x;
+  const int stride = gridDim.x * NODES_PER_BLOCK, nsweeps = (n1 - n0 + stride - 1) / stride;
   for (int c0 = 0; c0 < D; c0 += 256) {
     const int c = c0 + lane * 4;
     const bool active = c < D;
@@ -80,8 +84,8 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
     }
     f64x4 ps = {0, 0, 0, 0}, pq = {0, 0, 0, 0};
     for (int j = 0; j < nsweeps; ++j) {
-      const int t = blockIdx.x * NODES_PER_BLOCK + wid + (reverse ? nsweeps - 1 - j : j) * stride;
-      if (t >= N) continue;
+      const int t = n0 + blockIdx.x * NODES_PER_BLOCK + wid + (reverse ? nsweeps - 1 - j : j) * stride;
+      if (t >= n1) continue;
       const int k0 = rowptr[t], k1 = rowptr[t + 1];
       f32x4 acc = {0, 0, 0, 0};
       if (active) {
@@ -116,8 +120,8 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
         pq[q] += (double)acc[q] * (double)acc[q];
       }
     }
-    cn_block_store_parts(ps, red, parts_sum, D, c, active, wid, lane);
-    cn_block_store_parts(pq, red, parts_sq, D, c, active, wid, lane);
+    cn_block_store_parts_row(ps, red, parts_sum, D, c, active, wid, lane, prow);
+    cn_block_store_parts_row(pq, red, parts_sq, D, c, active, wid, lane, prow);
   }
 }
 
@@ -128,11 +132,20 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_bwd_kernel(
     float* gs, const float* __restrict__ de_out, const float* __restrict__ daggr, const float* __restrict__ env,
     const int* __restrict__ rowptr, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ sums, float inv_count, int N, int D,
-    double* __restrict__ parts_a, double* __restrict__ parts_b, int reverse) {
+    double* __restrict__ parts_a, double* __restrict__ parts_b, int reverse, const int* __restrict__ node_gptr) {
   __shared__ double red[NODES_PER_BLOCK * 256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int ld = 2 * D;
-  const int stride = gridDim.x * NODES_PER_BLOCK, nsweeps = (N + stride - 1) / stride;
+  int n0, n1;
+  cn_group_range(node_gptr, N, n0, n1);
+  mean_rstd += (size_t)blockIdx.y * 2 * D;
+  if (MODE == 1) sums += (size_t)blockIdx.y * 2 * D;
+  if (MODE == 1 && node_gptr && inv_count != 0.f) {   // training-mode BatchNorm backward: means over THIS group's edges
+    const int eg = rowptr[n1] - rowptr[n0];
+    inv_count = eg > 0 ? 1.0f / (float)eg : 0.f;
+  }
+  const int prow = blockIdx.y * gridDim.x + blockIdx.x;
+  const int stride = gridDim.x * NODES_PER_BLOCK, nsweeps = (n1 - n0 + stride - 1) / stride;
   for (int c0 = 0; c0 < D; c0 += 256) {
     const int c = c0 + lane * 4;
     const bool active = c < D;
@@ -150,8 +163,8 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_bwd_kernel(
     }
     f64x4 ta = {0, 0, 0, 0}, tb = {0, 0, 0, 0};
     for (int j = 0; j < nsweeps; ++j) {
-      const int t = blockIdx.x * NODES_PER_BLOCK + wid + (reverse ? nsweeps - 1 - j : j) * stride;
-      if (t >= N || !active) continue;
+      const int t = n0 + blockIdx.x * NODES_PER_BLOCK + wid + (reverse ? nsweeps - 1 - j : j) * stride;
+      if (t >= n1 || !active) continue;
       const int k0 = rowptr[t], k1 = rowptr[t + 1];
       const f32x4 dm = ld4(daggr + (size_t)t * D + c);
       f32x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};   // fp32 over one node's edges, fp64 across nodes
@@ -187,8 +200,8 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_bwd_kernel(
       cn_acc4(ta, pa);
       cn_acc4(tb, pb);
     }
-    cn_block_store_parts(ta, red, parts_a, D, c, active, wid, lane);
-    cn_block_store_parts(tb, red, parts_b, D, c, active, wid, lane);
+    cn_block_store_parts_row(ta, red, parts_a, D, c, active, wid, lane, prow);
+    cn_block_store_parts_row(tb, red, parts_b, D, c, active, wid, lane, prow);
   }
 }
 
@@ -356,14 +369,15 @@ extern "C" int cartnet_gate_scatter_nparts(int32_t N) { return gate_parts(N); }
 extern "C" int cartnet_gate_scatter_fwd(const float* gs, const float* e_in, const float* env, const int32_t* rowptr,
                                         const float* mean_rstd, const float* gamma, const float* beta, int32_t N,
                                         int32_t D, float* e_out, float* aggr, double* parts_sum, double* parts_sq,
-                                        void* stream) {
+                                        const CartnetGroups* groups, void* stream) {
   CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_fwd: D=%d must be a positive multiple of 4", D);
   CN_CHECK(gs && rowptr && mean_rstd && gamma && beta && aggr && parts_sum && parts_sq,
            "cartnet_gate_scatter_fwd: null pointer");
   CN_CHECK((e_in == nullptr) == (e_out == nullptr), "cartnet_gate_scatter_fwd: e_in and e_out must pair");
-  hipLaunchKernelGGL(cn_gate_scatter_fwd_kernel, dim3(gate_parts(N)), dim3(256), 0,
+  CN_CHECK(cn_groups_ok(groups), "cartnet_gate_scatter_fwd: bad groups");
+  hipLaunchKernelGGL(cn_gate_scatter_fwd_kernel, cn_group_grid(groups, gate_parts(N), true), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), gs, e_in, env, rowptr, mean_rstd, gamma, beta, N, D,
-                     e_out, aggr, parts_sum, parts_sq, /*reverse=*/1);
+                     e_out, aggr, parts_sum, parts_sq, /*reverse=*/1, groups ? groups->node_gptr : nullptr);
   CN_LAUNCH_CHECK("cartnet_gate_scatter_fwd");
   return 0;
 }
@@ -371,13 +385,16 @@ extern "C" int cartnet_gate_scatter_fwd(const float* gs, const float* e_in, cons
 extern "C" int cartnet_gate_scatter_bwd_stats(const float* gs, const float* de_out, const float* daggr,
                                               const float* env, const int32_t* rowptr, const float* mean_rstd,
                                               const float* gamma, const float* beta, int32_t N, int32_t D,
-                                              double* parts_a, double* parts_b, void* stream) {
+                                              double* parts_a, double* parts_b, const CartnetGroups* groups,
+                                              void* stream) {
   CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_bwd_stats: D=%d must be a multiple of 4", D);
   CN_CHECK(gs && daggr && rowptr && mean_rstd && gamma && beta && parts_a && parts_b,
            "cartnet_gate_scatter_bwd_stats: null pointer");
-  hipLaunchKernelGGL(cn_gate_scatter_bwd_kernel<0>, dim3(gate_parts(N)), dim3(256), 0,
+  CN_CHECK(cn_groups_ok(groups), "cartnet_gate_scatter_bwd_stats: bad groups");
+  hipLaunchKernelGGL(cn_gate_scatter_bwd_kernel<0>, cn_group_grid(groups, gate_parts(N), true), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), const_cast<float*>(gs), de_out, daggr, env, rowptr,
-                     mean_rstd, gamma, beta, (const float*)nullptr, 0.f, N, D, parts_a, parts_b, 0);
+                     mean_rstd, gamma, beta, (const float*)nullptr, 0.f, N, D, parts_a, parts_b, 0,
+                     groups ? groups->node_gptr : nullptr);
   CN_LAUNCH_CHECK("cartnet_gate_scatter_bwd_stats");
   return 0;
 }
@@ -385,14 +402,16 @@ extern "C" int cartnet_gate_scatter_bwd_stats(const float* gs, const float* de_o
 extern "C" int cartnet_gate_scatter_bwd_apply(float* gs, const float* de_out, const float* daggr, const float* env,
                                               const int32_t* rowptr, const float* mean_rstd, const float* gamma,
                                               const float* beta, const float* sums, int64_t E, int32_t training,
-                                              int32_t N, int32_t D, double* parts_dg, double* parts_ds, void* stream) {
+                                              int32_t N, int32_t D, double* parts_dg, double* parts_ds,
+                                              const CartnetGroups* groups, void* stream) {
   CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_bwd_apply: D=%d must be a multiple of 4", D);
   CN_CHECK(gs && daggr && rowptr && mean_rstd && gamma && beta && sums && parts_dg && parts_ds,
            "cartnet_gate_scatter_bwd_apply: null pointer");
   const float inv = (training && E > 0) ? (float)(1.0 / (double)E) : 0.f;
-  hipLaunchKernelGGL(cn_gate_scatter_bwd_kernel<1>, dim3(gate_parts(N)), dim3(256), 0,
+  CN_CHECK(cn_groups_ok(groups), "cartnet_gate_scatter_bwd_apply: bad groups");
+  hipLaunchKernelGGL(cn_gate_scatter_bwd_kernel<1>, cn_group_grid(groups, gate_parts(N), true), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), gs, de_out, daggr, env, rowptr, mean_rstd, gamma, beta,
-                     sums, inv, N, D, parts_dg, parts_ds, /*reverse=*/1);
+                     sums, inv, N, D, parts_dg, parts_ds, /*reverse=*/1, groups ? groups->node_gptr : nullptr);
   CN_LAUNCH_CHECK("cartnet_gate_scatter_bwd_apply");
   return 0;
 }

@@ -64,6 +64,12 @@ struct Work {
   double *pa, *pb, *pc[2], *pd[2], *cs_misc[4];
   size_t slab_floats;
   int gparts, nparts_n, tiles_e, tiles_n;
+  // BatchNorm groups (CartnetModel.bn_group_size > 0 and more than one group in this batch): gparts / nrows_n are then
+  // the TOTAL partial-sum rows of the per-edge / per-node statistics kernels (G x parts per group)
+  int G, nrows_n;
+  int *node_gptr, *edge_gptr;
+  CartnetGroups grp;
+  const CartnetGroups* groups;   // &grp, or nullptr for one group (set by the entry points, not by carve)
 };
 
 Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_bwd, char* base, size_t* total) {
@@ -76,6 +82,21 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
   w.ldf = (w.kf + 15) / 16 * 16;   // K of the first edge Linear padded to whole K-steps (pad columns are zero)
   w.gparts = cartnet_gate_scatter_nparts(N);
   w.nparts_n = cartnet_node_nparts(N);
+  w.nrows_n = w.nparts_n;
+  w.G = (m.bn_group_size > 0 && Bg > m.bn_group_size) ? (Bg + m.bn_group_size - 1) / m.bn_group_size : 1;
+  if (w.G > 1) {
+    const int per = (int)((Nn + (size_t)4 * w.G - 1) / ((size_t)4 * w.G));    // ceil(N / G / nodes-per-workgroup)
+    w.grp.G = w.G;
+    w.grp.edge_parts = per < 1 ? 1 : (per > 1024 ? 1024 : per);
+    w.grp.node_parts = per < 1 ? 1 : (per > 256 ? 256 : per);
+    w.gparts = w.G * w.grp.edge_parts;
+    w.nrows_n = w.G * w.grp.node_parts;
+  }
+  const size_t Gn = (size_t)w.G;
+  w.node_gptr = c.take<int>(Gn + 1);
+  w.edge_gptr = c.take<int>(Gn + 1);
+  w.grp.node_gptr = w.node_gptr;
+  w.grp.edge_gptr = w.edge_gptr;
   w.tiles_e = tiles_m(E);
   w.tiles_n = tiles_m(N);
   w.src32 = c.take<int>(En);
@@ -113,8 +134,8 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
       w.gs[l] = w.gs[0];
       w.aggr[l] = w.aggr[0];
     }
-    w.mr1[l] = c.take<float>(2 * D);
-    w.mr2[l] = c.take<float>(2 * D);
+    w.mr1[l] = c.take<float>(Gn * 2 * D);
+    w.mr2[l] = c.take<float>(Gn * 2 * D);
     if (l < L - 1) {   // the last layer writes straight into the caller's x_out / e_out
       w.xl[l] = need_bwd ? c.take<float>(Nn * D) : xping[l & 1];
       w.el[l] = need_bwd ? c.take<float>(En * D) : eping[l & 1];
@@ -168,8 +189,8 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
     w.de[0] = c.take<float>(En * D);
     w.de[1] = c.take<float>(En * D);
     w.daggr = c.take<float>(Nn * D);
-    w.sums1 = c.take<float>(2 * D);
-    w.sums2 = c.take<float>(2 * D);
+    w.sums1 = c.take<float>(Gn * 2 * D);
+    w.sums2 = c.take<float>(Gn * 2 * D);
     for (int i = 0; i < 2; ++i) {   // double-buffered: the weight-gradient stream reads them while the next layer runs
       w.dPn[i] = c.take<float>(Nn * 4 * D);
       w.dpre[i] = c.take<float>(En * 2 * D);
@@ -177,7 +198,7 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
     w.dhe = c.take<float>(En * 2 * D);
     w.dx0 = c.take<float>(Nn * 2 * D);
     w.seg_tmp = c.take<float>(Nn * 2 * D);
-    const size_t pmax = (size_t)(w.gparts > w.nparts_n ? w.gparts : w.nparts_n) * 2 * D;
+    const size_t pmax = (size_t)(w.gparts > w.nrows_n ? w.gparts : w.nrows_n) * 2 * D;
     w.pa = c.take<double>(pmax);
     w.pb = c.take<double>(pmax);
     const size_t tmax = (size_t)(w.tiles_e > w.tiles_n ? w.tiles_e : w.tiles_n);
@@ -310,14 +331,16 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
            "cartnet_model_forward: null output/workspace");
   CN_CHECK((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "cartnet_model_forward: workspace must be 256-byte aligned");
   size_t need = 0;
-  const Work w = carve(m, b.N, b.E, b.Bg, b.M, need_backward != 0, static_cast<char*>(workspace), &need);
+  Work w = carve(m, b.N, b.E, b.Bg, b.M, need_backward != 0, static_cast<char*>(workspace), &need);
   CN_CHECK(workspace_bytes >= need, "cartnet_model_forward: workspace %zu < required %zu bytes", workspace_bytes, need);
+  w.groups = w.G > 1 ? &w.grp : nullptr;
   const int D = m.D, L = m.L, H = D / 2, N = b.N;
   const int E = (int)b.E;
   const bool plain = !m.use_temperature && !m.atom_types;
 
   RUN(cartnet_csr_build(b.edge_index, b.E, N, b.graph_ptr, b.Bg, w.src32, w.tgt32, w.rowptr, w.colptr, w.perm, status,
                         st));
+  if (w.groups) RUN(cartnet_group_ptrs(b.graph_ptr, b.Bg, m.bn_group_size, w.rowptr, w.G, w.node_gptr, w.edge_gptr, st));
   // weights -> [in, out]
   {
     constexpr int TB = 40;   // cartnet_transpose takes up to 40 matrices per launch
@@ -465,17 +488,20 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       a.ngroups = 2; a.b_kstrided = 1; a.a_act = 1;
       a.A[0] = w.pre[l]; a.A[1] = w.pre[l] + D; a.B[0] = w.gate2T[l]; a.B[1] = w.aggr2T[l];
       a.C[0] = w.gs[l]; a.C[1] = w.gs[l] + D; a.bias[0] = q.gate2_b; a.bias[1] = q.aggr2_b;
-      a.colsum[0] = w.cs; a.colsq[0] = w.cq;
+      if (!w.groups) { a.colsum[0] = w.cs; a.colsq[0] = w.cq; }
       if (w.i_gs[l]) { a.b_split[0] = w.i_gs[l]; a.b_split[1] = w.i_gs[l] + img_blk(m); }
       RUN(cartnet_gemm(&a, st));
     }
+    // BatchNorm groups: a 128-row GEMM tile may straddle two groups, so the gate statistics are taken per group by a
+    // pass of their own over the gate half of gs (181 MB at the benchmark batch, ~40 us) instead of in the epilogue
+    if (w.groups && training) RUN(cartnet_colstats_grouped(w.gs[l], 2 * D, D, w.groups, w.cs, w.cq, st));
     RUN(cartnet_bn_finalize(w.cs, w.cq, w.tiles_e, b.E, D, m.bn_eps, m.bn_momentum, training, m.buf[l].norm_mean,
-                            m.buf[l].norm_var, m.buf[l].norm_nbt, w.mr1[l], st));
+                            m.buf[l].norm_var, m.buf[l].norm_nbt, w.mr1[l], w.groups, 1, 1, st));
     RUN(cartnet_gate_scatter_fwd(w.gs[l], e, m.use_envelope[l] ? w.env : nullptr, w.rowptr, w.mr1[l], q.norm_w,
-                                 q.norm_b, N, D, e_next, w.aggr[l], w.ps, w.pq, st));
+                                 q.norm_b, N, D, e_next, w.aggr[l], w.ps, w.pq, w.groups, st));
     RUN(cartnet_bn_finalize(w.ps, w.pq, w.gparts, N, D, m.bn_eps, m.bn_momentum, training, m.buf[l].norm2_mean,
-                            m.buf[l].norm2_var, m.buf[l].norm2_nbt, w.mr2[l], st));
-    RUN(cartnet_node_update_fwd(w.aggr[l], x, w.mr2[l], q.norm2_w, q.norm2_b, N, D, x_next, st));
+                            m.buf[l].norm2_var, m.buf[l].norm2_nbt, w.mr2[l], w.groups, 1, 0, st));
+    RUN(cartnet_node_update_fwd(w.aggr[l], x, w.mr2[l], q.norm2_w, q.norm2_b, N, D, x_next, w.groups, st));
     x = x_next;
     e = e_next;
   }
@@ -554,8 +580,9 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
                (!m.use_temperature || (G.temp_w && G.temp_b)) && (m.use_temperature || !m.atom_types || G.enc_bias),
            "cartnet_model_backward: a gradient destination is missing");
   size_t need = 0;
-  const Work w = carve(m, b.N, b.E, b.Bg, b.M, true, static_cast<char*>(workspace), &need);
+  Work w = carve(m, b.N, b.E, b.Bg, b.M, true, static_cast<char*>(workspace), &need);
   CN_CHECK(workspace_bytes >= need, "cartnet_model_backward: workspace %zu < required %zu bytes", workspace_bytes, need);
+  w.groups = w.G > 1 ? &w.grp : nullptr;      // node_gptr / edge_gptr were filled by the forward call
   const int D = m.D, L = m.L, H = D / 2, N = b.N;
   const int E = (int)b.E;
   g_events.next = 0;
@@ -626,26 +653,30 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     // the side stream must be done with this parity's buffers (used two layers ago)
     if (l + 2 < L && S.main_waits(side_done[l + 2]) != 0) { cartnet_set_error("cartnet_model_backward: wait failed"); return 2; }
     // node update: x_out = silu(bn2(aggr)) + x_in
-    RUN(cartnet_node_update_bwd_stats(w.aggr[l], dx, w.mr2[l], q.norm2_w, q.norm2_b, N, D, w.pa, w.pb, st));
-    {
+    RUN(cartnet_node_update_bwd_stats(w.aggr[l], dx, w.mr2[l], q.norm2_w, q.norm2_b, N, D, w.pa, w.pb, w.groups, st));
+    if (w.groups) {   // per-group sums for the apply pass, their total = the BatchNorm affine gradients
+      RUN(cartnet_group_sums_finalize(w.pa, w.pb, D, w.groups, 0, w.sums2, gq.norm2_b, gq.norm2_w, st));
+    } else {
       double* parts[2] = {w.pa, w.pb};
       float* outs[2] = {w.sums2, w.sums2 + D};
       float* grads2[2] = {gq.norm2_b, gq.norm2_w};      // the same sums are the BatchNorm affine gradients
       RUN(cartnet_colsum_finalize2(parts, outs, grads2, 2, w.nparts_n, D, st));
     }
     RUN(cartnet_node_update_bwd_apply(w.aggr[l], dx, w.mr2[l], q.norm2_w, q.norm2_b, w.sums2, training, N, D, w.daggr,
-                                      st));
+                                      w.groups, st));
     // gate * sender aggregation and the edge BatchNorm
     RUN(cartnet_gate_scatter_bwd_stats(gs, de, w.daggr, env, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, N, D, w.pa, w.pb,
-                                       st));
-    {
+                                       w.groups, st));
+    if (w.groups) {
+      RUN(cartnet_group_sums_finalize(w.pa, w.pb, D, w.groups, 1, w.sums1, gq.norm_b, gq.norm_w, st));
+    } else {
       double* parts[2] = {w.pa, w.pb};
       float* outs[2] = {w.sums1, w.sums1 + D};
       float* grads1[2] = {gq.norm_b, gq.norm_w};
       RUN(cartnet_colsum_finalize2(parts, outs, grads1, 2, w.gparts, D, st));
     }
     RUN(cartnet_gate_scatter_bwd_apply(gs, de, w.daggr, env, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, w.sums1, b.E,
-                                       training, N, D, w.pc[par], w.pd[par], st));   // gs = [dg | ds]
+                                       training, N, D, w.pc[par], w.pd[par], w.groups, st));   // gs = [dg | ds]
     FORK();
     {  // side: bias gradients of the second Linears, then their weight gradients (need silu(pre), which stays intact)
       double* parts[2] = {w.pc[par], w.pd[par]};

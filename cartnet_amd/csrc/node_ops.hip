@@ -128,42 +128,142 @@ __global__ __launch_bounds__(256) void cn_transpose_kernel(const TransposeJobs j
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm stats
+// Groups (G > 1: parts are [G][nparts][C], counts come from cnt_ptr[g+1] - cnt_ptr[g]): every group gets its own row of
+// mean_rstd, and the running statistics receive the G momentum updates one after the other, in group order -- what G
+// consecutive forward calls on the micro-batches would have done (num_batches_tracked += G).
 __global__ __launch_bounds__(1024) void cn_bn_finalize_kernel(
     const double* __restrict__ parts_sum, const double* __restrict__ parts_sq, int nparts, long long count, int C,
     float eps, float momentum, int training, float* __restrict__ running_mean, float* __restrict__ running_var,
-    int64_t* __restrict__ nbt, float* __restrict__ mean_rstd) {
+    int64_t* __restrict__ nbt, float* __restrict__ mean_rstd, int G, const int* __restrict__ cnt_ptr) {
   __shared__ double red[16 * 64];
   const int c = blockIdx.x * 64 + threadIdx.x;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && training && nbt) nbt[0] += 1;
+  const bool owner = threadIdx.x < 64 && c < C;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && training && nbt) nbt[0] += G;
   if (training) {
-    const double s = cn_block_colsum(parts_sum, nparts, C, blockIdx.x * 64, red);
-    const double q = cn_block_colsum(parts_sq, nparts, C, blockIdx.x * 64, red);
-    if (threadIdx.x >= 64 || c >= C) return;
-    const double n = (double)count;
-    const double mean = n > 0 ? s / n : 0.0;
-    double var = n > 0 ? q / n - mean * mean : 0.0;
-    if (var < 0.0) var = 0.0;
-    mean_rstd[c] = (float)mean;
-    mean_rstd[C + c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-      const double unb = count > 1 ? var * (n / (n - 1.0)) : var;
-      running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
-      running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+    double rm = 0.0, rv = 0.0;
+    if (owner && running_mean) {
+      rm = (double)running_mean[c];
+      rv = (double)running_var[c];
+    }
+    for (int g = 0; g < G; ++g) {
+      const size_t off = (size_t)g * nparts * C;
+      const double s = cn_block_colsum(parts_sum + off, nparts, C, blockIdx.x * 64, red);
+      const double q = cn_block_colsum(parts_sq + off, nparts, C, blockIdx.x * 64, red);
+      if (!owner) continue;
+      const long long cnt = cnt_ptr ? (long long)(cnt_ptr[g + 1] - cnt_ptr[g]) : count;
+      const double n = (double)cnt;
+      const double mean = n > 0 ? s / n : 0.0;
+      double var = n > 0 ? q / n - mean * mean : 0.0;
+      if (var < 0.0) var = 0.0;
+      mean_rstd[(size_t)g * 2 * C + c] = (float)mean;
+      mean_rstd[(size_t)g * 2 * C + C + c] = (float)(1.0 / sqrt(var + (double)eps));
+      if (running_mean) {
+        const double unb = cnt > 1 ? var * (n / (n - 1.0)) : var;
+        // rounded to fp32 after every update, like the reference's running buffers between two forward calls
+        rm = (double)(float)((1.0 - (double)momentum) * rm + (double)momentum * mean);
+        rv = (double)(float)((1.0 - (double)momentum) * rv + (double)momentum * unb);
+      }
+    }
+    if (owner && running_mean) {
+      running_mean[c] = (float)rm;
+      running_var[c] = (float)rv;
     }
   } else {
-    if (threadIdx.x >= 64 || c >= C) return;
-    mean_rstd[c] = running_mean[c];
-    mean_rstd[C + c] = (float)(1.0 / sqrt((double)running_var[c] + (double)eps));
+    if (!owner) return;
+    const float m = running_mean[c], r = (float)(1.0 / sqrt((double)running_var[c] + (double)eps));
+    for (int g = 0; g < G; ++g) {
+      mean_rstd[(size_t)g * 2 * C + c] = m;
+      mean_rstd[(size_t)g * 2 * C + C + c] = r;
+    }
   }
+}
+
+// node_gptr[g] = graph_ptr[min(g * group_size, Bg)], edge_gptr[g] = rowptr[node_gptr[g]]   (g <= G)
+__global__ void cn_group_ptrs_kernel(const int64_t* __restrict__ graph_ptr, int Bg, int group_size,
+                                     const int* __restrict__ rowptr, int G, int* __restrict__ node_gptr,
+                                     int* __restrict__ edge_gptr) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > G) return;
+  const long long cr = (long long)g * group_size;
+  const int n = (int)graph_ptr[cr < Bg ? cr : Bg];
+  node_gptr[g] = n;
+  edge_gptr[g] = rowptr[n];
+}
+
+// Per-group column sums / sums of squares of x [rows, C] (row stride ld): group g = blockIdx.y owns rows
+// [row_gptr[g], row_gptr[g+1]); partial row (g * gridDim.x + blockIdx.x) of parts_sum / parts_sq.  Four independent
+// row loads in flight per wave, fp64 accumulation (BatchNorm variance as E[v^2] - mean^2 needs the digits).
+__global__ __launch_bounds__(256) void cn_colstats_grouped_kernel(const float* __restrict__ x, int ld, int C,
+                                                                  const int* __restrict__ row_gptr,
+                                                                  double* __restrict__ parts_sum,
+                                                                  double* __restrict__ parts_sq) {
+  __shared__ double red[NODES_PER_BLOCK * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r0 = row_gptr[blockIdx.y], r1 = row_gptr[blockIdx.y + 1];
+  const int prow = blockIdx.y * gridDim.x + blockIdx.x;
+  const int stride = gridDim.x * NODES_PER_BLOCK;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + lane * 4;
+    const bool active = c < C;
+    f64x4 ps = {0, 0, 0, 0}, pq = {0, 0, 0, 0};
+    if (active) {
+      for (int r = r0 + blockIdx.x * NODES_PER_BLOCK + wid; r < r1; r += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int rr = r + u * stride;
+          v[u] = rr < r1 ? ld4(x + (size_t)rr * ld + c) : f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            ps[q] += (double)v[u][q];
+            pq[q] += (double)v[u][q] * (double)v[u][q];
+          }
+      }
+    }
+    cn_block_store_parts_row(ps, red, parts_sum, C, c, active, wid, lane, prow);
+    cn_block_store_parts_row(pq, red, parts_sq, C, c, active, wid, lane, prow);
+  }
+}
+
+// sums[g][which*D + c] = column sum of the group's partial rows (which = 0: parts_a, 1: parts_b); grads[which][c] = the
+// sum over all groups (BatchNorm affine gradients are shared by the groups).  grid (ceil(D/64), 2), 1024 threads.
+__global__ __launch_bounds__(1024) void cn_group_sums_finalize_kernel(const double* __restrict__ parts_a,
+                                                                      const double* __restrict__ parts_b, int nparts,
+                                                                      int G, int D, float* __restrict__ sums,
+                                                                      float* __restrict__ grad_a,
+                                                                      float* __restrict__ grad_b) {
+  __shared__ double red[16 * 64];
+  const int which = blockIdx.y;
+  const double* __restrict__ parts = which ? parts_b : parts_a;
+  float* __restrict__ grad = which ? grad_b : grad_a;
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const bool owner = threadIdx.x < 64 && c < D;
+  double total = 0.0;
+  for (int g = 0; g < G; ++g) {
+    const double t = cn_block_colsum(parts + (size_t)g * nparts * D, nparts, D, blockIdx.x * 64, red);
+    if (owner) {
+      sums[(size_t)g * 2 * D + which * D + c] = (float)t;
+      total += t;
+    }
+  }
+  if (owner && grad) grad[c] = (float)total;
 }
 
 // ------------------------------------------------------------------------------------------------ node update
 __global__ void cn_node_update_fwd_kernel(const float* __restrict__ aggr, const float* __restrict__ x_in,
                                           const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
-                                          const float* __restrict__ beta, int N, int D, float* __restrict__ x_out) {
-  const long long total4 = (long long)N * D / 4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-       i += (long long)gridDim.x * blockDim.x) {
+                                          const float* __restrict__ beta, int N, int D, float* __restrict__ x_out,
+                                          const int* __restrict__ node_gptr) {
+  int n0, n1;
+  cn_group_range(node_gptr, N, n0, n1);
+  mean_rstd += (size_t)blockIdx.y * 2 * D;
+  const long long base4 = (long long)n0 * D / 4, total4 = (long long)(n1 - n0) * D / 4;
+  for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < total4;
+       j += (long long)gridDim.x * blockDim.x) {
+    const long long i = base4 + j;
     const int c = (int)((i * 4) % D);
     const f32x4 a = ld4(aggr + i * 4), xi = ld4(x_in + i * 4);
     const f32x4 mean = ld4(mean_rstd + c), rstd = ld4(mean_rstd + D + c), gam = ld4(gamma + c), bet = ld4(beta + c);
@@ -179,9 +279,16 @@ template <int MODE>
 __global__ __launch_bounds__(256) void cn_node_update_bwd_kernel(
     const float* __restrict__ aggr, const float* __restrict__ dx_out, const float* __restrict__ mean_rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums, float inv_count,
-    int N, int D, double* __restrict__ parts_a, double* __restrict__ parts_b, float* __restrict__ daggr) {
+    int N, int D, double* __restrict__ parts_a, double* __restrict__ parts_b, float* __restrict__ daggr,
+    const int* __restrict__ node_gptr) {
   __shared__ double red[NODES_PER_BLOCK * 256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int n0, n1;
+  cn_group_range(node_gptr, N, n0, n1);
+  mean_rstd += (size_t)blockIdx.y * 2 * D;
+  if (MODE == 1) sums += (size_t)blockIdx.y * 2 * D;
+  if (MODE == 1 && node_gptr && inv_count != 0.f) inv_count = n1 > n0 ? 1.0f / (float)(n1 - n0) : 0.f;
+  const int prow = blockIdx.y * gridDim.x + blockIdx.x;
   for (int c0 = 0; c0 < D; c0 += 256) {
     const int c = c0 + lane * 4;
     const bool active = c < D;
@@ -198,7 +305,7 @@ __global__ __launch_bounds__(256) void cn_node_update_bwd_kernel(
       }
     }
     f64x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
-    for (int n = blockIdx.x * NODES_PER_BLOCK + wid; n < N; n += gridDim.x * NODES_PER_BLOCK) {
+    for (int n = n0 + blockIdx.x * NODES_PER_BLOCK + wid; n < n1; n += gridDim.x * NODES_PER_BLOCK) {
       if (!active) continue;
       const f32x4 a = ld4(aggr + (size_t)n * D + c), dy = ld4(dx_out + (size_t)n * D + c);
       f32x4 o;
@@ -216,8 +323,8 @@ __global__ __launch_bounds__(256) void cn_node_update_bwd_kernel(
       if (MODE == 1) st4(daggr + (size_t)n * D + c, o);
     }
     if (MODE == 0) {
-      cn_block_store_parts(pa, red, parts_a, D, c, active, wid, lane);
-      cn_block_store_parts(pb, red, parts_b, D, c, active, wid, lane);
+      cn_block_store_parts_row(pa, red, parts_a, D, c, active, wid, lane, prow);
+      cn_block_store_parts_row(pb, red, parts_b, D, c, active, wid, lane, prow);
     }
   }
 }
@@ -475,57 +582,108 @@ extern "C" int cartnet_node_embed_bwd(const int64_t* batch, const float* tempera
 
 extern "C" int cartnet_bn_finalize(double* parts_sum, double* parts_sq, int32_t nparts, int64_t count,
                                    int32_t C, float eps, float momentum, int32_t training, float* running_mean,
-                                   float* running_var, int64_t* num_batches_tracked, float* mean_rstd, void* stream) {
+                                   float* running_var, int64_t* num_batches_tracked, float* mean_rstd,
+                                   const CartnetGroups* groups, int32_t parts_over_edges, int32_t count_over_edges,
+                                   void* stream) {
   CN_CHECK(C >= 1 && mean_rstd, "cartnet_bn_finalize: bad arguments");
   if (training) CN_CHECK(parts_sum && parts_sq && nparts >= 0 && count >= 0, "cartnet_bn_finalize: missing partial sums");
   else CN_CHECK(running_mean && running_var, "cartnet_bn_finalize: eval mode needs running statistics");
   CN_CHECK((running_mean == nullptr) == (running_var == nullptr), "cartnet_bn_finalize: running stats must pair");
-  if (training) {
+  CN_CHECK(cn_groups_ok(groups), "cartnet_bn_finalize: bad groups");
+  int G = 1;
+  const int* cnt_ptr = nullptr;
+  if (groups) {   // [G][parts][C] partial rows, one statistics row per group
+    G = groups->G;
+    nparts = parts_over_edges ? groups->edge_parts : groups->node_parts;
+    cnt_ptr = count_over_edges ? groups->edge_gptr : groups->node_gptr;
+  } else if (training) {
     double* fp[2] = {parts_sum, parts_sq};
     nparts = cn_fold_parts(fp, 2, nparts, C, ST(stream));
   }
   hipLaunchKernelGGL(cn_bn_finalize_kernel, dim3(cn_ceil_div(C, 64)), dim3(1024), 0, ST(stream), parts_sum, parts_sq,
                      nparts, (long long)count, C, eps, momentum, training, running_mean, running_var,
-                     num_batches_tracked, mean_rstd);
+                     num_batches_tracked, mean_rstd, G, cnt_ptr);
   CN_LAUNCH_CHECK("cartnet_bn_finalize");
+  return 0;
+}
+
+extern "C" int cartnet_group_ptrs(const int64_t* graph_ptr, int32_t Bg, int32_t group_size, const int32_t* rowptr,
+                                  int32_t G, int32_t* node_gptr, int32_t* edge_gptr, void* stream) {
+  CN_CHECK(graph_ptr && rowptr && node_gptr && edge_gptr, "cartnet_group_ptrs: null pointer");
+  CN_CHECK(Bg >= 1 && group_size >= 1 && G == (Bg + group_size - 1) / group_size,
+           "cartnet_group_ptrs: G=%d does not match ceil(Bg=%d / group_size=%d)", G, Bg, group_size);
+  hipLaunchKernelGGL(cn_group_ptrs_kernel, dim3(cn_ceil_div(G + 1, 256)), dim3(256), 0, ST(stream), graph_ptr, Bg,
+                     group_size, rowptr, G, node_gptr, edge_gptr);
+  CN_LAUNCH_CHECK("cartnet_group_ptrs");
+  return 0;
+}
+
+extern "C" int cartnet_colstats_grouped(const float* x, int32_t ld, int32_t C, const CartnetGroups* groups,
+                                        double* parts_sum, double* parts_sq, void* stream) {
+  CN_CHECK(groups && cn_groups_ok(groups), "cartnet_colstats_grouped: groups required");
+  CN_CHECK(C >= 4 && C % 4 == 0 && ld % 4 == 0 && ld >= C, "cartnet_colstats_grouped: C=%d ld=%d must be multiples of 4", C, ld);
+  CN_CHECK(x && parts_sum && parts_sq, "cartnet_colstats_grouped: null pointer");
+  hipLaunchKernelGGL(cn_colstats_grouped_kernel, dim3(groups->edge_parts, groups->G), dim3(256), 0, ST(stream), x, ld, C,
+                     groups->edge_gptr, parts_sum, parts_sq);
+  CN_LAUNCH_CHECK("cartnet_colstats_grouped");
+  return 0;
+}
+
+extern "C" int cartnet_group_sums_finalize(const double* parts_a, const double* parts_b, int32_t D,
+                                           const CartnetGroups* groups, int32_t over_edges, float* sums, float* grad_a,
+                                           float* grad_b, void* stream) {
+  CN_CHECK(groups && cn_groups_ok(groups), "cartnet_group_sums_finalize: groups required");
+  CN_CHECK(parts_a && parts_b && sums && D >= 1, "cartnet_group_sums_finalize: null pointer");
+  hipLaunchKernelGGL(cn_group_sums_finalize_kernel, dim3(cn_ceil_div(D, 64), 2), dim3(1024), 0, ST(stream), parts_a,
+                     parts_b, over_edges ? groups->edge_parts : groups->node_parts, groups->G, D, sums, grad_a, grad_b);
+  CN_LAUNCH_CHECK("cartnet_group_sums_finalize");
   return 0;
 }
 
 extern "C" int cartnet_node_update_fwd(const float* aggr, const float* x_in, const float* mean_rstd,
                                        const float* gamma, const float* beta, int32_t N, int32_t D, float* x_out,
-                                       void* stream) {
+                                       const CartnetGroups* groups, void* stream) {
   CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_node_update_fwd: D=%d must be a multiple of 4", D);
   if (N == 0) return 0;
   CN_CHECK(aggr && x_in && mean_rstd && gamma && beta && x_out, "cartnet_node_update_fwd: null pointer");
-  long long blocks = ((long long)N * D / 4 + 255) / 256;
+  CN_CHECK(cn_groups_ok(groups), "cartnet_node_update_fwd: bad groups");
+  const int G = groups ? groups->G : 1;
+  long long blocks = ((long long)N * D / 4 / G + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(cn_node_update_fwd_kernel, dim3((int)blocks), dim3(256), 0, ST(stream), aggr, x_in, mean_rstd,
-                     gamma, beta, N, D, x_out);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cn_node_update_fwd_kernel, dim3((int)blocks, G), dim3(256), 0, ST(stream), aggr, x_in, mean_rstd,
+                     gamma, beta, N, D, x_out, groups ? groups->node_gptr : nullptr);
   CN_LAUNCH_CHECK("cartnet_node_update_fwd");
   return 0;
 }
 
 extern "C" int cartnet_node_update_bwd_stats(const float* aggr, const float* dx_out, const float* mean_rstd,
                                              const float* gamma, const float* beta, int32_t N, int32_t D,
-                                             double* parts_a, double* parts_b, void* stream) {
+                                             double* parts_a, double* parts_b, const CartnetGroups* groups,
+                                             void* stream) {
   CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_node_update_bwd_stats: D=%d must be a multiple of 4", D);
   CN_CHECK(aggr && dx_out && mean_rstd && gamma && beta && parts_a && parts_b,
            "cartnet_node_update_bwd_stats: null pointer");
-  hipLaunchKernelGGL(cn_node_update_bwd_kernel<0>, dim3(node_parts(N)), dim3(256), 0, ST(stream), aggr, dx_out,
-                     mean_rstd, gamma, beta, (const float*)nullptr, 0.f, N, D, parts_a, parts_b, (float*)nullptr);
+  CN_CHECK(cn_groups_ok(groups), "cartnet_node_update_bwd_stats: bad groups");
+  hipLaunchKernelGGL(cn_node_update_bwd_kernel<0>, cn_group_grid(groups, node_parts(N), false), dim3(256), 0, ST(stream),
+                     aggr, dx_out, mean_rstd, gamma, beta, (const float*)nullptr, 0.f, N, D, parts_a, parts_b,
+                     (float*)nullptr, groups ? groups->node_gptr : nullptr);
   CN_LAUNCH_CHECK("cartnet_node_update_bwd_stats");
   return 0;
 }
 
 extern "C" int cartnet_node_update_bwd_apply(const float* aggr, const float* dx_out, const float* mean_rstd,
                                              const float* gamma, const float* beta, const float* sums,
-                                             int32_t training, int32_t N, int32_t D, float* daggr, void* stream) {
+                                             int32_t training, int32_t N, int32_t D, float* daggr,
+                                             const CartnetGroups* groups, void* stream) {
   CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_node_update_bwd_apply: D=%d must be a multiple of 4", D);
   if (N == 0) return 0;
   CN_CHECK(aggr && dx_out && mean_rstd && gamma && beta && sums && daggr, "cartnet_node_update_bwd_apply: null pointer");
+  CN_CHECK(cn_groups_ok(groups), "cartnet_node_update_bwd_apply: bad groups");
   const float inv = (training && N > 0) ? (float)(1.0 / (double)N) : 0.f;
-  hipLaunchKernelGGL(cn_node_update_bwd_kernel<1>, dim3(node_parts(N)), dim3(256), 0, ST(stream), aggr, dx_out,
-                     mean_rstd, gamma, beta, sums, inv, N, D, (double*)nullptr, (double*)nullptr, daggr);
+  hipLaunchKernelGGL(cn_node_update_bwd_kernel<1>, cn_group_grid(groups, node_parts(N), false), dim3(256), 0, ST(stream),
+                     aggr, dx_out, mean_rstd, gamma, beta, sums, inv, N, D, (double*)nullptr, (double*)nullptr, daggr,
+                     groups ? groups->node_gptr : nullptr);
   CN_LAUNCH_CHECK("cartnet_node_update_bwd_apply");
   return 0;
 }

@@ -22,6 +22,7 @@ c_i32p = C.c_void_p
 c_i64p = C.c_void_p
 c_u8p = C.c_void_p
 c_stream = C.c_void_p
+c_groups = C.c_void_p       # const CartnetGroups* (None = one BatchNorm group: the whole batch)
 
 
 class GemmArgs(C.Structure):
@@ -85,8 +86,14 @@ class Model(C.Structure):
                                          "n_types")] + \
                [("use_envelope", C.c_int32 * MAX_LAYERS)] + \
                [(n, C.c_float) for n in ("radius", "env_radius", "bn_eps", "bn_momentum")] + \
-               [("gemm_precision", C.c_int32)] + \
+               [("gemm_precision", C.c_int32), ("bn_group_size", C.c_int32)] + \
                [("rbf_means", C.c_void_p), ("rbf_betas", C.c_void_p), ("p", Params), ("buf", LayerBuffers * MAX_LAYERS)]
+
+
+class Groups(C.Structure):
+    """CartnetGroups: BatchNorm groups inside one batch (include/cartnet_hip.h)."""
+    _fields_ = [("node_gptr", C.c_void_p), ("edge_gptr", C.c_void_p), ("G", C.c_int32), ("edge_parts", C.c_int32),
+                ("node_parts", C.c_int32)]
 
 
 class BatchDesc(C.Structure):
@@ -147,23 +154,28 @@ PROTOTYPES = {
     "cartnet_segment_sum_long": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
                                            c_f32p, C.c_int32, c_stream]),
     "cartnet_bn_finalize": (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float,
-                                      C.c_int32, c_f32p, c_f32p, c_i64p, c_f32p, c_stream]),
+                                      C.c_int32, c_f32p, c_f32p, c_i64p, c_f32p, c_groups, C.c_int32, C.c_int32,
+                                      c_stream]),
+    "cartnet_group_ptrs": (C.c_int, [c_i64p, C.c_int32, C.c_int32, c_i32p, C.c_int32, c_i32p, c_i32p, c_stream]),
+    "cartnet_colstats_grouped": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_groups, c_f32p, c_f32p, c_stream]),
+    "cartnet_group_sums_finalize": (C.c_int, [c_f32p, c_f32p, C.c_int32, c_groups, C.c_int32, c_f32p, c_f32p, c_f32p,
+                                              c_stream]),
     "cartnet_gate_scatter_nparts": (C.c_int, [C.c_int32]),
     "cartnet_gate_scatter_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, C.c_int32,
-                                           C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+                                           C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_groups, c_stream]),
     "cartnet_gate_scatter_bwd_stats": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p,
-                                                 C.c_int32, C.c_int32, c_f32p, c_f32p, c_stream]),
+                                                 C.c_int32, C.c_int32, c_f32p, c_f32p, c_groups, c_stream]),
     "cartnet_gate_scatter_bwd_apply": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p,
                                                  c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p,
-                                                 c_stream]),
+                                                 c_groups, c_stream]),
     "cartnet_segment_sum": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int32,
                                       c_stream]),
     "cartnet_node_update_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p,
-                                          c_stream]),
+                                          c_groups, c_stream]),
     "cartnet_node_update_bwd_stats": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p,
-                                                c_f32p, c_stream]),
+                                                c_f32p, c_groups, c_stream]),
     "cartnet_node_update_bwd_apply": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32,
-                                                C.c_int32, c_f32p, c_stream]),
+                                                C.c_int32, c_f32p, c_groups, c_stream]),
     "cartnet_mask_index": (C.c_int, [c_u8p, C.c_int32, c_i32p, c_i32p, c_stream]),
     "cartnet_cholesky_head_fwd": (C.c_int, [c_f32p, c_i32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p,
                                             c_stream]),

@@ -25,4 +25,6 @@ def create_model():
     else:
         raise Exception("Model not implemented")
     model.gemm_precision = int(getattr(cfg, "gemm_precision", 0))
+    if hasattr(model, "bn_group_size"):
+        model.bn_group_size = int(getattr(cfg, "bn_group_size", 0))
     return model

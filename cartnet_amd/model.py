@@ -256,6 +256,10 @@ class CartNet(nn.Module):
         self.validate_graph = False     # set True to sync-check edge_index ordering / ranges once per batch
         self.gemm_precision = 0         # 0: fp32 MFMA.  1: bf16x3 split-operand MFMA.  2: plain bf16 operands (csrc/gemm_x3.h)
         self.overlap_weight_gradients = True   # run weight-gradient GEMMs on a second stream during backward
+        # > 0: consecutive crystals of a batch form BatchNorm groups of this size -- the reference recipe's micro-batches
+        # (batch 4 x accumulation 16, scripts/train_cartnet_adp.sh:4) travel through the network as ONE batch of 64 with
+        # per-micro-batch statistics; pair it with cartnet_amd.train.grouped_loss (include/cartnet_hip.h: CartnetGroups)
+        self.bn_group_size = 0
         self._aux_stream = None
         self._status_ring = None        # in-flight pinned copies of the batches' graph status words (_defer_graph_check)
         self._param_names = [n for n, _ in self.named_parameters()]
@@ -272,6 +276,7 @@ class CartNet(nn.Module):
         md.radius, md.env_radius = float(enc.rbf.cutoff_upper), float(self.layers[0].envelope_radius)
         md.bn_eps, md.bn_momentum = BN_EPS, BN_MOMENTUM
         md.gemm_precision = int(self.gemm_precision)
+        md.bn_group_size = int(self.bn_group_size)
         B = dict(self.named_buffers())
         md.rbf_means, md.rbf_betas = B["encoder.rbf.means"].data_ptr(), B["encoder.rbf.betas"].data_ptr()
         for n, t in P.items():

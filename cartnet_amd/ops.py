@@ -455,7 +455,8 @@ def bn_finalize(parts_sum, parts_sq, nparts: int, count: int, Cc: int, eps: floa
         _vec(nbt, 1, "bn_finalize num_batches_tracked", torch.int64)
     _l.check(_l.load().cartnet_bn_finalize(_l.ptr(parts_sum), _l.ptr(parts_sq), int(nparts), int(count), int(Cc),
                                            float(eps), float(momentum), int(training), _l.ptr(running_mean),
-                                           _l.ptr(running_var), _l.ptr(nbt), mean_rstd.data_ptr(), _l.stream_ptr()),
+                                           _l.ptr(running_var), _l.ptr(nbt), mean_rstd.data_ptr(), None, 0, 0,
+                                           _l.stream_ptr()),
              "cartnet_bn_finalize")
 
 
@@ -486,7 +487,8 @@ def gate_scatter_fwd(gs, e_in, env, layout: GraphLayout, mean_rstd, gamma, beta,
     _l.check(_l.load().cartnet_gate_scatter_fwd(gs.data_ptr(), _l.ptr(e_in), _l.ptr(env), layout.rowptr.data_ptr(),
                                                 mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, D,
                                                 _l.ptr(e_out), aggr.data_ptr(), parts_sum.data_ptr(),
-                                                parts_sq.data_ptr(), _l.stream_ptr()), "cartnet_gate_scatter_fwd")
+                                                parts_sq.data_ptr(), None, _l.stream_ptr()),
+             "cartnet_gate_scatter_fwd")
 
 
 def gate_scatter_bwd_stats(gs, de_out, daggr, env, layout: GraphLayout, mean_rstd, gamma, beta, parts_a,
@@ -506,7 +508,7 @@ def gate_scatter_bwd_stats(gs, de_out, daggr, env, layout: GraphLayout, mean_rst
     _vec(parts_b, npart * D, "parts_b", torch.float64)
     _l.check(_l.load().cartnet_gate_scatter_bwd_stats(
         gs.data_ptr(), _l.ptr(de_out), daggr.data_ptr(), _l.ptr(env), layout.rowptr.data_ptr(),
-        mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, D, parts_a.data_ptr(), parts_b.data_ptr(),
+        mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, D, parts_a.data_ptr(), parts_b.data_ptr(), None,
         _l.stream_ptr()), "cartnet_gate_scatter_bwd_stats")
 
 
@@ -529,7 +531,7 @@ def gate_scatter_bwd_apply(gs, de_out, daggr, env, layout: GraphLayout, mean_rst
     _l.check(_l.load().cartnet_gate_scatter_bwd_apply(
         gs.data_ptr(), _l.ptr(de_out), daggr.data_ptr(), _l.ptr(env), layout.rowptr.data_ptr(),
         mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), E, int(training), N, D,
-        parts_dg.data_ptr(), parts_ds.data_ptr(), _l.stream_ptr()), "cartnet_gate_scatter_bwd_apply")
+        parts_dg.data_ptr(), parts_ds.data_ptr(), None, _l.stream_ptr()), "cartnet_gate_scatter_bwd_apply")
 
 
 def segment_sum(rows: Tensor, ptr_: Tensor, perm: Optional[Tensor], out: Tensor) -> None:
@@ -554,7 +556,7 @@ def node_update_fwd(aggr, x_in, mean_rstd, gamma, beta, x_out) -> None:
     _vec(gamma, D, "gamma")
     _vec(beta, D, "beta")
     _l.check(_l.load().cartnet_node_update_fwd(aggr.data_ptr(), x_in.data_ptr(), mean_rstd.data_ptr(),
-                                               gamma.data_ptr(), beta.data_ptr(), N, D, x_out.data_ptr(),
+                                               gamma.data_ptr(), beta.data_ptr(), N, D, x_out.data_ptr(), None,
                                                _l.stream_ptr()), "cartnet_node_update_fwd")
 
 
@@ -571,7 +573,7 @@ def node_update_bwd_stats(aggr, dx_out, mean_rstd, gamma, beta, parts_a, parts_b
     _vec(parts_b, npart * D, "parts_b", torch.float64)
     _l.check(_l.load().cartnet_node_update_bwd_stats(aggr.data_ptr(), dx_out.data_ptr(), mean_rstd.data_ptr(),
                                                      gamma.data_ptr(), beta.data_ptr(), N, D, parts_a.data_ptr(),
-                                                     parts_b.data_ptr(), _l.stream_ptr()),
+                                                     parts_b.data_ptr(), None, _l.stream_ptr()),
              "cartnet_node_update_bwd_stats")
 
 
@@ -587,7 +589,7 @@ def node_update_bwd_apply(aggr, dx_out, mean_rstd, gamma, beta, sums, training: 
     _vec(sums, 2 * D, "sums")
     _l.check(_l.load().cartnet_node_update_bwd_apply(aggr.data_ptr(), dx_out.data_ptr(), mean_rstd.data_ptr(),
                                                      gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(),
-                                                     int(training), N, D, daggr.data_ptr(), _l.stream_ptr()),
+                                                     int(training), N, D, daggr.data_ptr(), None, _l.stream_ptr()),
              "cartnet_node_update_bwd_apply")
 
 

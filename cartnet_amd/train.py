@@ -19,6 +19,27 @@ def compute_loss(pred: torch.Tensor, true: torch.Tensor):
     return diff.abs().mean(), (diff * diff).mean()
 
 
+def grouped_loss(pred: torch.Tensor, true: torch.Tensor, batch, group_size: int):
+    """(sum over groups of the group's MAE, same for MSE, number of groups) for a batch whose consecutive crystals
+    form micro-batches of ``group_size`` (model.bn_group_size): the reference computes the mean loss of every
+    micro-batch and accumulates their gradients unscaled (train/train.py:173-189), i.e. it descends the SUM of the
+    per-micro-batch means.  Rows of ``pred`` are the non-H atoms (Cholesky head) or the crystals (scalar head).
+    Device-side only -- no host synchronisation."""
+    Bg = int(batch.num_graphs)
+    G = (Bg + group_size - 1) // group_size
+    if pred.dim() == 3:                                   # [M, 3, 3]: one row per non-H atom
+        gid = torch.div(batch.batch[batch.non_H_mask], group_size, rounding_mode="floor")
+        per_row = float(pred.shape[1] * pred.shape[2])
+    else:                                                 # [Bg]
+        gid = torch.div(torch.arange(Bg, device=pred.device), group_size, rounding_mode="floor")
+        per_row = 1.0
+    rows = torch.zeros(G, dtype=pred.dtype, device=pred.device).index_add_(
+        0, gid, torch.ones(gid.shape[0], dtype=pred.dtype, device=pred.device))
+    w = 1.0 / (per_row * rows.clamp(min=1.0))[gid]        # 1 / (elements of the row's group)
+    diff = (pred - true).reshape(pred.shape[0], -1)
+    return (diff.abs().sum(dim=1) * w).sum(), ((diff * diff).sum(dim=1) * w).sum(), G
+
+
 def _pick_loss(mae, mse):
     if cfg.loss == "MAE":
         return mae
@@ -35,13 +56,21 @@ def train_epoch(loader, model, optimizer, batch_accumulation: int, scheduler: Op
     n_iter = len(loader)
     tot_mae = torch.zeros((), device=device)
     graphs = 0
+    micro = 0                                       # micro-batches seen (= iterations unless batches carry groups)
     t0 = time.perf_counter()
     flush = getattr(model, "flush_graph_checks", None)
     for it, batch in enumerate(loader):
         if batch is not None:                       # None: this rank has no crystals left for the step (sharded
             batch.to(device)                        # loaders, tiny data sets) -- it adds a zero gradient
             pred, true = model(batch)
-            mae, mse = compute_loss(pred, true)
+            gsz = int(getattr(model, "bn_group_size", 0) or 0)
+            if gsz > 0 and int(batch.num_graphs) > gsz:
+                # the batch carries several micro-batches of the reference recipe (CartnetGroups): sum of their losses
+                mae, mse, n_groups = grouped_loss(pred, true, batch, gsz)
+                micro += n_groups
+            else:
+                mae, mse = compute_loss(pred, true)
+                micro += 1
             loss = _pick_loss(mae, mse)
             loss.mean().backward()                  # not divided by the accumulation count (train/train.py:183)
             tot_mae += mae.detach()
@@ -56,7 +85,7 @@ def train_epoch(loader, model, optimizer, batch_accumulation: int, scheduler: Op
             optimizer.zero_grad()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"mae": float(tot_mae.item()) / max(n_iter, 1), "graphs": graphs, "seconds": dt}
+    return {"mae": float(tot_mae.item()) / max(micro, 1), "graphs": graphs, "seconds": dt}
 
 
 def eval_epoch(loader, model, device="cuda:0", adp_metrics=False, test_metrics=False):

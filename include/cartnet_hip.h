@@ -361,9 +361,43 @@ int cartnet_sort_by_key(const int64_t* keys, int32_t N, int32_t nkeys, int32_t* 
  * `momentum` and the unbiased variance; num_batches_tracked += 1.  training == 0: mean_rstd from running stats.
  * The partial rows are consumed (folded in place when nparts > 256, see cartnet_colsum_finalize).
  * ---------------------------------------------------------------------------------------------------- */
+/* BatchNorm groups.  The reference's ADP recipe trains on micro-batches of 4 crystals and accumulates 16 of them per
+ * optimiser step (scripts/train_cartnet_adp.sh:4, train/train.py:183-189): every micro-batch is a forward call of its
+ * own, so BatchNorm normalises over the 4 crystals of that call.  Launch-bound on any GPU.  Here the 16 micro-batches
+ * can travel through the network as ONE batch of 64 crystals whose consecutive crystals form G "groups": every
+ * statistics-carrying kernel then reduces per group (its nodes [node_gptr[g], node_gptr[g+1]), its edges
+ * [edge_gptr[g], edge_gptr[g+1]) -- edges are sorted by target, so a group's edges are contiguous), normalises every
+ * row with its group's statistics, and the running statistics take the G momentum updates in group order.  Results
+ * equal G separate calls.  A NULL CartnetGroups pointer means one group = the whole batch. */
+typedef struct CartnetGroups {
+  const int32_t* node_gptr;   /* [G+1] first node of every group (device)                                       */
+  const int32_t* edge_gptr;   /* [G+1] first edge of every group (device) = rowptr[node_gptr[g]]                */
+  int32_t G;                  /* number of groups                                                                */
+  int32_t edge_parts;         /* workgroups per group of the per-edge kernels: their partial sums are [G][edge_parts][D] */
+  int32_t node_parts;         /* the same for the per-node kernels                                              */
+} CartnetGroups;
+/* node_gptr[g] = graph_ptr[min(g*group_size, Bg)], edge_gptr[g] = rowptr[node_gptr[g]] for g = 0..G, G = ceil(Bg/group_size) */
+int cartnet_group_ptrs(const int64_t* graph_ptr, int32_t Bg, int32_t group_size, const int32_t* rowptr, int32_t G,
+                       int32_t* node_gptr, int32_t* edge_gptr, void* stream);
+/* Per-group column sums and sums of squares of x [rows, C] (row stride ld) over the groups' EDGE ranges, as fp64 partial
+ * rows [G][edge_parts][C] for cartnet_bn_finalize: the BatchNorm statistics of the gate pre-activation, which a
+ * single-group run takes from the GEMM epilogue (a 128-row tile may straddle two groups). */
+int cartnet_colstats_grouped(const float* x, int32_t ld, int32_t C, const CartnetGroups* groups, double* parts_sum,
+                             double* parts_sq, void* stream);
+/* Backward statistics per group: sums[g][0:D] / sums[g][D:2D] = column sums of group g's rows of parts_a / parts_b
+ * ([G][parts][D], parts = edge_parts if over_edges else node_parts); grad_a / grad_b (may be NULL) = the sums over all
+ * groups (the BatchNorm affine gradients). */
+int cartnet_group_sums_finalize(const double* parts_a, const double* parts_b, int32_t D, const CartnetGroups* groups,
+                                int32_t over_edges, float* sums, float* grad_a, float* grad_b, void* stream);
+
+/* groups != NULL: parts are [G][parts][C] with parts = edge_parts if parts_over_edges (rows written by a per-edge kernel)
+ * else node_parts; the row counts are the groups' edge counts if count_over_edges else their node counts (nparts and
+ * count are ignored); mean_rstd is [G][2C]; the running statistics receive G updates in group order and
+ * num_batches_tracked += G. */
 int cartnet_bn_finalize(double* parts_sum, double* parts_sq, int32_t nparts, int64_t count, int32_t C,
                         float eps, float momentum, int32_t training, float* running_mean, float* running_var,
-                        int64_t* num_batches_tracked, float* mean_rstd, void* stream);
+                        int64_t* num_batches_tracked, float* mean_rstd, const CartnetGroups* groups,
+                        int32_t parts_over_edges, int32_t count_over_edges, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Neighbour-equalised gate + aggregation (models/cartnet.py:238-243 message, :259 scatter-sum, :225 edge
@@ -377,7 +411,8 @@ int cartnet_bn_finalize(double* parts_sum, double* parts_sq, int32_t nparts, int
 int cartnet_gate_scatter_nparts(int32_t N);
 int cartnet_gate_scatter_fwd(const float* gs, const float* e_in, const float* env, const int32_t* rowptr,
                              const float* mean_rstd, const float* gamma, const float* beta, int32_t N, int32_t D,
-                             float* e_out, float* aggr, double* parts_sum, double* parts_sq, void* stream);
+                             float* e_out, float* aggr, double* parts_sum, double* parts_sq,
+                             const CartnetGroups* groups, void* stream);
 
 /* de_out may be NULL in both backward passes (last layer: the head does not read the edge features).
  * Backward, pass 1 (statistics): with dm = daggr[tgt], z = sigmoid(bn(g)), dbn = (dm*s + de_out) * env * z(1-z):
@@ -385,7 +420,7 @@ int cartnet_gate_scatter_fwd(const float* gs, const float* e_in, const float* en
 int cartnet_gate_scatter_bwd_stats(const float* gs, const float* de_out, const float* daggr, const float* env,
                                    const int32_t* rowptr, const float* mean_rstd, const float* gamma,
                                    const float* beta, int32_t N, int32_t D, double* parts_a, double* parts_b,
-                                   void* stream);
+                                   const CartnetGroups* groups, void* stream);
 /* Backward, pass 2 (apply), in place on gs: g <- dg = gamma*rstd*(dbn - sum_dbn/E - ghat*sum_dbn_ghat/E)
  * (the two mean terms are dropped when training == 0), s <- ds = dm * sigma.  sums[0:D] = sum dbn,
  * sums[D:2D] = sum dbn*ghat (from cartnet_colsum_finalize).  Column partial sums of dg and ds (bias gradients
@@ -393,7 +428,8 @@ int cartnet_gate_scatter_bwd_stats(const float* gs, const float* de_out, const f
 int cartnet_gate_scatter_bwd_apply(float* gs, const float* de_out, const float* daggr, const float* env,
                                    const int32_t* rowptr, const float* mean_rstd, const float* gamma,
                                    const float* beta, const float* sums, int64_t E, int32_t training, int32_t N,
-                                   int32_t D, double* parts_dg, double* parts_ds, void* stream);
+                                   int32_t D, double* parts_dg, double* parts_ds, const CartnetGroups* groups,
+                                   void* stream);
 
 /* Row-segment sums: out[t, :] = sum_{k in [ptr[t], ptr[t+1])} rows[(perm ? perm[k] : k), :]  (fixed order).
  * Backward of the two index_selects PyG performs per layer (x_i by target: perm = NULL; x_j by source: CSC). */
@@ -409,16 +445,17 @@ int cartnet_segment_sum_long(const float* rows, int32_t ld, const int32_t* ptr, 
  * Node update (models/cartnet.py:269 norm2, :223 SiLU + residual):  x_out = silu(bn(aggr)) + x_in.
  * ---------------------------------------------------------------------------------------------------- */
 int cartnet_node_update_fwd(const float* aggr, const float* x_in, const float* mean_rstd, const float* gamma,
-                            const float* beta, int32_t N, int32_t D, float* x_out, void* stream);
+                            const float* beta, int32_t N, int32_t D, float* x_out, const CartnetGroups* groups,
+                            void* stream);
 /* Backward pass 1: dxn = dx_out * silu'(xn); column partial sums of dxn and dxn*ahat -> parts_a/parts_b
  * [cartnet_node_nparts(N)][D]. */
 int cartnet_node_update_bwd_stats(const float* aggr, const float* dx_out, const float* mean_rstd,
                                   const float* gamma, const float* beta, int32_t N, int32_t D, double* parts_a,
-                                  double* parts_b, void* stream);
+                                  double* parts_b, const CartnetGroups* groups, void* stream);
 /* Backward pass 2: daggr = gamma*rstd*(dxn - sum_a/N - ahat*sum_b/N) (mean terms dropped when training == 0). */
 int cartnet_node_update_bwd_apply(const float* aggr, const float* dx_out, const float* mean_rstd,
                                   const float* gamma, const float* beta, const float* sums, int32_t training,
-                                  int32_t N, int32_t D, float* daggr, void* stream);
+                                  int32_t N, int32_t D, float* daggr, const CartnetGroups* groups, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Cholesky ADP head (models/cartnet.py:293-305).  hid [N, H] = pre-activation of head.MLP.0 for every atom;
@@ -490,6 +527,9 @@ typedef struct CartnetModel {
   int32_t use_envelope[CARTNET_MAX_LAYERS];
   float radius, env_radius, bn_eps, bn_momentum;
   int32_t gemm_precision;                       /* CartnetGemmArgs.precision for every GEMM of the network */
+  int32_t bn_group_size;                        /* > 0: consecutive crystals form BatchNorm groups of this size
+                                                   (CartnetGroups: the reference's micro-batches in one pass);
+                                                   <= 0: one group, the whole batch                          */
   const float* rbf_means; const float* rbf_betas;
   CartnetParams p;
   CartnetLayerBuffers buf[CARTNET_MAX_LAYERS];

@@ -70,6 +70,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--gemm_precision", type=int, default=0, choices=(0, 1, 2),
                    help="GEMM arithmetic: 0 exact fp32 products (fp32 MFMA), 1 bf16x3 split operands (fp32-level "
                         "accuracy on the bf16 MFMA), 2 plain bf16 operands")
+    p.add_argument("--fused_accumulation", action="store_true",
+                   help="run the batch x batch_accumulation micro-batches of an optimiser step as ONE pass with BatchNorm "
+                        "statistics and loss per micro-batch (CartnetGroups): the reference recipe's numbers at the "
+                        "large-batch rate")
     p.add_argument("--resident_dataset", action="store_true",
                    help="keep the splits as packed shards in HBM and build every batch (and its augmentation) on the GPU")
     return p
@@ -95,6 +99,12 @@ def fill_cfg(args) -> None:
     cfg.workers = args.workers
     cfg.device = args.device
     cfg.gemm_precision = args.gemm_precision
+    cfg.bn_group_size = 0
+    if args.fused_accumulation and cfg.model == "CartNet" and cfg.batch_accumulation > 1:
+        # the loader hands out whole optimiser steps; the model normalises (and train_epoch averages the loss) per
+        # micro-batch of the reference's size
+        cfg.bn_group_size = cfg.batch
+        cfg.batch, cfg.batch_accumulation = cfg.batch * cfg.batch_accumulation, 1
 
 
 def create_loaders(args, rank: int, world: int):

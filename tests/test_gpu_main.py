@@ -69,3 +69,17 @@ def test_main_runs_ecomformer(tmp_path, monkeypatch):
     res = entry.main(["--synthetic", "12", "--atoms", "10", "20", "--dim_in", "32", "--epochs", "2", "--batch", "3",
                       "--batch_accumulation", "1", "--name", "ecf", "--model", "ecomformer"])
     assert len(res["history"]) == 2 and res["history"][-1]["train_mae"] == res["history"][-1]["train_mae"]
+
+
+def test_main_fused_accumulation_reproduces_the_micro_batch_recipe(tmp_path, monkeypatch):
+    """--fused_accumulation: batch x accumulation micro-batches per optimiser step as one pass with per-micro-batch
+    BatchNorm and loss == the reference recipe run micro-batch by micro-batch (same loaders, same order)."""
+    import main as entry
+    monkeypatch.chdir(tmp_path)
+    common = ["--synthetic", "40", "--atoms", "10", "30", "--dim_in", "64", "--num_layers", "2", "--epochs", "2",
+              "--batch", "4", "--batch_accumulation", "4", "--lr", "1e-3"]
+    a = entry.main(common + ["--name", "micro"])
+    b = entry.main(common + ["--name", "fused", "--fused_accumulation"])
+    for ha, hb in zip(a["history"], b["history"]):
+        assert abs(ha["train_mae"] - hb["train_mae"]) < 2e-3 * abs(ha["train_mae"])
+        assert abs(ha["val_mae"] - hb["val_mae"]) < 2e-2 * abs(ha["val_mae"])
