@@ -228,28 +228,74 @@ __global__ __launch_bounds__(256) void cn_colstats_grouped_kernel(const float* _
   }
 }
 
-// sums[g][which*D + c] = column sum of the group's partial rows (which = 0: parts_a, 1: parts_b); grads[which][c] = the
-// sum over all groups (BatchNorm affine gradients are shared by the groups).  grid (ceil(D/64), 2), 1024 threads.
-__global__ __launch_bounds__(1024) void cn_group_sums_finalize_kernel(const double* __restrict__ parts_a,
-                                                                      const double* __restrict__ parts_b, int nparts,
-                                                                      int G, int D, float* __restrict__ sums,
-                                                                      float* __restrict__ grad_a,
-                                                                      float* __restrict__ grad_b) {
+// Grouped statistics in two steps so that the groups reduce in parallel (one workgroup per 64 columns x group; a single
+// workgroup walking 16 groups x ~200 partial rows took 160 us per BatchNorm).
+// Step 1: group g's mean / rstd -> mean_rstd[g]; its mean and unbiased variance are parked, as doubles, in row 0 of the
+// group's (now consumed) partial rows for step 2.
+__global__ __launch_bounds__(1024) void cn_bn_group_stats_kernel(double* __restrict__ parts_sum,
+                                                                 double* __restrict__ parts_sq, int nparts, int C,
+                                                                 float eps, const int* __restrict__ cnt_ptr,
+                                                                 float* __restrict__ mean_rstd) {
   __shared__ double red[16 * 64];
-  const int which = blockIdx.y;
-  const double* __restrict__ parts = which ? parts_b : parts_a;
-  float* __restrict__ grad = which ? grad_b : grad_a;
+  const int g = blockIdx.y;
   const int c = blockIdx.x * 64 + threadIdx.x;
-  const bool owner = threadIdx.x < 64 && c < D;
-  double total = 0.0;
+  const size_t off = (size_t)g * nparts * C;
+  const double s = cn_block_colsum(parts_sum + off, nparts, C, blockIdx.x * 64, red);
+  const double q = cn_block_colsum(parts_sq + off, nparts, C, blockIdx.x * 64, red);
+  if (threadIdx.x >= 64 || c >= C) return;
+  const long long cnt = (long long)(cnt_ptr[g + 1] - cnt_ptr[g]);
+  const double n = (double)cnt;
+  const double mean = n > 0 ? s / n : 0.0;
+  double var = n > 0 ? q / n - mean * mean : 0.0;
+  if (var < 0.0) var = 0.0;
+  mean_rstd[(size_t)g * 2 * C + c] = (float)mean;
+  mean_rstd[(size_t)g * 2 * C + C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  parts_sum[off + c] = mean;
+  parts_sq[off + c] = cnt > 1 ? var * (n / (n - 1.0)) : var;
+}
+
+// Step 2: the G momentum updates of the running statistics, in group order (rounded to fp32 after every update, like
+// the reference's buffers between two forward calls); num_batches_tracked += G.
+__global__ void cn_bn_running_kernel(const double* __restrict__ parts_sum, const double* __restrict__ parts_sq,
+                                     int nparts, int C, int G, float momentum, float* __restrict__ running_mean,
+                                     float* __restrict__ running_var, int64_t* __restrict__ nbt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) nbt[0] += G;
+  if (c >= C || !running_mean) return;
+  double rm = (double)running_mean[c], rv = (double)running_var[c];
   for (int g = 0; g < G; ++g) {
-    const double t = cn_block_colsum(parts + (size_t)g * nparts * D, nparts, D, blockIdx.x * 64, red);
-    if (owner) {
-      sums[(size_t)g * 2 * D + which * D + c] = (float)t;
-      total += t;
-    }
+    const size_t off = (size_t)g * nparts * C + c;
+    rm = (double)(float)((1.0 - (double)momentum) * rm + (double)momentum * parts_sum[off]);
+    rv = (double)(float)((1.0 - (double)momentum) * rv + (double)momentum * parts_sq[off]);
   }
-  if (owner && grad) grad[c] = (float)total;
+  running_mean[c] = (float)rm;
+  running_var[c] = (float)rv;
+}
+
+// Backward statistics per group: sums[g][which*D + c] = column sum of group g's partial rows (which = blockIdx.y: 0
+// parts_a, 1 parts_b); the double total is parked in row 0 of the group's partial rows for cn_group_grads_kernel, which
+// adds the groups in order (the BatchNorm affine gradients are shared by the groups).
+__global__ __launch_bounds__(1024) void cn_group_sums_kernel(double* __restrict__ parts_a, double* __restrict__ parts_b,
+                                                             int nparts, int D, float* __restrict__ sums) {
+  __shared__ double red[16 * 64];
+  const int which = blockIdx.y, g = blockIdx.z;
+  double* __restrict__ parts = (which ? parts_b : parts_a) + (size_t)g * nparts * D;
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const double t = cn_block_colsum(parts, nparts, D, blockIdx.x * 64, red);
+  if (threadIdx.x >= 64 || c >= D) return;
+  sums[(size_t)g * 2 * D + which * D + c] = (float)t;
+  parts[c] = t;
+}
+
+__global__ void cn_group_grads_kernel(const double* __restrict__ parts_a, const double* __restrict__ parts_b, int nparts,
+                                      int D, int G, float* __restrict__ grad_a, float* __restrict__ grad_b) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const double* __restrict__ parts = blockIdx.y ? parts_b : parts_a;
+  float* __restrict__ grad = blockIdx.y ? grad_b : grad_a;
+  if (c >= D || !grad) return;
+  double total = 0.0;
+  for (int g = 0; g < G; ++g) total += parts[(size_t)g * nparts * D + c];
+  grad[c] = (float)total;
 }
 
 // ------------------------------------------------------------------------------------------------ node update
@@ -591,18 +637,25 @@ extern "C" int cartnet_bn_finalize(double* parts_sum, double* parts_sq, int32_t 
   CN_CHECK((running_mean == nullptr) == (running_var == nullptr), "cartnet_bn_finalize: running stats must pair");
   CN_CHECK(cn_groups_ok(groups), "cartnet_bn_finalize: bad groups");
   int G = 1;
-  const int* cnt_ptr = nullptr;
   if (groups) {   // [G][parts][C] partial rows, one statistics row per group
     G = groups->G;
     nparts = parts_over_edges ? groups->edge_parts : groups->node_parts;
-    cnt_ptr = count_over_edges ? groups->edge_gptr : groups->node_gptr;
+    if (training) {
+      hipLaunchKernelGGL(cn_bn_group_stats_kernel, dim3(cn_ceil_div(C, 64), G), dim3(1024), 0, ST(stream), parts_sum,
+                         parts_sq, nparts, C, eps, count_over_edges ? groups->edge_gptr : groups->node_gptr, mean_rstd);
+      CN_LAUNCH_CHECK("cartnet_bn_finalize/groups");
+      hipLaunchKernelGGL(cn_bn_running_kernel, dim3(cn_ceil_div(C, 256)), dim3(256), 0, ST(stream), parts_sum, parts_sq,
+                         nparts, C, G, momentum, running_mean, running_var, num_batches_tracked);
+      CN_LAUNCH_CHECK("cartnet_bn_finalize/running");
+      return 0;
+    }
   } else if (training) {
     double* fp[2] = {parts_sum, parts_sq};
     nparts = cn_fold_parts(fp, 2, nparts, C, ST(stream));
   }
   hipLaunchKernelGGL(cn_bn_finalize_kernel, dim3(cn_ceil_div(C, 64)), dim3(1024), 0, ST(stream), parts_sum, parts_sq,
                      nparts, (long long)count, C, eps, momentum, training, running_mean, running_var,
-                     num_batches_tracked, mean_rstd, G, cnt_ptr);
+                     num_batches_tracked, mean_rstd, G, (const int*)nullptr);
   CN_LAUNCH_CHECK("cartnet_bn_finalize");
   return 0;
 }
@@ -629,14 +682,20 @@ extern "C" int cartnet_colstats_grouped(const float* x, int32_t ld, int32_t C, c
   return 0;
 }
 
-extern "C" int cartnet_group_sums_finalize(const double* parts_a, const double* parts_b, int32_t D,
-                                           const CartnetGroups* groups, int32_t over_edges, float* sums, float* grad_a,
-                                           float* grad_b, void* stream) {
+extern "C" int cartnet_group_sums_finalize(double* parts_a, double* parts_b, int32_t D, const CartnetGroups* groups,
+                                           int32_t over_edges, float* sums, float* grad_a, float* grad_b,
+                                           void* stream) {
   CN_CHECK(groups && cn_groups_ok(groups), "cartnet_group_sums_finalize: groups required");
   CN_CHECK(parts_a && parts_b && sums && D >= 1, "cartnet_group_sums_finalize: null pointer");
-  hipLaunchKernelGGL(cn_group_sums_finalize_kernel, dim3(cn_ceil_div(D, 64), 2), dim3(1024), 0, ST(stream), parts_a,
-                     parts_b, over_edges ? groups->edge_parts : groups->node_parts, groups->G, D, sums, grad_a, grad_b);
+  const int nparts = over_edges ? groups->edge_parts : groups->node_parts;
+  hipLaunchKernelGGL(cn_group_sums_kernel, dim3(cn_ceil_div(D, 64), 2, groups->G), dim3(1024), 0, ST(stream), parts_a,
+                     parts_b, nparts, D, sums);
   CN_LAUNCH_CHECK("cartnet_group_sums_finalize");
+  if (grad_a || grad_b) {
+    hipLaunchKernelGGL(cn_group_grads_kernel, dim3(cn_ceil_div(D, 256), 2), dim3(256), 0, ST(stream), parts_a, parts_b,
+                       nparts, D, groups->G, grad_a, grad_b);
+    CN_LAUNCH_CHECK("cartnet_group_sums_finalize/grads");
+  }
   return 0;
 }
 

@@ -24,19 +24,24 @@ def grouped_loss(pred: torch.Tensor, true: torch.Tensor, batch, group_size: int)
     form micro-batches of ``group_size`` (model.bn_group_size): the reference computes the mean loss of every
     micro-batch and accumulates their gradients unscaled (train/train.py:173-189), i.e. it descends the SUM of the
     per-micro-batch means.  Rows of ``pred`` are the non-H atoms (Cholesky head) or the crystals (scalar head).
-    Device-side only -- no host synchronisation."""
+    Device-side with static shapes only: no host synchronisation."""
     Bg = int(batch.num_graphs)
     G = (Bg + group_size - 1) // group_size
-    if pred.dim() == 3:                                   # [M, 3, 3]: one row per non-H atom
-        gid = torch.div(batch.batch[batch.non_H_mask], group_size, rounding_mode="floor")
+    dev = pred.device
+    M = int(pred.shape[0])
+    if pred.dim() == 3:                                   # [M, 3, 3]: row m belongs to the m-th non-H atom
         per_row = float(pred.shape[1] * pred.shape[2])
-    else:                                                 # [Bg]
-        gid = torch.div(torch.arange(Bg, device=pred.device), group_size, rounding_mode="floor")
+        mask = batch.non_H_mask
+        gid_atom = torch.div(batch.batch, group_size, rounding_mode="floor")
+        # rank of every non-H atom among the non-H atoms = its row; all shapes are static, nothing syncs
+        dest = torch.where(mask, torch.cumsum(mask, 0) - 1, torch.full_like(gid_atom, M))
+        gid = torch.zeros(M + 1, dtype=torch.int64, device=dev).scatter_(0, dest, gid_atom)[:M]
+    else:                                                 # [Bg]: one row per crystal
         per_row = 1.0
-    rows = torch.zeros(G, dtype=pred.dtype, device=pred.device).index_add_(
-        0, gid, torch.ones(gid.shape[0], dtype=pred.dtype, device=pred.device))
-    w = 1.0 / (per_row * rows.clamp(min=1.0))[gid]        # 1 / (elements of the row's group)
-    diff = (pred - true).reshape(pred.shape[0], -1)
+        gid = torch.div(torch.arange(Bg, device=dev), group_size, rounding_mode="floor")
+    rows = torch.zeros(G, dtype=pred.dtype, device=dev).index_add_(0, gid, torch.ones(M, dtype=pred.dtype, device=dev))
+    w = (1.0 / (per_row * rows.clamp(min=1.0)))[gid]       # 1 / (elements of the row's group)
+    diff = (pred - true).reshape(M, -1)
     return (diff.abs().sum(dim=1) * w).sum(), ((diff * diff).sum(dim=1) * w).sum(), G
 
 

@@ -386,8 +386,8 @@ int cartnet_colstats_grouped(const float* x, int32_t ld, int32_t C, const Cartne
                              double* parts_sq, void* stream);
 /* Backward statistics per group: sums[g][0:D] / sums[g][D:2D] = column sums of group g's rows of parts_a / parts_b
  * ([G][parts][D], parts = edge_parts if over_edges else node_parts); grad_a / grad_b (may be NULL) = the sums over all
- * groups (the BatchNorm affine gradients). */
-int cartnet_group_sums_finalize(const double* parts_a, const double* parts_b, int32_t D, const CartnetGroups* groups,
+ * groups (the BatchNorm affine gradients).  The partial rows are consumed (row 0 of every group is overwritten). */
+int cartnet_group_sums_finalize(double* parts_a, double* parts_b, int32_t D, const CartnetGroups* groups,
                                 int32_t over_edges, float* sums, float* grad_a, float* grad_b, void* stream);
 
 /* groups != NULL: parts are [G][parts][C] with parts = edge_parts if parts_over_edges (rows written by a per-edge kernel)
