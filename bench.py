@@ -43,20 +43,28 @@ def build_batch(n_graphs: int, first: int, atoms: int):
     return make_batch(n_graphs, atoms, first=first)
 
 
-def cpu_baseline(seconds_budget: float = 12.0):
-    """Time the oracle (plain-torch CPU restatement of models/cartnet.py, autograd backward) on 4 crystals."""
-    from cartnet_amd.model import make_state_dict
-    from oracle import cartnet_ref as orc
+def cpu_baseline(seconds_budget: float = 12.0, which: str = "cartnet"):
+    """Time the oracle (plain-torch CPU restatement of models/cartnet.py -- or models/comformer.py for
+    ``--model icomformer`` -- with autograd backward) on 4 crystals."""
     n_graphs = 4
     batch = build_batch(n_graphs, 10_000, 194)
-    sd = make_state_dict(256, 64, 4, seed=0)
+    if which == "icomformer":
+        from cartnet_amd.comformer import make_icomformer_state_dict
+        from oracle import icomformer_ref as orc
+        sd = make_icomformer_state_dict(256, seed=0)
+        fwd = lambda p: orc.icomformer_forward(p, batch, training=True)
+    else:
+        from cartnet_amd.model import make_state_dict
+        from oracle import cartnet_ref as orc
+        sd = make_state_dict(256, 64, 4, seed=0)
+        fwd = lambda p: orc.cartnet_forward(p, batch, num_layers=4, training=True)
     params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and "rbf" not in k
                   else v.clone()) for k, v in sd.items()}
     def step():
         for v in params.values():
             if v.requires_grad:
                 v.grad = None
-        pred = orc.cartnet_forward(params, batch, num_layers=4, training=True)
+        pred = fwd(params)
         (pred - batch.y).abs().mean().backward()
 
     def median_time(iters):
@@ -133,6 +141,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: ranks beyond the visible GPUs share them (gloo transport unless "
                          "CARTNET_DIST_BACKEND says otherwise)")
+    ap.add_argument("--model", choices=("cartnet", "icomformer"), default="cartnet",
+                    help="cartnet: the headline (BASELINE configs[1]); icomformer: BASELINE configs[4], the alternative "
+                         "message-passing path (models/comformer.py) on the same crystals")
     ap.add_argument("--bn-group-size", type=int, default=0,
                     help="> 0: BatchNorm statistics and loss per group of this many crystals (the reference recipe's "
                          "micro-batches of 4 inside one pass, CartnetGroups); 0: one BatchNorm batch (the headline)")
@@ -162,9 +173,16 @@ def main():
 
     cfg.radius = 5.0
     torch.manual_seed(0)
-    model = CartNet(dim_in=256, dim_rbf=64, num_layers=4).to(dev).train()
+    icf = args.model == "icomformer"
+    if icf:
+        from cartnet_amd.comformer import iComformer
+        if args.bn_group_size > 0:
+            raise SystemExit("--bn-group-size applies to CartNet only")
+        model = iComformer(256).to(dev).train()
+    else:
+        model = CartNet(dim_in=256, dim_rbf=64, num_layers=4).to(dev).train()
+        model.bn_group_size = args.bn_group_size
     model.gemm_precision = args.precision
-    model.bn_group_size = args.bn_group_size
     opt = FlatAdam(model, lr=1e-3)
     base = build_batch(args.graphs, 100_000 + rank * args.graphs, args.atoms).to(dev)
     N, E = int(base.x.shape[0]), int(base.edge_index.shape[1])
@@ -261,7 +279,7 @@ def main():
     # the chip with the weight-gradient stream.  Three extra single-stream steps (outside the timed region) give the
     # same launches undisturbed: kernel quality without the overlap.
     isolated = {}
-    if world == 1 and not args.no_kernel_timer:   # single process only: the extra steps would need every rank
+    if world == 1 and not args.no_kernel_timer and not icf:   # single process only: the extra steps would need every rank
         model.overlap_weight_gradients = False
         extra = [fresh() for _ in range(3)]
         torch.cuda.synchronize()
@@ -303,11 +321,15 @@ def main():
     graphs_total = args.graphs * world * args.steps
     value = graphs_total / dt
     out = {
-        "metric": "graphs/sec (CartNet 4x256, ~194 atoms/~2.8k edges), forward+backward+Adam",
+        "metric": "graphs/sec (iComformer D=256 on ADP shapes, ~194 atoms/~2.8k edges), forward+backward+Adam" if icf
+        else "graphs/sec (CartNet 4x256, ~194 atoms/~2.8k edges), forward+backward+Adam",
         "value": round(value, 2), "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: CartNet L=4 D=256 R=64 fp32 train step, {args.graphs} synthetic "
+        "config": {"workload": (f"BASELINE configs[4]: iComformer D=256 (4 attention layers + edge-update layer, Cholesky "
+                                f"head) fp32 train step, " if icf else
+                                f"BASELINE configs[1]: CartNet L=4 D=256 R=64 fp32 train step, ") +
+                               f"{args.graphs} synthetic "
                                f"ADP crystals x {args.atoms} atoms per GPU per step (N={N} atoms, E={E} edges per GPU)",
                    "graphs_per_gpu_per_step": args.graphs, "parallelism": f"graph-sharded dp{world}",
                    "batchnorm_groups": (f"{-(-args.graphs // args.bn_group_size)} groups of {args.bn_group_size} crystals "
@@ -316,9 +338,10 @@ def main():
                    "gemm_precision": "fp32 MFMA" if args.precision == 0 else
                    "bf16x3 split-operand MFMA (six bf16 MFMA products per fp32 product, fp32 accumulate) for all 256-wide GEMMs"},
         "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3),
-        "path_tflops_executed": round(value * FLOPS_EXEC_PER_GRAPH * (E / args.graphs / 2800.0) / 1e12 / world, 2),
-        "path_tflops_reference_equiv": round(value * FLOPS_REF_PER_GRAPH * (E / args.graphs / 2800.0) / 1e12 / world, 2),
     }
+    if not icf:
+        out["path_tflops_executed"] = round(value * FLOPS_EXEC_PER_GRAPH * (E / args.graphs / 2800.0) / 1e12 / world, 2)
+        out["path_tflops_reference_equiv"] = round(value * FLOPS_REF_PER_GRAPH * (E / args.graphs / 2800.0) / 1e12 / world, 2)
     # whole-path HBM figures (north_star asks for the fraction of the HBM roofline): compulsory bytes of the reference
     # formulation (68 MB per 2800-edge crystal, fwd+bwd, perfect fusion) and the bytes the PMC passes
     # counted for one step of this build (profiles/traffic.json), both over the measured step time, against 8 TB/s
@@ -328,14 +351,15 @@ def main():
         per_step = {}
     step_s = dt / args.steps
     alg = 68.0e6 * (E / 2800.0)
-    out["path_hbm"] = {"peak_TBps": 8.0,
-                       "algorithmic_bytes_per_step": int(alg), "algorithmic_TBps": round(alg / step_s / 1e12, 3),
-                       "algorithmic_frac": round(alg / step_s / 8.0e12, 4),
-                       "counted_from": "profiles/traffic.json (committed rocprofv3 PMC passes of the fp32 step; a constant "
-                                       "of the build, NOT measured by this run)",
-                       "counted_bytes_per_step": per_step.get("hbm_bytes"),
-                       "counted_TBps": round(per_step["hbm_bytes"] / step_s / 1e12, 3) if per_step.get("hbm_bytes") else None,
-                       "counted_frac": round(per_step["hbm_bytes"] / step_s / 8.0e12, 4) if per_step.get("hbm_bytes") else None}
+    if not icf:
+        out["path_hbm"] = {"peak_TBps": 8.0,
+                           "algorithmic_bytes_per_step": int(alg), "algorithmic_TBps": round(alg / step_s / 1e12, 3),
+                           "algorithmic_frac": round(alg / step_s / 8.0e12, 4),
+                           "counted_from": "profiles/traffic.json (committed rocprofv3 PMC passes of the fp32 step; a constant "
+                                           "of the build, NOT measured by this run)",
+                           "counted_bytes_per_step": per_step.get("hbm_bytes"),
+                           "counted_TBps": round(per_step["hbm_bytes"] / step_s / 1e12, 3) if per_step.get("hbm_bytes") else None,
+                           "counted_frac": round(per_step["hbm_bytes"] / step_s / 8.0e12, 4) if per_step.get("hbm_bytes") else None}
     if sustained is not None:
         out["sustained"] = sustained
     if x3 is not None:
@@ -391,7 +415,7 @@ def main():
                     "achieved": round(achi, 2), "frac": round(achi / peak, 4),
                     "avg_launch_us": round(1e3 * di["ms"] / di["launches"], 2)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(which=args.model)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
