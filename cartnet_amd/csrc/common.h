@@ -64,11 +64,17 @@ __device__ __forceinline__ void cn_block_store_parts(f64x4 v, double* lds, doubl
   cn_block_store_parts_row(v, lds, parts, D, c, active, wid, lane, blockIdx.x);
 }
 
-// BatchNorm groups (CartnetGroups, cartnet_hip.h): group g = blockIdx.y of a per-node / per-edge kernel owns the nodes
-// [n0, n1) and the statistics row g.  node_gptr == nullptr: one group, the whole batch.
-__device__ __forceinline__ void cn_group_range(const int* __restrict__ node_gptr, int N, int& n0, int& n1) {
-  n0 = node_gptr ? node_gptr[blockIdx.y] : 0;
-  n1 = node_gptr ? node_gptr[blockIdx.y + 1] : N;
+// BatchNorm groups (CartnetGroups, cartnet_hip.h): group `g` of a per-node / per-edge kernel owns the nodes [n0, n1)
+// and the statistics row g.  node_gptr == nullptr: one group, the whole batch.  With `reverse` (kernels that re-read
+// what their predecessor has just streamed in ascending order, see "Sweep direction" in edge_ops.hip) the groups and the
+// workgroups inside a group are dealt in descending order, so that the first workgroups start on the highest rows.
+__device__ __forceinline__ void cn_group_range(const int* __restrict__ node_gptr, int N, bool reverse, int& g, int& bx,
+                                               int& n0, int& n1) {
+  const bool flip = reverse && node_gptr != nullptr;
+  g = flip ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+  bx = flip ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+  n0 = node_gptr ? node_gptr[g] : 0;
+  n1 = node_gptr ? node_gptr[g + 1] : N;
 }
 
 __device__ __forceinline__ void cn_acc4(f64x4& a, f32x4 v) {

@@ -68,10 +68,10 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
   __shared__ double red[NODES_PER_BLOCK * 256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int ld = 2 * D;
-  int n0, n1;
-  cn_group_range(node_gptr, N, n0, n1);
-  mean_rstd += (size_t)blockIdx.y * 2 * D;
-  const int prow = blockIdx.y * gridDim.x + blockIdx.x;
+  int gi, bx, n0, n1;
+  cn_group_range(node_gptr, N, reverse != 0, gi, bx, n0, n1);
+  mean_rstd += (size_t)gi * 2 * D;
+  const int prow = gi * gridDim.x + bx;
   const int stride = gridDim.x * NODES_PER_BLOCK, nsweeps = (n1 - n0 + stride - 1) / stride;
   for (int c0 = 0; c0 < D; c0 += 256) {
     const int c = c0 + lane * 4;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
     }
     f64x4 ps = {0, 0, 0, 0}, pq = {0, 0, 0, 0};
     for (int j = 0; j < nsweeps; ++j) {
-      const int t = n0 + blockIdx.x * NODES_PER_BLOCK + wid + (reverse ? nsweeps - 1 - j : j) * stride;
+      const int t = n0 + bx * NODES_PER_BLOCK + wid + (reverse ? nsweeps - 1 - j : j) * stride;
       if (t >= n1) continue;
       const int k0 = rowptr[t], k1 = rowptr[t + 1];
       f32x4 acc = {0, 0, 0, 0};
@@ -136,15 +136,15 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_bwd_kernel(
   __shared__ double red[NODES_PER_BLOCK * 256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int ld = 2 * D;
-  int n0, n1;
-  cn_group_range(node_gptr, N, n0, n1);
-  mean_rstd += (size_t)blockIdx.y * 2 * D;
-  if (MODE == 1) sums += (size_t)blockIdx.y * 2 * D;
+  int gi, bx, n0, n1;
+  cn_group_range(node_gptr, N, reverse != 0, gi, bx, n0, n1);
+  mean_rstd += (size_t)gi * 2 * D;
+  if (MODE == 1) sums += (size_t)gi * 2 * D;
   if (MODE == 1 && node_gptr && inv_count != 0.f) {   // training-mode BatchNorm backward: means over THIS group's edges
     const int eg = rowptr[n1] - rowptr[n0];
     inv_count = eg > 0 ? 1.0f / (float)eg : 0.f;
   }
-  const int prow = blockIdx.y * gridDim.x + blockIdx.x;
+  const int prow = gi * gridDim.x + bx;
   const int stride = gridDim.x * NODES_PER_BLOCK, nsweeps = (n1 - n0 + stride - 1) / stride;
   for (int c0 = 0; c0 < D; c0 += 256) {
     const int c = c0 + lane * 4;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_bwd_kernel(
     }
     f64x4 ta = {0, 0, 0, 0}, tb = {0, 0, 0, 0};
     for (int j = 0; j < nsweeps; ++j) {
-      const int t = n0 + blockIdx.x * NODES_PER_BLOCK + wid + (reverse ? nsweeps - 1 - j : j) * stride;
+      const int t = n0 + bx * NODES_PER_BLOCK + wid + (reverse ? nsweeps - 1 - j : j) * stride;
       if (t >= n1 || !active) continue;
       const int k0 = rowptr[t], k1 = rowptr[t + 1];
       const f32x4 dm = ld4(daggr + (size_t)t * D + c);

@@ -303,9 +303,9 @@ __global__ void cn_node_update_fwd_kernel(const float* __restrict__ aggr, const 
                                           const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                           const float* __restrict__ beta, int N, int D, float* __restrict__ x_out,
                                           const int* __restrict__ node_gptr) {
-  int n0, n1;
-  cn_group_range(node_gptr, N, n0, n1);
-  mean_rstd += (size_t)blockIdx.y * 2 * D;
+  int gi, bx, n0, n1;
+  cn_group_range(node_gptr, N, false, gi, bx, n0, n1);
+  mean_rstd += (size_t)gi * 2 * D;
   const long long base4 = (long long)n0 * D / 4, total4 = (long long)(n1 - n0) * D / 4;
   for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < total4;
        j += (long long)gridDim.x * blockDim.x) {
@@ -329,12 +329,12 @@ __global__ __launch_bounds__(256) void cn_node_update_bwd_kernel(
     const int* __restrict__ node_gptr) {
   __shared__ double red[NODES_PER_BLOCK * 256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  int n0, n1;
-  cn_group_range(node_gptr, N, n0, n1);
-  mean_rstd += (size_t)blockIdx.y * 2 * D;
-  if (MODE == 1) sums += (size_t)blockIdx.y * 2 * D;
+  int gi, bx, n0, n1;
+  cn_group_range(node_gptr, N, false, gi, bx, n0, n1);
+  mean_rstd += (size_t)gi * 2 * D;
+  if (MODE == 1) sums += (size_t)gi * 2 * D;
   if (MODE == 1 && node_gptr && inv_count != 0.f) inv_count = n1 > n0 ? 1.0f / (float)(n1 - n0) : 0.f;
-  const int prow = blockIdx.y * gridDim.x + blockIdx.x;
+  const int prow = gi * gridDim.x + bx;
   for (int c0 = 0; c0 < D; c0 += 256) {
     const int c = c0 + lane * 4;
     const bool active = c < D;
