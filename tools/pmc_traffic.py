@@ -2,7 +2,8 @@
 
 FETCH_SIZE (KB) is doubled for gfx950 (wide coalesced 128-B reads are tallied at 64 B, MI355X_MICROARCH.md "HBM");
 WRITE_SIZE (KB) is taken as is.  Output: JSON keyed by kernel name, averages over all launches of that kernel in the
-profiled process (2 fp32 steps + the bf16x3 pass of bench.py, warm-ups included).
+profiled process (since round 2 the PMC passes run fp32 steps only, `bench.py --no-x3-pass`: 1 warm-up + 2 timed;
+a process that also ran the bf16x3 pass is recognised by its x3 kernels and labelled accordingly).
 Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
 """
 import csv, json, sys, collections
@@ -93,8 +94,9 @@ def main():
     tot_w = sum(1024.0 * w[k] for k in w)
     out["per_step"] = {"steps_profiled": steps, "fetch_bytes": int(tot_f / steps), "write_bytes": int(tot_w / steps),
                        "hbm_bytes": int((tot_f + tot_w) / steps),
-                       "note": "fabric-side bytes (Infinity-Cache hits included) averaged over the fp32 and bf16x3 steps "
-                               "of the profiled bench process"}
+                       "note": "fabric-side bytes (Infinity-Cache hits included) per optimiser step, averaged over the "
+                               + ("fp32 and bf16x3" if any("x3" in k for k in f) else "fp32-MFMA") +
+                               " steps of the profiled bench process"}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for _, k, n, fetch, write in rows[:16]:
         print(f"{short(k)[:70]:70s} n={n:4d} fetch {fetch/1e6:8.1f} MB write {write/1e6:8.1f} MB")

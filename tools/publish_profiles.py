@@ -28,15 +28,17 @@ plain = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().
 rf = plain["roofline"]
 traffic = json.load(open(os.path.join(dst, "traffic.json")))
 import csv
+_x3 = traffic['variants']['x3'].get('nn256')
+x3_nn_bytes = float('nan') if not _x3 else _x3.get('hbm_bytes_per_launch_edge_rows', _x3['hbm_bytes_per_launch'])
 rows = list(csv.DictReader(open(stats)))
 dom = next(r for r in rows if "cn_gemm_f32nn_kernel<false>" in r["Name"])
-md = f"""# Round 1 — rocprofv3 `--kernel-trace --stats` of the default bench command (1x MI355X)
+md = f"""# Round {int(tag[1:3])} — rocprofv3 `--kernel-trace --stats` of the default bench command (1x MI355X)
 
-Command (on the GPU box, `tools/collect_profiles.sh`): `cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d <out> -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline`
+Command (on the GPU box, `tools/collect_profiles.sh`): `cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d <out> -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --sustain-seconds 0`
 
 Files: `{tag}_bench_n1_kernel_stats.csv` (raw per-kernel stats), `{tag}_bench_n1_under_rocprof.json` (the bench line printed under the profiler),
 `{tag}_bench_n1.json` (un-profiled default run incl. `cpu_baseline`), `{tag}_pmc_fetch_size.csv` / `{tag}_pmc_write_size.csv` (separate `--pmc FETCH_SIZE` /
-`--pmc WRITE_SIZE` passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer`) and `traffic.json` (HBM bytes per launch per kernel derived from them by
+`--pmc WRITE_SIZE` passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-x3-pass`: fp32-MFMA steps only) and `traffic.json` (HBM bytes per launch per kernel derived from them by
 `tools/pmc_traffic.py`: FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is).
 
 The profiled process runs, in this order: 13 fp32-MFMA training steps on two streams (3 warm-up + 10 timed), 3 single-stream fp32 steps (the `roofline.isolated` pass) and
@@ -51,7 +53,7 @@ overlapped timed steps ({rf['achieved']} TFLOP/s, {rf['frac']} of the fp32 matri
 rocprofv3 reports {float(dom['AverageNs'])/1e3:.1f} us averaged over all {dom['Calls']} launches of that kernel in the process -- every shape it runs (the E-row layer GEMMs above,
 the small N-row node projections, the K = 80 first edge Linear) in the overlapped, warm-up and isolated steps alike; bench.py's average over the same set of shapes is
 {rf.get('kernel_avg_launch_us_all_shapes', 'n/a')} us in the overlapped steps (taken in warm-up steps 2-3: inside the timed steps only the dominant variant carries events) and {rf.get('kernel_avg_launch_us_all_shapes_isolated', 'n/a')} us isolated (the process mixes 13 overlapped with 3 isolated fp32 steps).  HBM traffic of that variant from the
-PMC passes: {traffic['variants']['fp32']['nn256'].get('hbm_bytes_per_launch_edge_rows', traffic['variants']['fp32']['nn256']['hbm_bytes_per_launch'])/1e6:.0f} MB per edge-sized launch (the kernel's launches with a grid of >= 500k threads: 14 per step -- the 13 of the dominant variant and the K = 80 first edge Linear; bf16x3 kernel on the same launches: {traffic['variants']['x3']['nn256'].get('hbm_bytes_per_launch_edge_rows', traffic['variants']['x3']['nn256']['hbm_bytes_per_launch'])/1e6:.0f} MB; averaged over all launches of the kernel incl. the small node projections: {traffic['variants']['fp32']['nn256']['hbm_bytes_per_launch']/1e6:.0f} MB).  Algorithmic bytes of those launches (operands read once, outputs written once, node-term gathers at their nominal size): 543 + 724 MB (layer GEMM 1), 1086 MB (dpre), 724 MB (dE), 905 MB (encoder) -- the counted traffic is at or below it, i.e. no wasted re-reads.
+PMC passes: {traffic['variants']['fp32']['nn256'].get('hbm_bytes_per_launch_edge_rows', traffic['variants']['fp32']['nn256']['hbm_bytes_per_launch'])/1e6:.0f} MB per edge-sized launch (the kernel's launches with a grid of >= 500k threads: 14 per step -- the 13 of the dominant variant and the K = 80 first edge Linear; bf16x3 kernel on the same launches: {x3_nn_bytes/1e6:.0f} MB (nan: the round's PMC passes ran fp32 steps only); averaged over all launches of the kernel incl. the small node projections: {traffic['variants']['fp32']['nn256']['hbm_bytes_per_launch']/1e6:.0f} MB).  Algorithmic bytes of those launches (operands read once, outputs written once, node-term gathers at their nominal size): 543 + 724 MB (layer GEMM 1), 1086 MB (dpre), 724 MB (dE), 905 MB (encoder) -- the counted traffic is at or below it, i.e. no wasted re-reads.
 
 Backward runs on two streams, so kernel durations of the two streams overlap in wall time (their sum exceeds the step time).
 
