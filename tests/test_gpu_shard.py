@@ -6,6 +6,7 @@ import torch
 
 from cartnet_amd import shard
 from cartnet_amd.data import Batch
+from cartnet_amd.model import CartNet, make_state_dict
 from cartnet_amd.synthetic import make_crystal
 
 pytestmark = pytest.mark.gpu
@@ -131,3 +132,28 @@ def test_full_size_batch_round_trip_and_throughput_sanity():
     b = ds.collate(sel)
     _assert_same(b, Batch.from_data_list([items[i] for i in sel]))
     assert bool((b.edge_index[1][1:] >= b.edge_index[1][:-1]).all())
+
+
+def test_shard_with_gpu_built_graphs_trains_like_the_host_built_one():
+    """configs[3] path in small: crystals given without edges, graphs from the GPU radius-graph builder
+    (shard.pack_with_gpu_graph) -> same packed arrays as the host builder (integers exact), then device collation with
+    augmentation, BatchNorm groups of 4 and one epoch of train_epoch: finite, every crystal seen once."""
+    from cartnet_amd.optim import FlatAdam
+    from cartnet_amd.synthetic import make_geometry
+    from cartnet_amd.train import train_epoch
+    n = 48
+    geo = [make_geometry(700 + g, None, n_range=(20, 60)) for g in range(n)]
+    arrays = shard.pack_with_gpu_graph(geo, 5.0, "cuda:0", chunk=20)
+    ref = shard.pack([make_crystal(700 + g, None, n_range=(20, 60)) for g in range(n)])
+    for k in ("atom_ptr", "edge_ptr", "y_ptr", "z", "edge_src", "edge_tgt", "non_h_mask"):
+        assert np.array_equal(arrays[k], ref[k]), k
+    for k in ("cart_dist", "cart_dir", "cell", "temperature", "y", "pos"):
+        assert np.allclose(arrays[k], ref[k], rtol=1e-6, atol=1e-6), k
+    ds = shard.DeviceShard(arrays)
+    m = CartNet(64, 16, 2)
+    m.load_state_dict(make_state_dict(64, 16, 2, seed=5))
+    m = m.cuda().train()
+    m.bn_group_size = 4
+    opt = FlatAdam(m, lr=1e-3)
+    r = train_epoch(shard.ShardLoader(ds, 16, shuffle=True, seed=3, augment=True), m, opt, 1)
+    assert r["graphs"] == n and r["mae"] == r["mae"] and opt.step_count == 3

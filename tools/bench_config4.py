@@ -19,10 +19,9 @@ import numpy as np
 import torch
 
 from cartnet_amd.config import cfg
-from cartnet_amd.graph import radius_graph_pbc
 from cartnet_amd.model import CartNet
 from cartnet_amd.optim import FlatAdam
-from cartnet_amd.shard import DeviceShard, ShardLoader
+from cartnet_amd.shard import DeviceShard, ShardLoader, pack_with_gpu_graph
 from cartnet_amd.synthetic import make_geometry
 from cartnet_amd.train import train_epoch
 
@@ -39,46 +38,14 @@ n = args.crystals
 t0 = time.perf_counter()
 geo = [make_geometry(30000 + i, None) for i in range(n)]
 t_geo = time.perf_counter() - t0
-natoms = np.array([int(d.x.shape[0]) for d in geo], dtype=np.int64)
-atom_ptr = np.concatenate([[0], np.cumsum(natoms)])
-
-# ---- edges on the GPU, `chunk` crystals per launch pair; indices rebased to the crystal
+# ---- edges on the GPU (cartnet_amd.shard.pack_with_gpu_graph: `chunk` crystals per launch pair, rebased to the crystal)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-src_l, tgt_l, dist_l, dir_l, ecount = [], [], [], [], []
-for c0 in range(0, n, args.chunk):
-    part = geo[c0:c0 + args.chunk]
-    pos = torch.cat([d.pos for d in part]).to(dev)
-    cell = torch.cat([d.cell for d in part]).to(dev)
-    sizes = torch.tensor([int(d.x.shape[0]) for d in part], dtype=torch.int64)
-    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(sizes, 0)]).to(dev)
-    ei, dist, dirs = radius_graph_pbc(pos, cell, ptr, 5.0)
-    gid = torch.repeat_interleave(torch.arange(len(part), device=dev), ptr[1:] - ptr[:-1])
-    g_of_edge = gid[ei[1]]
-    off = ptr[g_of_edge]
-    src_l.append((ei[0] - off).to(torch.int32).cpu())
-    tgt_l.append((ei[1] - off).to(torch.int32).cpu())
-    dist_l.append(dist.cpu())
-    dir_l.append(dirs.cpu())
-    ecount.append(torch.bincount(g_of_edge, minlength=len(part)).cpu())
+arrays = pack_with_gpu_graph(geo, 5.0, dev, args.chunk)
 torch.cuda.synchronize()
 t_graph = time.perf_counter() - t0
-ecount = torch.cat(ecount).numpy().astype(np.int64)
-ys = [d.y.reshape(-1, 9) for d in geo]
-arrays = {
-    "atom_ptr": atom_ptr.astype(np.int64),
-    "edge_ptr": np.concatenate([[0], np.cumsum(ecount)]).astype(np.int64),
-    "y_ptr": np.concatenate([[0], np.cumsum([y.shape[0] for y in ys])]).astype(np.int64),
-    "z": torch.cat([d.x for d in geo]).numpy().astype(np.int32),
-    "pos": torch.cat([d.pos for d in geo]).numpy().astype(np.float32),
-    "non_h_mask": torch.cat([d.non_H_mask for d in geo]).numpy().astype(np.uint8),
-    "edge_src": torch.cat(src_l).numpy(), "edge_tgt": torch.cat(tgt_l).numpy(),
-    "cart_dist": torch.cat(dist_l).numpy(), "cart_dir": torch.cat(dir_l).numpy().reshape(-1, 3),
-    "cell": torch.cat([d.cell.reshape(1, 9) for d in geo]).numpy().astype(np.float32),
-    "temperature": torch.cat([d.temperature.reshape(1) for d in geo]).numpy().astype(np.float32),
-    "y": torch.cat(ys).numpy().astype(np.float32),
-}
-del geo, src_l, tgt_l, dist_l, dir_l
+atom_ptr = arrays["atom_ptr"]
+del geo
 shard = DeviceShard(arrays, dev)
 out = {"workload": f"one rank's share of BASELINE configs[3]: {n} synthetic ADP crystals of 64..324 atoms "
                    f"({int(atom_ptr[-1])} atoms, {int(arrays['edge_ptr'][-1])} edges), SO(3) augmentation on, CartNet L=4 "
