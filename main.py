@@ -4,7 +4,8 @@
 What is kept: the argparse flags and their defaults (main.py:123-154), the copy into the global ``cfg``
 (:156-188), seed -> loaders -> ``create_model()`` -> Adam -> ``train`` (:196-227), OneCycleLR, gradient accumulation
 with the last-iteration flush, best-validation checkpoint ``{"model_state", "optimizer_state"}`` under
-``results/<name>/<seed>/ckpt/best.ckpt`` (train/train.py:91-102) and its reload for the test pass (:114-115).
+``results/<name>/<seed>/ckpt/best.ckpt`` (train/train.py:91-102) and its reload for the test pass (:114-115),
+``--inference`` / ``--montecarlo`` on a checkpoint (main.py:21-119, 212-225).
 What differs: the datasets (CSD / Jarvis need licences or the network) are replaced by synthetic ADP-shaped crystals
 (``--synthetic N`` graphs, ``--atoms lo hi``), wandb / GraphGym logging are dropped, ``--device`` replaces the hard-coded
 "cuda:0", and under ``torch.distributed.run`` the crystals are sharded across ranks with one gradient all-reduce per
@@ -70,6 +71,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--gemm_precision", type=int, default=0, choices=(0, 1, 2),
                    help="GEMM arithmetic: 0 exact fp32 products (fp32 MFMA), 1 bf16x3 split operands (fp32-level "
                         "accuracy on the bf16 MFMA), 2 plain bf16 operands")
+    p.add_argument("--montecarlo_rounds", type=int, default=100, help="passes of --montecarlo (the reference hard-codes 100)")
     p.add_argument("--fused_accumulation", action="store_true",
                    help="run the batch x batch_accumulation micro-batches of an optimiser step as ONE pass with BatchNorm "
                         "statistics and loss per micro-batch (CartnetGroups): the reference recipe's numbers at the "
@@ -128,6 +130,84 @@ def create_loaders(args, rank: int, world: int):
             DataLoader(va, cfg.batch), DataLoader(te, 1 if adp else cfg.batch)]
 
 
+def inference(model, loader, device, output_path: str) -> dict:
+    """main.py:21-60: eval mode, per test batch (batch size 1 on ADP, loader/loader.py:121) the prediction, the target
+    and the per-atom IoU / MAE / similarity index (train/metrics.py, here on the GPU); everything is pickled to
+    ``output_path``.  The synthetic crystals carry no refcode / original temperature: those two lists stay empty."""
+    import pickle
+    from cartnet_amd.metrics import compute_3D_IoU, get_similarity_index
+    model.eval()
+    out = {"pred": [], "true": [], "temp": [], "cell": [], "refcode": [], "pos": [], "atoms": [], "iou": [], "mae": [],
+           "similarity_index": []}
+    with torch.no_grad():
+        for batch in loader:
+            if batch is None:
+                continue
+            batch.to(device)
+            out["cell"].append(batch.cell.detach().to("cpu"))
+            out["atoms"].append(batch.x[batch.non_H_mask].detach().to("cpu"))     # read BEFORE forward overwrites x (main.py:40)
+            if hasattr(batch, "pos"):
+                out["pos"].append(batch.pos[batch.non_H_mask].detach().to("cpu"))
+            pred, true = model(batch)
+            out["pred"].append(pred.detach().to("cpu"))
+            out["true"].append(true.detach().to("cpu"))
+            out["iou"].append(compute_3D_IoU(pred, true).detach().to("cpu"))
+            out["mae"].append((pred - true).abs().detach().to("cpu"))
+            out["similarity_index"].append(get_similarity_index(pred, true).detach().to("cpu"))
+    if hasattr(model, "flush_graph_checks"):
+        model.flush_graph_checks()
+    iou, mae, sim = (torch.cat(out[k]) for k in ("iou", "mae", "similarity_index"))
+    with open(output_path, "wb") as f:
+        pickle.dump(out, f)
+    return {"iou_mean": float(iou.mean()), "iou_std": float(iou.std()), "mae_mean": float(mae.mean()),
+            "mae_std": float(mae.std()), "similarity_index_mean": float(sim.mean()),
+            "similarity_index_std": float(sim.std()), "output": output_path}
+
+
+def montecarlo(model, loader, device, output_path: str, rounds: int = 100, seed: int = 0) -> dict:
+    """main.py:62-119: for ``rounds`` passes over the test loader, predict, rotate ``cart_dir`` by a uniform random
+    rotation R, predict again and compare with the rotated first prediction R^T pred R (IoU, MAE, similarity index): how
+    equivariant the trained network has become.  One pickle per round, as the reference writes them."""
+    import pickle
+    from cartnet_amd.metrics import compute_3D_IoU, get_similarity_index
+    from cartnet_amd.shard import random_rotations
+    model.eval()
+    gen = torch.Generator(device=device).manual_seed(seed)
+    iou_all, mae_all, sim_all = [], [], []
+    with torch.no_grad():
+        for i in range(rounds):
+            out = {"pred": [], "true": [], "cell": [], "refcode": [], "pos": [], "atoms": [], "mae": [], "iou": [],
+                   "similarity_index": []}
+            for batch in loader:
+                if batch is None:
+                    continue
+                batch_copy = batch.clone()                                   # forward overwrites batch.x (main.py:87)
+                batch_copy.num_graphs = batch.num_graphs
+                batch.to(device)
+                out["cell"].append(batch.cell.detach().to("cpu"))
+                out["atoms"].append(batch.x[batch.non_H_mask].detach().to("cpu"))
+                pseudo_true, _ = model(batch)
+                R = random_rotations(1, gen, device)[0]
+                batch_copy.to(device)
+                batch_copy.cart_dir = batch_copy.cart_dir @ R
+                pseudo_true = R.transpose(-1, -2) @ pseudo_true @ R
+                pred, _ = model(batch_copy)
+                out["pred"].append(pred.detach().to("cpu"))
+                out["true"].append(pseudo_true.detach().to("cpu"))
+                out["iou"].append(compute_3D_IoU(pred, pseudo_true).detach().to("cpu"))
+                out["similarity_index"].append(get_similarity_index(pred, pseudo_true).detach().to("cpu"))
+                out["mae"].append((pred - pseudo_true).abs().detach().to("cpu"))
+            with open(output_path.replace(".pkl", f"_montecarlo_{i}.pkl"), "wb") as f:
+                pickle.dump(out, f)
+            iou_all += out["iou"]
+            mae_all += out["mae"]
+            sim_all += out["similarity_index"]
+    iou, mae, sim = torch.cat(iou_all), torch.cat(mae_all), torch.cat(sim_all)
+    return {"rounds": rounds, "iou_mean": float(iou.mean()), "iou_std": float(iou.std()), "mae_mean": float(mae.mean()),
+            "mae_std": float(mae.std()), "similarity_index_mean": float(sim.mean()),
+            "similarity_index_std": float(sim.std())}
+
+
 def main(argv=None) -> dict:
     args = build_parser().parse_args(argv)
     fill_cfg(args)
@@ -138,11 +218,22 @@ def main(argv=None) -> dict:
             local %= max(1, torch.cuda.device_count())
         cfg.device = f"cuda:{local}"
     torch.manual_seed(cfg.seed)
-    if args.inference or args.montecarlo:
-        raise SystemExit("--inference / --montecarlo write reports from the licensed ADP test set; not part of this build")
     loaders = create_loaders(args, rank, world)
     model = create_model()
     n_params = sum(p.numel() for p in model.parameters())
+    if args.inference or args.montecarlo:                                  # main.py:212-225 (ADP only, trained checkpoint)
+        assert cfg.dataset.name == "ADP", "ADPs inference only for ADP dataset."
+        assert args.checkpoint_path is not None, "Weights not provided."
+        ck = torch.load(args.checkpoint_path, map_location=cfg.device)
+        model.load_state_dict(ck["model_state"])
+        if args.inference:
+            res = inference(model, loaders[-1], cfg.device, args.inference_output)
+        else:
+            res = montecarlo(model, loaders[-1], cfg.device, args.inference_output, rounds=args.montecarlo_rounds,
+                             seed=cfg.seed)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        return res
     opt = FlatAdam(model, lr=cfg.lr)
     steps_per_epoch = len(loaders[0])
     total_steps = cfg.optim.max_epoch * steps_per_epoch // cfg.batch_accumulation + cfg.optim.max_epoch   # train.py:59

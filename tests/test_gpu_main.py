@@ -83,3 +83,26 @@ def test_main_fused_accumulation_reproduces_the_micro_batch_recipe(tmp_path, mon
     for ha, hb in zip(a["history"], b["history"]):
         assert abs(ha["train_mae"] - hb["train_mae"]) < 2e-3 * abs(ha["train_mae"])
         assert abs(ha["val_mae"] - hb["val_mae"]) < 2e-2 * abs(ha["val_mae"])
+
+
+def test_inference_and_montecarlo_on_a_checkpoint(tmp_path, monkeypatch):
+    """main.py:21-119, 212-225: --inference writes the pickle with pred / true / per-atom IoU, MAE, similarity index;
+    --montecarlo rotates cart_dir and reports how far pred(rotated) is from R^T pred R (one pickle per round)."""
+    import pickle
+    import main as entry
+    monkeypatch.chdir(tmp_path)
+    common = ["--synthetic", "20", "--atoms", "10", "30", "--dim_in", "64", "--num_layers", "2"]
+    entry.main(common + ["--epochs", "1", "--batch", "4", "--batch_accumulation", "1", "--name", "ck"])
+    ck = str(tmp_path / "results" / "ck" / "0" / "ckpt" / "best.ckpt")
+    res = entry.main(common + ["--inference", "--checkpoint_path", ck, "--inference_output", str(tmp_path / "inf.pkl")])
+    assert 0.0 < res["iou_mean"] <= 1.0 and res["mae_mean"] > 0
+    out = pickle.load(open(tmp_path / "inf.pkl", "rb"))
+    assert len(out["pred"]) == len(out["true"]) == len(out["iou"]) == 2            # 10 % of 20 crystals, batch size 1
+    assert out["pred"][0].shape == out["true"][0].shape and out["pred"][0].shape[1:] == (3, 3)
+    assert out["atoms"][0].dtype == torch.int64 and out["atoms"][0].shape[0] == out["pred"][0].shape[0]
+    mc = entry.main(common + ["--montecarlo", "--montecarlo_rounds", "3", "--checkpoint_path", ck,
+                              "--inference_output", str(tmp_path / "inf.pkl")])
+    assert mc["rounds"] == 3 and 0.0 <= mc["iou_mean"] <= 1.0 and mc["mae_mean"] >= 0
+    assert all(os.path.exists(tmp_path / f"inf_montecarlo_{i}.pkl") for i in range(3))
+    with pytest.raises(AssertionError, match="Weights not provided"):
+        entry.main(common + ["--inference"])
