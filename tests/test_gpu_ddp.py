@@ -53,3 +53,60 @@ def test_divergence_is_detected():
     import torch
     from cartnet_amd import distributed as cdist
     cdist.assert_replicas_in_sync(torch.nn.Linear(4, 4))
+
+
+_GROUPS_CHILD = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from cartnet_amd import distributed as cdist
+from cartnet_amd.config import cfg
+from cartnet_amd.data import Batch
+from cartnet_amd.model import CartNet, make_state_dict
+from cartnet_amd.optim import FlatAdam
+from cartnet_amd.synthetic import make_crystal
+from cartnet_amd.train import grouped_loss
+
+rank, world, local = cdist.init_from_env()
+cfg.radius = 5.0
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+items = [make_crystal(9500 + i, 12 + 3 * i) for i in range(8)]
+m = CartNet(64, 16, 2)
+m.load_state_dict(make_state_dict(64, 16, 2, seed=41))
+m = m.to(dev).train()
+m.bn_group_size = 2
+opt = FlatAdam(m, lr=1e-3)
+mine = items[4 * rank:4 * rank + 4] if world == 2 else items           # two groups of 2 per rank / four groups in one
+b = Batch.from_data_list(mine).to(dev)
+pred, true = m(b)
+grouped_loss(pred, true, b, 2)[0].backward()
+cdist.all_reduce_gradients(opt.flat_grad)                              # SUM over ranks = the accumulation of all 4 micro-batches
+torch.save(opt.flat_grad.cpu(), os.path.join(sys.argv[2], f"g_w{world}_r{rank}.pt"))
+if world > 1:
+    dist.destroy_process_group()
+'''
+
+
+def test_groups_make_data_parallel_runs_equal_to_the_accumulation_recipe(tmp_path):
+    """With BatchNorm groups a micro-batch never sees crystals outside itself, so sharding the micro-batches over ranks
+    changes nothing: the SUM-all-reduced gradient of 2 ranks x 2 groups equals the gradient of one process carrying all
+    4 groups -- the reference's accumulation over 4 micro-batches (train/train.py:183-189) -- without any sync-BatchNorm."""
+    import torch
+    script = tmp_path / "groups_child.py"
+    script.write_text(_GROUPS_CHILD)
+    env = dict(os.environ, CARTNET_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, str(script), ROOT, str(tmp_path)], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29536", str(script), ROOT, str(tmp_path)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-3000:]
+    g1 = torch.load(tmp_path / "g_w1_r0.pt")
+    g2a, g2b = torch.load(tmp_path / "g_w2_r0.pt"), torch.load(tmp_path / "g_w2_r1.pt")
+    assert torch.equal(g2a, g2b)
+    assert (g2a - g1).abs().max().item() <= 2e-5 * g1.abs().max().item()
