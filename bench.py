@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA GEMMs, 1: bf16x3 split-operand MFMA")
     ap.add_argument("--no-x3-pass", action="store_true", help="skip the extra bf16x3 timed pass")
+    ap.add_argument("--no-recipe-pass", action="store_true",
+                    help="skip the extra timed pass with BatchNorm groups of 4 (the reference recipe's micro-batches)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: ranks beyond the visible GPUs share them (gloo transport unless "
                          "CARTNET_DIST_BACKEND says otherwise)")
@@ -322,7 +324,7 @@ def main():
     # crystals, 16 accumulated per optimiser step (scripts/train_cartnet_adp.sh:4) -- carried as BatchNorm groups of 4
     # inside the same 64-crystal pass: reference-recipe semantics, reported next to the headline.
     recipe = None
-    if not icf and args.precision == 0 and args.bn_group_size == 0 and not args.no_x3_pass and args.graphs > 4:
+    if not icf and args.precision == 0 and args.bn_group_size == 0 and not args.no_recipe_pass and args.graphs > 4:
         model.bn_group_size = 4
 
         def gstep(b):

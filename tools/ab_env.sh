@@ -4,7 +4,7 @@
 VAR=${1:-CARTNET_NO_SEGSUM_FUSION}
 for v in A B A B; do
   if [ $v = B ]; then export $VAR=1; else unset $VAR; fi
-  python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timer --sustain-seconds 0 > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err
+  python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timer --no-recipe-pass --sustain-seconds 0 > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err
   python -c "
 import json; d=json.load(open('gpurun_out/ab_$v.json')); print('$v ($VAR=' + ('1' if '$v' == 'B' else 'unset') + ')', d['ms_per_step'], d['value'], d['bf16x3']['ms_per_step'], d['bf16x3']['value'])"
 done
