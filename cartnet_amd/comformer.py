@@ -135,8 +135,33 @@ def _split_k(K, tiles):
     return int(max(1, min((512 + tiles - 1) // tiles, K // 256)))
 
 
+_SIDE: Dict[str, Optional[torch.cuda.Stream]] = {"stream": None, "on": True}   # weight-gradient stream of the running backward
+
+
 def _wgrad(dY: List[torch.Tensor], X: List[torch.Tensor], outs: List[torch.Tensor], b_act=False):
-    """outs[g] = dY[g]^T @ (silu?)(X[g]) (row reduction split over workgroups, slabs summed in fixed order)."""
+    """outs[g] = dY[g]^T @ (silu?)(X[g]) (row reduction split over workgroups, slabs summed in fixed order).
+
+    Nothing inside backward reads a weight gradient (``_join_wgrads`` covers the one exception), so the product and its
+    slab reduction are queued on a second stream, next to the chain of activation gradients -- what
+    cartnet_model_backward does for CartNet.  Operands are never written again after this call (the callers keep
+    in-place updates in front of it) and are marked as in use by the side stream for the caching allocator."""
+    side = _SIDE["stream"] if _SIDE["on"] else None
+    if side is None:
+        return _wgrad_now(dY, X, outs, b_act)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _wgrad_now(dY, X, outs, b_act)
+    for t in list(dY) + list(X) + list(outs):
+        t.record_stream(side)
+
+
+def _join_wgrads():
+    """The main stream waits for every weight gradient queued so far."""
+    if _SIDE["stream"] is not None and _SIDE["on"]:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+
+
+def _wgrad_now(dY: List[torch.Tensor], X: List[torch.Tensor], outs: List[torch.Tensor], b_act=False):
     K, M = dY[0].shape
     N = X[0].shape[1]
     if K == 0:
@@ -217,8 +242,10 @@ class _Attention:
                [G[pre + ".key_update.2.weight"], G[pre + ".lin_msg_update.2.weight"]], b_act=True)
         tiles = ops.gemm_tiles_m(R)
         csk, csm = _parts(tiles * C, dev), _parts(tiles * C, dev)
+        dpr = _e((R, 2 * C), dev)       # not in place over pr: the weight-gradient stream may still be reading silu(pr)
         _gemm([gs[:, :C], gs[:, C:]], [P[pre + ".key_update.2.weight"], P[pre + ".lin_msg_update.2.weight"]],
-                 [pr[:, :C], pr[:, C:]], b_kstrided=True, dact=[pr[:, :C], pr[:, C:]], colsum=[csk, csm])   # pr = dpre
+                 [dpr[:, :C], dpr[:, C:]], b_kstrided=True, dact=[pr[:, :C], pr[:, C:]], colsum=[csk, csm])
+        pr = dpr
         G[pre + ".key_update.0.bias"], G[pre + ".lin_msg_update.0.bias"] = _e((C,), dev), _e((C,), dev)
         ops.colsum_finalize([csk, csm], tiles, [G[pre + ".key_update.0.bias"], G[pre + ".lin_msg_update.0.bias"]])
         dW1k, dW1m = _e((C, 3 * C), dev), _e((C, 3 * C), dev)
@@ -422,6 +449,9 @@ class _IComformerFunction(torch.autograd.Function):
         _GEMM_PRECISION[0] = ctx.gemm_precision
         ctx.sv = None
         P, model, lay = sv["P"], sv["model"], sv["lay"]
+        _SIDE["on"] = bool(getattr(model, "overlap_weight_gradients", True))
+        if _SIDE["on"] and (_SIDE["stream"] is None or _SIDE["stream"].device != dpred.device):
+            _SIDE["stream"] = torch.cuda.Stream(device=dpred.device)
         N, E, Bg, training = sv["N"], sv["E"], sv["Bg"], sv["training"]
         C = model.dim_in
         H = C // 2
@@ -670,6 +700,7 @@ class _IComformerFunction(torch.autograd.Function):
             G["rbf.1.weight"], G["rbf.1.bias"] = gw1, gb1
         else:
             gw2, gb2 = rbf_bwd("rbf_nl", dNLt)
+            _join_wgrads()                                   # gw1 / gw2 come from the weight-gradient stream
             G["rbf.1.weight"], G["rbf.1.bias"] = _e((C, C), dev), _e((C,), dev)
             ops.eltwise(2, gw1, gw2, G["rbf.1.weight"])
             ops.eltwise(2, gb1.view(1, C), gb2.view(1, C), G["rbf.1.bias"].view(1, C))
@@ -684,6 +715,7 @@ class _IComformerFunction(torch.autograd.Function):
         zperm, zptr, _ = ops.sort_by_key(sv["z"], N_ATOM_TYPES)
         G["embedding.weight"] = _e((N_ATOM_TYPES, C), dev)
         ops.segment_sum_long(dx, zptr, zperm, N, G["embedding.weight"])
+        _join_wgrads()          # autograd accumulates the gradients on this stream
         return (None, None, None) + tuple(G.get(n) for n in model._param_names)
 
 
@@ -706,6 +738,7 @@ class iComformer(nn.Module):
         self.cholesky = Cholesky_head(c)
         self.validate_graph = False
         self.gemm_precision = 0         # 0: fp32 MFMA.  1: bf16x3 split-operand MFMA.  2: plain bf16 operands
+        self.overlap_weight_gradients = True   # weight-gradient GEMMs on a second stream during backward
         self._param_names = [n for n, _ in self.named_parameters()]
 
     def forward(self, data):
@@ -760,6 +793,7 @@ class eComformer(nn.Module):
         self.cholesky = Cholesky_head(c)
         self.validate_graph = False
         self.gemm_precision = 0
+        self.overlap_weight_gradients = True
         self._param_names = [n for n, _ in self.named_parameters()]
 
     def forward(self, data):
