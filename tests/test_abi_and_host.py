@@ -191,3 +191,31 @@ def test_augmentation_rotates_targets_and_directions():
     assert torch.allclose(d.y, R.t() @ y0 @ R, atol=1e-7)
     assert torch.allclose(d.cart_dir, dir0 @ R, atol=1e-7)
     assert torch.allclose(d.cart_dir.norm(dim=-1), torch.ones(d.cart_dir.shape[0]), atol=1e-5)
+
+
+def test_bench_self_launch_builds_the_torchrun_child(monkeypatch):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: bench.py must start N ranks itself as a CHILD
+    torch.distributed.run (never an exec, before any GPU call) and return the child's exit code."""
+    import argparse
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--share-gpu"])
+    rc = bench.self_launch(argparse.Namespace(gpus=4, share_gpu=True))
+    assert rc == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and "--master-addr" in cmd and "127.0.0.1" in cmd
+    assert cmd[-5:] == ["--gpus", "4", "--steps", "3", "--share-gpu"] and cmd[-6].endswith("bench.py")
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["CARTNET_DIST_BACKEND"] == "gloo"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
