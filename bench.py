@@ -358,6 +358,25 @@ def main():
                               f"crystals ({-(-args.graphs // 4)} groups): the reference recipe batch 4 x accumulation "
                               f"{-(-args.graphs // 4)} in one pass; literal micro-batches of 4 run at ~1.6k graphs/s"}
 
+    # Inference rate (eval mode, no_grad: what --inference / --montecarlo of main.py run), same batch: untimed region
+    eval_fwd = None
+    if world == 1 and not args.no_recipe_pass:
+        model.eval()
+        with torch.no_grad():
+            for _ in range(2):
+                model(fresh())
+            evb = [fresh() for _ in range(args.steps)]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for bx in evb:
+                model(bx)
+            torch.cuda.synchronize()
+            dte = time.perf_counter() - t1
+        model.train()
+        eval_fwd = {"value": round(args.graphs * args.steps / dte, 2), "unit": "graphs/s",
+                    "ms_per_batch": round(1e3 * dte / args.steps, 3),
+                    "note": "forward only, eval mode (running BatchNorm statistics), torch.no_grad: nothing kept for backward"}
+
     graphs_total = args.graphs * world * args.steps
     value = graphs_total / dt
     out = {
@@ -406,6 +425,8 @@ def main():
         out["bf16x3"] = x3
     if recipe is not None:
         out["reference_recipe_groups_of_4"] = recipe
+    if eval_fwd is not None:
+        out["eval_forward"] = eval_fwd
     if rank == 0:
         summ = timed_summary
         if summ:
