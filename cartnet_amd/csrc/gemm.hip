@@ -1,9 +1,21 @@
 // Host side of the GEMM entry points + the small deterministic reduction kernels (split-K slabs, partial sums).
 // The MFMA kernel itself is in gemm_kernel.h, instantiated per tile width in gemm_bn{256,128,64}.hip.
 #include "gemm_x3.h"
+#include <stdlib.h>
 #include <vector>
 
 namespace cn_gemm {
+// Which DMA-fed fp32 kernel takes a prepacked activation x weight product: the 256-wide one (gemm_f32.h, two workgroups
+// per CU), or the 128-wide one (gemm_f32w128.h, three per CU) for the launches with the node-term gather epilogue (layer
+// GEMM 1) -- the one variant where a third resident workgroup pays: 402 vs 425 us sustained at the benchmark shape, the
+// training step 15.40 vs 15.57 ms (same box, interleaved).  Every other variant is equal or slower on the narrow tile
+// (SiLU on the A operand: -15 %, its prologue runs once per column tile).  CARTNET_F32NN_BN=256 / =128 force one kernel.
+bool use_f32nn128(const CartnetGemmArgs& a) {
+  static const int mode = [] { const char* e = getenv("CARTNET_F32NN_BN"); return e ? atoi(e) : 0; }();
+  if (mode == 128) return true;
+  if (mode == 256) return false;
+  return a.gather_i[0] != nullptr && !a.a_act;
+}
 extern template bool launch_bn<256>(const CartnetGemmArgs&, const GemmFlags&, hipStream_t);
 extern template bool launch_bn<128>(const CartnetGemmArgs&, const GemmFlags&, hipStream_t);
 extern template bool launch_bn<64>(const CartnetGemmArgs&, const GemmFlags&, hipStream_t);

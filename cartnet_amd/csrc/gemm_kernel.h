@@ -665,6 +665,9 @@ void launch_x3tn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3
 // gemm_f32.hip
 void launch_f32nn(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
 void launch_f32tn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
+// gemm_f32w128.hip: 128-wide DMA-fed fp32 kernel, chosen by use_f32nn128 (gemm.hip)
+void launch_f32nn128(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
+bool use_f32nn128(const CartnetGemmArgs& a);
 
 template <bool A_KS, bool B_KS, int BN, bool A_ACT, bool B_ACT>
 void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
@@ -706,7 +709,8 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
         const int nptr = a.ngroups > 1 ? a.ngroups : a.nsegs;
         for (int i = 0; i < nptr; ++i) prepacked = prepacked && a.b_split[i] != nullptr;
         if (prepacked) {
-          launch_f32nn(A_ACT, a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
+          if (use_f32nn128(a)) launch_f32nn128(A_ACT, a, fl, dim3(nm * tiles_n * 2, ns, a.ngroups), st);
+          else launch_f32nn(A_ACT, a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
           return;
         }
       }
