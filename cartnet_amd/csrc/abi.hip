@@ -12,4 +12,4 @@ void cartnet_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cartnet_last_error(void) { return g_err; }
-extern "C" int cartnet_abi_version(void) { return 3; }
+extern "C" int cartnet_abi_version(void) { return 4; }

@@ -124,6 +124,22 @@ __global__ void cn_colsum_finalize_f32_kernel(const float* __restrict__ parts, i
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// out[g][r, c] = silu(in[g][r, c]) with the GEMM kernels' own SiLU: CartnetGemmArgs.a_act_out for the launches whose
+// kernel does not write it in passing
+struct ActJobs {
+  const float* in[CARTNET_MAX_GROUPS];
+  float* out[CARTNET_MAX_GROUPS];
+};
+__global__ void cn_act_rows_kernel(const ActJobs jobs, int M, int K, int ld) {
+  const float* __restrict__ in = jobs.in[blockIdx.y];
+  float* __restrict__ out = jobs.out[blockIdx.y];
+  const size_t total = (size_t)M * K;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / K, c = i % K;
+    out[r * ld + c] = cn_gemm::fast_silu(in[r * ld + c]);
+  }
+}
+
 }  // namespace
 
 // Column-tile width of a launch (see the comment in cartnet_gemm_impl): 256 / 128 / 64 by N, narrower for launches
@@ -291,6 +307,28 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
   if (kchunk == 0) kchunk = cn_gemm::BK;
   fl.kchunk = kchunk;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a.a_act_out[0]) {
+    CN_CHECK(a.a_act && !a.a_kstrided && a.nsegs == 1, "cartnet_gemm: a_act_out needs a_act = 1, a k-contiguous A and no K-segments");
+    for (int gI = 0; gI < a.ngroups; ++gI) CN_CHECK(a.a_act_out[gI] != nullptr, "cartnet_gemm: a_act_out[%d] missing", gI);
+    // the pre-packed 256-wide fp32 kernel writes the activated operand on its way into LDS (gemm_f32ao.h); any other
+    // launch (narrow tiles of a small batch, precision 1 / 2, no weight image) gets it from an elementwise pass first
+    bool fused = bn == 256 && a.precision == 0 && !a.b_act && a.b_kstrided && a.splitk == 1 && fl.wide && vecA && vecB &&
+                 a.N % 256 == 0 && a.K > 0 && a.K % cn_gemm::BK == 0 && (double)a.M * a.lda * 4.0 < 4294967296.0;
+    for (int gI = 0; gI < a.ngroups; ++gI) fused = fused && a.b_split[gI] && aligned16(a.a_act_out[gI]);
+    if (!fused) {
+      ActJobs jobs;
+      for (int gI = 0; gI < CARTNET_MAX_GROUPS; ++gI) {
+        jobs.in[gI] = gI < a.ngroups ? a.A[gI] : nullptr;
+        jobs.out[gI] = gI < a.ngroups ? a.a_act_out[gI] : nullptr;
+        a.a_act_out[gI] = nullptr;
+      }
+      const long long total = (long long)a.M * a.K;
+      if (total > 0) {
+        const int blocks = (int)(total / 256 + 1 > 16384 ? 16384 : total / 256 + 1);
+        hipLaunchKernelGGL(cn_act_rows_kernel, dim3(blocks, a.ngroups), dim3(256), 0, st, jobs, a.M, a.K, a.lda);
+      }
+    }
+  }
   bool ok;
   if (bn == 256) ok = cn_gemm::launch_bn<256>(a, fl, st);
   else if (bn == 128) ok = cn_gemm::launch_bn<128>(a, fl, st);

@@ -668,6 +668,8 @@ void launch_f32tn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim
 // gemm_f32w128.hip: 128-wide DMA-fed fp32 kernel, chosen by use_f32nn128 (gemm.hip)
 void launch_f32nn128(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
 bool use_f32nn128(const CartnetGemmArgs& a);
+// gemm_f32ao.hip: the a_act form of the 256-wide kernel that also writes silu(A) (CartnetGemmArgs.a_act_out)
+void launch_f32nn_actout(const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
 
 template <bool A_KS, bool B_KS, int BN, bool A_ACT, bool B_ACT>
 void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
@@ -709,7 +711,8 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
         const int nptr = a.ngroups > 1 ? a.ngroups : a.nsegs;
         for (int i = 0; i < nptr; ++i) prepacked = prepacked && a.b_split[i] != nullptr;
         if (prepacked) {
-          if (use_f32nn128(a)) launch_f32nn128(A_ACT, a, fl, dim3(nm * tiles_n * 2, ns, a.ngroups), st);
+          if (A_ACT && a.a_act_out[0]) launch_f32nn_actout(a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
+          else if (use_f32nn128(a)) launch_f32nn128(A_ACT, a, fl, dim3(nm * tiles_n * 2, ns, a.ngroups), st);
           else launch_f32nn(A_ACT, a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
           return;
         }

@@ -58,6 +58,9 @@ struct Work {
   // forward transients
   float* Pn;
   double *cs, *cq, *ps, *pq;
+  // silu(pre) / silu(he_pre), written by the forward GEMMs that activate them (CartnetGemmArgs.a_act_out) for the weight
+  // gradients of the second Linears; nullptr = recompute the SiLU in the weight-gradient kernel
+  float *act[CARTNET_MAX_LAYERS], *he_act;
   // backward transients
   float *dhid, *head_parts, *head_tot, *dx[2], *de[2], *daggr, *sums1, *sums2, *dPn[2], *dpre[2], *dhe, *dx0, *seg_tmp,
       *slabs, *e0wT;
@@ -140,6 +143,13 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
       w.xl[l] = need_bwd ? c.take<float>(Nn * D) : xping[l & 1];
       w.el[l] = need_bwd ? c.take<float>(En * D) : eping[l & 1];
     }
+  }
+  // fp32 training: the activated operands are kept (1 extra [E, 2D] matrix per layer + one for the encoder) so that the
+  // weight gradients dW2 = dY^T silu(pre) read a plain operand and run on the all-DMA kernel.  CARTNET_ACT_OUT=0: off.
+  static const bool act_out_on = [] { const char* e = getenv("CARTNET_ACT_OUT"); return !e || atoi(e) != 0; }();
+  if (need_bwd && act_out_on && m.gemm_precision == 0 && D % 256 == 0) {
+    for (int l = 0; l < L; ++l) w.act[l] = c.take<float>(En * 2 * D);
+    w.he_act = c.take<float>(En * 2 * D);
   }
   w.hid = c.take<float>(Nn * H);
   w.p6 = c.take<float>((size_t)(M > 0 ? M : 1) * 6);
@@ -436,6 +446,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     CartnetGemmArgs a = gemm_args(E, D, 2 * D, 2 * D, D, D);
     a.A[0] = w.he_pre; a.B[0] = w.edge2T; a.C[0] = w.e0; a.cpre[0] = w.e0_pre; a.bias[0] = P.edge2_b;
     a.b_kstrided = 1; a.a_act = 1; a.out_act = 1; a.b_split[0] = w.i_edge2;
+    if (w.he_act) a.a_act_out[0] = w.he_act;
     RUN(cartnet_gemm(&a, st));
   }
   // ---- encoder, atoms (cartnet.py:145-154); out-of-table atomic numbers / batch ids are clamped and reported in `status`
@@ -490,6 +501,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       a.C[0] = w.gs[l]; a.C[1] = w.gs[l] + D; a.bias[0] = q.gate2_b; a.bias[1] = q.aggr2_b;
       if (!w.groups) { a.colsum[0] = w.cs; a.colsq[0] = w.cq; }
       if (w.i_gs[l]) { a.b_split[0] = w.i_gs[l]; a.b_split[1] = w.i_gs[l] + img_blk(m); }
+      if (w.act[l]) { a.a_act_out[0] = w.act[l]; a.a_act_out[1] = w.act[l] + D; }
       RUN(cartnet_gemm(&a, st));
     }
     // BatchNorm groups: a 128-row GEMM tile may straddle two groups, so the gate statistics are taken per group by a
@@ -683,9 +695,10 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       float* outs[2] = {gq.gate2_b, gq.aggr2_b};
       RUN(cartnet_colsum_finalize(parts, outs, 2, w.gparts, D, sw));
       const float* dY[2] = {gs, gs + D};
-      const float* X[2] = {pre, pre + D};
+      const bool kept = w.act[l] != nullptr;            // silu(pre) kept by the forward pass: plain operand
+      const float* X[2] = {kept ? w.act[l] : pre, (kept ? w.act[l] : pre) + D};
       float* o[2] = {gq.gate2_w, gq.aggr2_w};
-      RUN(wgrad(dY, 2 * D, X, 2 * D, o, D, b.E, D, D, 2, true, w, sw));
+      RUN(wgrad(dY, 2 * D, X, 2 * D, o, D, b.E, D, D, 2, !kept, w, sw));
     }
     {  // main: dpre = (dgs @ W2) * silu'(pre), into this parity's buffer
       CartnetGemmArgs a = gemm_args(E, D, D, 2 * D, D, 2 * D);
@@ -763,9 +776,10 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
   {
     FORK();
     const float* dY[1] = {de};
-    const float* X[1] = {w.he_pre};
+    const bool kept = w.he_act != nullptr;
+    const float* X[1] = {kept ? w.he_act : w.he_pre};
     float* o[1] = {G.edge2_w};
-    RUN(wgrad(dY, D, X, 2 * D, o, 2 * D, b.E, D, 2 * D, 1, true, w, sw));
+    RUN(wgrad(dY, D, X, 2 * D, o, 2 * D, b.E, D, 2 * D, 1, !kept, w, sw));
     CartnetGemmArgs a = gemm_args(E, 2 * D, D, D, 2 * D, 2 * D);
     a.A[0] = de; a.B[0] = P.edge2_w; a.C[0] = w.dhe; a.dact[0] = w.he_pre; a.ldd = 2 * D; a.b_kstrided = 1;
     a.b_split[0] = w.i_edge2_b;

@@ -40,6 +40,7 @@ class GemmArgs(C.Structure):
         ("a_kstrided", C.c_int32), ("b_kstrided", C.c_int32), ("a_act", C.c_int32), ("b_act", C.c_int32),
         ("out_act", C.c_int32), ("precision", C.c_int32),
         ("b_split", C.c_void_p * MAX_GROUPS), ("b_split_folded", C.c_void_p),
+        ("a_act_out", C.c_void_p * MAX_GROUPS),
     ]
 
 

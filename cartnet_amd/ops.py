@@ -75,13 +75,14 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
          a_kstrided: bool = False, b_kstrided: bool = False, a_act: bool = False, b_act: bool = False,
          out_act: bool = False, segments: bool = False, bias=None, gather_i=None, gather_j=None, tgt=None, src=None,
          resid=None, dact=None, cpre=None, colsum=None, colsq=None, splitk: int = 1, precision: int = 0,
-         b_split=None, b_split_folded=None) -> None:
+         b_split=None, b_split_folded=None, a_act_out=None) -> None:
     """C[g] = epilogue(sum_s opA(A[s]) @ opB(B[s])) on the fp32 matrix cores (see include/cartnet_hip.h).
 
     A / B / C_out: one tensor or a list.  With ``segments=False`` the lists are independent problems (groups) of
     identical shape; with ``segments=True`` A and B list K-segments that are summed into the single output.
     Shapes: A [M,K] (or [K,M] if a_kstrided), B [N,K] (or [K,N] if b_kstrided), C [M,N]
     (for splitk > 1: C is [splitk*M, N] contiguous slabs).
+    ``a_act_out`` (with ``a_act`` and ``b_split`` at precision 0): tensors shaped and strided like A that receive silu(A).
     """
     lib = _l.load()
     A, B, C_out = _aslist(A, 1), _aslist(B, 1), _aslist(C_out, 1)
@@ -185,6 +186,10 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
     for t in cp:
         if t is not None and _ld(t) != ldc:
             raise ValueError("gemm: cpre must share the output's leading dimension")
+    ao = per_group("a_act_out", a_act_out, (M, K), "a_act_out")
+    for t in ao:
+        if t is not None and (_ld(t) != lda or a_kstrided):
+            raise ValueError("gemm: a_act_out must share A's row stride (and A must be k-contiguous)")
     tiles_m = (M + 127) // 128
     cs = _aslist(colsum, ngroups)
     cq = _aslist(colsq, ngroups)

@@ -88,6 +88,12 @@ typedef struct CartnetGemmArgs {
                        /* optional, nsegs > 1 and N == 256: the segments' images one after the other (segment order).
                           Used when the A segments are adjacent column blocks of one matrix (A[s] == A[0] + s*K):
                           the sum over segments is then one product over K*nsegs. */
+  float* a_act_out[CARTNET_MAX_GROUPS];
+                       /* optional, needs a_act = 1, a k-contiguous A and no K-segments: silu(A[g]) is also WRITTEN, with
+                          A's row stride.  The pre-packed 256-wide fp32 kernel (precision 0, b_split) writes it as a
+                          by-product of staging A (each element is activated exactly once per column tile anyway); any
+                          other launch runs an elementwise pass first.  The second Linear's weight gradient
+                          dW = dY^T silu(pre) then reads it as a plain operand and takes the all-DMA kernel. */
 } CartnetGemmArgs;
 
 int cartnet_gemm(const CartnetGemmArgs* args, void* stream);

@@ -181,6 +181,57 @@ def test_gemm_with_weight_images(ops, precision, M, K, N, groups, act):
         assert rel_err(Cs[g], ref) < TOL, g
 
 
+@pytest.mark.parametrize("M,K,N,groups", [(1, 16, 256, 1), (127, 32, 256, 2), (300, 48, 256, 2), (1000, 80, 512, 1),
+                                          (33000, 256, 256, 2), (513, 512, 256, 1)])
+def test_gemm_writes_the_activated_operand(ops, M, K, N, groups):
+    """a_act_out: Y = silu(X) W^T + b as before (bitwise the kernel without the by-product) and silu(X) written with X's
+    row stride -- the groups are column blocks of one [M, groups*K] matrix as in the model (pre = [gate | aggr]); cells
+    outside the written blocks stay untouched; every pipeline length; ragged / single-row M; two column tiles."""
+    X = rnd(M, groups * K + 16, seed=11)
+    Xs = [X[:, g * K:(g + 1) * K] for g in range(groups)]
+    Ws = [rnd(N, K, seed=20 + g, scale=0.1) for g in range(groups)]
+    bs = [rnd(N, seed=30 + g) for g in range(groups)]
+    Bt = [w.t().contiguous() for w in Ws]
+    imgs = ops.pack_b([w.t() for w in Ws])
+    Cs = [torch.full((M, N), float("nan"), device=dev()) for _ in range(groups)]
+    C0 = [torch.full((M, N), float("nan"), device=dev()) for _ in range(groups)]
+    H = torch.full_like(X, -7.0)
+    Hs = [H[:, g * K:(g + 1) * K] for g in range(groups)]
+    tiles = ops.gemm_tiles_m(M)
+    cs = [torch.zeros(tiles * N, dtype=torch.float64, device=dev()) for _ in range(groups)]
+    ops.gemm(Xs, Bt, C0, b_kstrided=True, a_act=True, bias=bs, b_split=imgs)
+    ops.gemm(Xs, Bt, Cs, b_kstrided=True, a_act=True, bias=bs, b_split=imgs, a_act_out=Hs,
+             colsum=[cs[0]] + [None] * (groups - 1))
+    for g in range(groups):
+        assert torch.equal(Cs[g], C0[g]), g
+        ref = silu64(Xs[g].double())
+        assert rel_err(Hs[g], ref) < 1e-6, g
+    assert bool((H[:, groups * K:] == -7.0).all())
+    assert rel_err(cs[0].view(tiles, N).sum(0), Cs[0].double().sum(0)) < 1e-6
+    # the weight gradient from the kept operand == the one that recomputes the SiLU
+    dY = [rnd(M, N, seed=90 + g) for g in range(groups)]
+    W1 = [torch.empty(N, K, device=dev()) for _ in range(groups)]
+    W2 = [torch.empty(N, K, device=dev()) for _ in range(groups)]
+    ops.gemm(dY, Xs, W1, a_kstrided=True, b_kstrided=True, b_act=True)
+    ops.gemm(dY, Hs, W2, a_kstrided=True, b_kstrided=True)
+    for g in range(groups):
+        ref = dY[g].double().t() @ silu64(Xs[g].double())
+        assert rel_err(W1[g], ref) < TOL and rel_err(W2[g], ref) < TOL
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_gemm_activated_operand_without_the_fused_kernel(ops, precision):
+    """No weight image / few row tiles / bf16x3: silu(X) comes from the elementwise pass; a_act=False is refused."""
+    X, W = rnd(70, 40, seed=1)[:, :32], rnd(256, 32, seed=2)
+    C_ = torch.empty(70, 256, device=dev())
+    H = torch.full((70, 40), -7.0, device=dev())
+    ops.gemm(X, W.t().contiguous(), C_, b_kstrided=True, a_act=True, a_act_out=H[:, :32], precision=precision)
+    assert rel_err(H[:, :32], silu64(X.double())) < 1e-6 and bool((H[:, 32:] == -7.0).all())
+    assert rel_err(C_, silu64(X.double()) @ W.double().t()) < (TOL if precision == 0 else 1e-5)
+    with pytest.raises(RuntimeError, match="a_act_out"):
+        ops.gemm(X, W.t().contiguous(), C_, b_kstrided=True, a_act=False, a_act_out=H[:, :32])
+
+
 @pytest.mark.parametrize("case", ["plain", "gather", "dact_colsum", "resid_folded"])
 def test_gemm_edge_sized_rows_through_every_model_epilogue(ops, case):
     """M > 32768 rows at precision 0 with a weight image (hundreds of row tiles, ragged last tile), through every

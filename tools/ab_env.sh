@@ -1,10 +1,11 @@
 #!/bin/bash
 # Same-binary A/B on ONE GPU box: the training step with and without an environment switch (boxes of the pool differ by
-# +-2 %, more than most kernel changes are worth).  usage: bash tools/ab_env.sh VAR   ->  A = VAR unset, B = VAR=1
-VAR=${1:-CARTNET_NO_SEGSUM_FUSION}
+# +-2 %, more than most kernel changes are worth).  usage: bash tools/ab_env.sh VAR [VALUE]   ->  A = VAR unset, B = VAR=VALUE (default 1)
+VAR=${1:-CARTNET_ACT_OUT}
+VAL=${2:-1}
 for v in A B A B; do
-  if [ $v = B ]; then export $VAR=1; else unset $VAR; fi
+  if [ $v = B ]; then export $VAR=$VAL; else unset $VAR; fi
   python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timer --no-recipe-pass --sustain-seconds 0 > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err
   python -c "
-import json; d=json.load(open('gpurun_out/ab_$v.json')); print('$v ($VAR=' + ('1' if '$v' == 'B' else 'unset') + ')', d['ms_per_step'], d['value'], d['bf16x3']['ms_per_step'], d['bf16x3']['value'])"
+import json; d=json.load(open('gpurun_out/ab_$v.json')); print('$v ($VAR=' + ('$VAL' if '$v' == 'B' else 'unset') + ')', d['ms_per_step'], d['value'], d['bf16x3']['ms_per_step'], d['bf16x3']['value'])"
 done
