@@ -310,9 +310,9 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
   if (a.a_act_out[0]) {
     CN_CHECK(a.a_act && !a.a_kstrided && a.nsegs == 1, "cartnet_gemm: a_act_out needs a_act = 1, a k-contiguous A and no K-segments");
     for (int gI = 0; gI < a.ngroups; ++gI) CN_CHECK(a.a_act_out[gI] != nullptr, "cartnet_gemm: a_act_out[%d] missing", gI);
-    // the pre-packed 256-wide fp32 kernel writes the activated operand on its way into LDS (gemm_f32ao.h); any other
-    // launch (narrow tiles of a small batch, precision 1 / 2, no weight image) gets it from an elementwise pass first
-    bool fused = bn == 256 && a.precision == 0 && !a.b_act && a.b_kstrided && a.splitk == 1 && fl.wide && vecA && vecB &&
+    // the DMA-fed 256-wide kernels write the activated operand on its way into LDS (gemm_f32ao.h, gemm_x3ao.h); any
+    // other launch (narrow tiles of a small batch, no weight image) gets it from an elementwise pass first
+    bool fused = bn == 256 && !a.b_act && a.b_kstrided && a.splitk == 1 && fl.wide && vecA && vecB &&
                  a.N % 256 == 0 && a.K > 0 && a.K % cn_gemm::BK == 0 && (double)a.M * a.lda * 4.0 < 4294967296.0;
     for (int gI = 0; gI < a.ngroups; ++gI) fused = fused && a.b_split[gI] && aligned16(a.a_act_out[gI]);
     if (!fused) {

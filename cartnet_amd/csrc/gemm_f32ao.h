@@ -56,8 +56,14 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_actout_kernel(const
   // the activated A values leave for memory as they are staged: K-step v of this thread's row -> h[row, v*16 + akq*4 ..].
   // No predicate: rows past M are clamped to row M-1 (a_voff) and a second column tile stages the same values, so every
   // duplicate store writes identical bits to the same address.
-  float* h0 = reinterpret_cast<float*>(reinterpret_cast<char*>(p.a_act_out[g]) + a_voff);
-  auto h_store = [&](f32x4 v, int step_v) { *reinterpret_cast<f32x4*>(h0 + step_v * BK) = v; };
+  // (scalar base + the A tile's own 32-bit lane offset, as in a_issue: no address VGPRs)
+  const float* h0 = p.a_act_out[g];
+  auto h_store = [&](f32x4 v, int step_v) {
+    const float* base = h0 + step_v * BK;
+    // s_nop: a store of more than 8 bytes reads its data registers up to two cycles after issue; the hazard
+    // recogniser does not look inside inline asm, and the next VALU instruction may overwrite them
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(a_voff), "v"(v), "s"(base) : "memory");
+  };
   auto a_store = [&](f32x4 v, int buf, int step_v) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[c] = fast_silu(v[c]);

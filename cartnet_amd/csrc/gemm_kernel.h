@@ -670,6 +670,8 @@ void launch_f32nn128(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, 
 bool use_f32nn128(const CartnetGemmArgs& a);
 // gemm_f32ao.hip: the a_act form of the 256-wide kernel that also writes silu(A) (CartnetGemmArgs.a_act_out)
 void launch_f32nn_actout(const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
+// gemm_x3ao.hip: the same for the pre-split bf16x3 / bf16 kernel
+void launch_x3nn_actout(const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
 
 template <bool A_KS, bool B_KS, int BN, bool A_ACT, bool B_ACT>
 void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
@@ -694,7 +696,8 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
         const int nptr = a.ngroups > 1 ? a.ngroups : a.nsegs;
         for (int i = 0; i < nptr; ++i) presplit = presplit && a.b_split[i] != nullptr;
         if (presplit) {
-          launch_x3nn(A_ACT, a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
+          if (A_ACT && a.a_act_out[0]) launch_x3nn_actout(a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
+          else launch_x3nn(A_ACT, a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
           return;
         }
         if (fl.x3 == 1) {   // first-generation kernel (both operands split in flight); precision 2 has no such form

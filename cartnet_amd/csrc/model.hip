@@ -145,7 +145,10 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
     }
   }
   // fp32 training: the activated operands are kept (1 extra [E, 2D] matrix per layer + one for the encoder) so that the
-  // weight gradients dW2 = dY^T silu(pre) read a plain operand and run on the all-DMA kernel.  CARTNET_ACT_OUT=0: off.
+  // weight gradients dW2 = dY^T silu(pre) read a plain operand and run on the all-DMA kernel (step 15.26 vs 15.43 ms,
+  // same box, interleaved).  Not at precision 1 / 2: there the step got SLOWER (11.74 vs 11.56 ms) -- the bf16 step is
+  // power- and HBM-limited and 1.8 GB of extra writes cost more than the cheaper weight-gradient kernel returns.
+  // CARTNET_ACT_OUT=0: off.
   static const bool act_out_on = [] { const char* e = getenv("CARTNET_ACT_OUT"); return !e || atoi(e) != 0; }();
   if (need_bwd && act_out_on && m.gemm_precision == 0 && D % 256 == 0) {
     for (int l = 0; l < L; ++l) w.act[l] = c.take<float>(En * 2 * D);
