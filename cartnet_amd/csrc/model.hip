@@ -692,8 +692,8 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     }
     RUN(cartnet_gate_scatter_bwd_apply(gs, de, w.daggr, env, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, w.sums1, b.E,
                                        training, N, D, w.pc[par], w.pd[par], w.groups, st));   // gs = [dg | ds]
-    FORK();
-    {  // side: bias gradients of the second Linears, then their weight gradients (need silu(pre), which stays intact)
+    float* de_in = w.de[de_slot];
+    auto side_w2 = [&]() -> int {   // bias gradients of the second Linears, then their weight gradients
       double* parts[2] = {w.pc[par], w.pd[par]};
       float* outs[2] = {gq.gate2_b, gq.aggr2_b};
       RUN(cartnet_colsum_finalize(parts, outs, 2, w.gparts, D, sw));
@@ -701,9 +701,9 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       const bool kept = w.act[l] != nullptr;            // silu(pre) kept by the forward pass: plain operand
       const float* X[2] = {kept ? w.act[l] : pre, (kept ? w.act[l] : pre) + D};
       float* o[2] = {gq.gate2_w, gq.aggr2_w};
-      RUN(wgrad(dY, 2 * D, X, 2 * D, o, D, b.E, D, D, 2, !kept, w, sw));
-    }
-    {  // main: dpre = (dgs @ W2) * silu'(pre), into this parity's buffer
+      return wgrad(dY, 2 * D, X, 2 * D, o, D, b.E, D, D, 2, !kept, w, sw);
+    };
+    auto main_dpre = [&]() -> int {   // dpre = (dgs @ W2) * silu'(pre), into this parity's buffer
       CartnetGemmArgs a = gemm_args(E, D, D, 2 * D, D, 2 * D);
       a.ngroups = 2; a.b_kstrided = 1;
       a.A[0] = gs; a.A[1] = gs + D; a.B[0] = q.gate2_w; a.B[1] = q.aggr2_w;
@@ -711,18 +711,15 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       // (no column sums here: the bias gradients of the first Linears are the column sums of dpre over all edges =
       //  the column sums over atoms of its by-target segment sums, 14x fewer rows -- taken from dPn below)
       if (w.i_dpre[l]) { a.b_split[0] = w.i_dpre[l]; a.b_split[1] = w.i_dpre[l] + img_blk(m); }
-      RUN(cartnet_gemm(&a, st));
-    }
-    FORK();
-    {  // side: edge-block weight gradients of the first Linears
+      return cartnet_gemm(&a, st);
+    };
+    auto side_w1e = [&]() -> int {   // edge-block weight gradients of the first Linears
       const float* dY[2] = {dpre, dpre + D};
       const float* X[2] = {e_in, e_in};
       float* o[2] = {gq.gate0_w + 2 * D, gq.aggr0_w + 2 * D};
-      RUN(wgrad(dY, 2 * D, X, D, o, 3 * D, b.E, D, D, 2, false, w, sw));
-    }
-    // main: de_in = de_out + dpre @ W1[:, 2D:]  (layer 0: continue through the encoder's last SiLU)
-    float* de_in = w.de[de_slot];
-    {
+      return wgrad(dY, 2 * D, X, D, o, 3 * D, b.E, D, D, 2, false, w, sw);
+    };
+    auto main_de_in = [&]() -> int {   // de_in = de_out + dpre @ W1[:, 2D:]  (layer 0: continue through the encoder's last SiLU)
       CartnetGemmArgs a = gemm_args(E, D, D, 2 * D, 3 * D, D);
       a.nsegs = 2; a.b_kstrided = 1;
       a.A[0] = dpre; a.A[1] = dpre + D; a.B[0] = q.gate0_w + 2 * D; a.B[1] = q.aggr0_w + 2 * D;
@@ -735,27 +732,25 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
         float* outs[1] = {G.edge2_b};
         RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_e, D, st));
       }
-    }
+      return 0;
+    };
     // node-side halves: reduce dpre over each atom's incoming (target) and outgoing (source) edges
-    RUN(cartnet_segment_sum(dpre, 2 * D, w.rowptr, nullptr, N, 2 * D, dPn, 4 * D, st));
-    RUN(cartnet_segment_sum(dpre, 2 * D, w.colptr, w.perm, N, 2 * D, dPn + 2 * D, 4 * D, st));
-    FORK();
-    {  // side: bias gradients of the first Linears = column sums of the by-target half of dPn
+    auto segsums = [&](void* s_) -> int {
+      RUN(cartnet_segment_sum(dpre, 2 * D, w.rowptr, nullptr, N, 2 * D, dPn, 4 * D, s_));
+      return cartnet_segment_sum(dpre, 2 * D, w.colptr, w.perm, N, 2 * D, dPn + 2 * D, 4 * D, s_);
+    };
+    auto side_wn = [&]() -> int {   // bias gradients of the first Linears = column sums of the by-target half of dPn; node blocks
       double* parts[2] = {w.pc[par], w.pd[par]};      // the second Linears' bias sums were finalised above (same stream)
       float* outs[2] = {gq.gate0_b, gq.aggr0_b};
       RUN(cartnet_colsum_partial(dPn, 4 * D, N, D, parts[0], sw));
       RUN(cartnet_colsum_partial(dPn + D, 4 * D, N, D, parts[1], sw));
       RUN(cartnet_colsum_finalize(parts, outs, 2, cartnet_segment_nparts(N), D, sw));
-    }
-    {
       const float* dY[4] = {dPn, dPn + D, dPn + 2 * D, dPn + 3 * D};
       const float* X[4] = {x_in, x_in, x_in, x_in};
       float* o[4] = {gq.gate0_w, gq.aggr0_w, gq.gate0_w + D, gq.aggr0_w + D};
-      RUN(wgrad(dY, 4 * D, X, D, o, 3 * D, N, D, D, 4, false, w, sw));
-    }
-    side_done[l] = S.mark_side();
-    if (l == L - 1) RUN(deferred_side_jobs());
-    {
+      return wgrad(dY, 4 * D, X, D, o, 3 * D, N, D, D, 4, false, w, sw);
+    };
+    auto main_dx = [&]() -> int {
       CartnetGemmArgs a = gemm_args(N, D, D, 4 * D, 3 * D, D);
       a.nsegs = 4; a.b_kstrided = 1;
       a.A[0] = dPn; a.A[1] = dPn + D; a.A[2] = dPn + 2 * D; a.A[3] = dPn + 3 * D;
@@ -769,6 +764,24 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
         float* outs[1] = {G.atom_b};
         RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_n, D, st));
       }
+      return 0;
+    };
+    // (A "pairing" order -- segment sums on the side stream under de_in, dW1e deferred under the next layer's gate kernels, so
+    //  that a matrix-bound kernel always co-runs with an HBM-bound one -- measured no better: 15.27 vs 15.18 ms, same box,
+    //  interleaved; co-running kernels share the CUs at the sum of their isolated times, profiles/r02_cu_partition_experiment.md)
+    {
+      FORK();
+      RUN(side_w2());
+      RUN(main_dpre());
+      FORK();
+      RUN(side_w1e());
+      RUN(main_de_in());
+      RUN(segsums(st));
+      FORK();
+      RUN(side_wn());
+      side_done[l] = S.mark_side();
+      if (l == L - 1) RUN(deferred_side_jobs());
+      RUN(main_dx());
     }
     float* t = dx; dx = dx_other; dx_other = t;
     de = de_in;
