@@ -82,22 +82,36 @@ __device__ __forceinline__ void cn_acc4(f64x4& a, f32x4 v) {
   for (int q = 0; q < 4; ++q) a[q] += (double)v[q];
 }
 
-// Column sum of a [nparts][N] fp64 partial-sum matrix for 64 consecutive columns, by a 1024-thread block:
-// 16 row groups sum rows g, g+16, ... each, then thread c (< 64) adds the 16 group sums in group order.
-// Returns the total in threads 0..63 (column col0 + tid); fixed summation order -> bitwise reproducible.
+// Column sum of a [nparts][N] fp64 partial-sum matrix for CN_SUM_COLS consecutive columns, by a 1024-thread block:
+// 64 row groups sum rows g, g+64, ... each (eight independent loads in flight per thread, added in row order), then
+// thread c (< CN_SUM_COLS) adds the 64 group sums in group order.  Returns the total in threads 0..CN_SUM_COLS-1 (column
+// col0 + tid); fixed summation order -> bitwise reproducible.  Sixteen columns per block put N/16 blocks on a matrix of
+// a few thousand rows (the 1,384 row tiles of an edge-sized GEMM), which made the separate folding pass that used to
+// precede every finaliser (20 us per call, 22 calls per step) unnecessary.
+constexpr int CN_SUM_COLS = 16;
 __device__ __forceinline__ double cn_block_colsum(const double* __restrict__ parts, int nparts, int N, int col0,
-                                                  double* lds /* [16][64] */) {
-  const int tid = threadIdx.x, g = tid >> 6, cl = tid & 63;
+                                                  double* lds /* [64][CN_SUM_COLS] */) {
+  const int tid = threadIdx.x, g = tid >> 4, cl = tid & 15;
   const int c = col0 + cl;
   double acc = 0.0;
-  if (c < N)
-    for (int p = g; p < nparts; p += 16) acc += parts[(size_t)p * N + c];
+  if (c < N) {
+    const double* __restrict__ col = parts + c;
+    int p = g;
+    for (; p + 7 * 64 < nparts; p += 8 * 64) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(p + u * 64) * N];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; p < nparts; p += 64) acc += col[(size_t)p * N];
+  }
   __syncthreads();
-  lds[g * 64 + cl] = acc;
+  lds[g * CN_SUM_COLS + cl] = acc;
   __syncthreads();
   double tot = 0.0;
-  if (tid < 64)
-    for (int q = 0; q < 16; ++q) tot += lds[q * 64 + tid];
+  if (tid < CN_SUM_COLS)
+    for (int q = 0; q < 64; ++q) tot += lds[q * CN_SUM_COLS + tid];
   return tot;
 }
 
@@ -110,9 +124,3 @@ static inline bool cn_groups_ok(const CartnetGroups* g) {
 static inline dim3 cn_group_grid(const CartnetGroups* g, int default_parts, bool per_edge) {
   return g ? dim3(per_edge ? g->edge_parts : g->node_parts, g->G) : dim3(default_parts, 1);
 }
-
-// Long partial-sum matrices ([nparts][N] fp64, nparts in the thousands) are folded to CN_FOLD_ROWS rows first
-// (cn_fold_parts, gemm.hip: row r <- sum of rows r, r+R, r+2R, ... in that order, in place), so that the finalising
-// kernels -- a handful of blocks -- only have CN_FOLD_ROWS rows left to add.  Returns the row count to finalise.
-constexpr int CN_FOLD_ROWS = 32;
-int cn_fold_parts(double* const* parts, int njobs, int nparts, int N, hipStream_t st);

@@ -14,7 +14,11 @@ bool use_f32nn128(const CartnetGemmArgs& a) {
   static const int mode = [] { const char* e = getenv("CARTNET_F32NN_BN"); return e ? atoi(e) : 0; }();
   if (mode == 128) return true;
   if (mode == 256) return false;
-  return a.gather_i[0] != nullptr && !a.a_act;
+  if (a.gather_i[0] != nullptr && !a.a_act) return true;
+  // few row tiles (atom-sized M): 128-wide tiles put twice as many workgroups on the chip (the folded dX product of the
+  // node terms, M = 12,416, K = 1024: 97 tiles of 128 x 256 would use 97 of 256 CUs)
+  const long long tiles = (long long)((a.M + 127) / 128) * (a.N / 256) * a.ngroups;
+  return tiles < 200;
 }
 extern template bool launch_bn<256>(const CartnetGemmArgs&, const GemmFlags&, hipStream_t);
 extern template bool launch_bn<128>(const CartnetGemmArgs&, const GemmFlags&, hipStream_t);
@@ -75,26 +79,6 @@ __global__ __launch_bounds__(256) void cn_splitk_reduce4_kernel(const ReduceJobs
   }
 }
 
-struct FoldJobs {
-  double* parts[8];
-};
-
-// parts[r][c] <- sum_i parts[r + i*R][c] for r < R = CN_FOLD_ROWS, in place.  grid (ceil(N/64), R, njobs), 256 threads:
-// four row groups take i = g, g+4, ...; group sums are added in group order.  Row r (and every row r + i*R) is
-// touched by this block only, so the in-place update does not race.
-__global__ __launch_bounds__(256) void cn_fold_parts_kernel(const FoldJobs jobs, int nparts, int N) {
-  __shared__ double red[4][64];
-  double* __restrict__ parts = jobs.parts[blockIdx.z];
-  const int gq = threadIdx.x >> 6, cl = threadIdx.x & 63;
-  const int c = blockIdx.x * 64 + cl, r = blockIdx.y;
-  double acc = 0.0;
-  if (c < N)
-    for (int row = r + gq * CN_FOLD_ROWS; row < nparts; row += 4 * CN_FOLD_ROWS) acc += parts[(size_t)row * N + c];
-  red[gq][cl] = acc;
-  __syncthreads();
-  if (gq == 0 && c < N && r < nparts) parts[(size_t)r * N + c] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
-}
-
 struct FinalizeJobs {
   const double* parts[8];
   float* out[8];
@@ -105,9 +89,9 @@ __global__ __launch_bounds__(1024) void cn_colsum_finalize_kernel(const Finalize
   __shared__ double red[16 * 64];
   const double* __restrict__ parts = jobs.parts[blockIdx.y];
   float* __restrict__ out = jobs.out[blockIdx.y];
-  const double tot = cn_block_colsum(parts, nparts, N, blockIdx.x * 64, red);
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (threadIdx.x < 64 && c < N) {
+  const double tot = cn_block_colsum(parts, nparts, N, blockIdx.x * CN_SUM_COLS, red);
+  const int c = blockIdx.x * CN_SUM_COLS + threadIdx.x;
+  if (threadIdx.x < CN_SUM_COLS && c < N) {
     out[c] = (float)tot;
     if (jobs.out2[blockIdx.y]) jobs.out2[blockIdx.y][c] = (float)tot;
   }
@@ -142,6 +126,43 @@ __global__ void cn_act_rows_kernel(const ActJobs jobs, int M, int K, int ld) {
 
 }  // namespace
 
+// every row any epilogue operand touches is 16-byte aligned -> vector epilogue (GemmFlags.wide)
+static bool epilogue_rows_aligned(const CartnetGemmArgs& a) {
+  bool w = (a.ldc % 4 == 0) && (a.N % 4 == 0);
+  for (int gI = 0; gI < a.ngroups && w; ++gI) {
+    w = w && aligned16(a.C[gI]) && (!a.bias[gI] || aligned16(a.bias[gI])) && (!a.cpre[gI] || aligned16(a.cpre[gI]));
+    if (a.gather_i[gI]) w = w && aligned16(a.gather_i[gI]) && aligned16(a.gather_j[gI]) && (a.ldg % 4 == 0);
+    if (a.resid[gI]) w = w && aligned16(a.resid[gI]) && (a.ldr % 4 == 0);
+    if (a.dact[gI]) w = w && aligned16(a.dact[gI]) && (a.ldd % 4 == 0);
+  }
+  return w;
+}
+
+// K-segments that are adjacent column blocks of one matrix, with the image of the concatenated weight operand at hand:
+// one product over the concatenated K on the DMA-fed kernels.
+static bool segments_fold(const CartnetGemmArgs& a) {
+  if (!(a.nsegs > 1 && a.b_split_folded && a.N == cn_gemm::X3_BN && !a.a_kstrided && a.b_kstrided && a.splitk == 1 &&
+        a.ngroups == 1 && a.M > 0))
+    return false;
+  bool fold = epilogue_rows_aligned(a) && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.K % cn_gemm::BK == 0 &&
+              (long long)a.K * a.nsegs <= a.lda && (double)a.M * a.lda * 4.0 < 4294967296.0;
+  for (int s = 0; s < a.nsegs && fold; ++s)
+    fold = a.A[s] && a.B[s] && aligned16(a.A[s]) && aligned16(a.B[s]) && a.A[s] == a.A[0] + (size_t)s * a.K;
+  return fold;
+}
+
+// precision 0, an activation x weight product whose weight image is at hand and whose shape the DMA-fed fp32 kernels take
+static bool f32_image_path(const CartnetGemmArgs& a) {
+  if (a.precision != 0 || a.a_kstrided || !a.b_kstrided || a.splitk != 1 || a.M <= 0 || a.K <= 0 || a.N % 256 != 0)
+    return false;
+  if (a.nsegs > 1) return segments_fold(a);
+  bool ok = epilogue_rows_aligned(a) && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.K % cn_gemm::BK == 0 &&
+            (double)a.M * a.lda * 4.0 < 4294967296.0;
+  for (int gI = 0; gI < a.ngroups && ok; ++gI)
+    ok = a.b_split[gI] && a.A[gI] && a.B[gI] && aligned16(a.A[gI]) && aligned16(a.B[gI]);
+  return ok;
+}
+
 // Column-tile width of a launch (see the comment in cartnet_gemm_impl): 256 / 128 / 64 by N, narrower for launches
 // with few tiles.  Shared with the launch timer so that its variant names the kernel family that really runs.
 static int choose_bn(const CartnetGemmArgs& a) {
@@ -151,7 +172,9 @@ static int choose_bn(const CartnetGemmArgs& a) {
     // bf16x3 tiles are ~2x shorter: switch later (96: the benchmark batch's 97-row-tile dX product, K = 1024, stays on
     // the DMA-fed bf16x3 kernel -- +0.4 % on the step in a same-box A/B)
     const long long few = a.precision == 0 ? 200 : 96;
-    if (tiles < few) bn = (2 * tiles >= few) ? 128 : 64;
+    // fp32 with a weight image: from 64 tiles up the 128-wide DMA-fed kernel (use_f32nn128: 2 x tiles workgroups) beats the
+    // register-staged narrow kernels -- the folded dX product of the node terms 85 -> 68 us sustained
+    if (tiles < few && !(tiles >= 64 && f32_image_path(a))) bn = (2 * tiles >= few) ? 128 : 64;
   }
   return bn;
 }
@@ -268,16 +291,7 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
   fl.split0 = 0;
   fl.k_lo = 0;
   fl.k_hi = a.K;
-  {  // vector epilogue: every row any epilogue operand touches must be 16-byte aligned
-    bool w = (a.ldc % 4 == 0) && (a.N % 4 == 0);
-    for (int gI = 0; gI < a.ngroups && w; ++gI) {
-      w = w && aligned16(a.C[gI]) && (!a.bias[gI] || aligned16(a.bias[gI])) && (!a.cpre[gI] || aligned16(a.cpre[gI]));
-      if (a.gather_i[gI]) w = w && aligned16(a.gather_i[gI]) && aligned16(a.gather_j[gI]) && (a.ldg % 4 == 0);
-      if (a.resid[gI]) w = w && aligned16(a.resid[gI]) && (a.ldr % 4 == 0);
-      if (a.dact[gI]) w = w && aligned16(a.dact[gI]) && (a.ldd % 4 == 0);
-    }
-    fl.wide = w ? 1 : 0;
-  }
+  fl.wide = epilogue_rows_aligned(a) ? 1 : 0;
   CN_CHECK(a.precision >= 0 && a.precision <= 2, "cartnet_gemm: precision=%d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = bf16)",
            a.precision);
   // Few row tiles (atom-sized M, small batches): 128 x 256 tiles would leave most of the 256 CUs idle and the launch
@@ -286,18 +300,12 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
   // exist for 256-wide tiles only and their tiles are 6x shorter to begin with: measured a loss), and later at
   // precision 1.
   int bn = choose_bn(a);
-  if (bn == 256 && a.nsegs > 1 && a.b_split_folded && a.N == cn_gemm::X3_BN && !a.a_kstrided && a.b_kstrided &&
-      a.splitk == 1 && a.ngroups == 1 && a.M > 0) {
+  if (bn == 256 && segments_fold(a)) {
     // K-segments that are adjacent column blocks of one matrix: one product over the concatenated K.  Folded only when
-    // the pre-split kernel is certain to take the launch (B[0] alone does not describe the folded operand).
-    bool fold = fl.wide && vecA && vecB && a.K % cn_gemm::BK == 0 && (long long)a.K * a.nsegs <= a.lda &&
-                (double)a.M * a.lda * 4.0 < 4294967296.0;
-    for (int s = 1; s < a.nsegs; ++s) fold = fold && a.A[s] == a.A[0] + (size_t)s * a.K;
-    if (fold) {
-      a.K *= a.nsegs;
-      a.nsegs = 1;
-      a.b_split[0] = a.b_split_folded;
-    }
+    // the DMA-fed kernel is certain to take the launch (B[0] alone does not describe the folded operand).
+    a.K *= a.nsegs;
+    a.nsegs = 1;
+    a.b_split[0] = a.b_split_folded;
   }
   fl.x3 = a.precision;
   fl.vecA = vecA ? 1 : 0;
@@ -337,15 +345,6 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
            a.a_kstrided, a.b_kstrided, a.a_act, a.b_act);
   CN_LAUNCH_CHECK("cartnet_gemm");
   return 0;
-}
-
-int cn_fold_parts(double* const* parts, int njobs, int nparts, int N, hipStream_t st) {
-  if (nparts <= 8 * CN_FOLD_ROWS || N <= 0 || njobs <= 0 || njobs > 8) return nparts;
-  FoldJobs jobs;
-  for (int j = 0; j < 8; ++j) jobs.parts[j] = j < njobs ? parts[j] : nullptr;
-  hipLaunchKernelGGL(cn_fold_parts_kernel, dim3(cn_ceil_div(N, 64), CN_FOLD_ROWS, njobs), dim3(256), 0, st, jobs, nparts,
-                     N);
-  return CN_FOLD_ROWS;
 }
 
 extern "C" int cartnet_splitk_reduce(const float* const* slabs, float* const* outs, int32_t njobs, int32_t splitk,
@@ -394,8 +393,7 @@ extern "C" int cartnet_colsum_finalize2(double* const* parts, float* const* outs
     jobs.out2[j] = (j < njobs && outs2) ? outs2[j] : nullptr;
     if (j < njobs) CN_CHECK(parts[j] && outs[j], "cartnet_colsum_finalize: null pointer in job %d", j);
   }
-  nparts = cn_fold_parts(parts, njobs, nparts, N, reinterpret_cast<hipStream_t>(stream));
-  hipLaunchKernelGGL(cn_colsum_finalize_kernel, dim3(cn_ceil_div(N, 64), njobs), dim3(1024), 0,
+  hipLaunchKernelGGL(cn_colsum_finalize_kernel, dim3(cn_ceil_div(N, CN_SUM_COLS), njobs), dim3(1024), 0,
                      reinterpret_cast<hipStream_t>(stream), jobs, nparts, N);
   CN_LAUNCH_CHECK("cartnet_colsum_finalize");
   return 0;

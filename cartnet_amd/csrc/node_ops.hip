@@ -136,8 +136,8 @@ __global__ __launch_bounds__(1024) void cn_bn_finalize_kernel(
     float eps, float momentum, int training, float* __restrict__ running_mean, float* __restrict__ running_var,
     int64_t* __restrict__ nbt, float* __restrict__ mean_rstd, int G, const int* __restrict__ cnt_ptr) {
   __shared__ double red[16 * 64];
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  const bool owner = threadIdx.x < 64 && c < C;
+  const int c = blockIdx.x * CN_SUM_COLS + threadIdx.x;
+  const bool owner = threadIdx.x < CN_SUM_COLS && c < C;
   if (blockIdx.x == 0 && threadIdx.x == 0 && training && nbt) nbt[0] += G;
   if (training) {
     double rm = 0.0, rv = 0.0;
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(1024) void cn_bn_finalize_kernel(
     }
     for (int g = 0; g < G; ++g) {
       const size_t off = (size_t)g * nparts * C;
-      const double s = cn_block_colsum(parts_sum + off, nparts, C, blockIdx.x * 64, red);
-      const double q = cn_block_colsum(parts_sq + off, nparts, C, blockIdx.x * 64, red);
+      const double s = cn_block_colsum(parts_sum + off, nparts, C, blockIdx.x * CN_SUM_COLS, red);
+      const double q = cn_block_colsum(parts_sq + off, nparts, C, blockIdx.x * CN_SUM_COLS, red);
       if (!owner) continue;
       const long long cnt = cnt_ptr ? (long long)(cnt_ptr[g + 1] - cnt_ptr[g]) : count;
       const double n = (double)cnt;
@@ -238,11 +238,11 @@ __global__ __launch_bounds__(1024) void cn_bn_group_stats_kernel(double* __restr
                                                                  float* __restrict__ mean_rstd) {
   __shared__ double red[16 * 64];
   const int g = blockIdx.y;
-  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int c = blockIdx.x * CN_SUM_COLS + threadIdx.x;
   const size_t off = (size_t)g * nparts * C;
-  const double s = cn_block_colsum(parts_sum + off, nparts, C, blockIdx.x * 64, red);
-  const double q = cn_block_colsum(parts_sq + off, nparts, C, blockIdx.x * 64, red);
-  if (threadIdx.x >= 64 || c >= C) return;
+  const double s = cn_block_colsum(parts_sum + off, nparts, C, blockIdx.x * CN_SUM_COLS, red);
+  const double q = cn_block_colsum(parts_sq + off, nparts, C, blockIdx.x * CN_SUM_COLS, red);
+  if (threadIdx.x >= CN_SUM_COLS || c >= C) return;
   const long long cnt = (long long)(cnt_ptr[g + 1] - cnt_ptr[g]);
   const double n = (double)cnt;
   const double mean = n > 0 ? s / n : 0.0;
@@ -280,9 +280,9 @@ __global__ __launch_bounds__(1024) void cn_group_sums_kernel(double* __restrict_
   __shared__ double red[16 * 64];
   const int which = blockIdx.y, g = blockIdx.z;
   double* __restrict__ parts = (which ? parts_b : parts_a) + (size_t)g * nparts * D;
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  const double t = cn_block_colsum(parts, nparts, D, blockIdx.x * 64, red);
-  if (threadIdx.x >= 64 || c >= D) return;
+  const int c = blockIdx.x * CN_SUM_COLS + threadIdx.x;
+  const double t = cn_block_colsum(parts, nparts, D, blockIdx.x * CN_SUM_COLS, red);
+  if (threadIdx.x >= CN_SUM_COLS || c >= D) return;
   sums[(size_t)g * 2 * D + which * D + c] = (float)t;
   parts[c] = t;
 }
@@ -641,7 +641,7 @@ extern "C" int cartnet_bn_finalize(double* parts_sum, double* parts_sq, int32_t 
     G = groups->G;
     nparts = parts_over_edges ? groups->edge_parts : groups->node_parts;
     if (training) {
-      hipLaunchKernelGGL(cn_bn_group_stats_kernel, dim3(cn_ceil_div(C, 64), G), dim3(1024), 0, ST(stream), parts_sum,
+      hipLaunchKernelGGL(cn_bn_group_stats_kernel, dim3(cn_ceil_div(C, CN_SUM_COLS), G), dim3(1024), 0, ST(stream), parts_sum,
                          parts_sq, nparts, C, eps, count_over_edges ? groups->edge_gptr : groups->node_gptr, mean_rstd);
       CN_LAUNCH_CHECK("cartnet_bn_finalize/groups");
       hipLaunchKernelGGL(cn_bn_running_kernel, dim3(cn_ceil_div(C, 256)), dim3(256), 0, ST(stream), parts_sum, parts_sq,
@@ -649,11 +649,8 @@ extern "C" int cartnet_bn_finalize(double* parts_sum, double* parts_sq, int32_t 
       CN_LAUNCH_CHECK("cartnet_bn_finalize/running");
       return 0;
     }
-  } else if (training) {
-    double* fp[2] = {parts_sum, parts_sq};
-    nparts = cn_fold_parts(fp, 2, nparts, C, ST(stream));
   }
-  hipLaunchKernelGGL(cn_bn_finalize_kernel, dim3(cn_ceil_div(C, 64)), dim3(1024), 0, ST(stream), parts_sum, parts_sq,
+  hipLaunchKernelGGL(cn_bn_finalize_kernel, dim3(cn_ceil_div(C, CN_SUM_COLS)), dim3(1024), 0, ST(stream), parts_sum, parts_sq,
                      nparts, (long long)count, C, eps, momentum, training, running_mean, running_var,
                      num_batches_tracked, mean_rstd, G, (const int*)nullptr);
   CN_LAUNCH_CHECK("cartnet_bn_finalize");
@@ -688,7 +685,7 @@ extern "C" int cartnet_group_sums_finalize(double* parts_a, double* parts_b, int
   CN_CHECK(groups && cn_groups_ok(groups), "cartnet_group_sums_finalize: groups required");
   CN_CHECK(parts_a && parts_b && sums && D >= 1, "cartnet_group_sums_finalize: null pointer");
   const int nparts = over_edges ? groups->edge_parts : groups->node_parts;
-  hipLaunchKernelGGL(cn_group_sums_kernel, dim3(cn_ceil_div(D, 64), 2, groups->G), dim3(1024), 0, ST(stream), parts_a,
+  hipLaunchKernelGGL(cn_group_sums_kernel, dim3(cn_ceil_div(D, CN_SUM_COLS), 2, groups->G), dim3(1024), 0, ST(stream), parts_a,
                      parts_b, nparts, D, sums);
   CN_LAUNCH_CHECK("cartnet_group_sums_finalize");
   if (grad_a || grad_b) {

@@ -164,7 +164,9 @@ def test_gemm_rejects_bad_shapes(ops):
 @pytest.mark.parametrize("precision", [0, 1])
 @pytest.mark.parametrize("M,K,N,groups,act", [(1, 16, 256, 1, False), (127, 32, 256, 2, True), (128, 48, 512, 1, False),
                                               (300, 64, 256, 4, False), (1000, 80, 256, 1, True),
-                                              (129, 256, 512, 2, False), (513, 512, 256, 1, True)])
+                                              (129, 256, 512, 2, False), (513, 512, 256, 1, True),
+                                              (12416, 256, 256, 1, True), (9000, 64, 512, 1, False),
+                                              (8200, 48, 256, 2, False)])
 def test_gemm_with_weight_images(ops, precision, M, K, N, groups, act):
     """Y[g] = (silu?)(X[g]) W[g]^T + b[g] through the DMA-fed kernels: K from one K-step (pipeline head only) to 32
     (steady-state loop), ragged and single-row M, one and two column tiles, grouped launches."""
@@ -232,6 +234,26 @@ def test_gemm_activated_operand_without_the_fused_kernel(ops, precision):
     assert rel_err(C_, silu64(X.double()) @ W.double().t()) < (TOL if precision == 0 else 1e-5)
     with pytest.raises(RuntimeError, match="a_act_out"):
         ops.gemm(X, W.t().contiguous(), C_, b_kstrided=True, a_act=False, a_act_out=H[:, :32])
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_gemm_atom_sized_rows_folded_segments(ops, precision):
+    """The dX product of the node terms at the benchmark shape: M = 12,416 atoms (97 row tiles: at precision 0 the
+    128-wide DMA-fed kernel), four K-segments that are column blocks of one [M, 1024] matrix, residual, silu' and bias
+    gradient sums (layer 0's form)."""
+    M, K, N = 12416 + 5, 256, 256
+    X = rnd(M, 4 * K, seed=3)
+    Ws = [rnd(K, N, seed=20 + i, scale=0.1) for i in range(4)]
+    resid, pre = rnd(M, N, seed=5), rnd(M, N, seed=6)
+    tiles = ops.gemm_tiles_m(M)
+    cs = torch.full((tiles * N,), float("nan"), dtype=torch.float64, device=dev())
+    C_ = torch.full((M, N), float("nan"), device=dev())
+    img = torch.cat((ops.pack_b if precision == 0 else ops.split_b)(Ws))
+    ops.gemm([X[:, i * K:(i + 1) * K] for i in range(4)], Ws, C_, b_kstrided=True, segments=True, resid=resid, dact=pre,
+             colsum=cs, b_split_folded=img, precision=precision)
+    ref = (sum(X[:, i * K:(i + 1) * K].double() @ Ws[i].double() for i in range(4)) + resid.double()) * dsilu64(pre.double())
+    assert rel_err(C_, ref) < TOL
+    assert rel_err(cs.view(tiles, N).sum(0), C_.double().sum(0)) < 1e-6
 
 
 @pytest.mark.parametrize("case", ["plain", "gather", "dact_colsum", "resid_folded"])
