@@ -12,4 +12,4 @@ void cartnet_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cartnet_last_error(void) { return g_err; }
-extern "C" int cartnet_abi_version(void) { return 4; }
+extern "C" int cartnet_abi_version(void) { return 5; }

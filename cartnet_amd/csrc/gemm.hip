@@ -86,7 +86,7 @@ struct FinalizeJobs {
 };
 
 __global__ __launch_bounds__(1024) void cn_colsum_finalize_kernel(const FinalizeJobs jobs, int nparts, int N) {
-  __shared__ double red[16 * 64];
+  __shared__ double red[64 * CN_SUM_COLS];
   const double* __restrict__ parts = jobs.parts[blockIdx.y];
   float* __restrict__ out = jobs.out[blockIdx.y];
   const double tot = cn_block_colsum(parts, nparts, N, blockIdx.x * CN_SUM_COLS, red);

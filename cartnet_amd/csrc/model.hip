@@ -57,7 +57,7 @@ struct Work {
       *i_de[CARTNET_MAX_LAYERS], *i_dx[CARTNET_MAX_LAYERS];
   // forward transients
   float* Pn;
-  double *cs, *cq, *ps, *pq;
+  double *cs, *cq, *ps, *pq, *bnrow;   // bnrow [2D + 2]: the summed row of a sync-BatchNorm exchange
   // silu(pre) / silu(he_pre), written by the forward GEMMs that activate them (CartnetGemmArgs.a_act_out) for the weight
   // gradients of the second Linears; nullptr = recompute the SiLU in the weight-gradient kernel
   float *act[CARTNET_MAX_LAYERS], *he_act;
@@ -193,6 +193,7 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
   w.cq = c.take<double>(big * D);
   w.ps = c.take<double>((size_t)w.gparts * D);
   w.pq = c.take<double>((size_t)w.gparts * D);
+  w.bnrow = c.take<double>((size_t)2 * D + 2);
   if (need_bwd) {
     w.dhid = c.take<float>(Nn * H);
     w.head_parts = c.take<float>((size_t)w.nparts_n * (7 * H + 8));
@@ -467,6 +468,20 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     RUN(cartnet_gemm(&a, st));
   }
 
+  // BatchNorm statistics from partial column sums; with CartnetModel.bn_allreduce (sync-BatchNorm) the sums of all ranks
+  const bool sync_bn = training && m.bn_allreduce != nullptr;
+  CN_CHECK(!(sync_bn && w.groups), "cartnet_model_forward: sync-BatchNorm and BatchNorm groups are mutually exclusive");
+  auto bn_stats = [&](double* psum, double* psq, int nparts, long long count, float* rmean, float* rvar, int64_t* nbt,
+                      float* mean_rstd, int over_edges) -> int {
+    if (!sync_bn)
+      return cartnet_bn_finalize(psum, psq, nparts, count, D, m.bn_eps, m.bn_momentum, training, rmean, rvar, nbt, mean_rstd,
+                                 w.groups, 1, over_edges, st);
+    RUN(cartnet_bn_sync_gather(psum, psq, nparts, D, count, w.bnrow, nullptr, nullptr, st));
+    CN_CHECK(m.bn_allreduce(m.bn_allreduce_user, w.bnrow, 2 * (int64_t)D + 1, st) == 0,
+             "cartnet_model_forward: the sync-BatchNorm all-reduce callback failed");
+    return cartnet_bn_finalize_row(w.bnrow, D, m.bn_eps, m.bn_momentum, rmean, rvar, nbt, mean_rstd, st);
+  };
+
   // ---- message-passing layers (cartnet.py:204-274)
   const float* x = w.xenc;
   const float* e = w.e0;
@@ -510,12 +525,10 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     // BatchNorm groups: a 128-row GEMM tile may straddle two groups, so the gate statistics are taken per group by a
     // pass of their own over the gate half of gs (181 MB at the benchmark batch, ~40 us) instead of in the epilogue
     if (w.groups && training) RUN(cartnet_colstats_grouped(w.gs[l], 2 * D, D, w.groups, w.cs, w.cq, st));
-    RUN(cartnet_bn_finalize(w.cs, w.cq, w.tiles_e, b.E, D, m.bn_eps, m.bn_momentum, training, m.buf[l].norm_mean,
-                            m.buf[l].norm_var, m.buf[l].norm_nbt, w.mr1[l], w.groups, 1, 1, st));
+    RUN(bn_stats(w.cs, w.cq, w.tiles_e, b.E, m.buf[l].norm_mean, m.buf[l].norm_var, m.buf[l].norm_nbt, w.mr1[l], 1));
     RUN(cartnet_gate_scatter_fwd(w.gs[l], e, m.use_envelope[l] ? w.env : nullptr, w.rowptr, w.mr1[l], q.norm_w,
                                  q.norm_b, N, D, e_next, w.aggr[l], w.ps, w.pq, w.groups, st));
-    RUN(cartnet_bn_finalize(w.ps, w.pq, w.gparts, N, D, m.bn_eps, m.bn_momentum, training, m.buf[l].norm2_mean,
-                            m.buf[l].norm2_var, m.buf[l].norm2_nbt, w.mr2[l], w.groups, 1, 0, st));
+    RUN(bn_stats(w.ps, w.pq, w.gparts, N, m.buf[l].norm2_mean, m.buf[l].norm2_var, m.buf[l].norm2_nbt, w.mr2[l], 0));
     RUN(cartnet_node_update_fwd(w.aggr[l], x, w.mr2[l], q.norm2_w, q.norm2_b, N, D, x_next, w.groups, st));
     x = x_next;
     e = e_next;
@@ -650,6 +663,17 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
   hipEvent_t side_done[CARTNET_MAX_LAYERS + 2];
   for (int i = 0; i < CARTNET_MAX_LAYERS + 2; ++i) side_done[i] = nullptr;
 
+  // sync-BatchNorm: the sums of the BatchNorm backward over all ranks for the apply pass (pre-scaled so that the kernels'
+  // division by the LOCAL row count yields sum_global / count_global); the affine gradients keep the local sums
+  const bool sync_bn = training && m.bn_allreduce != nullptr;
+  CN_CHECK(!(sync_bn && w.groups), "cartnet_model_backward: sync-BatchNorm and BatchNorm groups are mutually exclusive");
+  auto bn_sums_sync = [&](double* pa, double* pb, int nparts, long long count, float* sums, float* grad_b, float* grad_w) -> int {
+    RUN(cartnet_bn_sync_gather(pa, pb, nparts, D, count, w.bnrow, grad_b, grad_w, st));
+    CN_CHECK(m.bn_allreduce(m.bn_allreduce_user, w.bnrow, 2 * (int64_t)D + 1, st) == 0,
+             "cartnet_model_backward: the sync-BatchNorm all-reduce callback failed");
+    return cartnet_bn_sync_scale(w.bnrow, D, count, sums, st);
+  };
+
   // ---- layers, last to first
   for (int l = L - 1; l >= 0; --l) {
     const CartnetLayerParams& q = P.layer[l];
@@ -669,7 +693,9 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     if (l + 2 < L && S.main_waits(side_done[l + 2]) != 0) { cartnet_set_error("cartnet_model_backward: wait failed"); return 2; }
     // node update: x_out = silu(bn2(aggr)) + x_in
     RUN(cartnet_node_update_bwd_stats(w.aggr[l], dx, w.mr2[l], q.norm2_w, q.norm2_b, N, D, w.pa, w.pb, w.groups, st));
-    if (w.groups) {   // per-group sums for the apply pass, their total = the BatchNorm affine gradients
+    if (sync_bn) {
+      RUN(bn_sums_sync(w.pa, w.pb, w.nparts_n, N, w.sums2, gq.norm2_b, gq.norm2_w));
+    } else if (w.groups) {   // per-group sums for the apply pass, their total = the BatchNorm affine gradients
       RUN(cartnet_group_sums_finalize(w.pa, w.pb, D, w.groups, 0, w.sums2, gq.norm2_b, gq.norm2_w, st));
     } else {
       double* parts[2] = {w.pa, w.pb};
@@ -682,7 +708,9 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     // gate * sender aggregation and the edge BatchNorm
     RUN(cartnet_gate_scatter_bwd_stats(gs, de, w.daggr, env, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, N, D, w.pa, w.pb,
                                        w.groups, st));
-    if (w.groups) {
+    if (sync_bn) {
+      RUN(bn_sums_sync(w.pa, w.pb, w.gparts, b.E, w.sums1, gq.norm_b, gq.norm_w));
+    } else if (w.groups) {
       RUN(cartnet_group_sums_finalize(w.pa, w.pb, D, w.groups, 1, w.sums1, gq.norm_b, gq.norm_w, st));
     } else {
       double* parts[2] = {w.pa, w.pb};

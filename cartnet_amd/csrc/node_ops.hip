@@ -134,8 +134,9 @@ __global__ __launch_bounds__(256) void cn_transpose_kernel(const TransposeJobs j
 __global__ __launch_bounds__(1024) void cn_bn_finalize_kernel(
     const double* __restrict__ parts_sum, const double* __restrict__ parts_sq, int nparts, long long count, int C,
     float eps, float momentum, int training, float* __restrict__ running_mean, float* __restrict__ running_var,
-    int64_t* __restrict__ nbt, float* __restrict__ mean_rstd, int G, const int* __restrict__ cnt_ptr) {
-  __shared__ double red[16 * 64];
+    int64_t* __restrict__ nbt, float* __restrict__ mean_rstd, int G, const int* __restrict__ cnt_ptr,
+    const double* __restrict__ count_dev /* optional: the row count as a device double (sync-BatchNorm) */) {
+  __shared__ double red[64 * CN_SUM_COLS];
   const int c = blockIdx.x * CN_SUM_COLS + threadIdx.x;
   const bool owner = threadIdx.x < CN_SUM_COLS && c < C;
   if (blockIdx.x == 0 && threadIdx.x == 0 && training && nbt) nbt[0] += G;
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(1024) void cn_bn_finalize_kernel(
       const double s = cn_block_colsum(parts_sum + off, nparts, C, blockIdx.x * CN_SUM_COLS, red);
       const double q = cn_block_colsum(parts_sq + off, nparts, C, blockIdx.x * CN_SUM_COLS, red);
       if (!owner) continue;
-      const long long cnt = cnt_ptr ? (long long)(cnt_ptr[g + 1] - cnt_ptr[g]) : count;
+      const long long cnt = count_dev ? (long long)(count_dev[0] + 0.5)
+                                      : (cnt_ptr ? (long long)(cnt_ptr[g + 1] - cnt_ptr[g]) : count);
       const double n = (double)cnt;
       const double mean = n > 0 ? s / n : 0.0;
       double var = n > 0 ? q / n - mean * mean : 0.0;
@@ -176,6 +178,31 @@ __global__ __launch_bounds__(1024) void cn_bn_finalize_kernel(
       mean_rstd[(size_t)g * 2 * C + C + c] = r;
     }
   }
+}
+
+// Sync-BatchNorm (cartnet_hip.h): row[which*C + c] = column sum of parts_{a,b} (which = blockIdx.y), row[2C] = the local
+// row count; out_{a,b} (optional) = the same local sums as fp32.
+__global__ __launch_bounds__(1024) void cn_bn_sync_gather_kernel(const double* __restrict__ parts_a,
+                                                                 const double* __restrict__ parts_b, int nparts, int C,
+                                                                 double local_count, double* __restrict__ row,
+                                                                 float* __restrict__ out_a, float* __restrict__ out_b) {
+  __shared__ double red[64 * CN_SUM_COLS];
+  const int which = blockIdx.y;
+  const double t = cn_block_colsum(which ? parts_b : parts_a, nparts, C, blockIdx.x * CN_SUM_COLS, red);
+  const int c = blockIdx.x * CN_SUM_COLS + threadIdx.x;
+  if (blockIdx.x == 0 && which == 0 && threadIdx.x == 0) row[2 * (size_t)C] = local_count;
+  if (threadIdx.x >= CN_SUM_COLS || c >= C) return;
+  row[(size_t)which * C + c] = t;
+  float* __restrict__ out = which ? out_b : out_a;
+  if (out) out[c] = (float)t;
+}
+
+__global__ void cn_bn_sync_scale_kernel(const double* __restrict__ row, int C, double local_count,
+                                        float* __restrict__ sums) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * C) return;
+  const double total = row[2 * (size_t)C];
+  sums[i] = total > 0.0 ? (float)(row[i] * (local_count / total)) : 0.f;
 }
 
 // node_gptr[g] = graph_ptr[min(g * group_size, Bg)], edge_gptr[g] = rowptr[node_gptr[g]]   (g <= G)
@@ -236,7 +263,7 @@ __global__ __launch_bounds__(1024) void cn_bn_group_stats_kernel(double* __restr
                                                                  double* __restrict__ parts_sq, int nparts, int C,
                                                                  float eps, const int* __restrict__ cnt_ptr,
                                                                  float* __restrict__ mean_rstd) {
-  __shared__ double red[16 * 64];
+  __shared__ double red[64 * CN_SUM_COLS];
   const int g = blockIdx.y;
   const int c = blockIdx.x * CN_SUM_COLS + threadIdx.x;
   const size_t off = (size_t)g * nparts * C;
@@ -277,7 +304,7 @@ __global__ void cn_bn_running_kernel(const double* __restrict__ parts_sum, const
 // adds the groups in order (the BatchNorm affine gradients are shared by the groups).
 __global__ __launch_bounds__(1024) void cn_group_sums_kernel(double* __restrict__ parts_a, double* __restrict__ parts_b,
                                                              int nparts, int D, float* __restrict__ sums) {
-  __shared__ double red[16 * 64];
+  __shared__ double red[64 * CN_SUM_COLS];
   const int which = blockIdx.y, g = blockIdx.z;
   double* __restrict__ parts = (which ? parts_b : parts_a) + (size_t)g * nparts * D;
   const int c = blockIdx.x * CN_SUM_COLS + threadIdx.x;
@@ -652,8 +679,36 @@ extern "C" int cartnet_bn_finalize(double* parts_sum, double* parts_sq, int32_t 
   }
   hipLaunchKernelGGL(cn_bn_finalize_kernel, dim3(cn_ceil_div(C, CN_SUM_COLS)), dim3(1024), 0, ST(stream), parts_sum, parts_sq,
                      nparts, (long long)count, C, eps, momentum, training, running_mean, running_var,
-                     num_batches_tracked, mean_rstd, G, (const int*)nullptr);
+                     num_batches_tracked, mean_rstd, G, (const int*)nullptr, (const double*)nullptr);
   CN_LAUNCH_CHECK("cartnet_bn_finalize");
+  return 0;
+}
+
+extern "C" int cartnet_bn_sync_gather(const double* parts_a, const double* parts_b, int32_t nparts, int32_t C,
+                                      int64_t local_count, double* row, float* out_a, float* out_b, void* stream) {
+  CN_CHECK(parts_a && parts_b && row && nparts >= 0 && C >= 1 && local_count >= 0, "cartnet_bn_sync_gather: bad arguments");
+  hipLaunchKernelGGL(cn_bn_sync_gather_kernel, dim3(cn_ceil_div(C, CN_SUM_COLS), 2), dim3(1024), 0, ST(stream), parts_a,
+                     parts_b, nparts, C, (double)local_count, row, out_a, out_b);
+  CN_LAUNCH_CHECK("cartnet_bn_sync_gather");
+  return 0;
+}
+
+extern "C" int cartnet_bn_finalize_row(const double* row, int32_t C, float eps, float momentum, float* running_mean,
+                                       float* running_var, int64_t* num_batches_tracked, float* mean_rstd, void* stream) {
+  CN_CHECK(row && mean_rstd && C >= 1, "cartnet_bn_finalize_row: bad arguments");
+  CN_CHECK((running_mean == nullptr) == (running_var == nullptr), "cartnet_bn_finalize_row: running stats must pair");
+  hipLaunchKernelGGL(cn_bn_finalize_kernel, dim3(cn_ceil_div(C, CN_SUM_COLS)), dim3(1024), 0, ST(stream), row, row + C, 1,
+                     (long long)0, C, eps, momentum, 1, running_mean, running_var, num_batches_tracked, mean_rstd, 1,
+                     (const int*)nullptr, row + 2 * (size_t)C);
+  CN_LAUNCH_CHECK("cartnet_bn_finalize_row");
+  return 0;
+}
+
+extern "C" int cartnet_bn_sync_scale(const double* row, int32_t C, int64_t local_count, float* sums, void* stream) {
+  CN_CHECK(row && sums && C >= 1 && local_count >= 0, "cartnet_bn_sync_scale: bad arguments");
+  hipLaunchKernelGGL(cn_bn_sync_scale_kernel, dim3(cn_ceil_div(2 * C, 256)), dim3(256), 0, ST(stream), row, C,
+                     (double)local_count, sums);
+  CN_LAUNCH_CHECK("cartnet_bn_sync_scale");
   return 0;
 }
 

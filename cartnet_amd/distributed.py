@@ -104,6 +104,13 @@ def all_reduce_gradients(flat_grad: torch.Tensor) -> float:
     return 1.0 / dist.get_world_size()
 
 
+def all_reduce_sum_(t: torch.Tensor) -> None:
+    """In-place SUM all-reduce of a (device) tensor, enqueued in the current stream's order; no-op for one rank.
+    The sync-BatchNorm exchange of cartnet_amd.model.CartNet (2D+1 doubles per BatchNorm and direction)."""
+    if _active():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 def broadcast_buffers(model: torch.nn.Module, src: int = 0) -> None:
     if not _active():
         return

@@ -82,13 +82,18 @@ class Params(C.Structure):
                [(n, C.c_void_p) for n in ("head0_w", "head0_b", "head2_w", "head2_b")]
 
 
+# CartnetAllReduceFn: int (*)(void* user, double* buf, int64_t count, void* stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
 class Model(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("D", "R", "L", "invariant", "use_temperature", "atom_types", "cholesky",
                                          "n_types")] + \
                [("use_envelope", C.c_int32 * MAX_LAYERS)] + \
                [(n, C.c_float) for n in ("radius", "env_radius", "bn_eps", "bn_momentum")] + \
                [("gemm_precision", C.c_int32), ("bn_group_size", C.c_int32)] + \
-               [("rbf_means", C.c_void_p), ("rbf_betas", C.c_void_p), ("p", Params), ("buf", LayerBuffers * MAX_LAYERS)]
+               [("rbf_means", C.c_void_p), ("rbf_betas", C.c_void_p), ("p", Params), ("buf", LayerBuffers * MAX_LAYERS),
+                ("bn_allreduce", ALLREDUCE_FN), ("bn_allreduce_user", C.c_void_p)]
 
 
 class Groups(C.Structure):
@@ -157,6 +162,9 @@ PROTOTYPES = {
     "cartnet_bn_finalize": (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float,
                                       C.c_int32, c_f32p, c_f32p, c_i64p, c_f32p, c_groups, C.c_int32, C.c_int32,
                                       c_stream]),
+    "cartnet_bn_sync_gather": (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int64, c_f32p, c_f32p, c_f32p, c_stream]),
+    "cartnet_bn_finalize_row": (C.c_int, [c_f32p, C.c_int32, C.c_float, C.c_float, c_f32p, c_f32p, c_i64p, c_f32p, c_stream]),
+    "cartnet_bn_sync_scale": (C.c_int, [c_f32p, C.c_int32, C.c_int64, c_f32p, c_stream]),
     "cartnet_group_ptrs": (C.c_int, [c_i64p, C.c_int32, C.c_int32, c_i32p, C.c_int32, c_i32p, c_i32p, c_stream]),
     "cartnet_colstats_grouped": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_groups, c_f32p, c_f32p, c_stream]),
     "cartnet_group_sums_finalize": (C.c_int, [c_f32p, c_f32p, C.c_int32, c_groups, C.c_int32, c_f32p, c_f32p, c_f32p,

@@ -27,4 +27,6 @@ def create_model():
     model.gemm_precision = int(getattr(cfg, "gemm_precision", 0))
     if hasattr(model, "bn_group_size"):
         model.bn_group_size = int(getattr(cfg, "bn_group_size", 0))
+    if hasattr(model, "sync_batchnorm"):
+        model.sync_batchnorm = bool(getattr(cfg, "sync_batchnorm", False))
     return model

@@ -183,6 +183,13 @@ class _CartNetFunction(torch.autograd.Function):
         md = model._model_desc(dict(zip(model._param_names, params)))
         nbytes = int(lib.cartnet_workspace_bytes(C.byref(md), N, E, Bg, M, int(need_grad)))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        sync_cb = None
+        if model.sync_batchnorm and training:
+            if model.bn_group_size > 0:
+                raise ValueError("sync_batchnorm and bn_group_size are mutually exclusive")
+            sync_cb = _make_bn_allreduce(ws)
+            md.bn_allreduce = sync_cb
+            keep.append(sync_cb)            # the C side calls it again in backward: must outlive ctx.saved
         x_out = torch.empty((N, D), dtype=torch.float32, device=dev)
         e_store = torch.empty((max(E, 1), D), dtype=torch.float32, device=dev)   # never a null pointer, even for E = 0
         e_out = e_store[:E]
@@ -190,6 +197,7 @@ class _CartNetFunction(torch.autograd.Function):
         _l.check(lib.cartnet_model_forward(C.byref(md), C.byref(bd), ws.data_ptr(), nbytes, int(training),
                                            int(need_grad), pred.data_ptr(), x_out.data_ptr(), e_store.data_ptr(),
                                            status.data_ptr(), _l.stream_ptr()), "cartnet_model_forward")
+        _raise_callback_error(sync_cb)
         if model.validate_graph:
             ops.raise_on_graph_status(int(status.item()))
         else:
@@ -220,11 +228,42 @@ class _CartNetFunction(torch.autograd.Function):
         _l.check(lib.cartnet_model_backward(C.byref(md), C.byref(bd), ws.data_ptr(), nbytes, int(training),
                                             dpred.data_ptr(), x_out.data_ptr(), C.byref(gd), _l.stream_ptr(), aux),
                  "cartnet_model_backward")
+        for k in keep:
+            _raise_callback_error(k if isinstance(k, _l.ALLREDUCE_FN) else None)
         sink = model._flat_grad
         if sink is not None and sink.numel() == G.flat.numel():
             sink.add_(G.flat)              # one accumulation into the optimiser's flat gradient buffer
             return (None, None, None) + (None,) * len(model._param_names)
         return (None, None, None) + tuple(G[name] for name in model._param_names)
+
+
+def _make_bn_allreduce(ws: torch.Tensor):
+    """CartnetModel.bn_allreduce for one forward/backward pair: the C side hands over a pointer into the workspace; the
+    2D+1 doubles behind it are SUM-all-reduced over the ranks with torch.distributed (RCCL on GPUs) in stream order."""
+    from . import distributed as cdist
+    base, nbytes = ws.data_ptr(), ws.numel()
+    err = []
+
+    def cb(_user, buf, count, _stream):
+        try:
+            off = int(buf) - base
+            if off < 0 or off + 8 * int(count) > nbytes or off % 8:
+                raise RuntimeError("sync-BatchNorm buffer outside the workspace")
+            cdist.all_reduce_sum_(ws[off:off + 8 * int(count)].view(torch.float64))
+            return 0
+        except Exception as exc:        # must not propagate through the C frames
+            err.append(exc)
+            return 1
+
+    fn = _l.ALLREDUCE_FN(cb)
+    fn._cartnet_errors = err
+    return fn
+
+
+def _raise_callback_error(fn) -> None:
+    errs = getattr(fn, "_cartnet_errors", None)
+    if errs:
+        raise errs.pop(0)
 
 
 class CartNet(nn.Module):
@@ -260,6 +299,10 @@ class CartNet(nn.Module):
         # (batch 4 x accumulation 16, scripts/train_cartnet_adp.sh:4) travel through the network as ONE batch of 64 with
         # per-micro-batch statistics; pair it with cartnet_amd.train.grouped_loss (include/cartnet_hip.h: CartnetGroups)
         self.bn_group_size = 0
+        # True: every BatchNorm's statistics (forward) and gradient sums (backward) are summed over the data-parallel ranks
+        # (torch.distributed), so that N ranks with a shard each compute what one process would on the union batch
+        # (SURVEY.md 8e "sync-BN", optional; default = per-rank statistics, the reference's single-process semantics)
+        self.sync_batchnorm = False
         self._aux_stream = None
         self._status_ring = None        # in-flight pinned copies of the batches' graph status words (_defer_graph_check)
         self._param_names = [n for n, _ in self.named_parameters()]

@@ -65,6 +65,9 @@ def train_epoch(loader, model, optimizer, batch_accumulation: int, scheduler: Op
     t0 = time.perf_counter()
     flush = getattr(model, "flush_graph_checks", None)
     for it, batch in enumerate(loader):
+        if batch is None and getattr(model, "sync_batchnorm", False):
+            raise RuntimeError("sync_batchnorm: this rank has no crystals for a step the other ranks run -- every rank "
+                               "must take part in each BatchNorm exchange (use more crystals per step than ranks)")
         if batch is not None:                       # None: this rank has no crystals left for the step (sharded
             batch.to(device)                        # loaders, tiny data sets) -- it adds a zero gradient
             pred, true = model(batch)

@@ -405,6 +405,23 @@ int cartnet_bn_finalize(double* parts_sum, double* parts_sq, int32_t nparts, int
                         int64_t* num_batches_tracked, float* mean_rstd, const CartnetGroups* groups,
                         int32_t parts_over_edges, int32_t count_over_edges, void* stream);
 
+/* Sync-BatchNorm across data-parallel ranks (optional; the reference's BatchNorm1d layers at
+ * models/cartnet.py:198-199,238,269 see one process's batch): the column sums behind every BatchNorm statistic are
+ * summed over the ranks before the statistic is formed, so that N ranks with a shard each compute what one process
+ * would on the union batch.  Three small steps around the caller's all-reduce:
+ *   cartnet_bn_sync_gather:   row[0:C] = column sums of parts_a, row[C:2C] = of parts_b, row[2C] = local_count (fp64);
+ *                             out_a / out_b (optional, fp32 [C]) receive the LOCAL sums (backward: the BatchNorm affine
+ *                             gradients stay local -- the gradient all-reduce adds them up like every other gradient)
+ *   (caller: in-place SUM all-reduce of the 2C+1 doubles of `row`)
+ *   cartnet_bn_finalize_row:  forward: mean / rstd / running statistics from the summed row (count = row[2C])
+ *   cartnet_bn_sync_scale:    backward: sums[0:2C] = row[0:2C] * local_count / row[2C] -- the apply kernels divide by
+ *                             the local count, so the pre-scaled sums give them sum_global / count_global. */
+int cartnet_bn_sync_gather(const double* parts_a, const double* parts_b, int32_t nparts, int32_t C, int64_t local_count,
+                           double* row, float* out_a, float* out_b, void* stream);
+int cartnet_bn_finalize_row(const double* row, int32_t C, float eps, float momentum, float* running_mean,
+                            float* running_var, int64_t* num_batches_tracked, float* mean_rstd, void* stream);
+int cartnet_bn_sync_scale(const double* row, int32_t C, int64_t local_count, float* sums, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Neighbour-equalised gate + aggregation (models/cartnet.py:238-243 message, :259 scatter-sum, :225 edge
  * residual).  gs [E, 2D]: columns 0:D = pre-BatchNorm gate g, D:2D = sender s.  One wavefront walks the edges of
@@ -527,6 +544,8 @@ typedef struct CartnetParams {                  /* used both for parameters (inp
   float* head2_w; float* head2_b;               /* head.MLP.2 [6 or 1, D/2]              */
 } CartnetParams;
 
+typedef int (*CartnetAllReduceFn)(void* user, double* buf, int64_t count, void* stream);
+
 typedef struct CartnetModel {
   int32_t D, R, L;                              /* dim_in, dim_rbf, num_layers                       */
   int32_t invariant, use_temperature, atom_types, cholesky, n_types;
@@ -539,6 +558,11 @@ typedef struct CartnetModel {
   const float* rbf_means; const float* rbf_betas;
   CartnetParams p;
   CartnetLayerBuffers buf[CARTNET_MAX_LAYERS];
+  /* Sync-BatchNorm (training mode only, not with bn_group_size): when set, called once per BatchNorm in forward and
+     once in backward with a device buffer of `count` doubles; must enqueue an in-place SUM all-reduce over the ranks,
+     ordered after the work already queued on `stream` and before what is queued next.  Non-zero return = error. */
+  CartnetAllReduceFn bn_allreduce;
+  void* bn_allreduce_user;
 } CartnetModel;
 
 typedef struct CartnetBatch {

@@ -110,3 +110,70 @@ def test_groups_make_data_parallel_runs_equal_to_the_accumulation_recipe(tmp_pat
     g2a, g2b = torch.load(tmp_path / "g_w2_r0.pt"), torch.load(tmp_path / "g_w2_r1.pt")
     assert torch.equal(g2a, g2b)
     assert (g2a - g1).abs().max().item() <= 2e-5 * g1.abs().max().item()
+
+
+_SYNC_CHILD = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from cartnet_amd import distributed as cdist
+from cartnet_amd.config import cfg
+from cartnet_amd.data import Batch
+from cartnet_amd.model import CartNet, make_state_dict
+from cartnet_amd.optim import FlatAdam
+from cartnet_amd.synthetic import make_crystal
+
+rank, world, local = cdist.init_from_env()
+cfg.radius = 5.0
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+items = [make_crystal(9700 + i, 9 + 4 * i) for i in range(6)]          # 9..29 atoms: the two shards differ in size
+m = CartNet(64, 16, 2)
+m.load_state_dict(make_state_dict(64, 16, 2, seed=43))
+m = m.to(dev).train()
+m.sync_batchnorm = world > 1
+opt = FlatAdam(m, lr=1e-3)
+mine = items[:2] if (world == 2 and rank == 0) else (items[2:] if world == 2 else items)   # 2 + 4 crystals
+b = Batch.from_data_list(mine).to(dev)
+pred, true = m(b)
+(pred - true).abs().sum().backward()                                   # a SUM: the union loss is the sum of the shard losses
+cdist.all_reduce_gradients(opt.flat_grad)
+bufs = {k: v.cpu() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+torch.save({"grad": opt.flat_grad.cpu(), "pred": pred.detach().cpu(), "bufs": bufs},
+           os.path.join(sys.argv[2], f"s_w{world}_r{rank}.pt"))
+if world > 1:
+    dist.destroy_process_group()
+'''
+
+
+def test_sync_batchnorm_makes_two_shards_equal_to_the_union_batch(tmp_path):
+    """CartNet.sync_batchnorm (SURVEY.md 8e): two ranks with 2 and 4 crystals, every BatchNorm's sums exchanged in
+    forward and backward -> predictions, the SUM-all-reduced gradient and the running statistics equal those of one
+    process on all 6 crystals (without it the shards' statistics differ and so does everything downstream)."""
+    import torch
+    script = tmp_path / "sync_child.py"
+    script.write_text(_SYNC_CHILD)
+    env = dict(os.environ, CARTNET_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, str(script), ROOT, str(tmp_path)], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29537", str(script), ROOT, str(tmp_path)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-3000:]
+    ref = torch.load(tmp_path / "s_w1_r0.pt")
+    r0, r1 = torch.load(tmp_path / "s_w2_r0.pt"), torch.load(tmp_path / "s_w2_r1.pt")
+    pred2 = torch.cat([r0["pred"], r1["pred"]])
+    assert pred2.shape == ref["pred"].shape
+    assert (pred2 - ref["pred"]).abs().max().item() <= 1e-5 * ref["pred"].abs().max().item()
+    assert torch.equal(r0["grad"], r1["grad"])
+    assert (r0["grad"] - ref["grad"]).abs().max().item() <= 3e-5 * ref["grad"].abs().max().item()
+    for k, v in ref["bufs"].items():
+        for r in (r0, r1):
+            if v.dtype == torch.int64:
+                assert torch.equal(r["bufs"][k], v), k
+            else:
+                assert torch.allclose(r["bufs"][k], v, rtol=1e-5, atol=1e-7), k

@@ -49,8 +49,20 @@ t = cdist.max_over_ranks(3.25, dev)
 cdist.assert_replicas_in_sync(model)                       # MAX and MIN all-reduce of the parameter checksums
 cdist.broadcast_buffers(model)
 moved = float((opt.flat_param - p_before).abs().max().item())
+# sync-BatchNorm: 16 + 16 RCCL all-reduces of 2D+1 doubles inside forward / backward; over one rank the sums are unchanged,
+# so prediction and gradient must equal the per-rank-statistics run to rounding (the finalisers take another path)
+preds, grads = [], []
+for sync in (False, True):
+    model.sync_batchnorm = sync
+    opt.zero_grad()
+    bb = make_batch(4, 194, first=31000).to(dev)
+    pred, true = model(bb)
+    (pred - true).abs().mean().backward()
+    preds.append(pred.detach().clone()); grads.append(opt.flat_grad.clone())
+sync_pred = float((preds[0] - preds[1]).abs().max().item() / preds[0].abs().max().item())
+sync_grad = float((grads[0] - grads[1]).abs().max().item() / grads[0].abs().max().item())
 print(json.dumps({"backend": dist.get_backend(), "same": same, "max": t, "moved": moved,
-                  "grad_norm": float(g_before.norm().item())}), flush=True)
+                  "grad_norm": float(g_before.norm().item()), "sync_pred": sync_pred, "sync_grad": sync_grad}), flush=True)
 dist.destroy_process_group()
 '''
 
@@ -66,6 +78,7 @@ def test_rccl_world_of_one_runs_every_collective_of_the_training_step(tmp_path):
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["backend"] == "nccl" and d["same"] is True and d["max"] == 3.25
     assert d["grad_norm"] > 0 and 0 < d["moved"] <= 1.1e-3            # one Adam step at lr 1e-3 moves each weight by <= lr
+    assert d["sync_pred"] <= 1e-6 and d["sync_grad"] <= 1e-5
 
 
 def test_bench_starts_its_own_ranks(tmp_path):
