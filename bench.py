@@ -450,6 +450,10 @@ def main():
             peak = PEAK_FP32_MFMA_TFLOPS if args.precision == 0 else 2500.0 / 6.0
             fam = "f32" if args.precision == 0 else "x3"
             kernel_name = f"cn_gemm_{fam}{'tn' if key.startswith('tn') else 'nn'}_kernel"
+            if "+out" in key:
+                kernel_name = f"cn_gemm_{fam}nn_actout_kernel"      # gemm_f32ao.h / gemm_x3ao.h
+            elif key.startswith("nn128") and args.precision == 0:
+                kernel_name = "cn_gemm_f32nn128_kernel"             # gemm_f32w128.h
             # traffic.json aggregates every launch of the kernel template (all shapes): a per-launch average
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
                                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
@@ -460,6 +464,12 @@ def main():
                                                                  for k, v in sorted(vsumm.items())
                                                                  if v["ms"] / vsteps >= 0.05},
                                "all_gemm_variants_from": "warm-up steps 2.." if warm_summary else "timed steps"}
+            # the whole step against the same peak: every cartnet_gemm FLOP of a step over the step's wall time (two
+            # co-running GEMMs each read ~2x their isolated duration in `frac` above; this figure does not care)
+            gflop = sum(v["flops"] for v in vsumm.values()) / vsteps
+            out["roofline"]["whole_step"] = {"gemm_flops_per_step": int(gflop),
+                                             "achieved": round(gflop / step_s / 1e12, 2),
+                                             "frac": round(gflop / step_s / 1e12 / peak, 4)}
             # all launches of the same kernel template (every shape), for comparison with rocprofv3's per-kernel average
             base = key.split("[")[0]
             same = [v for k, v in vsumm.items() if k.split("[")[0] == base]

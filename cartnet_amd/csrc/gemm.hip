@@ -234,13 +234,17 @@ extern "C" int cartnet_profile_gemm_read(CartnetGemmProfile* out, int32_t max_en
 extern "C" int cartnet_gemm(const CartnetGemmArgs* args, void* stream) {
   if (!g_prof_on || !args) return cartnet_gemm_impl(args, stream);
   GemmRecord r;
-  const int bn = choose_bn(*args) / 64;
+  int bn = choose_bn(*args) / 64;
+  // the variant names the kernel that runs: the 128-wide DMA-fed kernel reports tile width 128, the kernels that also
+  // write silu(A) set bit 9
+  const bool actout = args->a_act_out[0] != nullptr;
+  if (bn == 4 && !actout && f32_image_path(*args) && cn_gemm::use_f32nn128(*args)) bn = 2;
   // bit 8: the streamed dimension (rows of an activation x weight product, reduction length of a weight gradient) is
   // edge-sized; bits 10..: the other inner dimension / 16 (K of an NN product, M of a weight gradient), capped
   const long long streamed = args->a_kstrided ? args->K : args->M;
   const int inner = args->a_kstrided ? args->M : args->K;
   r.variant = (args->a_kstrided ? 1 : 0) | (args->b_kstrided ? 2 : 0) | (args->a_act ? 4 : 0) | (args->b_act ? 8 : 0) |
-              (bn << 4) | (streamed >= 32768 ? 256 : 0) | ((inner > 4080 ? 255 : inner / 16) << 10);
+              (bn << 4) | (streamed >= 32768 ? 256 : 0) | (actout ? 512 : 0) | ((inner > 4080 ? 255 : inner / 16) << 10);
   if (g_prof_only >= 0 && r.variant != g_prof_only) return cartnet_gemm_impl(args, stream);
   const int nptr = args->ngroups > 1 ? args->ngroups : args->nsegs;
   r.flops = 2.0 * args->M * args->N * (double)args->K * nptr;

@@ -34,7 +34,7 @@ def profile_gemm_read() -> dict:
     for i in range(n):
         v = buf[i].variant
         name = ("tn" if v & 1 else ("nn" if v & 2 else "nt")) + str(64 * ((v >> 4) & 15)) + \
-            ("+silu(A)" if v & 4 else "") + ("+silu(B)" if v & 8 else "") + \
+            ("+silu(A)" if v & 4 else "") + ("+out" if v & 512 else "") + ("+silu(B)" if v & 8 else "") + \
             (f"[{'E' if v & 256 else 'N'}-rows,{'M' if v & 1 else 'K'}={16 * (v >> 10)}]")
         out[name] = {"launches": int(buf[i].launches), "flops": float(buf[i].flops), "ms": float(buf[i].ms),
                      "variant": int(v)}

@@ -55,6 +55,14 @@ def main():
         else:
             m3 = re.match(r"cn_gemm::cn_gemm_f32(nn|tn)_kernel<(\w+)>", name)
             m2 = re.match(r"cn_gemm::cn_gemm_x3(nn|tn)_kernel<(\w+), (\w+)>", name)
+            m4 = re.match(r"cn_gemm::cn_gemm_f32nn128_kernel<(\w+)>", name)
+            if m4 or name == "cn_gemm::cn_gemm_f32nn_actout_kernel":
+                key = ("nn128" + ("+silu(A)" if m4.group(1) == "true" else "")) if m4 else "nn256+silu(A)+out"
+                v = variants["fp32"].setdefault(key, {"launches_profiled": 0, "fetch": 0.0, "write": 0.0})
+                v["launches_profiled"] += n
+                v["fetch"] += fetch * n
+                v["write"] += write * n
+                continue
             if m3:
                 m2 = m3
             elif not m2 or m2.group(3) == "true":
@@ -81,12 +89,15 @@ def main():
     wb, wbc = per_kernel(sys.argv[2], "WRITE_SIZE", BIG_GRID)
     for k in fb:
         name = short(k)
-        for pat, mode in ((r"cn_gemm::cn_gemm_f32nn_kernel<false>", "fp32"), (r"cn_gemm::cn_gemm_x3nn_kernel<false, false>", "x3")):
-            if name == pat and "nn256" in variants[mode]:
+        for pat, mode, key in ((r"cn_gemm::cn_gemm_f32nn_kernel<false>", "fp32", "nn256"),
+                               (r"cn_gemm::cn_gemm_f32nn128_kernel<false>", "fp32", "nn128"),
+                               (r"cn_gemm::cn_gemm_f32tn_kernel<false>", "fp32", "tn256"),
+                               (r"cn_gemm::cn_gemm_x3nn_kernel<false, false>", "x3", "nn256")):
+            if name == pat and key in variants[mode]:
                 n = fbc[k]
-                variants[mode]["nn256"]["hbm_bytes_per_launch_edge_rows"] = int(
+                variants[mode][key]["hbm_bytes_per_launch_edge_rows"] = int(
                     (2.0 * 1024.0 * fb[k] + 1024.0 * wb.get(k, 0.0)) / n)
-                variants[mode]["nn256"]["launches_profiled_edge_rows"] = n
+                variants[mode][key]["launches_profiled_edge_rows"] = n
     out["variants"] = variants
     # whole-step traffic: every dispatch of the profiled process / number of optimiser steps in it (cn_adam_kernel)
     steps = max(1, max((fc[k] for k in f if "adam" in k), default=1))

@@ -27,33 +27,38 @@ under = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).read().st
 plain = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
 rf = plain["roofline"]
 traffic = json.load(open(os.path.join(dst, "traffic.json")))
-import csv
-_x3 = traffic['variants']['x3'].get('nn256')
-x3_nn_bytes = float('nan') if not _x3 else _x3.get('hbm_bytes_per_launch_edge_rows', _x3['hbm_bytes_per_launch'])
+import csv, re
 rows = list(csv.DictReader(open(stats)))
-dom = next(r for r in rows if "cn_gemm_f32nn_kernel<false>" in r["Name"])
+kname = re.search(r"\((cn_gemm_\w+)\)", rf["kernel"]).group(1)                  # kernel behind the dominant launch group
+cands = [r for r in rows if kname in r["Name"]]
+dom = max(cands, key=lambda r: float(r["TotalDurationNs"]))
+vkey = rf["kernel"].split("variant ")[1].split(" (")[0]
+tv = traffic["variants"]["fp32"].get(vkey.split("[")[0], {})
+tbytes = tv.get("hbm_bytes_per_launch_edge_rows", tv.get("hbm_bytes_per_launch"))
 md = f"""# Round {int(tag[1:3])} — rocprofv3 `--kernel-trace --stats` of the default bench command (1x MI355X)
 
-Command (on the GPU box, `tools/collect_profiles.sh`): `cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d <out> -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --sustain-seconds 0`
+Command (on the GPU box, `tools/collect_profiles.sh`): `cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d <out> -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-recipe-pass --sustain-seconds 0`
 
 Files: `{tag}_bench_n1_kernel_stats.csv` (raw per-kernel stats), `{tag}_bench_n1_under_rocprof.json` (the bench line printed under the profiler),
-`{tag}_bench_n1.json` (un-profiled default run incl. `cpu_baseline`), `{tag}_pmc_fetch_size.csv` / `{tag}_pmc_write_size.csv` (separate `--pmc FETCH_SIZE` /
+`{tag}_bench_n1.json` (un-profiled default run incl. `cpu_baseline` and `sustained`), `{tag}_pmc_fetch_size.csv` / `{tag}_pmc_write_size.csv` (separate `--pmc FETCH_SIZE` /
 `--pmc WRITE_SIZE` passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-x3-pass`: fp32-MFMA steps only) and `traffic.json` (HBM bytes per launch per kernel derived from them by
 `tools/pmc_traffic.py`: FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is).
 
-The profiled process runs, in this order: 13 fp32-MFMA training steps on two streams (3 warm-up + 10 timed), 3 single-stream fp32 steps (the `roofline.isolated` pass) and
-12 bf16x3 steps (2 + 10, the `bf16x3` object of the bench line); kernel names tell the GEMM families apart (`cn_gemm_f32nn/f32tn_kernel`, `cn_gemm_kernel<..., 0>` = fp32 MFMA; `cn_gemm_x3nn/x3tn_kernel` = bf16x3).
+The profiled process runs, in this order: 13 fp32-MFMA training steps on two streams (3 warm-up + 10 timed), 3 single-stream fp32 steps (the `roofline.isolated` pass),
+12 bf16x3 steps (2 + 10, the `bf16x3` object of the bench line) and the eval-forward pass; kernel names tell the GEMM families apart (`cn_gemm_f32nn / f32nn128 / f32nn_actout / f32tn_kernel`,
+`cn_gemm_kernel<..., 0>` = fp32 MFMA; `cn_gemm_x3nn / x3tn_kernel` = bf16x3).
 
 Bench line under the profiler: {under['value']} graphs/s, {under['ms_per_step']} ms/step (bf16x3 pass: {under['bf16x3']['value']} graphs/s, {under['bf16x3']['ms_per_step']} ms/step).
-Un-profiled: {plain['value']} graphs/s, {plain['ms_per_step']} ms/step; bf16x3 pass {plain['bf16x3']['value']} graphs/s, {plain['bf16x3']['ms_per_step']} ms/step; cpu_baseline {plain['cpu_baseline']['value']} graphs/s on {plain['cpu_baseline']['cores']} threads.
+Un-profiled: {plain['value']} graphs/s, {plain['ms_per_step']} ms/step; sustained {plain.get('sustained', {}).get('value')} graphs/s over {plain.get('sustained', {}).get('seconds')} s; bf16x3 pass {plain['bf16x3']['value']} graphs/s, {plain['bf16x3']['ms_per_step']} ms/step; cpu_baseline {plain['cpu_baseline']['value']} graphs/s on {plain['cpu_baseline']['cores']} threads.
 
-Dominant launch group `{rf['kernel']}` = kernel `cn_gemm_f32nn_kernel<false>` (the DMA-fed fp32-MFMA kernel of `csrc/gemm_f32.h`; the few launches of that variant without a
-weight image -- none in this model at D = 256 -- would run `cn_gemm_kernel<false, true, 256, ...>`): HIP events inside bench.py give {rf['avg_launch_us']} us per launch over the
-overlapped timed steps ({rf['achieved']} TFLOP/s, {rf['frac']} of the fp32 matrix peak) and {rf['isolated']['avg_launch_us']} us isolated ({rf['isolated']['achieved']} TFLOP/s, {rf['isolated']['frac']});
-rocprofv3 reports {float(dom['AverageNs'])/1e3:.1f} us averaged over all {dom['Calls']} launches of that kernel in the process -- every shape it runs (the E-row layer GEMMs above,
-the small N-row node projections, the K = 80 first edge Linear) in the overlapped, warm-up and isolated steps alike; bench.py's average over the same set of shapes is
-{rf.get('kernel_avg_launch_us_all_shapes', 'n/a')} us in the overlapped steps (taken in warm-up steps 2-3: inside the timed steps only the dominant variant carries events) and {rf.get('kernel_avg_launch_us_all_shapes_isolated', 'n/a')} us isolated (the process mixes 13 overlapped with 3 isolated fp32 steps).  HBM traffic of that variant from the
-PMC passes: {traffic['variants']['fp32']['nn256'].get('hbm_bytes_per_launch_edge_rows', traffic['variants']['fp32']['nn256']['hbm_bytes_per_launch'])/1e6:.0f} MB per edge-sized launch (the kernel's launches with a grid of >= 500k threads: 14 per step -- the 13 of the dominant variant and the K = 80 first edge Linear; bf16x3 kernel on the same launches: {x3_nn_bytes/1e6:.0f} MB (nan: the round's PMC passes ran fp32 steps only); averaged over all launches of the kernel incl. the small node projections: {traffic['variants']['fp32']['nn256']['hbm_bytes_per_launch']/1e6:.0f} MB).  Algorithmic bytes of those launches (operands read once, outputs written once, node-term gathers at their nominal size): 543 + 724 MB (layer GEMM 1), 1086 MB (dpre), 724 MB (dE), 905 MB (encoder) -- the counted traffic is at or below it, i.e. no wasted re-reads.
+Dominant launch group (largest total time among the `cartnet_gemm` variants of the timed steps): `{rf['kernel']}`, i.e. kernel `{dom['Name'].split('(')[0]}`.
+HIP events inside bench.py give {rf['avg_launch_us']} us per launch over the overlapped timed steps ({rf['achieved']} TFLOP/s, {rf['frac']} of the fp32 matrix peak) and
+{rf.get('isolated', {}).get('avg_launch_us')} us isolated ({rf.get('isolated', {}).get('achieved')} TFLOP/s, {rf.get('isolated', {}).get('frac')});
+rocprofv3 reports {float(dom['AverageNs'])/1e3:.1f} us averaged over all {dom['Calls']} launches of that kernel in the process -- every shape it runs, in the overlapped, warm-up and
+isolated steps alike; bench.py's average over the same set of shapes is {rf.get('kernel_avg_launch_us_all_shapes', 'n/a')} us in the overlapped steps (taken in warm-up steps 2-3: inside the
+timed steps only the dominant variant carries events) and {rf.get('kernel_avg_launch_us_all_shapes_isolated', 'n/a')} us isolated (the process mixes 13 overlapped with 3 isolated fp32 steps).
+HBM traffic of that variant from the PMC passes: {(tbytes or float('nan'))/1e6:.0f} MB per launch (algorithmic: a weight-gradient product reads two [E, 256] x 2-group operands once = 726 MB;
+an activation x weight product of the layer reads [E, 256 or 512] and writes [E, 512]: 1086 MB for dpre, 724 MB for dE).
 
 Backward runs on two streams, so kernel durations of the two streams overlap in wall time (their sum exceeds the step time).
 
