@@ -1,9 +1,18 @@
 // Periodic radius graph on the GPU (reference: dataset/utils.py:57-237 radius_graph_pbc, used by
 // dataset/figshare_dataset.py:65-68).  Emits edges in the reference's order -- target atom, then source atom, then
 // periodic image in cartesian_prod(a1, a2, a3) order -- so edge_index[1] comes out sorted and feeds cartnet_csr_build
-// directly.  Two passes (count, fill), one wavefront per target atom walking its candidates 64 at a time; the order
-// inside a row comes from ballot prefix counts, so there are no atomics and the output is deterministic.
-// Arithmetic mirrors the reference's fp32 operation order with explicitly rounded (non-fused) operations.
+// directly.  Two passes (count, fill), one wavefront per target atom, one lane per source atom (64 sources per round);
+// a lane walks only the periodic images that CAN lie within the radius of its pair (see "image box" below) in the
+// reference's image order; the position of a lane's edges inside the row comes from a wave prefix sum of the lanes'
+// counts, so there are no atomics and the output is deterministic.
+// Arithmetic of the distance test mirrors the reference's fp32 operation order with explicitly rounded (non-fused)
+// operations; the image box only decides which candidates are tested, with a margin far above fp32 rounding.
+//
+// Image box.  The reference tests every image u in [-R1,R1] x [-R2,R2] x [-R3,R3] (R_d = ceil(radius |b_d|), b_d the
+// reciprocal lattice vectors) against every pair: 27-125 distance tests per pair of which a handful pass.  With
+// f_d = (p_i - p_j) . b_d the fractional offset of the pair, |f_d - u_d| = |(p_i - p_j - cell^T u) . b_d| <= d |b_d|, so an
+// image within the radius has u_d in [f_d - radius |b_d|, f_d + radius |b_d|]: at the benchmark crystals (a ~ 13 A,
+// radius 5) that is 1-2 values per axis instead of 3, ~6 tests per pair instead of 27.  Same edges, same order.
 #include "common.h"
 #include <math.h>
 
@@ -20,7 +29,8 @@ __device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b);
 __device__ __forceinline__ float sub(float a, float b) { return __fsub_rn(a, b); }
 
 // reps[g, d] = ceil(radius * |cross(a_{d+1}, a_{d+2}) / V|)   (dataset/utils.py:133-157)
-__global__ void cn_rg_reps_kernel(const float* __restrict__ cell, int Bg, float radius, int* __restrict__ reps) {
+__global__ void cn_rg_reps_kernel(const float* __restrict__ cell, int Bg, float radius, int* __restrict__ reps,
+                                  float* __restrict__ recip /* [Bg][12]: b_1, b_2, b_3, radius |b_d| */) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= Bg) return;
   const float* a = cell + (size_t)g * 9;
@@ -39,6 +49,12 @@ __global__ void cn_rg_reps_kernel(const float* __restrict__ cell, int Bg, float 
     const float x = cs[d][0] / vol, y = cs[d][1] / vol, z = cs[d][2] / vol;
     const float nrm = sqrtf(add(add(mul(x, x), mul(y, y)), mul(z, z)));
     reps[g * 3 + d] = (int)ceilf(mul(radius, nrm));
+    if (recip) {
+      recip[g * 12 + d * 3] = x;
+      recip[g * 12 + d * 3 + 1] = y;
+      recip[g * 12 + d * 3 + 2] = z;
+      recip[g * 12 + 9 + d] = radius * nrm;
+    }
   }
 }
 
@@ -46,47 +62,69 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void cn_rg_kernel(const float* __restrict__ pos, const float* __restrict__ cell,
                                                     const int64_t* __restrict__ graph_ptr,
                                                     const int64_t* __restrict__ batch, const int* __restrict__ reps,
-                                                    int N, float r2, float eps2, int* __restrict__ deg,
-                                                    const int64_t* __restrict__ rowptr, int64_t* __restrict__ ei,
-                                                    long long E, float* __restrict__ dist, float* __restrict__ dir,
-                                                    float* __restrict__ dist_sq) {
+                                                    const float* __restrict__ recip, int N, float r2, float eps2,
+                                                    int* __restrict__ deg, const int64_t* __restrict__ rowptr,
+                                                    int64_t* __restrict__ ei, long long E, float* __restrict__ dist,
+                                                    float* __restrict__ dir, float* __restrict__ dist_sq) {
   const int lane = threadIdx.x & 63;
   const int i1 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i1 >= N) return;
   const int g = (int)batch[i1];
   const int n0 = (int)graph_ptr[g], n = (int)graph_ptr[g + 1] - n0;
   const int R1 = reps[g * 3], R2 = reps[g * 3 + 1], R3 = reps[g * 3 + 2];
-  const int m2 = 2 * R2 + 1, m3 = 2 * R3 + 1;
-  const int ncells = (2 * R1 + 1) * m2 * m3;
   const float* a = cell + (size_t)g * 9;
+  const float* rb = recip + (size_t)g * 12;
   const float px = pos[(size_t)i1 * 3], py = pos[(size_t)i1 * 3 + 1], pz = pos[(size_t)i1 * 3 + 2];
-  const long long total = (long long)n * ncells;
   long long out = FILL ? rowptr[i1] : 0;
   int count = 0;
-  for (long long base = 0; base < total; base += 64) {
-    const long long cand = base + lane;
-    bool valid = false;
-    float dx = 0.f, dy = 0.f, dz = 0.f, d2 = 0.f;
-    int i2 = 0;
-    if (cand < total) {
-      i2 = (int)(cand / ncells);
-      const int c = (int)(cand - (long long)i2 * ncells);
-      const float u3 = (float)(c % m3 - R3), u2 = (float)((c / m3) % m2 - R2), u1 = (float)(c / (m3 * m2) - R1);
-      // image offset = cell^T u, accumulated as (a1 u1 + a3 u3) + a2 u2 -- the order torch.bmm uses for this 3-term sum
-      const float ox = add(add(mul(a[0], u1), mul(a[6], u3)), mul(a[3], u2));
-      const float oy = add(add(mul(a[1], u1), mul(a[7], u3)), mul(a[4], u2));
-      const float oz = add(add(mul(a[2], u1), mul(a[8], u3)), mul(a[5], u2));
+  for (int base = 0; base < n; base += 64) {
+    const int i2 = base + lane;
+    const bool have = i2 < n;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    int lo1 = 0, hi1 = -1, lo2 = 0, hi2 = -1, lo3 = 0, hi3 = -1;     // empty box for lanes past the last source
+    if (have) {
       const float* q = pos + (size_t)(n0 + i2) * 3;
-      dx = sub(px, add(q[0], ox));
-      dy = sub(py, add(q[1], oy));
-      dz = sub(pz, add(q[2], oz));
-      d2 = add(add(mul(dx, dx), mul(dy, dy)), mul(dz, dz));
-      valid = (d2 <= r2) && (d2 > eps2);
+      qx = q[0]; qy = q[1]; qz = q[2];
+      const float ex = px - qx, ey = py - qy, ez = pz - qz;
+      // fractional offset of the pair and the image interval per axis; the margin (1e-3 of a lattice step, plus 1e-5
+      // relative) is four orders above the rounding of these dot products -- it only ever ADDS candidates
+      const float f1 = ex * rb[0] + ey * rb[1] + ez * rb[2];
+      const float f2 = ex * rb[3] + ey * rb[4] + ez * rb[5];
+      const float f3 = ex * rb[6] + ey * rb[7] + ez * rb[8];
+      const float m1 = rb[9] + 1e-3f + 1e-5f * fabsf(f1), m2 = rb[10] + 1e-3f + 1e-5f * fabsf(f2),
+                  m3 = rb[11] + 1e-3f + 1e-5f * fabsf(f3);
+      lo1 = max(-R1, (int)ceilf(f1 - m1)); hi1 = min(R1, (int)floorf(f1 + m1));
+      lo2 = max(-R2, (int)ceilf(f2 - m2)); hi2 = min(R2, (int)floorf(f2 + m2));
+      lo3 = max(-R3, (int)ceilf(f3 - m3)); hi3 = min(R3, (int)floorf(f3 + m3));
     }
-    const unsigned long long m = __ballot(valid);
+    // every image of the box in cartesian_prod order (u1 slowest, u3 fastest); `emit` decides what happens to a hit
+    auto walk = [&](auto emit) {
+      for (int u1i = lo1; u1i <= hi1; ++u1i)
+        for (int u2i = lo2; u2i <= hi2; ++u2i)
+          for (int u3i = lo3; u3i <= hi3; ++u3i) {
+            const float u1 = (float)u1i, u2 = (float)u2i, u3 = (float)u3i;
+            // image offset = cell^T u, accumulated as (a1 u1 + a3 u3) + a2 u2 -- the order torch.bmm uses for this sum
+            const float ox = add(add(mul(a[0], u1), mul(a[6], u3)), mul(a[3], u2));
+            const float oy = add(add(mul(a[1], u1), mul(a[7], u3)), mul(a[4], u2));
+            const float oz = add(add(mul(a[2], u1), mul(a[8], u3)), mul(a[5], u2));
+            const float dx = sub(px, add(qx, ox)), dy = sub(py, add(qy, oy)), dz = sub(pz, add(qz, oz));
+            const float d2 = add(add(mul(dx, dx), mul(dy, dy)), mul(dz, dz));
+            if ((d2 <= r2) && (d2 > eps2)) emit(dx, dy, dz, d2);
+          }
+    };
+    int mine = 0;
+    walk([&](float, float, float, float) { ++mine; });
+    // inclusive prefix sum of the lanes' counts: lane l's edges follow those of lanes 0..l-1 (source order)
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    const int round_total = __shfl(incl, 63);
     if (FILL) {
-      if (valid) {
-        const long long p = out + __popcll(m & ((1ull << lane) - 1ull));
+      long long p = out + (incl - mine);
+      walk([&](float dx, float dy, float dz, float d2) {
         if (p < E) {
           ei[p] = (int64_t)(n0 + i2);
           ei[E + p] = (int64_t)i1;
@@ -98,10 +136,11 @@ __global__ __launch_bounds__(256) void cn_rg_kernel(const float* __restrict__ po
           dir[p * 3 + 1] = dy / dn;
           dir[p * 3 + 2] = dz / dn;
         }
-      }
-      out += __popcll(m);
+        ++p;
+      });
+      out += round_total;
     } else {
-      count += __popcll(m);
+      count += round_total;
     }
   }
   if (!FILL && lane == 0) deg[i1] = count;
@@ -191,11 +230,12 @@ extern "C" int cartnet_radius_graph_count(const float* pos, const float* cell, c
                                           int32_t* deg, void* stream) {
   CN_CHECK(N >= 0 && Bg >= 1 && radius > 0.f, "cartnet_radius_graph_count: bad sizes");
   CN_CHECK(cell && graph_ptr && reps && (N == 0 || (pos && batch && deg)), "cartnet_radius_graph_count: null pointer");
-  hipLaunchKernelGGL(cn_rg_reps_kernel, dim3(cn_ceil_div(Bg, 64)), dim3(64), 0, ST(stream), cell, Bg, radius, reps);
+  float* recip = reinterpret_cast<float*>(reps + 3 * (size_t)Bg);      // second part of the caller's [15 * Bg] buffer
+  hipLaunchKernelGGL(cn_rg_reps_kernel, dim3(cn_ceil_div(Bg, 64)), dim3(64), 0, ST(stream), cell, Bg, radius, reps, recip);
   CN_LAUNCH_CHECK("cartnet_radius_graph_count/reps");
   if (N == 0) return 0;
   hipLaunchKernelGGL(cn_rg_kernel<false>, dim3(cn_ceil_div(N, 4)), dim3(256), 0, ST(stream), pos, cell, graph_ptr, batch,
-                     reps, N, radius * radius, 0.0001f, deg, (const int64_t*)nullptr, (int64_t*)nullptr, 0LL,
+                     reps, recip, N, radius * radius, 0.0001f, deg, (const int64_t*)nullptr, (int64_t*)nullptr, 0LL,
                      (float*)nullptr, (float*)nullptr, (float*)nullptr);
   CN_LAUNCH_CHECK("cartnet_radius_graph_count");
   return 0;
@@ -209,8 +249,9 @@ extern "C" int cartnet_radius_graph_fill(const float* pos, const float* cell, co
   if (N == 0 || E == 0) return 0;
   CN_CHECK(pos && cell && graph_ptr && batch && reps && rowptr && edge_index && cart_dist && cart_dir,
            "cartnet_radius_graph_fill: null pointer");
+  const float* recip = reinterpret_cast<const float*>(reps + 3 * (size_t)Bg);
   hipLaunchKernelGGL(cn_rg_kernel<true>, dim3(cn_ceil_div(N, 4)), dim3(256), 0, ST(stream), pos, cell, graph_ptr, batch,
-                     reps, N, radius * radius, 0.0001f, (int*)nullptr, rowptr, edge_index, (long long)E, cart_dist,
+                     reps, recip, N, radius * radius, 0.0001f, (int*)nullptr, rowptr, edge_index, (long long)E, cart_dist,
                      cart_dir, cart_dist_sq);
   CN_LAUNCH_CHECK("cartnet_radius_graph_fill");
   return 0;

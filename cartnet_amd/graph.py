@@ -35,7 +35,7 @@ def radius_graph_pbc(pos: torch.Tensor, cell: torch.Tensor, ptr: torch.Tensor, r
     batch = torch.repeat_interleave(torch.arange(Bg, device=dev), ptr[1:] - ptr[:-1]).contiguous()
     if batch.numel() != N:
         raise ValueError("ptr does not cover all atoms")
-    reps = torch.empty(Bg * 3, dtype=torch.int32, device=dev)
+    reps = torch.empty(Bg * 15, dtype=torch.int32, device=dev)      # int32 [Bg,3] repetitions + fp32 [Bg,12] reciprocal lattice
     deg = torch.zeros(max(N, 1), dtype=torch.int32, device=dev)
     _l.check(lib.cartnet_radius_graph_count(pos.data_ptr(), cell.data_ptr(), ptr.data_ptr(), batch.data_ptr(), N, Bg,
                                             float(radius), reps.data_ptr(), deg.data_ptr(), _l.stream_ptr()),

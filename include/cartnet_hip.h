@@ -184,7 +184,9 @@ int cartnet_colsum_partial(const float* x, int32_t ld, int32_t R, int32_t C, dou
  * Periodic radius graph on the GPU (reference: dataset/utils.py:57-237 radius_graph_pbc as used by
  * dataset/figshare_dataset.py:65-68; pairs with d^2 <= 1e-4 dropped).  Edges come out in the
  * reference's order (target, source, periodic image), i.e. edge_index[1] ascending.
- *   count: reps[Bg,3] = periodic repetitions per lattice direction, deg[N] = in-degree of every atom.
+ *   count: reps = caller's scratch of 15 * Bg 4-byte words, kept for fill: int32 [Bg,3] periodic repetitions per
+ *          lattice direction, then fp32 [Bg,12] reciprocal lattice vectors and radius |b_d| (the per-pair image box:
+ *          only images that can lie within the radius are tested); deg[N] = in-degree of every atom.
  *   fill:  rowptr[N+1] = exclusive prefix sum of deg (int64), E = rowptr[N]; writes edge_index [2,E] (int64,
  *          row 0 source, row 1 target), cart_dist [E], cart_dir [E,3] = (pos_target - (pos_source + offset)) / dist,
  *          and, if cart_dist_sq is not NULL, the squared distances [E] the neighbour cap ranks by.
