@@ -15,6 +15,9 @@ base = Batch.from_data_list([make_crystal(5000 + i, n, adp=False) for i, n in en
 print("N", base.x.shape[0], "E", base.edge_index.shape[1], flush=True)
 model = CartNet(256, 64, 4, temperature=False, cholesky=False).to(dev).train()
 opt = FlatAdam(model, lr=1e-3)
+if "--no-overlap" in sys.argv:
+    model.overlap_weight_gradients = False
+print("weight-gradient stream:", model.overlap_weight_gradients, flush=True)
 def fresh():
     b = base.clone(); b.num_graphs = base.num_graphs; b._cartnet_layout = None; b._cartnet_mask_index = None
     return b
