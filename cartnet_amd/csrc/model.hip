@@ -660,6 +660,8 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
   float* dx_other = w.dx[1];
   float* de = nullptr;   // the head does not read the edge features
   int de_slot = 0;
+  static const int pairs_env = [] { const char* e = getenv("CARTNET_BWD_PAIRS"); return e ? atoi(e) : -1; }();
+  const bool pairs = pairs_env >= 0 ? pairs_env != 0 : m.gemm_precision >= 1;
   hipEvent_t side_done[CARTNET_MAX_LAYERS + 2];
   for (int i = 0; i < CARTNET_MAX_LAYERS + 2; ++i) side_done[i] = nullptr;
 
@@ -794,10 +796,26 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       }
       return 0;
     };
-    // (A "pairing" order -- segment sums on the side stream under de_in, dW1e deferred under the next layer's gate kernels, so
-    //  that a matrix-bound kernel always co-runs with an HBM-bound one -- measured no better: 15.27 vs 15.18 ms, same box,
-    //  interleaved; co-running kernels share the CUs at the sum of their isolated times, profiles/r02_cu_partition_experiment.md)
-    {
+    // Two orders.  fp32: the weight-gradient stream only carries parameter-gradient work; the main stream the whole chain
+    // dpre -> dE -> segment sums -> dX.  bf16x3 / bf16 (pairs): the matrix pipe is far from busy (the kernels wait on memory
+    // and barriers), the weight-gradient stream idles 45 % of the step, and dE does not depend on the segment sums -- so
+    // segment sums + the node-term weight gradients go to the side stream UNDER dE and only dX waits for them.  At fp32 the
+    // same order measured no better (15.27 vs 15.18 ms: both streams already saturate the chip).
+    if (pairs && S.dual) {
+      FORK();
+      RUN(side_w2());
+      RUN(main_dpre());
+      FORK();
+      RUN(segsums(sw));
+      hipEvent_t seg_done = S.mark_side();
+      RUN(side_wn());
+      RUN(side_w1e());
+      side_done[l] = S.mark_side();
+      if (l == L - 1) RUN(deferred_side_jobs());
+      RUN(main_de_in());
+      if (S.main_waits(seg_done) != 0) { cartnet_set_error("cartnet_model_backward: wait failed"); return 2; }
+      RUN(main_dx());
+    } else {
       FORK();
       RUN(side_w2());
       RUN(main_dpre());
