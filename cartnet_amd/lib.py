@@ -123,6 +123,7 @@ class Collated(C.Structure):
 PROTOTYPES = {
     "cartnet_last_error": (C.c_char_p, []),
     "cartnet_abi_version": (C.c_int, []),
+    "cartnet_abi_struct_sizes": (C.c_int, [C.POINTER(C.c_size_t), C.c_int32]),
     "cartnet_gemm": (C.c_int, [C.POINTER(GemmArgs), c_stream]),
     "cartnet_gemm_split_b_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "cartnet_gemm_split_b": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
@@ -254,6 +255,16 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the symbol is missing -> loud
         fn.restype = res
         fn.argtypes = args
+    # the ctypes mirrors above must have the C layouts: a mismatch would otherwise show up as a device fault
+    mirrors = [GemmArgs, Shard, Collated, GemmProfile, Groups, LayerParams, LayerBuffers, Params, Model, BatchDesc]
+    sizes = (C.c_size_t * 16)()
+    n = lib.cartnet_abi_struct_sizes(sizes, 16)
+    if n != len(mirrors):
+        raise CartnetHipError(f"{LIB_PATH}: {n} ABI structs, this binding mirrors {len(mirrors)} -- rebuild the library")
+    for cls, sz in zip(mirrors, sizes):
+        if C.sizeof(cls) != sz:
+            raise CartnetHipError(f"{LIB_PATH}: sizeof({cls.__name__}) is {sz} in the library, {C.sizeof(cls)} in "
+                                  "cartnet_amd/lib.py -- rebuild the library (python -m cartnet_amd.build)")
     _lib = lib
     return lib
 

@@ -26,6 +26,10 @@ extern "C" {
 
 const char* cartnet_last_error(void);
 int cartnet_abi_version(void);
+/* sizeof of every struct below, in header order (CartnetGemmArgs, CartnetShard, CartnetCollated, CartnetGemmProfile,
+ * CartnetGroups, CartnetLayerParams, CartnetLayerBuffers, CartnetParams, CartnetModel, CartnetBatch); returns the
+ * number of structs.  A binding checks its mirrors against these when it loads the library. */
+int cartnet_abi_struct_sizes(size_t* out, int32_t capacity);
 
 /* ------------------------------------------------------------------------------------------------------
  * Dense per-row GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 accumulate).

@@ -29,6 +29,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.load().cartnet_abi_version() == 5
 
 
+def test_ctypes_mirrors_have_the_c_struct_layouts():
+    """lib.load() compares sizeof of every struct that crosses the ABI with the library's own (cartnet_abi_struct_sizes);
+    here the same numbers once more plus two offsets that moved this round (fields appended to CartnetGemmArgs /
+    CartnetModel must sit where the C side reads them)."""
+    from cartnet_amd import lib
+    l = lib.load()
+    sizes = (ctypes.c_size_t * 16)()
+    n = l.cartnet_abi_struct_sizes(sizes, 16)
+    mirrors = [lib.GemmArgs, lib.Shard, lib.Collated, lib.GemmProfile, lib.Groups, lib.LayerParams, lib.LayerBuffers,
+               lib.Params, lib.Model, lib.BatchDesc]
+    assert n == len(mirrors)
+    assert [ctypes.sizeof(m) for m in mirrors] == list(sizes[:n])
+    assert lib.GemmArgs.a_act_out.offset + 8 * lib.MAX_GROUPS == ctypes.sizeof(lib.GemmArgs)       # last field
+    assert lib.Model.bn_allreduce.offset + 16 == ctypes.sizeof(lib.Model)                            # last two fields
+
+
 def test_host_side_argument_validation_without_gpu():
     """Shape / null checks happen on the host before any launch: callable on a machine with no GPU."""
     from cartnet_amd import lib
