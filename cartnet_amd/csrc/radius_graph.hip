@@ -24,6 +24,8 @@
 // like the reference's torch ops, and both passes evaluate the same expression.
 namespace {
 
+constexpr int CN_RG_MAX_REPS = 16;
+
 __device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ float sub(float a, float b) { return __fsub_rn(a, b); }
@@ -48,7 +50,10 @@ __global__ void cn_rg_reps_kernel(const float* __restrict__ cell, int Bg, float 
   for (int d = 0; d < 3; ++d) {
     const float x = cs[d][0] / vol, y = cs[d][1] / vol, z = cs[d][2] / vol;
     const float nrm = sqrtf(add(add(mul(x, x), mul(y, y)), mul(z, z)));
-    reps[g * 3 + d] = (int)ceilf(mul(radius, nrm));
+    // a degenerate cell (zero volume: inf / NaN here) must not become an endless image loop: repetitions are capped at
+    // CN_RG_MAX_REPS (a lattice vector shorter than radius / 16 is not a crystal), NaN gives 0
+    const float want = ceilf(mul(radius, nrm));
+    reps[g * 3 + d] = (want >= 0.f && want <= (float)CN_RG_MAX_REPS) ? (int)want : (want > (float)CN_RG_MAX_REPS ? CN_RG_MAX_REPS : 0);
     if (recip) {
       recip[g * 12 + d * 3] = x;
       recip[g * 12 + d * 3 + 1] = y;
@@ -93,9 +98,13 @@ __global__ __launch_bounds__(256) void cn_rg_kernel(const float* __restrict__ po
       const float f3 = ex * rb[6] + ey * rb[7] + ez * rb[8];
       const float m1 = rb[9] + 1e-3f + 1e-5f * fabsf(f1), m2 = rb[10] + 1e-3f + 1e-5f * fabsf(f2),
                   m3 = rb[11] + 1e-3f + 1e-5f * fabsf(f3);
-      lo1 = max(-R1, (int)ceilf(f1 - m1)); hi1 = min(R1, (int)floorf(f1 + m1));
-      lo2 = max(-R2, (int)ceilf(f2 - m2)); hi2 = min(R2, (int)floorf(f2 + m2));
-      lo3 = max(-R3, (int)ceilf(f3 - m3)); hi3 = min(R3, (int)floorf(f3 + m3));
+      // clamped in floating point before the conversion (an int conversion of inf / NaN is undefined; fmaxf / fminf
+      // drop a NaN operand, which leaves the reference's full range)
+      auto lo_of = [](float v, int R) { return (int)fminf((float)(R + 1), fmaxf((float)-R, ceilf(v))); };
+      auto hi_of = [](float v, int R) { return (int)fmaxf((float)(-R - 1), fminf((float)R, floorf(v))); };
+      lo1 = lo_of(f1 - m1, R1); hi1 = hi_of(f1 + m1, R1);
+      lo2 = lo_of(f2 - m2, R2); hi2 = hi_of(f2 + m2, R2);
+      lo3 = lo_of(f3 - m3, R3); hi3 = hi_of(f3 + m3, R3);
     }
     // every image of the box in cartesian_prod order (u1 slowest, u3 fastest); `emit` decides what happens to a hit
     auto walk = [&](auto emit) {

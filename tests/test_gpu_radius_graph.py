@@ -113,3 +113,26 @@ def test_count_and_fill_passes_agree_on_pairs_at_the_cutoff():
         assert torch.equal(mine, ref_ei), k
         assert torch.allclose(dist[sel].cpu(), ref_dist, rtol=1e-6, atol=0)          # fp32 rounding of sqrt / division
         assert torch.allclose(dirs[sel].cpu(), ref_dir, rtol=0, atol=1e-6), k
+
+
+def test_degenerate_cells_do_not_hang_or_fault():
+    """A zero-volume cell (coplanar lattice vectors), an all-zero cell and a needle-thin one: the reference divides by
+    the volume and produces inf / NaN repetition counts; here the counts are capped and the image box tolerates
+    non-finite bounds, so the call returns (whatever edges it returns) instead of looping or faulting, and a healthy
+    crystal in the same batch still gets its exact graph."""
+    from cartnet_amd.graph import radius_graph_pbc
+    from cartnet_amd.synthetic import make_geometry, radius_graph_pbc_single
+    good = make_geometry(777, 40)
+    cells = [torch.tensor([[4.0, 0, 0], [0, 4.0, 0], [4.0, 4.0, 0]]),          # coplanar: volume 0
+             torch.zeros(3, 3),
+             torch.tensor([[6.0, 0, 0], [0, 6.0, 0], [0, 0, 1e-4]]),            # needle: thousands of images wanted
+             good.cell[0]]
+    pos = [torch.rand(5, 3, generator=torch.Generator().manual_seed(i)) * 3 for i in range(3)] + [good.pos]
+    ptr = torch.tensor([0, 5, 10, 15, 15 + good.pos.shape[0]])
+    ei, dist, dirs = radius_graph_pbc(torch.cat(pos).cuda(), torch.stack(cells).cuda(), ptr.cuda(), 5.0)
+    torch.cuda.synchronize()
+    assert ei.shape[0] == 2 and dist.shape[0] == ei.shape[1]
+    sel = ei[1] >= 15
+    ref_ei, ref_dist, _ = radius_graph_pbc_single(good.pos, good.cell[0], 5.0)
+    assert torch.equal((ei[:, sel] - 15).cpu(), ref_ei)
+    assert torch.allclose(dist[sel].cpu(), ref_dist, rtol=1e-6, atol=0)
