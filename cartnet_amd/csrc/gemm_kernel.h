@@ -34,7 +34,9 @@ struct GemmFlags {
 
 // SiLU inside the GEMM uses the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each); forward and backward use the
 // same functions, so the recomputed activation in the weight-gradient GEMM equals the forward one bit for bit.
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// (__builtin_amdgcn_rcpf is the bare v_rcp_f32; __frcp_rn / 1.0f / x compile to the correctly rounded division sequence --
+//  v_div_scale, v_rcp, four FMAs, v_div_fmas, v_div_fixup -- ten VALU instructions per element in front of the MFMAs)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_silu(float x) { return x * fast_sigmoid(x); }
 __device__ __forceinline__ float fast_dsilu(float x) {
   const float s = fast_sigmoid(x);
