@@ -30,8 +30,10 @@ void cartnet_set_error(const char* fmt, ...);
     }                                                                            \
   } while (0)
 
-__device__ __forceinline__ float cn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float cn_silu(float x) { return x / (1.0f + expf(-x)); }
+// Hardware exp / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each): expf + a true division cost ~25 VALU instructions per
+// element, which the gate kernels (E x D sigmoids per layer and direction) pay while they share the chip with a GEMM.
+__device__ __forceinline__ float cn_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float cn_silu(float x) { return x * cn_sigmoid(x); }
 // d/dx [x * sigmoid(x)] = s * (1 + x * (1 - s))
 __device__ __forceinline__ float cn_dsilu(float x) {
   float s = cn_sigmoid(x);
