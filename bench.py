@@ -136,8 +136,10 @@ def main():
     ap.add_argument("--atoms", type=int, default=194)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA GEMMs, 1: bf16x3 split-operand MFMA")
+    ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA GEMMs, 1: bf16x3 split-operand MFMA, 2: plain bf16 operands")
     ap.add_argument("--no-x3-pass", action="store_true", help="skip the extra bf16x3 timed pass")
+    ap.add_argument("--half-storage", action="store_true",
+                    help="with --precision 2: the layers' edge-sized intermediates live in HBM as bf16 (CartNet.half_storage)")
     ap.add_argument("--no-recipe-pass", action="store_true",
                     help="skip the extra timed pass with BatchNorm groups of 4 (the reference recipe's micro-batches)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -185,6 +187,8 @@ def main():
         model = CartNet(dim_in=256, dim_rbf=64, num_layers=4).to(dev).train()
         model.bn_group_size = args.bn_group_size
     model.gemm_precision = args.precision
+    if args.half_storage:
+        model.half_storage = True
     opt = FlatAdam(model, lr=1e-3)
     base = build_batch(args.graphs, 100_000 + rank * args.graphs, args.atoms).to(dev)
     N, E = int(base.x.shape[0]), int(base.edge_index.shape[1])
@@ -384,7 +388,7 @@ def main():
         else "graphs/sec (CartNet 4x256, ~194 atoms/~2.8k edges), forward+backward+Adam",
         "value": round(value, 2), "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16" if args.precision == 2 else "f32", "data": "synthetic",
         "config": {"workload": (f"BASELINE configs[4]: iComformer D=256 (4 attention layers + edge-update layer, Cholesky "
                                 f"head) fp32 train step, " if icf else
                                 f"BASELINE configs[1]: CartNet L=4 D=256 R=64 fp32 train step, ") +
@@ -395,7 +399,10 @@ def main():
                                         "(reference-recipe micro-batches in one pass)") if args.bn_group_size > 0
                    else "one (the whole per-GPU batch)",
                    "gemm_precision": "fp32 MFMA" if args.precision == 0 else
-                   "bf16x3 split-operand MFMA (six bf16 MFMA products per fp32 product, fp32 accumulate) for all 256-wide GEMMs"},
+                   ("bf16x3 split-operand MFMA (six bf16 MFMA products per fp32 product, fp32 accumulate) for all 256-wide GEMMs"
+                    if args.precision == 1 else
+                    "plain bf16 MFMA operands, fp32 accumulate; " +
+                    ("bf16 storage of pre / gs / dpre" if args.half_storage else "fp32 storage"))},
         "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3),
     }
     if not icf:
@@ -447,7 +454,7 @@ def main():
                 except Exception:
                     traffic = None
             # bf16x3 kernels retire an fp32 product with six bf16 MFMAs: their ceiling is the dense bf16 peak / 6
-            peak = PEAK_FP32_MFMA_TFLOPS if args.precision == 0 else 2500.0 / 6.0
+            peak = PEAK_FP32_MFMA_TFLOPS if args.precision == 0 else (2500.0 / 6.0 if args.precision == 1 else 2500.0)
             fam = "f32" if args.precision == 0 else "x3"
             kernel_name = f"cn_gemm_{fam}{'tn' if key.startswith('tn') else 'nn'}_kernel"
             if "+out" in key:

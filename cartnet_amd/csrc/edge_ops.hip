@@ -17,6 +17,20 @@ constexpr int GATE_BATCH = 4;     // edges whose row loads are in flight togethe
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// Rows kept in memory as bf16 ("half storage", the *_h entry points): `base` then points at bf16
+// elements, `idx` counts elements either way; the arithmetic stays fp32.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <bool H>
+__device__ __forceinline__ f32x4 ldrow(const float* base, size_t idx) {
+  if constexpr (H) return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(base) + idx), f32x4);
+  else return ld4(base + idx);
+}
+template <bool H>
+__device__ __forceinline__ void strow(float* base, size_t idx, f32x4 v) {
+  if constexpr (H) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + idx) = __builtin_convertvector(v, bf16x4);
+  else st4(base + idx, v);
+}
+
 // One workgroup per FEAT_EDGES edges: the per-edge scalars (cutoff, exp(-alpha d), envelope) are computed once by
 // the first FEAT_EDGES threads and shared through LDS, so an output element costs one exp instead of two and a cos.
 constexpr int FEAT_EDGES = 64;
@@ -60,6 +74,7 @@ __global__ __launch_bounds__(256) void cn_edge_features_kernel(
 // (measured at the benchmark shape: backward pair 331 -> 288 us, segment-sum pair 150 -> 129 us).  Results do not
 // depend on the direction except for the order in which a workgroup adds its nodes into the fp64 partial sums.
 // ------------------------------------------------------------------------------------------------ gate forward
+template <bool GH>
 __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
     const float* __restrict__ gs, const float* __restrict__ e_in, const float* __restrict__ env,
     const int* __restrict__ rowptr, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
@@ -97,8 +112,8 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
 #pragma unroll
           for (int u = 0; u < GATE_BATCH; ++u) {
             const int kk = min(k + u, k1 - 1);
-            g[u] = ld4(gs + (size_t)kk * ld + c);
-            sv[u] = ld4(gs + (size_t)kk * ld + D + c);
+            g[u] = ldrow<GH>(gs, (size_t)kk * ld + c);
+            sv[u] = ldrow<GH>(gs, (size_t)kk * ld + D + c);
             ei[u] = e_out ? ld4(e_in + (size_t)kk * D + c) : f32x4{0, 0, 0, 0};
             ev[u] = env ? env[kk] : 1.0f;
           }
@@ -127,7 +142,7 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
 
 // ------------------------------------------------------------------------------------------------ gate backward
 // MODE 0: statistics (sum dbn, sum dbn*ghat).  MODE 1: apply in place (g <- dg, s <- ds) + sums of dg, ds.
-template <int MODE>
+template <int MODE, bool GH>
 __global__ __launch_bounds__(256) void cn_gate_scatter_bwd_kernel(
     float* gs, const float* __restrict__ de_out, const float* __restrict__ daggr, const float* __restrict__ env,
     const int* __restrict__ rowptr, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
@@ -170,8 +185,8 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_bwd_kernel(
       f32x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};   // fp32 over one node's edges, fp64 across nodes
 #pragma unroll 2
       for (int k = k0; k < k1; ++k) {
-        const f32x4 g = ld4(gs + (size_t)k * ld + c);
-        const f32x4 s = ld4(gs + (size_t)k * ld + D + c);
+        const f32x4 g = ldrow<GH>(gs, (size_t)k * ld + c);
+        const f32x4 s = ldrow<GH>(gs, (size_t)k * ld + D + c);
         f32x4 de = {0, 0, 0, 0};
         if (de_out) de = ld4(de_out + (size_t)k * D + c);
         const float ev = env ? env[k] : 1.0f;
@@ -193,8 +208,8 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_bwd_kernel(
           }
         }
         if (MODE == 1) {
-          st4(gs + (size_t)k * ld + c, dgv);
-          st4(gs + (size_t)k * ld + D + c, dsv);
+          strow<GH>(gs, (size_t)k * ld + c, dgv);
+          strow<GH>(gs, (size_t)k * ld + D + c, dsv);
         }
       }
       cn_acc4(ta, pa);
@@ -211,6 +226,7 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_bwd_kernel(
 // bounds and permutation entries are wave-uniform, so they travel through the scalar unit.
 constexpr int SEG_BATCH = 8;
 
+template <bool RH>
 __global__ __launch_bounds__(256) void cn_segment_sum_kernel(const float* __restrict__ rows, int ld,
                                                              const int* __restrict__ ptr,
                                                              const int* __restrict__ perm, int N, int W,
@@ -226,13 +242,12 @@ __global__ __launch_bounds__(256) void cn_segment_sum_kernel(const float* __rest
     const int c = (int)(it % chunks) * 256 + lane * 4;
     if (c >= W) continue;
     const int k0 = ptr[t], k1 = ptr[t + 1];
-    const float* __restrict__ col = rows + c;
     f32x4 acc = {0, 0, 0, 0};
     int k = k0;
     for (; k + SEG_BATCH <= k1; k += SEG_BATCH) {
       f32x4 v[SEG_BATCH];
 #pragma unroll
-      for (int u = 0; u < SEG_BATCH; ++u) v[u] = ld4(col + (size_t)(perm ? perm[k + u] : k + u) * ld);
+      for (int u = 0; u < SEG_BATCH; ++u) v[u] = ldrow<RH>(rows, (size_t)(perm ? perm[k + u] : k + u) * ld + c);
 #pragma unroll
       for (int u = 0; u < SEG_BATCH; ++u) acc += v[u];
     }
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(256) void cn_segment_sum_kernel(const float* __rest
 #pragma unroll
       for (int u = 0; u < SEG_BATCH - 1; ++u) {
         const int kk = min(k + u, k1 - 1);
-        v[u] = ld4(col + (size_t)(perm ? perm[kk] : kk) * ld);
+        v[u] = ldrow<RH>(rows, (size_t)(perm ? perm[kk] : kk) * ld + c);
       }
 #pragma unroll
       for (int u = 0; u < SEG_BATCH - 1; ++u)
@@ -366,19 +381,62 @@ extern "C" int cartnet_edge_features(const float* cart_dist, const float* cart_d
 
 extern "C" int cartnet_gate_scatter_nparts(int32_t N) { return gate_parts(N); }
 
-extern "C" int cartnet_gate_scatter_fwd(const float* gs, const float* e_in, const float* env, const int32_t* rowptr,
-                                        const float* mean_rstd, const float* gamma, const float* beta, int32_t N,
-                                        int32_t D, float* e_out, float* aggr, double* parts_sum, double* parts_sq,
-                                        const CartnetGroups* groups, void* stream) {
+static int gate_scatter_fwd_impl(bool half, const float* gs, const float* e_in, const float* env, const int32_t* rowptr,
+                                 const float* mean_rstd, const float* gamma, const float* beta, int32_t N,
+                                 int32_t D, float* e_out, float* aggr, double* parts_sum, double* parts_sq,
+                                 const CartnetGroups* groups, void* stream) {
   CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_fwd: D=%d must be a positive multiple of 4", D);
   CN_CHECK(gs && rowptr && mean_rstd && gamma && beta && aggr && parts_sum && parts_sq,
            "cartnet_gate_scatter_fwd: null pointer");
   CN_CHECK((e_in == nullptr) == (e_out == nullptr), "cartnet_gate_scatter_fwd: e_in and e_out must pair");
   CN_CHECK(cn_groups_ok(groups), "cartnet_gate_scatter_fwd: bad groups");
-  hipLaunchKernelGGL(cn_gate_scatter_fwd_kernel, cn_group_grid(groups, gate_parts(N), true), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), gs, e_in, env, rowptr, mean_rstd, gamma, beta, N, D,
-                     e_out, aggr, parts_sum, parts_sq, /*reverse=*/1, groups ? groups->node_gptr : nullptr);
+  if (half)
+    hipLaunchKernelGGL(cn_gate_scatter_fwd_kernel<true>, cn_group_grid(groups, gate_parts(N), true), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), gs, e_in, env, rowptr, mean_rstd, gamma, beta, N, D,
+                       e_out, aggr, parts_sum, parts_sq, /*reverse=*/1, groups ? groups->node_gptr : nullptr);
+  else
+    hipLaunchKernelGGL(cn_gate_scatter_fwd_kernel<false>, cn_group_grid(groups, gate_parts(N), true), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), gs, e_in, env, rowptr, mean_rstd, gamma, beta, N, D,
+                       e_out, aggr, parts_sum, parts_sq, /*reverse=*/1, groups ? groups->node_gptr : nullptr);
   CN_LAUNCH_CHECK("cartnet_gate_scatter_fwd");
+  return 0;
+}
+
+extern "C" int cartnet_gate_scatter_fwd(const float* gs, const float* e_in, const float* env, const int32_t* rowptr,
+                                        const float* mean_rstd, const float* gamma, const float* beta, int32_t N,
+                                        int32_t D, float* e_out, float* aggr, double* parts_sum, double* parts_sq,
+                                        const CartnetGroups* groups, void* stream) {
+  return gate_scatter_fwd_impl(false, gs, e_in, env, rowptr, mean_rstd, gamma, beta, N, D, e_out, aggr, parts_sum, parts_sq,
+                               groups, stream);
+}
+extern "C" int cartnet_gate_scatter_fwd_h(const void* gs_bf16, const float* e_in, const float* env, const int32_t* rowptr,
+                                          const float* mean_rstd, const float* gamma, const float* beta, int32_t N,
+                                          int32_t D, float* e_out, float* aggr, double* parts_sum, double* parts_sq,
+                                          const CartnetGroups* groups, void* stream) {
+  return gate_scatter_fwd_impl(true, static_cast<const float*>(gs_bf16), e_in, env, rowptr, mean_rstd, gamma, beta, N, D,
+                               e_out, aggr, parts_sum, parts_sq, groups, stream);
+}
+
+static int gate_scatter_bwd_stats_impl(bool half, const float* gs, const float* de_out, const float* daggr,
+                                       const float* env, const int32_t* rowptr, const float* mean_rstd,
+                                       const float* gamma, const float* beta, int32_t N, int32_t D,
+                                       double* parts_a, double* parts_b, const CartnetGroups* groups,
+                                       void* stream) {
+  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_bwd_stats: D=%d must be a multiple of 4", D);
+  CN_CHECK(gs && daggr && rowptr && mean_rstd && gamma && beta && parts_a && parts_b,
+           "cartnet_gate_scatter_bwd_stats: null pointer");
+  CN_CHECK(cn_groups_ok(groups), "cartnet_gate_scatter_bwd_stats: bad groups");
+  if (half)
+    hipLaunchKernelGGL((cn_gate_scatter_bwd_kernel<0, true>), cn_group_grid(groups, gate_parts(N), true), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), const_cast<float*>(gs), de_out, daggr, env, rowptr,
+                       mean_rstd, gamma, beta, (const float*)nullptr, 0.f, N, D, parts_a, parts_b, 0,
+                       groups ? groups->node_gptr : nullptr);
+  else
+    hipLaunchKernelGGL((cn_gate_scatter_bwd_kernel<0, false>), cn_group_grid(groups, gate_parts(N), true), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), const_cast<float*>(gs), de_out, daggr, env, rowptr,
+                       mean_rstd, gamma, beta, (const float*)nullptr, 0.f, N, D, parts_a, parts_b, 0,
+                       groups ? groups->node_gptr : nullptr);
+  CN_LAUNCH_CHECK("cartnet_gate_scatter_bwd_stats");
   return 0;
 }
 
@@ -387,15 +445,37 @@ extern "C" int cartnet_gate_scatter_bwd_stats(const float* gs, const float* de_o
                                               const float* gamma, const float* beta, int32_t N, int32_t D,
                                               double* parts_a, double* parts_b, const CartnetGroups* groups,
                                               void* stream) {
-  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_bwd_stats: D=%d must be a multiple of 4", D);
-  CN_CHECK(gs && daggr && rowptr && mean_rstd && gamma && beta && parts_a && parts_b,
-           "cartnet_gate_scatter_bwd_stats: null pointer");
-  CN_CHECK(cn_groups_ok(groups), "cartnet_gate_scatter_bwd_stats: bad groups");
-  hipLaunchKernelGGL(cn_gate_scatter_bwd_kernel<0>, cn_group_grid(groups, gate_parts(N), true), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), const_cast<float*>(gs), de_out, daggr, env, rowptr,
-                     mean_rstd, gamma, beta, (const float*)nullptr, 0.f, N, D, parts_a, parts_b, 0,
-                     groups ? groups->node_gptr : nullptr);
-  CN_LAUNCH_CHECK("cartnet_gate_scatter_bwd_stats");
+  return gate_scatter_bwd_stats_impl(false, gs, de_out, daggr, env, rowptr, mean_rstd, gamma, beta, N, D, parts_a, parts_b,
+                                     groups, stream);
+}
+extern "C" int cartnet_gate_scatter_bwd_stats_h(const void* gs_bf16, const float* de_out, const float* daggr,
+                                                const float* env, const int32_t* rowptr, const float* mean_rstd,
+                                                const float* gamma, const float* beta, int32_t N, int32_t D,
+                                                double* parts_a, double* parts_b, const CartnetGroups* groups,
+                                                void* stream) {
+  return gate_scatter_bwd_stats_impl(true, static_cast<const float*>(gs_bf16), de_out, daggr, env, rowptr, mean_rstd, gamma,
+                                     beta, N, D, parts_a, parts_b, groups, stream);
+}
+
+static int gate_scatter_bwd_apply_impl(bool half, float* gs, const float* de_out, const float* daggr, const float* env,
+                                       const int32_t* rowptr, const float* mean_rstd, const float* gamma,
+                                       const float* beta, const float* sums, int64_t E, int32_t training,
+                                       int32_t N, int32_t D, double* parts_dg, double* parts_ds,
+                                       const CartnetGroups* groups, void* stream) {
+  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_bwd_apply: D=%d must be a multiple of 4", D);
+  CN_CHECK(gs && daggr && rowptr && mean_rstd && gamma && beta && sums && parts_dg && parts_ds,
+           "cartnet_gate_scatter_bwd_apply: null pointer");
+  const float inv = (training && E > 0) ? (float)(1.0 / (double)E) : 0.f;
+  CN_CHECK(cn_groups_ok(groups), "cartnet_gate_scatter_bwd_apply: bad groups");
+  if (half)
+    hipLaunchKernelGGL((cn_gate_scatter_bwd_kernel<1, true>), cn_group_grid(groups, gate_parts(N), true), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), gs, de_out, daggr, env, rowptr, mean_rstd, gamma, beta,
+                       sums, inv, N, D, parts_dg, parts_ds, /*reverse=*/1, groups ? groups->node_gptr : nullptr);
+  else
+    hipLaunchKernelGGL((cn_gate_scatter_bwd_kernel<1, false>), cn_group_grid(groups, gate_parts(N), true), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), gs, de_out, daggr, env, rowptr, mean_rstd, gamma, beta,
+                       sums, inv, N, D, parts_dg, parts_ds, /*reverse=*/1, groups ? groups->node_gptr : nullptr);
+  CN_LAUNCH_CHECK("cartnet_gate_scatter_bwd_apply");
   return 0;
 }
 
@@ -404,20 +484,20 @@ extern "C" int cartnet_gate_scatter_bwd_apply(float* gs, const float* de_out, co
                                               const float* beta, const float* sums, int64_t E, int32_t training,
                                               int32_t N, int32_t D, double* parts_dg, double* parts_ds,
                                               const CartnetGroups* groups, void* stream) {
-  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_bwd_apply: D=%d must be a multiple of 4", D);
-  CN_CHECK(gs && daggr && rowptr && mean_rstd && gamma && beta && sums && parts_dg && parts_ds,
-           "cartnet_gate_scatter_bwd_apply: null pointer");
-  const float inv = (training && E > 0) ? (float)(1.0 / (double)E) : 0.f;
-  CN_CHECK(cn_groups_ok(groups), "cartnet_gate_scatter_bwd_apply: bad groups");
-  hipLaunchKernelGGL(cn_gate_scatter_bwd_kernel<1>, cn_group_grid(groups, gate_parts(N), true), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), gs, de_out, daggr, env, rowptr, mean_rstd, gamma, beta,
-                     sums, inv, N, D, parts_dg, parts_ds, /*reverse=*/1, groups ? groups->node_gptr : nullptr);
-  CN_LAUNCH_CHECK("cartnet_gate_scatter_bwd_apply");
-  return 0;
+  return gate_scatter_bwd_apply_impl(false, gs, de_out, daggr, env, rowptr, mean_rstd, gamma, beta, sums, E, training, N, D,
+                                     parts_dg, parts_ds, groups, stream);
+}
+extern "C" int cartnet_gate_scatter_bwd_apply_h(void* gs_bf16, const float* de_out, const float* daggr, const float* env,
+                                                const int32_t* rowptr, const float* mean_rstd, const float* gamma,
+                                                const float* beta, const float* sums, int64_t E, int32_t training,
+                                                int32_t N, int32_t D, double* parts_dg, double* parts_ds,
+                                                const CartnetGroups* groups, void* stream) {
+  return gate_scatter_bwd_apply_impl(true, static_cast<float*>(gs_bf16), de_out, daggr, env, rowptr, mean_rstd, gamma, beta,
+                                     sums, E, training, N, D, parts_dg, parts_ds, groups, stream);
 }
 
-extern "C" int cartnet_segment_sum(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t N,
-                                   int32_t W, float* out, int32_t ldo, void* stream) {
+static int segment_sum_impl(bool half, const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t N,
+                            int32_t W, float* out, int32_t ldo, void* stream) {
   CN_CHECK(N >= 0 && W >= 4 && W % 4 == 0 && ld % 4 == 0 && ldo % 4 == 0 && ld >= W && ldo >= W,
            "cartnet_segment_sum: W=%d ld=%d ldo=%d must be multiples of 4", W, ld, ldo);
   if (N == 0) return 0;
@@ -425,10 +505,23 @@ extern "C" int cartnet_segment_sum(const float* rows, int32_t ld, const int32_t*
   long long items = (long long)N * ((W + 255) / 256);
   long long blocks = (items + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;   // one item per wave up to 64k blocks
   if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(cn_segment_sum_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     rows, ld, ptr, perm, N, W, out, ldo, /*reverse=*/perm ? 1 : 0);
+  if (half)
+    hipLaunchKernelGGL(cn_segment_sum_kernel<true>, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       rows, ld, ptr, perm, N, W, out, ldo, /*reverse=*/perm ? 1 : 0);
+  else
+    hipLaunchKernelGGL(cn_segment_sum_kernel<false>, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       rows, ld, ptr, perm, N, W, out, ldo, /*reverse=*/perm ? 1 : 0);
   CN_LAUNCH_CHECK("cartnet_segment_sum");
   return 0;
+}
+
+extern "C" int cartnet_segment_sum(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t N,
+                                   int32_t W, float* out, int32_t ldo, void* stream) {
+  return segment_sum_impl(false, rows, ld, ptr, perm, N, W, out, ldo, stream);
+}
+extern "C" int cartnet_segment_sum_h(const void* rows_bf16, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t N,
+                                     int32_t W, float* out, int32_t ldo, void* stream) {
+  return segment_sum_impl(true, static_cast<const float*>(rows_bf16), ld, ptr, perm, N, W, out, ldo, stream);
 }
 
 extern "C" int cartnet_segment_sum_long(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm,

@@ -5,6 +5,7 @@
 #include <vector>
 
 namespace cn_gemm {
+thread_local bool g_half_launched = false;
 // Which DMA-fed fp32 kernel takes a prepacked activation x weight product: the 256-wide one (gemm_f32.h, two workgroups
 // per CU), or the 128-wide one (gemm_f32w128.h, three per CU) for the launches with the node-term gather epilogue (layer
 // GEMM 1) -- the one variant where a third resident workgroup pays: 402 vs 425 us sustained at the benchmark shape, the
@@ -147,7 +148,9 @@ static bool segments_fold(const CartnetGemmArgs& a) {
   bool fold = epilogue_rows_aligned(a) && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.K % cn_gemm::BK == 0 &&
               (long long)a.K * a.nsegs <= a.lda && (double)a.M * a.lda * 4.0 < 4294967296.0;
   for (int s = 0; s < a.nsegs && fold; ++s)
-    fold = a.A[s] && a.B[s] && aligned16(a.A[s]) && aligned16(a.B[s]) && a.A[s] == a.A[0] + (size_t)s * a.K;
+    fold = a.A[s] && a.B[s] && aligned16(a.A[s]) && aligned16(a.B[s]) &&
+           reinterpret_cast<const char*>(a.A[s]) ==
+               reinterpret_cast<const char*>(a.A[0]) + (size_t)s * a.K * (a.a_half ? 2 : 4);
   return fold;
 }
 
@@ -341,12 +344,24 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
       }
     }
   }
+  const bool half = cn_gemm::any_half(a);
+  if (half) {
+    CN_CHECK(a.precision == 2 && bn == 256 && a.K > 0,
+             "cartnet_gemm: a_half / b_half / c_half / dact_half need precision 2 and a 256-wide launch");
+    CN_CHECK(!a.a_act_out[0] && !(a.a_kstrided && (a.c_half || a.dact_half)) && !(!a.a_kstrided && a.b_half),
+             "cartnet_gemm: half storage: a_act_out, a bf16 weight-gradient output and a bf16 weight operand are not supported");
+    cn_gemm::g_half_launched = false;
+  }
   bool ok;
   if (bn == 256) ok = cn_gemm::launch_bn<256>(a, fl, st);
   else if (bn == 128) ok = cn_gemm::launch_bn<128>(a, fl, st);
   else ok = cn_gemm::launch_bn<64>(a, fl, st);
   CN_CHECK(ok, "cartnet_gemm: unsupported layout/activation combination (a_ks=%d b_ks=%d a_act=%d b_act=%d)",
            a.a_kstrided, a.b_kstrided, a.a_act, a.b_act);
+  CN_CHECK(!half || cn_gemm::g_half_launched,
+           "cartnet_gemm: no half-storage kernel for this launch (needs the pre-split weight image of an activation x "
+           "weight product, or a weight gradient with M %% 4 == 0; 16-byte aligned rows; a compiled operand combination: "
+           "csrc/gemm_h.hip)");
   CN_LAUNCH_CHECK("cartnet_gemm");
   return 0;
 }

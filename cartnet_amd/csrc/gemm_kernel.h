@@ -674,6 +674,11 @@ bool use_f32nn128(const CartnetGemmArgs& a);
 void launch_f32nn_actout(const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
 // gemm_x3ao.hip: the same for the pre-split bf16x3 / bf16 kernel
 void launch_x3nn_actout(const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
+// gemm_h.hip: precision 2 with operands / output stored as bf16 (CartnetGemmArgs.*_half); false = combination not compiled
+bool launch_hnn(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
+bool launch_htn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
+inline bool any_half(const CartnetGemmArgs& a) { return a.a_half || a.b_half || a.c_half || a.dact_half; }
+extern thread_local bool g_half_launched;     // set by launch_variant when a half-storage kernel took the launch
 
 template <bool A_KS, bool B_KS, int BN, bool A_ACT, bool B_ACT>
 void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
@@ -697,12 +702,16 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
         bool presplit = fl.wide && a.splitk == 1 && m0 == 0 && a.nsegs == 1 && (double)a.M * a.lda * 4.0 < 4294967296.0;
         const int nptr = a.ngroups > 1 ? a.ngroups : a.nsegs;
         for (int i = 0; i < nptr; ++i) presplit = presplit && a.b_split[i] != nullptr;
+        if (presplit && fl.x3 == 2 && any_half(a)) {
+          g_half_launched = launch_hnn(A_ACT, a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
+          return;
+        }
         if (presplit) {
           if (A_ACT && a.a_act_out[0]) launch_x3nn_actout(a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
           else launch_x3nn(A_ACT, a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
           return;
         }
-        if (fl.x3 == 1) {   // first-generation kernel (both operands split in flight); precision 2 has no such form
+        if (fl.x3 == 1 && !any_half(a)) {   // first-generation kernel (both operands split in flight); precision 2 has no such form
           hipLaunchKernelGGL((cn_gemm_kernel<A_KS, B_KS, BN, A_ACT, B_ACT, true, 1>), dim3(nm * tiles_n, ns, a.ngroups),
                              dim3(NTHREADS), 0, st, a, fl);
           return;
@@ -723,6 +732,7 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
         }
       }
     }
+    if (any_half(a)) return;      // bf16 operands: only the half-storage kernels may read them (cartnet_gemm reports it)
     hipLaunchKernelGGL((cn_gemm_kernel<A_KS, B_KS, BN, A_ACT, B_ACT, FAST, 0>), dim3(nm * tiles_n, ns, a.ngroups),
                        dim3(NTHREADS), 0, st, a, fl);
   };
@@ -733,6 +743,16 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
     // precision 0: the all-DMA fp32 kernel (gemm_f32.h), whole 128-row tiles only
     // (SiLU on the B operand stays on the register-staged kernel at precision 0: applying it to the DMA-fed
     //  fragments costs every wave 32 transcendental pairs per K-step in front of its MFMAs -- measured 15 % slower)
+    if (fl.x3 == 2 && any_half(a)) {
+      // half-storage weight gradient: one kernel over all of K (it masks a ragged last K-step itself), S slabs
+      if (a.M % 4 == 0 && fl.vecA && fl.vecB && a.nsegs == 1 && a.N % BN == 0 && a.M > 0 && a.K >= 1 &&
+          (a.splitk > 1 || fl.wide)) {
+        fl.tile_m0 = 0; fl.split0 = 0; fl.k_lo = 0; fl.k_hi = a.K;
+        fl.kchunk = round_up(cn_ceil_div(a.K, a.splitk));
+        g_half_launched = launch_htn(B_ACT, a, fl, dim3(cn_ceil_div(a.M, BM) * tiles_n, a.splitk, a.ngroups), st);
+      }
+      return;
+    }
     const bool tn_ok = fl.x3 ? (a.M % 4 == 0) : (a.M % BM == 0 && !B_ACT);
     auto launch_tn = [&](dim3 grid) {
       if (fl.x3) launch_x3tn(B_ACT, a, fl, grid, st);

@@ -127,10 +127,16 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
     eping[0] = c.take<float>(En * D);
     eping[1] = c.take<float>(En * D);
   }
+  // half storage (CartnetModel.half_storage at precision 2): pre / gs / dpre hold bf16 elements -- half the bytes, same
+  // element counts and leading dimensions; the float* members then carry bf16 pointers (see hcol below)
+  const bool half = m.half_storage != 0 && m.gemm_precision == 2;
+  auto take_edge2d = [&]() -> float* {
+    return half ? reinterpret_cast<float*>(c.take<uint16_t>(En * 2 * D)) : c.take<float>(En * 2 * D);
+  };
   for (int l = 0; l < L; ++l) {
     if (need_bwd || l == 0) {
-      w.pre[l] = c.take<float>(En * 2 * D);
-      w.gs[l] = c.take<float>(En * 2 * D);
+      w.pre[l] = take_edge2d();
+      w.gs[l] = take_edge2d();
       w.aggr[l] = c.take<float>(Nn * D);
     } else {
       w.pre[l] = w.pre[0];
@@ -207,7 +213,7 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
     w.sums2 = c.take<float>(Gn * 2 * D);
     for (int i = 0; i < 2; ++i) {   // double-buffered: the weight-gradient stream reads them while the next layer runs
       w.dPn[i] = c.take<float>(Nn * 4 * D);
-      w.dpre[i] = c.take<float>(En * 2 * D);
+      w.dpre[i] = take_edge2d();
     }
     w.dhe = c.take<float>(En * 2 * D);
     w.dx0 = c.take<float>(Nn * 2 * D);
@@ -255,6 +261,35 @@ inline CartnetGemmArgs gemm_args(int M, int N, int K, int lda, int ldb, int ldc)
   return a;
 }
 
+// the fp32 forms under the _h forms' signatures (void* for the tensor that changes its element type)
+inline int cartnet_gate_scatter_fwd_f(const void* gs, const float* e_in, const float* env, const int32_t* rowptr,
+                                      const float* mr, const float* ga, const float* be, int32_t N, int32_t D, float* e_out,
+                                      float* aggr, double* ps, double* pq, const CartnetGroups* g, void* st) {
+  return cartnet_gate_scatter_fwd(static_cast<const float*>(gs), e_in, env, rowptr, mr, ga, be, N, D, e_out, aggr, ps, pq, g, st);
+}
+inline int cartnet_gate_scatter_bwd_stats_f(const void* gs, const float* de, const float* da, const float* env,
+                                            const int32_t* rowptr, const float* mr, const float* ga, const float* be,
+                                            int32_t N, int32_t D, double* pa, double* pb, const CartnetGroups* g, void* st) {
+  return cartnet_gate_scatter_bwd_stats(static_cast<const float*>(gs), de, da, env, rowptr, mr, ga, be, N, D, pa, pb, g, st);
+}
+inline int cartnet_gate_scatter_bwd_apply_f(void* gs, const float* de, const float* da, const float* env, const int32_t* rowptr,
+                                            const float* mr, const float* ga, const float* be, const float* sums, int64_t E,
+                                            int32_t training, int32_t N, int32_t D, double* pdg, double* pds,
+                                            const CartnetGroups* g, void* st) {
+  return cartnet_gate_scatter_bwd_apply(static_cast<float*>(gs), de, da, env, rowptr, mr, ga, be, sums, E, training, N, D, pdg,
+                                        pds, g, st);
+}
+inline int cartnet_segment_sum_f(const void* rows, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t N, int32_t W,
+                                 float* out, int32_t ldo, void* st) {
+  return cartnet_segment_sum(static_cast<const float*>(rows), ld, ptr, perm, N, W, out, ldo, st);
+}
+
+// column `elems` of a row-major matrix whose elements are fp32 or (half storage) bf16
+inline float* hcol(float* p, size_t elems, bool half) {
+  return half ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(p) + elems) : p + elems;
+}
+inline const float* hcol(const float* p, size_t elems, bool half) { return hcol(const_cast<float*>(p), elems, half); }
+
 #define RUN(call)            \
   do {                       \
     int _rc = (call);        \
@@ -263,7 +298,7 @@ inline CartnetGemmArgs gemm_args(int M, int N, int K, int lda, int ldb, int ldc)
 
 // outs[g] = dY[g]^T @ (silu?)(X[g]): reduction over `K` rows, split over workgroups, slabs summed in fixed order.
 int wgrad(const float* const* dY, int ldy, const float* const* X, int ldx, float* const* outs, int ldo, long long K,
-          int M, int N, int groups, bool b_act, const Work& w, void* st) {
+          int M, int N, int groups, bool b_act, const Work& w, void* st, bool dy_half = false, bool x_half = false) {
   if (K <= 0) {   // no rows: the gradient is zero
     for (int g = 0; g < groups; ++g)
       for (int r = 0; r < M; ++r)
@@ -276,6 +311,8 @@ int wgrad(const float* const* dY, int ldy, const float* const* X, int ldx, float
   a.a_kstrided = 1;
   a.b_kstrided = 1;
   a.b_act = b_act ? 1 : 0;
+  a.a_half = dy_half ? 1 : 0;
+  a.b_half = x_half ? 1 : 0;
   a.splitk = S;
   const float* slabp[CARTNET_MAX_GROUPS];
   for (int g = 0; g < groups; ++g) {
@@ -482,6 +519,9 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     return cartnet_bn_finalize_row(w.bnrow, D, m.bn_eps, m.bn_momentum, rmean, rvar, nbt, mean_rstd, st);
   };
 
+  const bool half = m.half_storage != 0 && m.gemm_precision == 2;
+  CN_CHECK(!m.half_storage || (m.gemm_precision == 2 && !w.groups && D % 256 == 0),
+           "cartnet_model_forward: half_storage needs gemm_precision 2, D %% 256 == 0 and no BatchNorm groups");
   // ---- message-passing layers (cartnet.py:204-274)
   const float* x = w.xenc;
   const float* e = w.e0;
@@ -506,7 +546,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       a.ngroups = 2; a.b_kstrided = 1;
       a.A[0] = e; a.A[1] = e;
       a.B[0] = w.gate0T[l] + (size_t)2 * D * D; a.B[1] = w.aggr0T[l] + (size_t)2 * D * D;
-      a.C[0] = w.pre[l]; a.C[1] = w.pre[l] + D;
+      a.C[0] = w.pre[l]; a.C[1] = hcol(w.pre[l], D, half); a.c_half = half;
       a.gather_i[0] = w.Pn; a.gather_i[1] = w.Pn + D; a.gather_j[0] = w.Pn + 2 * D; a.gather_j[1] = w.Pn + 3 * D;
       a.ldg = 4 * D; a.tgt = w.tgt32; a.src = w.src32;
       if (w.i_pre[l]) { a.b_split[0] = w.i_pre[l]; a.b_split[1] = w.i_pre[l] + img_blk(m); }
@@ -515,8 +555,9 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     {  // gs = silu(pre) W2^T + b2, BatchNorm statistics of the gate half
       CartnetGemmArgs a = gemm_args(E, D, D, 2 * D, D, 2 * D);
       a.ngroups = 2; a.b_kstrided = 1; a.a_act = 1;
-      a.A[0] = w.pre[l]; a.A[1] = w.pre[l] + D; a.B[0] = w.gate2T[l]; a.B[1] = w.aggr2T[l];
-      a.C[0] = w.gs[l]; a.C[1] = w.gs[l] + D; a.bias[0] = q.gate2_b; a.bias[1] = q.aggr2_b;
+      a.A[0] = w.pre[l]; a.A[1] = hcol(w.pre[l], D, half); a.B[0] = w.gate2T[l]; a.B[1] = w.aggr2T[l];
+      a.C[0] = w.gs[l]; a.C[1] = hcol(w.gs[l], D, half); a.bias[0] = q.gate2_b; a.bias[1] = q.aggr2_b;
+      a.a_half = half; a.c_half = half;
       if (!w.groups) { a.colsum[0] = w.cs; a.colsq[0] = w.cq; }
       if (w.i_gs[l]) { a.b_split[0] = w.i_gs[l]; a.b_split[1] = w.i_gs[l] + img_blk(m); }
       if (w.act[l]) { a.a_act_out[0] = w.act[l]; a.a_act_out[1] = w.act[l] + D; }
@@ -526,8 +567,9 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     // pass of their own over the gate half of gs (181 MB at the benchmark batch, ~40 us) instead of in the epilogue
     if (w.groups && training) RUN(cartnet_colstats_grouped(w.gs[l], 2 * D, D, w.groups, w.cs, w.cq, st));
     RUN(bn_stats(w.cs, w.cq, w.tiles_e, b.E, m.buf[l].norm_mean, m.buf[l].norm_var, m.buf[l].norm_nbt, w.mr1[l], 1));
-    RUN(cartnet_gate_scatter_fwd(w.gs[l], e, m.use_envelope[l] ? w.env : nullptr, w.rowptr, w.mr1[l], q.norm_w,
-                                 q.norm_b, N, D, e_next, w.aggr[l], w.ps, w.pq, w.groups, st));
+    RUN((half ? cartnet_gate_scatter_fwd_h : cartnet_gate_scatter_fwd_f)(
+        w.gs[l], e, m.use_envelope[l] ? w.env : nullptr, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, N, D, e_next, w.aggr[l],
+        w.ps, w.pq, w.groups, st));
     RUN(bn_stats(w.ps, w.pq, w.gparts, N, m.buf[l].norm2_mean, m.buf[l].norm2_var, m.buf[l].norm2_nbt, w.mr2[l], 0));
     RUN(cartnet_node_update_fwd(w.aggr[l], x, w.mr2[l], q.norm2_w, q.norm2_b, N, D, x_next, w.groups, st));
     x = x_next;
@@ -665,6 +707,9 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
   hipEvent_t side_done[CARTNET_MAX_LAYERS + 2];
   for (int i = 0; i < CARTNET_MAX_LAYERS + 2; ++i) side_done[i] = nullptr;
 
+  const bool half = m.half_storage != 0 && m.gemm_precision == 2;
+  CN_CHECK(!m.half_storage || (m.gemm_precision == 2 && !w.groups && D % 256 == 0),
+           "cartnet_model_backward: half_storage needs gemm_precision 2, D %% 256 == 0 and no BatchNorm groups");
   // sync-BatchNorm: the sums of the BatchNorm backward over all ranks for the apply pass (pre-scaled so that the kernels'
   // division by the LOCAL row count yields sum_global / count_global); the affine gradients keep the local sums
   const bool sync_bn = training && m.bn_allreduce != nullptr;
@@ -708,8 +753,8 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     RUN(cartnet_node_update_bwd_apply(w.aggr[l], dx, w.mr2[l], q.norm2_w, q.norm2_b, w.sums2, training, N, D, w.daggr,
                                       w.groups, st));
     // gate * sender aggregation and the edge BatchNorm
-    RUN(cartnet_gate_scatter_bwd_stats(gs, de, w.daggr, env, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, N, D, w.pa, w.pb,
-                                       w.groups, st));
+    RUN((half ? cartnet_gate_scatter_bwd_stats_h : cartnet_gate_scatter_bwd_stats_f)(
+        gs, de, w.daggr, env, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, N, D, w.pa, w.pb, w.groups, st));
     if (sync_bn) {
       RUN(bn_sums_sync(w.pa, w.pb, w.gparts, b.E, w.sums1, gq.norm_b, gq.norm_w));
     } else if (w.groups) {
@@ -720,39 +765,42 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       float* grads1[2] = {gq.norm_b, gq.norm_w};
       RUN(cartnet_colsum_finalize2(parts, outs, grads1, 2, w.gparts, D, st));
     }
-    RUN(cartnet_gate_scatter_bwd_apply(gs, de, w.daggr, env, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, w.sums1, b.E,
-                                       training, N, D, w.pc[par], w.pd[par], w.groups, st));   // gs = [dg | ds]
+    RUN((half ? cartnet_gate_scatter_bwd_apply_h : cartnet_gate_scatter_bwd_apply_f)(
+        gs, de, w.daggr, env, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, w.sums1, b.E, training, N, D, w.pc[par], w.pd[par],
+        w.groups, st));   // gs = [dg | ds]
     float* de_in = w.de[de_slot];
     auto side_w2 = [&]() -> int {   // bias gradients of the second Linears, then their weight gradients
       double* parts[2] = {w.pc[par], w.pd[par]};
       float* outs[2] = {gq.gate2_b, gq.aggr2_b};
       RUN(cartnet_colsum_finalize(parts, outs, 2, w.gparts, D, sw));
-      const float* dY[2] = {gs, gs + D};
-      const bool kept = w.act[l] != nullptr;            // silu(pre) kept by the forward pass: plain operand
-      const float* X[2] = {kept ? w.act[l] : pre, (kept ? w.act[l] : pre) + D};
+      const float* dY[2] = {gs, hcol(gs, D, half)};
+      const bool kept = w.act[l] != nullptr;            // silu(pre) kept by the forward pass: plain operand (precision 0)
+      const float* X[2] = {kept ? w.act[l] : pre, hcol(kept ? w.act[l] : pre, D, half && !kept)};
       float* o[2] = {gq.gate2_w, gq.aggr2_w};
-      return wgrad(dY, 2 * D, X, 2 * D, o, D, b.E, D, D, 2, !kept, w, sw);
+      return wgrad(dY, 2 * D, X, 2 * D, o, D, b.E, D, D, 2, !kept, w, sw, half, half && !kept);
     };
     auto main_dpre = [&]() -> int {   // dpre = (dgs @ W2) * silu'(pre), into this parity's buffer
       CartnetGemmArgs a = gemm_args(E, D, D, 2 * D, D, 2 * D);
       a.ngroups = 2; a.b_kstrided = 1;
-      a.A[0] = gs; a.A[1] = gs + D; a.B[0] = q.gate2_w; a.B[1] = q.aggr2_w;
-      a.C[0] = dpre; a.C[1] = dpre + D; a.dact[0] = pre; a.dact[1] = pre + D; a.ldd = 2 * D;
+      a.A[0] = gs; a.A[1] = hcol(gs, D, half); a.B[0] = q.gate2_w; a.B[1] = q.aggr2_w;
+      a.C[0] = dpre; a.C[1] = hcol(dpre, D, half); a.dact[0] = pre; a.dact[1] = hcol(pre, D, half); a.ldd = 2 * D;
+      a.a_half = half; a.c_half = half; a.dact_half = half;
       // (no column sums here: the bias gradients of the first Linears are the column sums of dpre over all edges =
       //  the column sums over atoms of its by-target segment sums, 14x fewer rows -- taken from dPn below)
       if (w.i_dpre[l]) { a.b_split[0] = w.i_dpre[l]; a.b_split[1] = w.i_dpre[l] + img_blk(m); }
       return cartnet_gemm(&a, st);
     };
     auto side_w1e = [&]() -> int {   // edge-block weight gradients of the first Linears
-      const float* dY[2] = {dpre, dpre + D};
+      const float* dY[2] = {dpre, hcol(dpre, D, half)};
       const float* X[2] = {e_in, e_in};
       float* o[2] = {gq.gate0_w + 2 * D, gq.aggr0_w + 2 * D};
-      return wgrad(dY, 2 * D, X, D, o, 3 * D, b.E, D, D, 2, false, w, sw);
+      return wgrad(dY, 2 * D, X, D, o, 3 * D, b.E, D, D, 2, false, w, sw, half, false);
     };
     auto main_de_in = [&]() -> int {   // de_in = de_out + dpre @ W1[:, 2D:]  (layer 0: continue through the encoder's last SiLU)
       CartnetGemmArgs a = gemm_args(E, D, D, 2 * D, 3 * D, D);
       a.nsegs = 2; a.b_kstrided = 1;
-      a.A[0] = dpre; a.A[1] = dpre + D; a.B[0] = q.gate0_w + 2 * D; a.B[1] = q.aggr0_w + 2 * D;
+      a.A[0] = dpre; a.A[1] = hcol(dpre, D, half); a.B[0] = q.gate0_w + 2 * D; a.B[1] = q.aggr0_w + 2 * D;
+      a.a_half = half;
       a.C[0] = de_in; a.resid[0] = de; a.ldr = D;
       a.b_split_folded = w.i_de[l];
       if (l == 0) { a.dact[0] = w.e0_pre; a.ldd = D; a.colsum[0] = w.cs_misc[0]; }
@@ -766,8 +814,9 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     };
     // node-side halves: reduce dpre over each atom's incoming (target) and outgoing (source) edges
     auto segsums = [&](void* s_) -> int {
-      RUN(cartnet_segment_sum(dpre, 2 * D, w.rowptr, nullptr, N, 2 * D, dPn, 4 * D, s_));
-      return cartnet_segment_sum(dpre, 2 * D, w.colptr, w.perm, N, 2 * D, dPn + 2 * D, 4 * D, s_);
+      RUN((half ? cartnet_segment_sum_h : cartnet_segment_sum_f)(dpre, 2 * D, w.rowptr, nullptr, N, 2 * D, dPn, 4 * D, s_));
+      return (half ? cartnet_segment_sum_h : cartnet_segment_sum_f)(dpre, 2 * D, w.colptr, w.perm, N, 2 * D, dPn + 2 * D,
+                                                                    4 * D, s_);
     };
     auto side_wn = [&]() -> int {   // bias gradients of the first Linears = column sums of the by-target half of dPn; node blocks
       double* parts[2] = {w.pc[par], w.pd[par]};      // the second Linears' bias sums were finalised above (same stream)

@@ -41,6 +41,7 @@ class GemmArgs(C.Structure):
         ("out_act", C.c_int32), ("precision", C.c_int32),
         ("b_split", C.c_void_p * MAX_GROUPS), ("b_split_folded", C.c_void_p),
         ("a_act_out", C.c_void_p * MAX_GROUPS),
+        ("a_half", C.c_int32), ("b_half", C.c_int32), ("c_half", C.c_int32), ("dact_half", C.c_int32),
     ]
 
 
@@ -93,7 +94,7 @@ class Model(C.Structure):
                [(n, C.c_float) for n in ("radius", "env_radius", "bn_eps", "bn_momentum")] + \
                [("gemm_precision", C.c_int32), ("bn_group_size", C.c_int32)] + \
                [("rbf_means", C.c_void_p), ("rbf_betas", C.c_void_p), ("p", Params), ("buf", LayerBuffers * MAX_LAYERS),
-                ("bn_allreduce", ALLREDUCE_FN), ("bn_allreduce_user", C.c_void_p)]
+                ("bn_allreduce", ALLREDUCE_FN), ("bn_allreduce_user", C.c_void_p), ("half_storage", C.c_int32)]
 
 
 class Groups(C.Structure):
@@ -180,6 +181,15 @@ PROTOTYPES = {
                                                  c_groups, c_stream]),
     "cartnet_segment_sum": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int32,
                                       c_stream]),
+    "cartnet_segment_sum_h": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int32,
+                                        c_stream]),
+    "cartnet_gate_scatter_fwd_h": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, C.c_int32,
+                                             C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_groups, c_stream]),
+    "cartnet_gate_scatter_bwd_stats_h": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p,
+                                                   C.c_int32, C.c_int32, c_f32p, c_f32p, c_groups, c_stream]),
+    "cartnet_gate_scatter_bwd_apply_h": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p,
+                                                   c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p,
+                                                   c_groups, c_stream]),
     "cartnet_node_update_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p,
                                           c_groups, c_stream]),
     "cartnet_node_update_bwd_stats": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p,

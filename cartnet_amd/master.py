@@ -27,6 +27,8 @@ def create_model():
     model.gemm_precision = int(getattr(cfg, "gemm_precision", 0))
     if hasattr(model, "bn_group_size"):
         model.bn_group_size = int(getattr(cfg, "bn_group_size", 0))
+    if hasattr(model, "half_storage"):
+        model.half_storage = bool(getattr(cfg, "half_storage", False))
     if hasattr(model, "sync_batchnorm"):
         model.sync_batchnorm = bool(getattr(cfg, "sync_batchnorm", False))
     return model

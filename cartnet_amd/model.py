@@ -303,6 +303,9 @@ class CartNet(nn.Module):
         # (torch.distributed), so that N ranks with a shard each compute what one process would on the union batch
         # (SURVEY.md 8e "sync-BN", optional; default = per-rank statistics, the reference's single-process semantics)
         self.sync_batchnorm = False
+        # gemm_precision 2 only: pre / gs / dpre [E, 2D] of every layer are kept in the workspace as bf16 ("bf16 storage /
+        # fp32 accumulate"): half the bytes of the tensors that dominate the step's HBM traffic
+        self.half_storage = False
         self._aux_stream = None
         self._status_ring = None        # in-flight pinned copies of the batches' graph status words (_defer_graph_check)
         self._param_names = [n for n, _ in self.named_parameters()]
@@ -320,6 +323,9 @@ class CartNet(nn.Module):
         md.bn_eps, md.bn_momentum = BN_EPS, BN_MOMENTUM
         md.gemm_precision = int(self.gemm_precision)
         md.bn_group_size = int(self.bn_group_size)
+        if self.half_storage and (int(self.gemm_precision) != 2 or self.bn_group_size > 0 or self.dim_in % 256 != 0):
+            raise ValueError("half_storage needs gemm_precision = 2, dim_in % 256 == 0 and no BatchNorm groups")
+        md.half_storage = int(bool(self.half_storage))
         B = self._buffers_dict()
         md.rbf_means, md.rbf_betas = B["encoder.rbf.means"].data_ptr(), B["encoder.rbf.betas"].data_ptr()
         for n, t in P.items():

@@ -41,8 +41,10 @@ def profile_gemm_read() -> dict:
     return out
 
 
-def _f32_2d(t: Tensor, name: str) -> None:
-    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2):
+def _f32_2d(t: Tensor, name: str, half_ok: bool = False) -> None:
+    """2-D fp32 CUDA tensor with unit column stride; ``half_ok``: bf16 storage is accepted too (precision-2 GEMMs)."""
+    if not (torch.is_tensor(t) and t.is_cuda and t.dim() == 2 and
+            (t.dtype == torch.float32 or (half_ok and t.dtype == torch.bfloat16))):
         raise ValueError(f"{name}: expected a 2-D fp32 CUDA tensor, got {type(t).__name__} "
                          f"{getattr(t, 'dtype', None)} {tuple(getattr(t, 'shape', ()))} cuda={getattr(t, 'is_cuda', None)}")
     if t.shape[1] > 1 and t.stride(1) != 1:
@@ -93,8 +95,15 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
     if len(C_out) != ngroups:
         raise ValueError(f"gemm: expected {ngroups} outputs, got {len(C_out)}")
     for i, (a, b) in enumerate(zip(A, B)):
-        _f32_2d(a, f"gemm A[{i}]")
-        _f32_2d(b, f"gemm B[{i}]")
+        _f32_2d(a, f"gemm A[{i}]", half_ok=True)
+        _f32_2d(b, f"gemm B[{i}]", half_ok=True)
+
+    def is_half(ts, what):          # bf16 storage of an operand: all of its tensors or none
+        ts = [t for t in ts if t is not None]
+        n = sum(t.dtype == torch.bfloat16 for t in ts)
+        if n not in (0, len(ts)):
+            raise ValueError(f"gemm {what}: fp32 and bf16 tensors mixed")
+        return n > 0
     M, K = (A[0].shape[1], A[0].shape[0]) if a_kstrided else (A[0].shape[0], A[0].shape[1])
     N, Kb = (B[0].shape[1], B[0].shape[0]) if b_kstrided else (B[0].shape[0], B[0].shape[1])
     if K != Kb:
@@ -106,7 +115,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
             raise ValueError("gemm: all groups / segments must share shapes and leading dimensions")
     rows_c = M * splitk
     for i, c in enumerate(C_out):
-        _f32_2d(c, f"gemm C[{i}]")
+        _f32_2d(c, f"gemm C[{i}]", half_ok=True)
         if tuple(c.shape) != (rows_c, N):
             raise ValueError(f"gemm C[{i}]: expected shape {(rows_c, N)}, got {tuple(c.shape)}")
     ldc = _ld(C_out[0])
@@ -119,6 +128,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
     args.a_kstrided, args.b_kstrided = int(a_kstrided), int(b_kstrided)
     args.a_act, args.b_act, args.out_act = int(a_act), int(b_act), int(out_act)
     args.precision = int(precision)
+    args.a_half, args.b_half, args.c_half = int(is_half(A, "A")), int(is_half(B, "B")), int(is_half(C_out, "C"))
     for i in range(nptr):
         args.A[i] = A[i].data_ptr()
         args.B[i] = B[i].data_ptr()
@@ -155,7 +165,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
             if vector:
                 _vec(t, shape, f"gemm {name}[{g}]")
             else:
-                _f32_2d(t, f"gemm {name}[{g}]")
+                _f32_2d(t, f"gemm {name}[{g}]", half_ok=(name == "dact"))
                 if shape is not None and tuple(t.shape) != shape:
                     raise ValueError(f"gemm {name}[{g}]: expected shape {shape}, got {tuple(t.shape)}")
                 if ld is None:
@@ -181,7 +191,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
                 raise ValueError("gemm: gather_i / gather_j must pair up with N columns and equal row stride")
         args.tgt, args.src = tgt.data_ptr(), src.data_ptr()
     per_group("resid", resid, (M, N), "resid", "ldr")
-    per_group("dact", dact, (M, N), "dact", "ldd")
+    args.dact_half = int(is_half(per_group("dact", dact, (M, N), "dact", "ldd"), "dact"))
     cp = per_group("cpre", cpre, (M, N), "cpre")
     for t in cp:
         if t is not None and _ld(t) != ldc:

@@ -98,6 +98,12 @@ typedef struct CartnetGemmArgs {
                           by-product of staging A (each element is activated exactly once per column tile anyway); any
                           other launch runs an elementwise pass first.  The second Linear's weight gradient
                           dW = dY^T silu(pre) then reads it as a plain operand and takes the all-DMA kernel. */
+  int32_t a_half, b_half, c_half, dact_half;
+                       /* precision 2 only ("bf16 storage / fp32 accumulate"): the operand lives in
+                          memory as bf16 -- A[g] / B[g] / C[g] / dact[g] then point at bf16 elements (leading dimensions
+                          stay in ELEMENTS).  Honoured by the half-storage kernels (csrc/gemm_h.h): activation x weight
+                          products with a pre-split weight image (b_split) and weight gradients (both operands
+                          k-strided); every other launch with one of these flags set is refused. */
 } CartnetGemmArgs;
 
 int cartnet_gemm(const CartnetGemmArgs* args, void* stream);
@@ -460,10 +466,30 @@ int cartnet_gate_scatter_bwd_apply(float* gs, const float* de_out, const float* 
                                    int32_t D, double* parts_dg, double* parts_ds, const CartnetGroups* groups,
                                    void* stream);
 
+/* Half-storage forms ("bf16 storage / fp32 accumulate"; used by the model when
+ * CartnetModel.half_storage is set at gemm_precision 2): the same three kernels with gs [E, 2D] kept in memory as bf16
+ * (the apply pass writes dg / ds back as bf16); everything else -- e, aggr, sums, statistics -- stays fp32 / fp64. */
+int cartnet_gate_scatter_fwd_h(const void* gs_bf16, const float* e_in, const float* env, const int32_t* rowptr,
+                               const float* mean_rstd, const float* gamma, const float* beta, int32_t N, int32_t D,
+                               float* e_out, float* aggr, double* parts_sum, double* parts_sq,
+                               const CartnetGroups* groups, void* stream);
+int cartnet_gate_scatter_bwd_stats_h(const void* gs_bf16, const float* de_out, const float* daggr, const float* env,
+                                     const int32_t* rowptr, const float* mean_rstd, const float* gamma,
+                                     const float* beta, int32_t N, int32_t D, double* parts_a, double* parts_b,
+                                     const CartnetGroups* groups, void* stream);
+int cartnet_gate_scatter_bwd_apply_h(void* gs_bf16, const float* de_out, const float* daggr, const float* env,
+                                     const int32_t* rowptr, const float* mean_rstd, const float* gamma,
+                                     const float* beta, const float* sums, int64_t E, int32_t training, int32_t N,
+                                     int32_t D, double* parts_dg, double* parts_ds, const CartnetGroups* groups,
+                                     void* stream);
+
 /* Row-segment sums: out[t, :] = sum_{k in [ptr[t], ptr[t+1])} rows[(perm ? perm[k] : k), :]  (fixed order).
  * Backward of the two index_selects PyG performs per layer (x_i by target: perm = NULL; x_j by source: CSC). */
 int cartnet_segment_sum(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t N,
                         int32_t W, float* out, int32_t ldo, void* stream);
+/* rows kept as bf16 (ld in elements), fp32 sums */
+int cartnet_segment_sum_h(const void* rows_bf16, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t N,
+                          int32_t W, float* out, int32_t ldo, void* stream);
 /* Same sums for FEW, very uneven segments (atoms grouped by element): sorted positions [0,total) are cut into
  * 128-row chunks summed by independent wavefronts into tmp [total, W] (one partial row per run), then each segment
  * adds its partial rows in position order -- evenly loaded and still bitwise reproducible. */
@@ -569,6 +595,12 @@ typedef struct CartnetModel {
      ordered after the work already queued on `stream` and before what is queued next.  Non-zero return = error. */
   CartnetAllReduceFn bn_allreduce;
   void* bn_allreduce_user;
+  /* gemm_precision == 2 only: the three edge-sized tensors of every layer that are kept for backward / handed from
+     kernel to kernel -- pre [E, 2D], gs / dgs [E, 2D], dpre [E, 2D] -- live in the workspace as bf16 (the MFMA operands
+     are bf16 at this precision anyway; accumulation, BatchNorm statistics, the residual streams x / e and every
+     gradient of a parameter stay fp32).  SURVEY.md 8d config 3: "bf16 storage / fp32 accumulate".  Not with
+     bn_group_size (the per-group statistics pass reads gs as fp32). */
+  int32_t half_storage;
 } CartnetModel;
 
 typedef struct CartnetBatch {

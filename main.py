@@ -76,6 +76,9 @@ def build_parser() -> argparse.ArgumentParser:
                    help="run the batch x batch_accumulation micro-batches of an optimiser step as ONE pass with BatchNorm "
                         "statistics and loss per micro-batch (CartnetGroups): the reference recipe's numbers at the "
                         "large-batch rate")
+    p.add_argument("--bf16_storage", action="store_true",
+                   help="with --gemm_precision 2: keep the layers' edge-sized intermediate tensors in HBM as bf16 (fp32 "
+                        "accumulate, fp32 BatchNorm statistics)")
     p.add_argument("--sync_batchnorm", action="store_true",
                    help="data-parallel runs: BatchNorm statistics over the crystals of ALL ranks (one small all-reduce per "
                         "BatchNorm and direction) instead of per rank; CartNet only, not with --fused_accumulation")
@@ -105,6 +108,7 @@ def fill_cfg(args) -> None:
     cfg.device = args.device
     cfg.gemm_precision = args.gemm_precision
     cfg.bn_group_size = 0
+    cfg.half_storage = bool(args.bf16_storage) and cfg.model == "CartNet" and args.gemm_precision == 2
     cfg.sync_batchnorm = bool(args.sync_batchnorm) and cfg.model == "CartNet" and not args.fused_accumulation
     if args.fused_accumulation and cfg.model == "CartNet" and cfg.batch_accumulation > 1:
         # the loader hands out whole optimiser steps; the model normalises (and train_epoch averages the loss) per

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(cdll, name), f"{name} is declared in include/cartnet_hip.h but not exported"
     # the ctypes prototypes cover exactly the declared set
     assert sorted(lib.PROTOTYPES) == declared
-    assert lib.load().cartnet_abi_version() == 5
+    assert lib.load().cartnet_abi_version() == 6
 
 
 def test_ctypes_mirrors_have_the_c_struct_layouts():
@@ -41,8 +41,8 @@ def test_ctypes_mirrors_have_the_c_struct_layouts():
                lib.Params, lib.Model, lib.BatchDesc]
     assert n == len(mirrors)
     assert [ctypes.sizeof(m) for m in mirrors] == list(sizes[:n])
-    assert lib.GemmArgs.a_act_out.offset + 8 * lib.MAX_GROUPS == ctypes.sizeof(lib.GemmArgs)       # last field
-    assert lib.Model.bn_allreduce.offset + 16 == ctypes.sizeof(lib.Model)                            # last two fields
+    assert lib.GemmArgs.dact_half.offset + 4 == ctypes.sizeof(lib.GemmArgs)                         # last field
+    assert lib.Model.half_storage.offset + 8 == ctypes.sizeof(lib.Model)                             # last field + tail padding
 
 
 def test_host_side_argument_validation_without_gpu():

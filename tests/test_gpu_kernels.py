@@ -709,3 +709,104 @@ def test_adam_matches_torch(ops):
         opt.step()
         ops.adam_step(p, gstep, m, v, 1e-3, 0.9, 0.999, 1e-8, step, 1.0)
     assert rel_err(p, p_ref.data) < 1e-6
+
+
+# ---- half storage (precision 2, operands / output kept in memory as bf16: csrc/gemm_h.h)
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M", [1, 127, 300, 33000])
+def test_gemm_half_storage_activation_products(ops, M):
+    """The forms the model chains at precision 2 with bf16 storage: fp32 A -> bf16 C with node-term gathers (layer GEMM 1),
+    silu(bf16 A) -> fp32 / bf16 C with BatchNorm sums (GEMM 2), [bf16] A with silu'(bf16) -> fp32 / bf16 C (dpre), bf16 A ->
+    fp32 C with a residual (dE).  References are built from the SAME bf16-rounded operands in fp64, so what is left is the
+    bf16 rounding of the MFMA operands (weights, silu values) and of the stored output."""
+    K, N, G = 256, 256, 2
+    tol = 2e-2
+    X = rnd(M, G * K, seed=3)
+    Ws = [rnd(N, K, seed=20 + g, scale=0.1) for g in range(G)]
+    Bt = [w.t().contiguous() for w in Ws]
+    imgs = ops.split_b([w.t() for w in Ws])
+    Xs = [X[:, g * K:(g + 1) * K] for g in range(G)]
+    # (1) fp32 A -> bf16 C, gather epilogue
+    nn = 50
+    P = rnd(nn, 4 * N, seed=7)
+    g_ = torch.Generator().manual_seed(3)
+    tgt = torch.sort(torch.randint(0, nn, (M,), generator=g_)).values.to(torch.int32).to(dev())
+    src = torch.randint(0, nn, (M,), generator=g_).to(torch.int32).to(dev())
+    Ch = torch.full((M, G * N), float("nan"), device=dev(), dtype=torch.bfloat16)
+    ops.gemm(Xs, Bt, [Ch[:, :N], Ch[:, N:]], b_kstrided=True, b_split=imgs, precision=2,
+             gather_i=[P[:, :N], P[:, N:2 * N]], gather_j=[P[:, 2 * N:3 * N], P[:, 3 * N:]], tgt=tgt, src=src)
+    Pd = P.double()
+    for g in range(G):
+        ref = Xs[g].double() @ Ws[g].double().t() + Pd[tgt.long(), g * N:(g + 1) * N] + Pd[src.long(), (2 + g) * N:(3 + g) * N]
+        assert rel_err(Ch[:, g * N:(g + 1) * N].float(), ref) < tol, g
+    # (2) silu(bf16 A) -> fp32 C and -> bf16 C, with BatchNorm sums of group 0
+    Ah = _bf(X)
+    Ahs = [Ah[:, g * K:(g + 1) * K] for g in range(G)]
+    tiles = ops.gemm_tiles_m(M)
+    for out_dtype in (torch.float32, torch.bfloat16):
+        C2 = torch.full((M, G * N), float("nan"), device=dev(), dtype=out_dtype)
+        cs = torch.zeros(tiles * N, dtype=torch.float64, device=dev())
+        cq = torch.zeros(tiles * N, dtype=torch.float64, device=dev())
+        ops.gemm(Ahs, Bt, [C2[:, :N], C2[:, N:]], b_kstrided=True, b_split=imgs, precision=2, a_act=True,
+                 colsum=[cs, None], colsq=[cq, None])
+        for g in range(G):
+            ref = silu64(Ahs[g].double()) @ Ws[g].double().t()
+            assert rel_err(C2[:, g * N:(g + 1) * N].float(), ref) < tol, (g, out_dtype)
+        ref0 = silu64(Ahs[0].double()) @ Ws[0].double().t()
+        assert rel_err(cs.view(tiles, N).sum(0), ref0.sum(0)) < tol          # sums are taken before the output is rounded
+    # (3) dpre: [fp32 | bf16] A, silu'(bf16 pre) -> fp32 / bf16 C
+    pre = _bf(rnd(M, G * N, seed=9))
+    for a_half, c_half in ((False, False), (True, False), (True, True)):
+        A3 = Ah if a_half else X
+        A3s = [A3[:, g * K:(g + 1) * K] for g in range(G)]
+        C3 = torch.full((M, G * N), float("nan"), device=dev(), dtype=torch.bfloat16 if c_half else torch.float32)
+        ops.gemm(A3s, Bt, [C3[:, :N], C3[:, N:]], b_kstrided=True, b_split=imgs, precision=2,
+                 dact=[pre[:, :N], pre[:, N:]])
+        for g in range(G):
+            ref = (A3s[g].double() @ Ws[g].double().t()) * dsilu64(pre[:, g * N:(g + 1) * N].double())
+            assert rel_err(C3[:, g * N:(g + 1) * N].float(), ref) < tol, (g, a_half, c_half)
+    # (4) dE: bf16 A -> fp32 C + residual
+    resid = rnd(M, N, seed=12)
+    C4 = torch.full((M, N), float("nan"), device=dev())
+    ops.gemm(Ahs[0], Bt[0], C4, b_kstrided=True, b_split=imgs[:1], precision=2, resid=resid)
+    assert rel_err(C4, Ahs[0].double() @ Ws[0].double().t() + resid.double()) < tol
+
+
+@pytest.mark.parametrize("K", [16, 100, 4099, 40003])
+def test_gemm_half_storage_weight_gradients(ops, K):
+    """dW = dY^T (silu?)(X) with bf16 dY and / or bf16 X: whole and ragged K (the kernel masks the rows past K itself),
+    one launch and split-K slabs summed by cartnet_splitk_reduce."""
+    M, N, G = 256, 256, 2
+    tol = 2e-2
+    dY, Xm = rnd(K, G * M, seed=5), rnd(K, G * N, seed=6)
+    for a_half, b_half, act in ((False, True, True), (True, True, True), (True, False, False), (True, True, False)):
+        A = _bf(dY) if a_half else dY
+        B = _bf(Xm) if b_half else Xm
+        As = [A[:, g * M:(g + 1) * M] for g in range(G)]
+        Bs = [B[:, g * N:(g + 1) * N] for g in range(G)]
+        ref = [As[g].double().t() @ (silu64(Bs[g].double()) if act else Bs[g].double()) for g in range(G)]
+        scale = max(r.abs().max().item() for r in ref)
+        for S in (1, 4):
+            if S > 1 and K < 32:
+                continue
+            outs = [torch.full((M, N), float("nan"), device=dev()) for _ in range(G)]
+            if S == 1:
+                ops.gemm(As, Bs, outs, a_kstrided=True, b_kstrided=True, b_act=act, precision=2)
+            else:
+                slabs = [torch.full((S * M, N), float("nan"), device=dev()) for _ in range(G)]
+                ops.gemm(As, Bs, slabs, a_kstrided=True, b_kstrided=True, b_act=act, precision=2, splitk=S)
+                ops.splitk_reduce(slabs, S, outs)
+            for g in range(G):
+                assert (outs[g].double().cpu() - ref[g].cpu()).abs().max().item() < tol * scale, (a_half, b_half, act, S, g)
+
+
+def test_gemm_half_storage_is_refused_where_no_kernel_reads_it(ops):
+    X, W = rnd(300, 256, seed=1), rnd(256, 256, seed=2)
+    C_ = torch.empty(300, 256, device=dev())
+    with pytest.raises(RuntimeError, match="half"):      # precision 0
+        ops.gemm(_bf(X), W.t().contiguous(), C_, b_kstrided=True, b_split=ops.pack_b([W.t()]))
+    with pytest.raises(RuntimeError, match="half"):      # no weight image
+        ops.gemm(_bf(X), W.t().contiguous(), C_, b_kstrided=True, precision=2)

@@ -273,6 +273,62 @@ def test_bf16_mode_on_adp_config2_fixture():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
 
 
+def test_bf16_storage_on_jarvis_shapes_and_adp_fixture():
+    """BASELINE configs[2] as SURVEY.md 8d defines it -- bf16 STORAGE, fp32 accumulate (CartNet.half_storage at
+    gemm_precision 2: pre / gs / dpre of every layer live in HBM as bf16): same bf16 tolerances against the fp64 oracle
+    as the fp32-storage bf16 mode, bitwise reproducible, a smaller workspace; the configs[1]-shaped golden fixture stays
+    finite and SPD; refused at the other precisions."""
+    from cartnet_amd import lib as _lib
+    import ctypes
+    b, hp, sd = _jarvis_case()
+    names = None
+    outs = []
+    for half in (False, True):
+        m = _model(hp, sd, 2).train()
+        m.half_storage = half
+        bb = gu.clone_batch(b).to("cuda:0")
+        pred, true = m(bb)
+        (pred - true).abs().mean().backward()
+        names = [k for k, _ in m.named_parameters()]
+        outs.append((pred.detach().clone(), {k: p.grad.detach().double().cpu() for k, p in m.named_parameters()}))
+        if half:                       # bitwise reproducible
+            m.zero_grad()
+            bb2 = gu.clone_batch(b).to("cuda:0")
+            pred2, true2 = m(bb2)
+            (pred2 - true2).abs().mean().backward()
+            assert torch.equal(pred2, pred)
+            assert all(torch.equal(p.grad.double().cpu(), outs[-1][1][k]) for k, p in m.named_parameters())
+    ref, gref = _oracle_run(b, hp, sd, set(names))
+    gmax = max(v.abs().max().item() for v in gref.values())
+    for pred, got in outs:
+        gerr = max((got[k].reshape(gref[k].shape) - gref[k]).abs().max().item() for k in names) / gmax
+        assert rel_err(pred, ref) < BF16_PRED_TOL and gerr < BF16_GRAD_TOL, (rel_err(pred, ref), gerr)
+    assert not torch.equal(outs[0][0], outs[1][0]), "half storage must change the rounding somewhere"
+    # workspace: three [E, 2D] tensors per layer at half size
+    m = _model(hp, sd, 2)
+    sizes = []
+    for half in (False, True):
+        m.half_storage = half
+        md = m._model_desc(dict(m.named_parameters()))
+        sizes.append(int(_lib.load().cartnet_workspace_bytes(ctypes.byref(md), int(b.x.shape[0]), int(b.edge_index.shape[1]),
+                                                             int(b.num_graphs), 0, 1)))
+    E, D, L = int(b.edge_index.shape[1]), 256, 4
+    assert sizes[0] - sizes[1] >= (2 * L + 2) * E * 2 * D * 2 - 4096 * 16
+    # ADP fixture
+    z, hp2, b2, sd2 = gu.load("config2")
+    m2 = _model(hp2, sd2, 2).train()
+    m2.half_storage = True
+    bb = gu.clone_batch(b2).to("cuda:0")
+    pred, true = m2(bb)
+    assert rel_err(pred, torch.from_numpy(z["train_pred_f64"])) < BF16_PRED_TOL
+    assert torch.linalg.eigvalsh(pred.detach().double().cpu()).min().item() > 0
+    (pred - true).abs().mean().backward()
+    assert all(torch.isfinite(p.grad).all() for p in m2.parameters())
+    m2.gemm_precision = 1
+    with pytest.raises(ValueError, match="half_storage"):
+        m2(gu.clone_batch(b2).to("cuda:0"))
+
+
 @pytest.mark.parametrize("precision", [0, 1])
 @pytest.mark.parametrize("variant", ["invariant", "no_temperature", "no_envelope"])
 def test_model_variants_at_width_256_against_oracle(variant, precision):

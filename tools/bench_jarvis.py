@@ -26,12 +26,13 @@ def step(b):
     loss = (pred - true).abs().mean()
     loss.backward()
     opt.step(1.0); opt.zero_grad()
-for prec in (0, 1, 2):
+for prec, half in ((0, False), (1, False), (2, False), (2, True)):
     model.gemm_precision = prec
+    model.half_storage = half
     bs = [fresh() for _ in range(25)]
     for b in bs[:5]: step(b)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for b in bs[5:]: step(b)
     t_enq = time.perf_counter() - t0
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"precision {prec}: {1e3*dt/20:.3f} ms/step ({1e3*t_enq/20:.3f} ms host enqueue)  {64*20/dt:.0f} graphs/s", flush=True)
+    print(f"precision {prec}{' + bf16 storage' if half else ''}: {1e3*dt/20:.3f} ms/step ({1e3*t_enq/20:.3f} ms host enqueue)  {64*20/dt:.0f} graphs/s", flush=True)
