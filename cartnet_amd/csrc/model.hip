@@ -113,7 +113,8 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
   w.idx = c.take<int>(Nn);
   w.feat = c.take<float>(En * w.ldf);
   w.env = c.take<float>(En);
-  w.he_pre = c.take<float>(En * 2 * D);
+  w.he_pre = (m.half_storage != 0 && m.gemm_precision == 2) ? reinterpret_cast<float*>(c.take<uint16_t>(En * 2 * D))
+                                                              : c.take<float>(En * 2 * D);   // bf16 under half storage
   w.e0_pre = c.take<float>(En * D);
   w.e0 = c.take<float>(En * D);
   w.x0 = c.take<float>(Nn * 2 * D);
@@ -474,19 +475,22 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       RUN(cartnet_gemm_split_b(src.data(), dst.data(), Ks.data(), Ns.data(), sk.data(), sn.data(), (int32_t)src.size(), st));
   }
 
+  const bool half = m.half_storage != 0 && m.gemm_precision == 2;
+  CN_CHECK(!m.half_storage || (m.gemm_precision == 2 && !w.groups && D % 256 == 0),
+           "cartnet_model_forward: half_storage needs gemm_precision 2, D %% 256 == 0 and no BatchNorm groups");
   // ---- encoder, edges (cartnet.py:159)
   RUN(cartnet_edge_features(b.cart_dist, b.cart_dir, m.rbf_means, m.rbf_betas, b.E, m.R, m.invariant, m.radius,
                             m.env_radius, w.feat, w.ldf, w.env, st));
   {
     CartnetGemmArgs a = gemm_args(E, 2 * D, w.ldf, w.ldf, 2 * D, 2 * D);
     a.A[0] = w.feat; a.B[0] = w.edge0T; a.C[0] = w.he_pre; a.bias[0] = P.edge0_b; a.b_kstrided = 1;
-    a.b_split[0] = w.i_edge0;
+    a.b_split[0] = w.i_edge0; a.c_half = half;
     RUN(cartnet_gemm(&a, st));
   }
   {
     CartnetGemmArgs a = gemm_args(E, D, 2 * D, 2 * D, D, D);
     a.A[0] = w.he_pre; a.B[0] = w.edge2T; a.C[0] = w.e0; a.cpre[0] = w.e0_pre; a.bias[0] = P.edge2_b;
-    a.b_kstrided = 1; a.a_act = 1; a.out_act = 1; a.b_split[0] = w.i_edge2;
+    a.b_kstrided = 1; a.a_act = 1; a.out_act = 1; a.b_split[0] = w.i_edge2; a.a_half = half;
     if (w.he_act) a.a_act_out[0] = w.he_act;
     RUN(cartnet_gemm(&a, st));
   }
@@ -519,9 +523,6 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     return cartnet_bn_finalize_row(w.bnrow, D, m.bn_eps, m.bn_momentum, rmean, rvar, nbt, mean_rstd, st);
   };
 
-  const bool half = m.half_storage != 0 && m.gemm_precision == 2;
-  CN_CHECK(!m.half_storage || (m.gemm_precision == 2 && !w.groups && D % 256 == 0),
-           "cartnet_model_forward: half_storage needs gemm_precision 2, D %% 256 == 0 and no BatchNorm groups");
   // ---- message-passing layers (cartnet.py:204-274)
   const float* x = w.xenc;
   const float* e = w.e0;
@@ -890,9 +891,10 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     const bool kept = w.he_act != nullptr;
     const float* X[1] = {kept ? w.he_act : w.he_pre};
     float* o[1] = {G.edge2_w};
-    RUN(wgrad(dY, D, X, 2 * D, o, 2 * D, b.E, D, 2 * D, 1, !kept, w, sw));
+    RUN(wgrad(dY, D, X, 2 * D, o, 2 * D, b.E, D, 2 * D, 1, !kept, w, sw, false, half && !kept));
     CartnetGemmArgs a = gemm_args(E, 2 * D, D, D, 2 * D, 2 * D);
     a.A[0] = de; a.B[0] = P.edge2_w; a.C[0] = w.dhe; a.dact[0] = w.he_pre; a.ldd = 2 * D; a.b_kstrided = 1;
+    a.dact_half = half;
     a.b_split[0] = w.i_edge2_b;
     a.colsum[0] = w.cs_misc[2];
     RUN(cartnet_gemm(&a, st));       // dhe = d(he_pre)

@@ -596,7 +596,8 @@ typedef struct CartnetModel {
   CartnetAllReduceFn bn_allreduce;
   void* bn_allreduce_user;
   /* gemm_precision == 2 only: the three edge-sized tensors of every layer that are kept for backward / handed from
-     kernel to kernel -- pre [E, 2D], gs / dgs [E, 2D], dpre [E, 2D] -- live in the workspace as bf16 (the MFMA operands
+     kernel to kernel -- pre [E, 2D], gs / dgs [E, 2D], dpre [E, 2D] -- and the edge encoder's pre-activation [E, 2D]
+     live in the workspace as bf16 (the MFMA operands
      are bf16 at this precision anyway; accumulation, BatchNorm statistics, the residual streams x / e and every
      gradient of a parameter stay fp32).  SURVEY.md 8d config 3: "bf16 storage / fp32 accumulate".  Not with
      bn_group_size (the per-group statistics pass reads gs as fp32). */
