@@ -805,7 +805,23 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       a.C[0] = de_in; a.resid[0] = de; a.ldr = D;
       a.b_split_folded = w.i_de[l];
       if (l == 0) { a.dact[0] = w.e0_pre; a.ldd = D; a.colsum[0] = w.cs_misc[0]; }
-      RUN(cartnet_gemm(&a, st));
+      if (half && D != 256) {
+        // the two K-segments only fold into one product at N = 256 (gemm.hip: segments_fold), and no kernel reads bf16
+        // K-segments: two single-segment products instead, the second adding onto the first in place (every output
+        // element is read and written by the same thread); the layer-0 epilogue goes on the second
+        CartnetGemmArgs a1 = gemm_args(E, D, D, 2 * D, 3 * D, D);
+        a1.b_kstrided = 1; a1.a_half = 1;
+        a1.A[0] = dpre; a1.B[0] = q.gate0_w + 2 * D; a1.C[0] = de_in; a1.resid[0] = de; a1.ldr = D;
+        a1.b_split[0] = w.i_de[l];
+        RUN(cartnet_gemm(&a1, st));
+        CartnetGemmArgs a2 = a1;
+        a2.A[0] = hcol(dpre, D, true); a2.B[0] = q.aggr0_w + 2 * D; a2.resid[0] = de_in;
+        a2.b_split[0] = w.i_de[l] + img_blk(m);
+        if (l == 0) { a2.dact[0] = w.e0_pre; a2.ldd = D; a2.colsum[0] = w.cs_misc[0]; }
+        RUN(cartnet_gemm(&a2, st));
+      } else {
+        RUN(cartnet_gemm(&a, st));
+      }
       if (l == 0) {
         double* parts[1] = {w.cs_misc[0]};
         float* outs[1] = {G.edge2_b};

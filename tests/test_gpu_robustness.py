@@ -301,3 +301,49 @@ def test_optimizer_state_is_interchangeable_with_torch_adam():
     # the flat layout of round-1 checkpoints still loads
     fd.load_state_dict({"step": 7, "lr": 5e-4, "exp_avg": fd.exp_avg.clone(), "exp_avg_sq": fd.exp_avg_sq.clone()})
     assert fd.step_count == 7 and fd.lr == 5e-4
+
+
+@pytest.mark.parametrize("case", ["no_edges", "isolated_atoms_and_ragged", "width_512"])
+def test_half_storage_edge_cases(case):
+    """CartNet.half_storage (gemm_precision 2, bf16 storage): a batch without any edge, a batch with isolated atoms and a
+    ragged edge count (E % 16 != 0: the weight-gradient kernel masks its last K-step), and D = 512 (two column tiles per
+    group) -- finite, reproducible, and as close to the fp64 oracle as the same model with fp32 storage has to be."""
+    from cartnet_amd.data import Batch
+    from cartnet_amd.model import make_state_dict
+    from cartnet_amd.synthetic import make_crystal
+    D = 512 if case == "width_512" else 256
+    items = [make_crystal(70 + i, n) for i, n in enumerate((3, 1, 17, 6))]
+    if case == "no_edges":
+        for d in items:
+            d.edge_index = torch.zeros(2, 0, dtype=torch.int64)
+            d.cart_dist, d.cart_dir = torch.zeros(0), torch.zeros(0, 3)
+    elif case == "isolated_atoms_and_ragged":
+        d = items[2]                                  # drop every edge into atom 5 and one more: isolated target, odd E
+        keep = d.edge_index[1] != 5
+        keep[int(torch.nonzero(keep)[0])] = False
+        d.edge_index, d.cart_dist, d.cart_dir = d.edge_index[:, keep], d.cart_dist[keep], d.cart_dir[keep]
+    b = Batch.from_data_list(items)
+    hp = dict(dim_in=D, dim_rbf=64, num_layers=2, radius=5.0, invariant=False, temperature=True, use_envelope=True,
+              atom_types=True, cholesky=True)
+    sd = make_state_dict(D, 64, 2, seed=8)
+    res = []
+    for half in (False, True, True):
+        m = _model(hp, sd).train()
+        m.gemm_precision, m.half_storage = 2, half
+        pred, true = m(_fresh(b))
+        (pred - true).abs().mean().backward()
+        g = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+        assert torch.isfinite(pred).all() and torch.isfinite(g).all()
+        res.append((pred.detach().clone(), g.clone()))
+    assert torch.equal(res[1][0], res[2][0]) and torch.equal(res[1][1], res[2][1])
+    # both storage modes against the fp64 oracle, at the bf16 mode's tolerances (tests/test_gpu_model.py)
+    from test_gpu_model import BF16_GRAD_TOL, BF16_PRED_TOL, _oracle_run
+    names = [k for k, _ in m.named_parameters()]
+    ref, gref = _oracle_run(b, hp, sd, set(names))
+    gflat = torch.cat([gref[k].reshape(-1) for k in names]).cuda()
+    for pred, g in (res[0], res[1]):
+        assert rel_err(pred, ref) < BF16_PRED_TOL
+        # 27 atoms, MAE loss: the worst entry is a bias gradient of the aggregation branch (a column sum with heavy
+        # cancellation) -- 0.04 of the largest gradient with fp32 storage at D = 512, 0.08 with bf16 storage; twice the
+        # 64-crystal tolerance
+        assert (g.double() - gflat).abs().max().item() <= 2 * BF16_GRAD_TOL * gflat.abs().max().item()
