@@ -63,6 +63,20 @@ def test_main_at_width_256_with_bf16x3_gemms(tmp_path, monkeypatch):
         assert abs(ha["train_mae"] - hb["train_mae"]) < 1e-3 * abs(ha["train_mae"])
 
 
+def test_main_jarvis_style_run_with_bf16_storage(tmp_path, monkeypatch):
+    """BASELINE configs[2] through the CLI: scalar head (a non-ADP dataset name), no temperature, --gemm_precision 2
+    --bf16_storage.  Trains, stays finite, and follows the fp32-storage bf16 run to bf16 accuracy."""
+    import main as entry
+    monkeypatch.chdir(tmp_path)
+    common = ["--synthetic", "24", "--atoms", "2", "20", "--dim_in", "256", "--num_layers", "2", "--epochs", "2",
+              "--batch", "8", "--batch_accumulation", "1", "--lr", "1e-3", "--dataset", "jarvis", "--gemm_precision", "2"]
+    a = entry.main(common + ["--name", "p2"])
+    b = entry.main(common + ["--name", "p2h", "--bf16_storage"])
+    for ha, hb in zip(a["history"], b["history"]):
+        assert hb["train_mae"] == hb["train_mae"]                                  # finite
+        assert abs(ha["train_mae"] - hb["train_mae"]) < 5e-2 * abs(ha["train_mae"])
+
+
 def test_main_runs_ecomformer(tmp_path, monkeypatch):
     import main as entry
     monkeypatch.chdir(tmp_path)
