@@ -59,10 +59,20 @@ for sync in (False, True):
     pred, true = model(bb)
     (pred - true).abs().mean().backward()
     preds.append(pred.detach().clone()); grads.append(opt.flat_grad.clone())
+# the same exchange under the bf16 mode with bf16 storage (the statistics are taken before the output is rounded)
+model.gemm_precision, model.half_storage, model.sync_batchnorm = 2, True, True
+opt.zero_grad()
+bb = make_batch(4, 194, first=31000).to(dev)
+pred, true = model(bb)
+(pred - true).abs().mean().backward()
+half_ok = bool(torch.isfinite(pred).all() and torch.isfinite(opt.flat_grad).all() and
+               (pred - preds[0]).abs().max().item() < 3e-2 * preds[0].abs().max().item())
+model.gemm_precision, model.half_storage, model.sync_batchnorm = 0, False, False
 sync_pred = float((preds[0] - preds[1]).abs().max().item() / preds[0].abs().max().item())
 sync_grad = float((grads[0] - grads[1]).abs().max().item() / grads[0].abs().max().item())
 print(json.dumps({"backend": dist.get_backend(), "same": same, "max": t, "moved": moved,
-                  "grad_norm": float(g_before.norm().item()), "sync_pred": sync_pred, "sync_grad": sync_grad}), flush=True)
+                  "grad_norm": float(g_before.norm().item()), "sync_pred": sync_pred, "sync_grad": sync_grad,
+                  "half_sync_ok": half_ok}), flush=True)
 dist.destroy_process_group()
 '''
 
@@ -78,7 +88,7 @@ def test_rccl_world_of_one_runs_every_collective_of_the_training_step(tmp_path):
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["backend"] == "nccl" and d["same"] is True and d["max"] == 3.25
     assert d["grad_norm"] > 0 and 0 < d["moved"] <= 1.1e-3            # one Adam step at lr 1e-3 moves each weight by <= lr
-    assert d["sync_pred"] <= 1e-6 and d["sync_grad"] <= 1e-5
+    assert d["sync_pred"] <= 1e-6 and d["sync_grad"] <= 1e-5 and d["half_sync_ok"] is True
 
 
 def test_bench_starts_its_own_ranks(tmp_path):
