@@ -559,7 +559,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       a.A[0] = w.pre[l]; a.A[1] = hcol(w.pre[l], D, half); a.B[0] = w.gate2T[l]; a.B[1] = w.aggr2T[l];
       a.C[0] = w.gs[l]; a.C[1] = hcol(w.gs[l], D, half); a.bias[0] = q.gate2_b; a.bias[1] = q.aggr2_b;
       a.a_half = half; a.c_half = half;
-      if (!w.groups) { a.colsum[0] = w.cs; a.colsq[0] = w.cq; }
+      if (!w.groups && training) { a.colsum[0] = w.cs; a.colsq[0] = w.cq; }   // eval mode normalises with the running statistics
       if (w.i_gs[l]) { a.b_split[0] = w.i_gs[l]; a.b_split[1] = w.i_gs[l] + img_blk(m); }
       if (w.act[l]) { a.a_act_out[0] = w.act[l]; a.a_act_out[1] = w.act[l] + D; }
       RUN(cartnet_gemm(&a, st));
