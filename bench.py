@@ -17,6 +17,11 @@ Extra objects on the line:
                 on a bounded sample (rank 0, N = 1 only)
   sustained     >= --sustain-seconds of the same steps after the timed region (graphs/s over the whole stretch and the
                 min / max ms per step over 100-step windows): clock / thermal steady state on the record
+  telemetry     sclk / mclk / socket power / temperatures of THIS rank's card from sysfs (cartnet_amd/telemetry.py, plain
+                file reads): a snapshot before the timed region, samples every 50 ms DURING it, during the sustained
+                stretch and at its end -- so a slow box can be told from a slow build
+  calibration   the box's own ceiling for the GEMM kernel: 50 back-to-back launches of the plain two-group layer product
+                (E rows, K = N = 256) on cn_gemm_f32nn_kernel, alone on the chip, as TFLOP/s and fraction of 157.3
 """
 from __future__ import annotations
 
@@ -151,6 +156,7 @@ def main():
     ap.add_argument("--bn-group-size", type=int, default=0,
                     help="> 0: BatchNorm statistics and loss per group of this many crystals (the reference recipe's "
                          "micro-batches of 4 inside one pass, CartnetGroups); 0: one BatchNorm batch (the headline)")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the isolated plain-GEMM calibration launches")
     ap.add_argument("--sustain-seconds", type=float, default=6.0,
                     help="length of the sustained stretch after the timed region (0 disables; N = 1 only)")
     args = ap.parse_args()
@@ -236,9 +242,12 @@ def main():
         warm_summary = ops.profile_gemm_read()
         if warm_summary:
             only = warm_summary[max(warm_summary, key=lambda k: warm_summary[k]["ms"])]["variant"]
+    from cartnet_amd import telemetry as tele
+    telemetry = {"before_timed": tele.compact(tele.read(local))} if rank == 0 else None
     cdist.barrier()
     torch.cuda.synchronize()
     ops.profile_gemm(timer, only=only)
+    sampler = tele.Sampler(local).start() if rank == 0 else None
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(batches[args.warmup + i])
@@ -247,6 +256,8 @@ def main():
     cdist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if sampler is not None:
+        telemetry["during_timed"] = sampler.stop()
     ops.profile_gemm(False)
     timed_summary = ops.profile_gemm_read() if (rank == 0 and not args.no_kernel_timer) else {}
     dt = cdist.max_over_ranks(dt, dev)
@@ -256,12 +267,14 @@ def main():
     # Sustained stretch (outside the timed region, same step, same batches re-armed): long enough for the clock and
     # the power management to settle under the fp32 matrix load; windows of 100 steps are timed with one host sync each.
     sustained = None
-    if world == 1 and args.sustain_seconds > 0:
+    if args.sustain_seconds > 0:
         win = 100
-        est = max(dt / args.steps, 1e-4)
+        est = max(cdist.max_over_ranks(dt, dev) / args.steps, 1e-4)      # the same window count on every rank
         n_win = max(1, int(args.sustain_seconds / (est * win) + 0.999))
         pool = [fresh() for _ in range(4)]
         ms = []
+        sampler = tele.Sampler(local).start() if rank == 0 else None
+        cdist.barrier()
         torch.cuda.synchronize()
         ts0 = time.perf_counter()
         for wi in range(n_win):
@@ -274,9 +287,13 @@ def main():
                 step(bx)
             torch.cuda.synchronize()
             ms.append(1e3 * (time.perf_counter() - tw) / win)
-        tot = time.perf_counter() - ts0
+        if sampler is not None:
+            telemetry["during_sustained"] = sampler.stop()
+            telemetry["sustained_end"] = tele.compact(tele.read(local))
+        cdist.barrier()
+        tot = cdist.max_over_ranks(time.perf_counter() - ts0, dev)
         sustained = {"seconds": round(tot, 2), "steps": n_win * win,
-                     "value": round(args.graphs * n_win * win / tot, 2), "unit": "graphs/s",
+                     "value": round(args.graphs * world * n_win * win / tot, 2), "unit": "graphs/s",
                      "ms_per_step_min_window": round(min(ms), 3), "ms_per_step_max_window": round(max(ms), 3),
                      "ms_per_step_first_window": round(ms[0], 3), "ms_per_step_last_window": round(ms[-1], 3),
                      "window_steps": win}
@@ -296,6 +313,40 @@ def main():
         ops.profile_gemm(False)
         isolated = ops.profile_gemm_read()
         model.overlap_weight_gradients = True
+
+    # Calibration: what THIS box gives the plain GEMM kernel, alone on the chip and warm (right after the sustained
+    # stretch): the two-group layer product gs = h @ [W2g | W2a] at the benchmark's E rows, K = N = 256, weights as a
+    # DMA image -> cn_gemm_f32nn_kernel<false>, 50 launches back to back between two events on the launch stream.
+    calibration = None
+    if not args.no_calibration:
+        Dm = 256
+        gcal = torch.Generator().manual_seed(7)
+        hcal = torch.randn(E, 2 * Dm, generator=gcal).to(dev)
+        wcal = [(torch.randn(Dm, Dm, generator=gcal) * 0.05).to(dev) for _ in range(2)]
+        ocal = torch.empty(E, 2 * Dm, device=dev)
+        img = ops.pack_b(wcal)
+
+        def cal():
+            ops.gemm([hcal[:, :Dm], hcal[:, Dm:]], wcal, [ocal[:, :Dm], ocal[:, Dm:]], b_kstrided=True, b_split=img,
+                     precision=0)
+        for _ in range(150):            # ~60 ms of the same launches first: a burst from an idle card reads up to 25 % low
+            cal()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        sampler = tele.Sampler(local, period=0.005).start() if rank == 0 else None
+        ev0.record()
+        for _ in range(50):
+            cal()
+        ev1.record()
+        torch.cuda.synchronize()
+        cal_tel = sampler.stop() if sampler is not None else None
+        us = 1e3 * ev0.elapsed_time(ev1) / 50
+        fl = 2.0 * E * Dm * Dm * 2
+        calibration = {"kernel": "cn_gemm_f32nn_kernel<false>: plain two-group product [E, 256] x [256, 256] x 2, E = %d" % E,
+                       "launches": 50, "avg_launch_us": round(us, 2), "achieved": round(fl / us / 1e6, 2),
+                       "unit": "TFLOP/s", "peak": PEAK_FP32_MFMA_TFLOPS,
+                       "frac": round(fl / us / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4), "telemetry": cal_tel}
+        del hcal, ocal, img
 
     # Second timed pass with the bf16x3 split-operand GEMMs (same parity budget, every parity test runs both): the
     # same K steps bracketed the same way, reported next to the headline fp32-MFMA number, never instead of it.
@@ -454,6 +505,11 @@ def main():
                            "counted_frac": round(per_step["hbm_bytes"] / step_s / 8.0e12, 4) if per_step.get("hbm_bytes") else None}
     if sustained is not None:
         out["sustained"] = sustained
+    if telemetry is not None:
+        telemetry["end_of_run"] = tele.compact(tele.read(local))
+        out["telemetry"] = telemetry
+    if calibration is not None:
+        out["calibration"] = calibration
     if x3 is not None:
         out["bf16x3"] = x3
     if bf16s is not None:
@@ -505,6 +561,12 @@ def main():
             out["roofline"]["whole_step"] = {"gemm_flops_per_step": int(gflop),
                                              "achieved": round(gflop / step_s / 1e12, 2),
                                              "frac": round(gflop / step_s / 1e12 / peak, 4)}
+            # the same figures as scalars of `roofline` itself (a parser that keeps only scalar keys keeps them)
+            out["roofline"]["whole_step_achieved"] = out["roofline"]["whole_step"]["achieved"]
+            out["roofline"]["whole_step_frac"] = out["roofline"]["whole_step"]["frac"]
+            if calibration is not None:
+                out["roofline"]["calibration_frac"] = calibration["frac"]
+                out["roofline"]["calibration_avg_launch_us"] = calibration["avg_launch_us"]
             # all launches of the same kernel template (every shape), for comparison with rocprofv3's per-kernel average
             base = key.split("[")[0]
             same = [v for k, v in vsumm.items() if k.split("[")[0] == base]
@@ -522,6 +584,12 @@ def main():
                     "note": "same launches in 3 extra single-stream steps (no overlap with the weight-gradient stream)",
                     "achieved": round(achi, 2), "frac": round(achi / peak, 4),
                     "avg_launch_us": round(1e3 * di["ms"] / di["launches"], 2)}
+                out["roofline"]["isolated_achieved"] = out["roofline"]["isolated"]["achieved"]
+                out["roofline"]["isolated_frac"] = out["roofline"]["isolated"]["frac"]
+                out["roofline"]["isolated_avg_launch_us"] = out["roofline"]["isolated"]["avg_launch_us"]
+            if isolated:
+                # the step as the sum of its GEMM launches' isolated durations (what two streams would cost run serially)
+                out["roofline"]["isolated_gemm_ms_per_step"] = round(sum(v["ms"] for v in isolated.values()) / 3, 3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(which=args.model)
         print(json.dumps(out), flush=True)

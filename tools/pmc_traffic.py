@@ -98,6 +98,22 @@ def main():
                 variants[mode][key]["hbm_bytes_per_launch_edge_rows"] = int(
                     (2.0 * 1024.0 * fb[k] + 1024.0 * wb.get(k, 0.0)) / n)
                 variants[mode][key]["launches_profiled_edge_rows"] = n
+    # The weight-gradient kernel: split-K gives its E-row and N-row launches the same grid (512 workgroups), so the
+    # edge-sized launches are told apart by what they fetched (>= 400 MB: both operands are [E, 256] x groups); the
+    # write pass is matched launch by launch through the kernel's dispatch ORDER (same command, same sequence).
+    def per_dispatch(path, counter, kernel):
+        rows_ = [(int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(open(path))
+                 if r["Counter_Name"] == counter and short(r["Kernel_Name"]) == kernel]
+        rows_.sort()
+        return [v for _, v in rows_]
+    tnk = "cn_gemm::cn_gemm_f32tn_kernel<false>"
+    fd, wd = per_dispatch(sys.argv[1], "FETCH_SIZE", tnk), per_dispatch(sys.argv[2], "WRITE_SIZE", tnk)
+    if fd and len(fd) == len(wd) and "tn256" in variants["fp32"]:
+        big = [i for i, v in enumerate(fd) if 2.0 * 1024.0 * v >= 4.0e8]
+        if big:
+            variants["fp32"]["tn256"]["hbm_bytes_per_launch_edge_rows"] = int(
+                sum(2.0 * 1024.0 * fd[i] + 1024.0 * wd[i] for i in big) / len(big))
+            variants["fp32"]["tn256"]["launches_profiled_edge_rows"] = len(big)
     out["variants"] = variants
     # whole-step traffic: every dispatch of the profiled process / number of optimiser steps in it (cn_adam_kernel)
     steps = max(1, max((fc[k] for k in f if "adam" in k), default=1))
