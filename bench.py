@@ -590,6 +590,9 @@ def main():
             if isolated:
                 # the step as the sum of its GEMM launches' isolated durations (what two streams would cost run serially)
                 out["roofline"]["isolated_gemm_ms_per_step"] = round(sum(v["ms"] for v in isolated.values()) / 3, 3)
+                out["roofline"]["isolated_gemm_variants_us_per_launch"] = {
+                    k: round(1e3 * v["ms"] / max(1, v["launches"]), 1) for k, v in sorted(isolated.items())
+                    if v["ms"] / 3 >= 0.05}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(which=args.model)
         print(json.dumps(out), flush=True)

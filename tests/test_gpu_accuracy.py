@@ -118,6 +118,7 @@ def test_gemm_stress_operands_both_precisions(ops, case, form, M, K, N):
     e = {p: comp_err_u(run(ops, A, B, p), A64, B64, ref) for p in (0, 1)}
     # the error of a K-term fp32 dot product grows at most like K u (typically sqrt(K) u); both precisions are far below
     bound = BOUND_U * max(1.0, math.sqrt(K / 512.0))
+    print(f"ACCURACY {case:26s} {form:10s} M={M:6d} K={K:5d} N={N:4d}  fp32 MFMA {e[0]:7.2f} u   bf16x3 {e[1]:7.2f} u")
     assert e[0] < bound, (case, form, e)
     assert e[1] < bound, (case, form, e)
     assert e[1] <= 2.0 * e[0] + 1.0, (case, form, e)      # bf16x3 never worse than 2x the fp32 MFMA (+1 u of slack)
@@ -133,6 +134,7 @@ def test_gemm_denormal_low_pieces_are_a_documented_limit(ops):
     ref = A64 @ B64
     e0 = comp_err_u(run_nn_image(ops, A, B, 0), A64, B64, ref)
     e1 = comp_err_u(run_nn_image(ops, A, B, 1), A64, B64, ref)
+    print(f"ACCURACY denormal low pieces: fp32 MFMA {e0:.2f} u, bf16x3 {e1:.2f} u")
     assert e0 < BOUND_U
     assert e1 < 2.0 ** 10, (e0, e1)      # <= 2^-14 relative to sum |a||b|: two pieces always survive
 
@@ -209,12 +211,17 @@ def test_gate_sigmoid_edge_values(ops):
     v = torch.tensor(EDGE + [0.0] * (D - len(EDGE)))
     N, deg = 5, 3
     E = N * deg
+    tgt = torch.arange(N).repeat_interleave(deg)
+    ei = torch.stack([(tgt + 1) % N, tgt]).to(dev())                     # sorted by target, `deg` edges each
+    lay = ops.GraphLayout(ei, N, torch.tensor([0, N], dtype=torch.int64, device=dev()))
     gs = torch.cat([v.expand(E, D), torch.ones(E, D)], dim=1).contiguous().to(dev())
     e_in = torch.zeros(E, D, device=dev())
-    rowptr = torch.arange(0, E + 1, deg, dtype=torch.int32, device=dev())
     mr = torch.cat([torch.zeros(D), torch.ones(D)]).to(dev())
     ga, be = torch.ones(D, device=dev()), torch.zeros(D, device=dev())
-    e_out, aggr, _, _ = ops.gate_scatter_fwd(gs, e_in, None, rowptr, mr, ga, be)
+    e_out, aggr = torch.empty(E, D, device=dev()), torch.empty(N, D, device=dev())
+    nparts = ops.gate_nparts(N)
+    ps, pq = (torch.zeros(nparts * D, dtype=torch.float64, device=dev()) for _ in range(2))
+    ops.gate_scatter_fwd(gs, e_in, None, lay, mr, ga, be, e_out, aggr, ps, pq)
     want = torch.sigmoid(v.double()).float()
     ok, pair = same_special(e_out, want.expand(E, D), atol=1e-30)
     assert ok, pair

@@ -126,6 +126,53 @@ def test_train_step_gradients_and_bn_state_against_reference_golden(name, precis
             assert int(got) == int(ref), k
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("name", ["tiny_adp", "config1"])
+def test_mse_loss_train_step_against_the_oracle(name, precision):
+    """cfg.loss = "MSE" (reference train/train.py:173-178 picks the loss by name, train/metrics.py:27 is MSELoss with mean
+    reduction): one iteration of cartnet_amd.train.train_epoch on the fixture's batch -- forward, compute_loss, the
+    configured loss, backward, optimiser boundary -- against the fp64 oracle's autograd of the same loss."""
+    from cartnet_amd.config import cfg
+    from cartnet_amd.train import train_epoch
+    from oracle import cartnet_ref as orc
+    z, hp, b, sd = gu.load(name)
+    m = _model(hp, sd, precision).train()
+
+    class Capture:                      # stands where the optimiser stands: keeps what the step would consume
+        def __init__(self):
+            self.grads, self.steps = None, 0
+
+        def zero_grad(self):
+            m.zero_grad(set_to_none=True)
+
+        def step(self):
+            self.grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+            self.steps += 1
+    opt = Capture()
+    old = cfg.loss
+    cfg.loss = "MSE"
+    try:
+        stats = train_epoch([gu.clone_batch(b)], m, opt, batch_accumulation=1)
+    finally:
+        cfg.loss = old
+    assert opt.steps == 1 and stats["graphs"] == b.num_graphs
+
+    sd64 = {k: (v.double().requires_grad_(k in opt.grads) if v.is_floating_point() else v) for k, v in sd.items()}
+    b64 = gu.clone_batch(b)
+    for k, v in list(b64.__dict__.items()):
+        if torch.is_tensor(v) and v.is_floating_point():
+            setattr(b64, k, v.double())
+    ref = orc.cartnet_forward(sd64, b64, training=True, **gu.oracle_kwargs(hp))
+    mse = ((ref - b64.y) ** 2).mean()
+    mse.backward()
+    assert abs(stats["mae"] - (ref - b64.y).abs().mean().item()) < 1e-5 * (ref - b64.y).abs().mean().item()
+    _check_grads(opt.grads, {k: sd64[k].grad for k in opt.grads}, f"MSE {name}")
+    # and it is NOT the MAE gradient (the loss switch is live): the two differ by far more than the tolerance
+    gmae = torch.from_numpy(z["grad64_" + next(iter(opt.grads))])
+    g0 = opt.grads[next(iter(opt.grads))].double().cpu()
+    assert (g0 - gmae).abs().max().item() > 1e-3 * gmae.abs().max().item()
+
+
 @pytest.mark.parametrize("seed,n_graphs,dim,layers,cholesky", [(0, 5, 32, 3, True), (1, 3, 128, 1, True),
                                                                (2, 6, 32, 2, False)])
 def test_against_oracle_on_ragged_batches(seed, n_graphs, dim, layers, cholesky):

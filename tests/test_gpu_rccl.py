@@ -68,11 +68,33 @@ pred, true = model(bb)
 half_ok = bool(torch.isfinite(pred).all() and torch.isfinite(opt.flat_grad).all() and
                (pred - preds[0]).abs().max().item() < 3e-2 * preds[0].abs().max().item())
 model.gemm_precision, model.half_storage, model.sync_batchnorm = 0, False, False
+# train_epoch with the reference recipe carried as BatchNorm groups (main.py --fused_accumulation: micro-batches of 4 inside
+# a batch of 8), three optimiser steps, every gradient all-reduce through librccl (train/train.py:186-189)
+from cartnet_amd.data import DataLoader
+from cartnet_amd.synthetic import make_crystal
+from cartnet_amd.train import train_epoch
+cfg.loss = "MAE"
+model.bn_group_size = 4
+items = [make_crystal(33000 + i, 20 + (i % 5)) for i in range(24)]
+loader = DataLoader(items, 8, shuffle=True, seed=1)
+calls = []
+_orig = cdist.all_reduce_gradients
+def _counting(flat):
+    calls.append(int(flat.numel()))
+    return _orig(flat)
+cdist.all_reduce_gradients = _counting
+p0 = opt.flat_param.clone()
+stats = train_epoch(loader, model, opt, batch_accumulation=1, device=dev)
+cdist.all_reduce_gradients = _orig
+cdist.assert_replicas_in_sync(model)
+model.bn_group_size = 0
+fused = {"steps": len(calls), "graphs": stats["graphs"], "finite": bool(torch.isfinite(opt.flat_param).all()),
+         "moved": float((opt.flat_param - p0).abs().max().item()), "mae": stats["mae"]}
 sync_pred = float((preds[0] - preds[1]).abs().max().item() / preds[0].abs().max().item())
 sync_grad = float((grads[0] - grads[1]).abs().max().item() / grads[0].abs().max().item())
 print(json.dumps({"backend": dist.get_backend(), "same": same, "max": t, "moved": moved,
                   "grad_norm": float(g_before.norm().item()), "sync_pred": sync_pred, "sync_grad": sync_grad,
-                  "half_sync_ok": half_ok}), flush=True)
+                  "half_sync_ok": half_ok, "fused": fused}), flush=True)
 dist.destroy_process_group()
 '''
 
@@ -89,6 +111,8 @@ def test_rccl_world_of_one_runs_every_collective_of_the_training_step(tmp_path):
     assert d["backend"] == "nccl" and d["same"] is True and d["max"] == 3.25
     assert d["grad_norm"] > 0 and 0 < d["moved"] <= 1.1e-3            # one Adam step at lr 1e-3 moves each weight by <= lr
     assert d["sync_pred"] <= 1e-6 and d["sync_grad"] <= 1e-5 and d["half_sync_ok"] is True
+    f = d["fused"]                     # three optimiser steps of train_epoch, one RCCL all-reduce each
+    assert f["steps"] == 3 and f["graphs"] == 24 and f["finite"] and 0 < f["moved"] <= 3.3e-3 and f["mae"] == f["mae"]
 
 
 def test_bench_starts_its_own_ranks(tmp_path):

@@ -1,0 +1,138 @@
+"""Larger worlds rehearsed on ONE card.  The GPU pool allows at most 6 processes on a card at once
+(pytest's own process holds a context too), so the largest world that can touch the card here is FOUR ranks sharing it
+over gloo (`--share-gpu` / CARTNET_DIST_BACKEND=gloo: RCCL only replaces the transport; its own code path runs as a
+world of one in test_gpu_rccl.py).  The world-of-EIGHT rehearsal of the sharding, step-count and all-reduce logic runs on
+the CPU over gloo in tests/test_ddp_gloo.py (`-m "not gpu"`).  Reference recipe being sharded:
+scripts/train_cartnet_adp.sh:3-14 (N independent processes there), train/train.py:186-189 (accumulation boundary)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORLD = 4
+
+
+def test_bench_line_with_four_ranks_on_one_card(tmp_path):
+    """bench.py starts its own four ranks (child torch.distributed.run before any GPU call), they share the card, rank 0
+    prints ONE JSON line for the whole job: n_gpus 4, weak scaling, `sustained` present for world > 1 too."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CARTNET_DIST_FORCE")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(WORLD), "--share-gpu", "--graphs", "4", "--steps", "3",
+           "--warmup", "2", "--sustain-seconds", "0.5", "--no-x3-pass", "--no-recipe-pass"]
+    out = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == WORLD and d["config"]["parallelism"] == f"graph-sharded dp{WORLD}" and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - WORLD * 4 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3
+    assert "cpu_baseline" not in d and d["sustained"]["steps"] >= 100 and d["sustained"]["value"] > 0
+    assert "telemetry" in d and "calibration" in d and 0 < d["calibration"]["frac"] < 1
+
+
+_CHILD = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from cartnet_amd import distributed as cdist
+from cartnet_amd.config import cfg
+from cartnet_amd.data import Batch, DataLoader
+from cartnet_amd.model import CartNet, make_state_dict
+from cartnet_amd.optim import FlatAdam
+from cartnet_amd.synthetic import make_crystal
+from cartnet_amd.train import train_epoch
+
+rank, world, local = cdist.init_from_env()
+cfg.radius = 5.0
+cfg.loss = "MAE"
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+n_items, batch = int(sys.argv[3]), int(sys.argv[4])
+gen = torch.Generator().manual_seed(77)
+sizes = torch.randint(3, 41, (n_items,), generator=gen).tolist()          # ragged: 3 .. 40 atoms
+items = [make_crystal(12000 + i, n) for i, n in enumerate(sizes)]
+
+
+def model():
+    m = CartNet(64, 16, 2)
+    m.load_state_dict(make_state_dict(64, 16, 2, seed=43))
+    m = m.to(dev).train()
+    m.bn_group_size = 1            # every crystal its own BatchNorm group and loss term: the sum over crystals does not
+    return m                       # depend on how they are cut into ranks and batches
+
+
+class Recording(FlatAdam):
+    """FlatAdam that remembers the (all-reduced) gradient of every optimiser step."""
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.seen = []
+
+    def step(self, grad_scale=1.0):
+        self.seen.append((self.flat_grad.clone(), grad_scale))
+        super().step(grad_scale)
+
+
+# pass 1: the whole epoch accumulated into ONE optimiser step -> its all-reduced gradient is the union's gradient
+m = model()
+opt = Recording(m, lr=1e-3)
+loader = DataLoader(items, batch, rank=rank, world_size=world)
+batches = loader._batches()
+n_iter = len(loader)
+stats = train_epoch(loader, m, opt, batch_accumulation=n_iter)
+g_union, scale = opt.seen[0]
+# pass 2: one optimiser step per iteration; every rank must take the same number of them and end with equal parameters
+m2 = model()
+opt2 = Recording(m2, lr=1e-3)
+loader2 = DataLoader(items, batch, rank=rank, world_size=world)
+train_epoch(loader2, m2, opt2, batch_accumulation=1)
+cdist.assert_replicas_in_sync(m2)
+steps = torch.tensor([len(opt2.seen)], dtype=torch.int64)
+if world > 1:
+    lo, hi = steps.clone(), steps.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    assert int(lo) == int(hi) == n_iter, (int(lo), int(hi), n_iter)
+torch.save({"g": g_union.cpu(), "scale": scale, "n_iter": n_iter, "steps1": len(opt.seen), "steps2": len(opt2.seen),
+            "empty_steps": sum(1 for b in batches if not b), "crystals": sorted(j for b in batches for j in b),
+            "graphs": stats["graphs"], "p": opt2.flat_param.detach().cpu()},
+           os.path.join(sys.argv[2], f"w{world}_r{rank}.pt"))
+if world > 1:
+    dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("n_items,batch,expect_empty", [(37, 4, False), (6, 1, True)])
+def test_ragged_set_over_four_ranks_equals_one_process_on_the_union(tmp_path, n_items, batch, expect_empty):
+    """cartnet_amd.train.train_epoch on a ragged synthetic set, sharded by cartnet_amd.data.DataLoader over four ranks
+    (edge-balanced uneven shards; with 6 crystals and batch 1 two ranks run an EMPTY second step and add a zero
+    gradient) against one process on the union: same optimiser-step count on every rank, nothing dropped or doubled,
+    summed gradient equal (BatchNorm groups of one crystal make the sum independent of the cut), replicas in sync."""
+    import torch
+    script = tmp_path / "world_child.py"
+    script.write_text(_CHILD)
+    env = dict(os.environ, CARTNET_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CARTNET_DIST_FORCE"):
+        env.pop(k, None)
+    args = [ROOT, str(tmp_path), str(n_items), str(batch)]
+    one = subprocess.run([sys.executable, str(script)] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(WORLD),
+                           "--master-addr", "127.0.0.1", "--master-port", "29561", str(script)] + args,
+                          env=env, capture_output=True, text=True, timeout=900)
+    assert many.returncode == 0, many.stderr[-3000:]
+    ref = torch.load(tmp_path / "w1_r0.pt")
+    ranks = [torch.load(tmp_path / f"w{WORLD}_r{r}.pt") for r in range(WORLD)]
+    assert ref["crystals"] == list(range(n_items))
+    assert sorted(j for r in ranks for j in r["crystals"]) == list(range(n_items))       # disjoint and exhaustive
+    assert sum(r["graphs"] for r in ranks) == n_items
+    assert len({r["n_iter"] for r in ranks}) == 1 and all(r["steps1"] == 1 and r["steps2"] == r["n_iter"] for r in ranks)
+    assert (sum(r["empty_steps"] for r in ranks) > 0) == expect_empty
+    assert all(r["scale"] == 1.0 / WORLD for r in ranks) and ref["scale"] == 1.0
+    for r in ranks[1:]:
+        assert torch.equal(r["g"], ranks[0]["g"]) and torch.equal(r["p"], ranks[0]["p"])
+    gmax = ref["g"].abs().max().item()
+    assert (ranks[0]["g"] - ref["g"]).abs().max().item() <= 3e-5 * gmax

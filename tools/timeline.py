@@ -69,3 +69,10 @@ for s, e, n, q in step:
 for k, v in sorted(total.items(), key=lambda kv: -kv[1])[:40]:
     print(f"{k:72s} {calls[k]:5d} {1e-6 * v:8.3f} {1e-6 * alone.get(k, 0):9.3f}")
 print(f"{'TOTAL':72s} {len(step):5d} {1e-6 * sum(total.values()):8.3f} {1e-6 * sum(alone.values()):9.3f}")
+
+# --list: every launch of the step in start order, one line each: start offset, duration, queue, kernel -- the Gantt view
+if "--list" in sys.argv:
+    qs = sorted({q for _, _, _, q in step})
+    print("\nstart_us   dur_us  queue  kernel")
+    for s, e, n, q in step:
+        print(f"{1e-3 * (s - t0):8.1f} {1e-3 * (e - s):8.1f}  q{qs.index(q)}  {short(n)}")
