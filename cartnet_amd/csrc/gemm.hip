@@ -98,13 +98,36 @@ __global__ __launch_bounds__(1024) void cn_colsum_finalize_kernel(const Finalize
   }
 }
 
-__global__ void cn_colsum_finalize_f32_kernel(const float* __restrict__ parts, int nparts, int N,
-                                              float* __restrict__ out) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// fp32 partial rows -> fp32 column sums, accumulated in fp64 in a fixed order: 32 columns x 32 row groups per block
+// (a thread walks rows rg, rg + 32, ... with four independent loads in flight; the 32 partial sums of a column are
+// added in row-group order).  The one-thread-per-column form took 260 us for the head's 256 x 904 partial matrix
+// (a dependent load-add chain per thread, eight blocks on the whole chip) and sat alone on the weight-gradient stream.
+__global__ __launch_bounds__(1024) void cn_colsum_finalize_f32_kernel(const float* __restrict__ parts, int nparts, int N,
+                                                                      float* __restrict__ out) {
+  __shared__ double red[32][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + cl;
   double acc = 0.0;
-  for (int q = 0; q < nparts; ++q) acc += (double)parts[(size_t)q * N + n];
-  out[n] = (float)acc;
+  if (n < N) {
+    int q = rg;
+    for (; q + 96 < nparts; q += 128) {
+      const float v0 = parts[(size_t)q * N + n], v1 = parts[(size_t)(q + 32) * N + n],
+                  v2 = parts[(size_t)(q + 64) * N + n], v3 = parts[(size_t)(q + 96) * N + n];
+      acc += (double)v0;
+      acc += (double)v1;
+      acc += (double)v2;
+      acc += (double)v3;
+    }
+    for (; q < nparts; q += 32) acc += (double)parts[(size_t)q * N + n];
+  }
+  red[rg][cl] = acc;
+  __syncthreads();
+  if (rg == 0 && n < N) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) t += red[r][cl];
+    out[n] = (float)t;
+  }
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -422,7 +445,7 @@ extern "C" int cartnet_colsum_finalize_f32(const float* parts, int32_t nparts, i
   CN_CHECK(parts && out, "cartnet_colsum_finalize_f32: null pointer");
   CN_CHECK(nparts >= 0 && N >= 0, "cartnet_colsum_finalize_f32: bad shape");
   if (N == 0) return 0;
-  hipLaunchKernelGGL(cn_colsum_finalize_f32_kernel, dim3(cn_ceil_div(N, 128)), dim3(128), 0,
+  hipLaunchKernelGGL(cn_colsum_finalize_f32_kernel, dim3(cn_ceil_div(N, 32)), dim3(1024), 0,
                      reinterpret_cast<hipStream_t>(stream), parts, nparts, N, out);
   CN_LAUNCH_CHECK("cartnet_colsum_finalize_f32");
   return 0;

@@ -114,70 +114,103 @@ __global__ __launch_bounds__(256) void cn_csc_build_kernel(const int* __restrict
   }
 }
 
-// Stable counting sort of N items by an int64 key in [0, nkeys), one workgroup (atom types: nkeys = 119).
-__global__ __launch_bounds__(1024) void cn_sort_by_key_kernel(const int64_t* __restrict__ keys, int N, int nkeys,
-                                                              int* __restrict__ perm, int* __restrict__ ptr,
-                                                              int* __restrict__ status) {
-  __shared__ int cnt[1024];
-  __shared__ int skey[1024];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < nkeys; i += 1024) cnt[i] = 0;
+// Stable counting sort of N items by an int64 key in [0, nkeys), one workgroup of 16 waves (atom types: nkeys = 119).
+// Wave w owns the contiguous item range [w * per, (w + 1) * per): pass 1 counts its keys into cnt[w][.]; the counts
+// become offsets (exclusive prefix over the waves inside a key, exclusive prefix over the keys); pass 2 walks the range
+// again in chunks of 64 and ranks the lanes of a chunk key by key with wave ballots (a crystal has a handful of
+// elements, so a chunk needs a handful of rounds), so equal keys keep their input order.  The first version ranked
+// every item with a serial scan over the preceding items of its 1024-chunk: 420 us for 12,416 atoms, alone on the
+// weight-gradient stream.  Dynamic LDS: (SORT_WAVES + 1) * nkeys ints.
+constexpr int SORT_WAVES = 16;
+
+__device__ __forceinline__ int cn_sort_key(const int64_t* __restrict__ keys, int i, int nkeys, int* status) {
+  long long k = keys[i];
+  if (k < 0 || k >= nkeys) {     // clamped like the forward gather (cn_node_embed_kernel), so perm stays a full permutation
+    if (status) atomicOr(status, 16);
+    k = k < 0 ? 0 : nkeys - 1;
+  }
+  return (int)k;
+}
+
+__global__ __launch_bounds__(64 * SORT_WAVES) void cn_sort_by_key_kernel(const int64_t* __restrict__ keys, int N, int nkeys,
+                                                                         int* __restrict__ perm, int* __restrict__ ptr,
+                                                                         int* __restrict__ status) {
+  extern __shared__ int sort_lds[];
+  int* cnt = sort_lds;                          // [SORT_WAVES][nkeys]
+  int* base = sort_lds + SORT_WAVES * nkeys;    // [nkeys]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int per = ((N + SORT_WAVES - 1) / SORT_WAVES + 63) / 64 * 64;
+  const int i0 = min(N, w * per), i1 = min(N, i0 + per);
+  for (int i = tid; i < SORT_WAVES * nkeys; i += 64 * SORT_WAVES) cnt[i] = 0;
   __syncthreads();
-  for (int i = tid; i < N; i += 1024) {
-    long long k = keys[i];
-    if (k < 0 || k >= nkeys) {     // clamped like the forward gather (cn_node_embed_kernel), so perm stays a full permutation
-      atomicOr(status, 16);
-      k = k < 0 ? 0 : nkeys - 1;
+  for (int i = i0 + lane; i < i1; i += 64) atomicAdd(&cnt[w * nkeys + cn_sort_key(keys, i, nkeys, status)], 1);
+  __syncthreads();
+  for (int k = tid; k < nkeys; k += 64 * SORT_WAVES) {     // per key: counts -> offsets of the waves inside the key
+    int run = 0;
+    for (int v = 0; v < SORT_WAVES; ++v) {
+      const int c = cnt[v * nkeys + k];
+      cnt[v * nkeys + k] = run;
+      run += c;
     }
-    atomicAdd(&cnt[(int)k], 1);
+    base[k] = run;                                          // total of the key, turned into its start below
   }
   __syncthreads();
   if (tid == 0) {
     int run = 0;
-    for (int i = 0; i < nkeys; ++i) {
-      const int v = cnt[i];
-      cnt[i] = run;
-      ptr[i] = run;
+    for (int k = 0; k < nkeys; ++k) {
+      const int v = base[k];
+      base[k] = run;
+      ptr[k] = run;
       run += v;
     }
     ptr[nkeys] = run;
   }
   __syncthreads();
-  for (int base = 0; base < N; base += 1024) {
-    const int i = base + tid;
-    int key = -1;
-    if (i < N) {
-      const long long k = keys[i];
-      key = k < 0 ? 0 : (k >= nkeys ? nkeys - 1 : (int)k);
+  volatile int* vcnt = cnt;     // lane `leader` writes what all lanes of the wave read in the next round
+  for (int c0 = i0; c0 < i1; c0 += 64) {
+    const int i = c0 + lane;
+    const bool valid = i < i1;
+    const int key = valid ? cn_sort_key(keys, i, nkeys, nullptr) : -1;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int k0 = __shfl(key, leader);
+      const unsigned long long same = __ballot(valid && key == k0);
+      const int off = vcnt[w * nkeys + k0];
+      if (valid && key == k0) perm[base[k0] + off + __popcll(same & ((1ull << lane) - 1ull))] = i;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == leader) vcnt[w * nkeys + k0] = off + __popcll(same);
+      __builtin_amdgcn_wave_barrier();
+      todo &= ~same;
     }
-    skey[tid] = key;
-    __syncthreads();
-    int cur = 0, rank = 0;
-    if (key >= 0) {
-      cur = cnt[key];
-      for (int t = 0; t < tid; ++t) rank += (skey[t] == key) ? 1 : 0;
-    }
-    __syncthreads();
-    if (key >= 0) {
-      perm[cur + rank] = i;
-      atomicAdd(&cnt[key], 1);
-    }
-    __syncthreads();
   }
+}
+
+struct ZeroJobs {
+  int* p[4];
+  long long n[4];
+};
+__global__ __launch_bounds__(256) void cn_zero_ints_kernel(const ZeroJobs z) {
+  int* __restrict__ p = z.p[blockIdx.y];
+  const long long n = z.n[blockIdx.y];
+  if (!p) return;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0;
 }
 
 }  // namespace
 
 extern "C" int cartnet_sort_by_key(const int64_t* keys, int32_t N, int32_t nkeys, int32_t* perm, int32_t* ptr,
                                    int32_t* status, void* stream) {
-  CN_CHECK(N >= 0 && nkeys >= 1 && nkeys <= 1024, "cartnet_sort_by_key: nkeys=%d out of range (1..1024)", nkeys);
+  CN_CHECK(N >= 0 && nkeys >= 1 && nkeys <= 512, "cartnet_sort_by_key: nkeys=%d out of range (1..512)", nkeys);
   CN_CHECK((keys || N == 0) && perm && ptr && status, "cartnet_sort_by_key: null pointer");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) {
     cartnet_set_error("cartnet_sort_by_key: memset failed");
     return 2;
   }
-  hipLaunchKernelGGL(cn_sort_by_key_kernel, dim3(1), dim3(1024), 0, st, keys, N, nkeys, perm, ptr, status);
+  hipLaunchKernelGGL(cn_sort_by_key_kernel, dim3(1), dim3(64 * SORT_WAVES), sizeof(int) * (SORT_WAVES + 1) * nkeys, st, keys, N,
+                     nkeys, perm, ptr, status);
   CN_LAUNCH_CHECK("cartnet_sort_by_key");
   return 0;
 }
@@ -191,17 +224,21 @@ extern "C" int cartnet_csr_build(const int64_t* edge_index, int64_t E, int32_t N
   CN_CHECK((colptr == nullptr) == (perm == nullptr), "cartnet_csr_build: colptr and perm must pair");
   CN_CHECK(graph_ptr == nullptr || Bg >= 1, "cartnet_csr_build: Bg=%d", Bg);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) {
-    cartnet_set_error("cartnet_csr_build: memset failed");
-    return 2;
-  }
   // Defaults for entries a malformed batch (unsorted targets, edges across crystals, an oversized crystal) leaves
-  // unwritten: empty segments and row 0 instead of whatever the buffers held.
-  if (hipMemsetAsync(rowptr, 0, sizeof(int32_t) * ((size_t)N + 1), st) != hipSuccess ||
-      (colptr && hipMemsetAsync(colptr, 0, sizeof(int32_t) * ((size_t)N + 1), st) != hipSuccess) ||
-      (perm && E > 0 && hipMemsetAsync(perm, 0, sizeof(int32_t) * (size_t)E, st) != hipSuccess)) {
-    cartnet_set_error("cartnet_csr_build: memset failed");
-    return 2;
+  // unwritten: empty segments and row 0 instead of whatever the buffers held; the status word starts at 0.  One launch
+  // for the four buffers (four hipMemsetAsync calls were four ~6 us dispatches at the head of every forward pass).
+  {
+    ZeroJobs z;
+    z.p[0] = status; z.n[0] = 1;
+    z.p[1] = rowptr; z.n[1] = (long long)N + 1;
+    z.p[2] = colptr; z.n[2] = colptr ? (long long)N + 1 : 0;
+    z.p[3] = perm;   z.n[3] = perm ? (long long)E : 0;
+    long long most = z.n[1] > z.n[3] ? z.n[1] : z.n[3];
+    int zb = (int)((most + 1023) / 1024);
+    if (zb > 1024) zb = 1024;
+    if (zb < 1) zb = 1;
+    hipLaunchKernelGGL(cn_zero_ints_kernel, dim3(zb, 4), dim3(256), 0, st, z);
+    CN_LAUNCH_CHECK("cartnet_csr_build/zero");
   }
   int blocks = cn_ceil_div(E + 1, 256);
   if (blocks > 4096) blocks = 4096;

@@ -63,7 +63,7 @@ struct Work {
   float *act[CARTNET_MAX_LAYERS], *he_act;
   // backward transients
   float *dhid, *head_parts, *head_tot, *dx[2], *de[2], *daggr, *sums1, *sums2, *dPn[2], *dpre[2], *dhe, *dx0, *seg_tmp,
-      *slabs, *e0wT;
+      *slabs, *slabs2, *e0wT;
   double *pa, *pb, *pc[2], *pd[2], *cs_misc[4];
   size_t slab_floats;
   int gparts, nparts_n, tiles_e, tiles_n;
@@ -240,6 +240,11 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
     mx(wgrad_slab_floats(1, N, D, 2 * D));
     w.slab_floats = sl;
     w.slabs = c.take<float>(sl > 0 ? sl : 1);
+    // the encoder's first Linear reduces its weight gradient on the main stream while the side stream uses `slabs`
+    size_t sl2 = wgrad_slab_floats(1, E, 2 * D, w.kf);
+    const size_t sl2b = wgrad_slab_floats(1, E, w.ldf, 2 * D);
+    if (sl2b > sl2) sl2 = sl2b;
+    w.slabs2 = c.take<float>(sl2 > 0 ? sl2 : 1);
   }
   *total = align_up(c.off);
   return w;
@@ -363,6 +368,45 @@ int check_model(const CartnetModel* m, const CartnetBatch* b, const char* who) {
 
 }  // namespace
 
+namespace {
+// Events that order the weight-gradient stream against the main stream (created once per thread, timing disabled).
+struct EventPool {
+  std::vector<hipEvent_t> ev;
+  size_t next = 0;
+  hipEvent_t get() {
+    if (next == ev.size()) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      ev.push_back(e);
+    }
+    return ev[next++];
+  }
+};
+thread_local EventPool g_events;
+
+struct Streams {
+  hipStream_t main, side;
+  bool dual;
+  // after(main) -> side waits; returns 0 on success
+  int fork() {
+    if (!dual) return 0;
+    hipEvent_t e = g_events.get();
+    if (!e || hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return 2;
+    return 0;
+  }
+  hipEvent_t mark_side() {
+    if (!dual) return nullptr;
+    hipEvent_t e = g_events.get();
+    if (!e || hipEventRecord(e, side) != hipSuccess) return nullptr;
+    return e;
+  }
+  int main_waits(hipEvent_t e) {
+    if (!dual || !e) return 0;
+    return hipStreamWaitEvent(main, e, 0) == hipSuccess ? 0 : 2;
+  }
+};
+}  // namespace
+
 extern "C" size_t cartnet_workspace_bytes(const CartnetModel* model, int32_t N, int64_t E, int32_t Bg, int32_t M,
                                           int32_t need_backward) {
   if (!model || model->L < 1 || model->L > CARTNET_MAX_LAYERS) return 0;
@@ -373,7 +417,7 @@ extern "C" size_t cartnet_workspace_bytes(const CartnetModel* model, int32_t N, 
 
 extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBatch* batch, void* workspace,
                                      size_t workspace_bytes, int32_t training, int32_t need_backward, float* pred,
-                                     float* x_out, float* e_out, int32_t* status, void* st) {
+                                     float* x_out, float* e_out, int32_t* status, void* st, void* aux_stream) {
   RUN(check_model(model, batch, "cartnet_model_forward"));
   g_precision = model->gemm_precision;
   const CartnetModel& m = *model;
@@ -390,17 +434,29 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
   const int E = (int)b.E;
   const bool plain = !m.use_temperature && !m.atom_types;
 
+  // Second stream (optional): what does not depend on the graph -- the weight transposes and images -- and the atom
+  // branch of the encoder with the first layer's node terms (few row tiles: they leave most of the chip idle) run on it
+  // next to the layout build and the edge encoder; the main stream waits for them where it needs them and the two
+  // streams are joined before the call returns.
+  g_events.next = 0;
+  static const bool fwd_aux_on = [] { const char* e = getenv("CARTNET_FWD_AUX"); return !e || atoi(e) != 0; }();   // A/B switch
+  if (!fwd_aux_on) aux_stream = nullptr;
+  Streams S{(hipStream_t)st, aux_stream ? (hipStream_t)aux_stream : (hipStream_t)st, aux_stream != nullptr && aux_stream != st};
+  void* sw = (void*)S.side;
+#define FORK() do { if (S.fork() != 0) { cartnet_set_error("cartnet_model_forward: stream fork failed"); return 2; } } while (0)
+#define MAIN_WAITS(ev) do { if (S.main_waits(ev) != 0) { cartnet_set_error("cartnet_model_forward: stream wait failed"); return 2; } } while (0)
+  FORK();      // the side stream starts after whatever the caller queued (the optimiser step that wrote the weights)
   RUN(cartnet_csr_build(b.edge_index, b.E, N, b.graph_ptr, b.Bg, w.src32, w.tgt32, w.rowptr, w.colptr, w.perm, status,
                         st));
   if (w.groups) RUN(cartnet_group_ptrs(b.graph_ptr, b.Bg, m.bn_group_size, w.rowptr, w.G, w.node_gptr, w.edge_gptr, st));
-  // weights -> [in, out]
+  // weights -> [in, out]   (side stream)
   {
     constexpr int TB = 40;   // cartnet_transpose takes up to 40 matrices per launch
     const float* src[TB]; float* dst[TB]; int32_t rows[TB], cols[TB], lds[TB], ldd[TB];
     int n = 0;
     auto flush = [&]() -> int {
       if (n == 0) return 0;
-      int rc = cartnet_transpose(src, dst, rows, cols, lds, ldd, n, st);
+      int rc = cartnet_transpose(src, dst, rows, cols, lds, ldd, n, sw);
       n = 0;
       return rc;
     };
@@ -411,7 +467,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     };
     if (w.ldf > w.kf &&
         hipMemsetAsync(w.edge0T + (size_t)w.kf * 2 * D, 0, sizeof(float) * (size_t)(w.ldf - w.kf) * 2 * D,
-                       (hipStream_t)st) != hipSuccess) {
+                       S.side) != hipSuccess) {
       cartnet_set_error("cartnet_model_forward: memset failed");
       return 2;
     }
@@ -470,10 +526,12 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       }
     }
     if (m.gemm_precision == 0)
-      RUN(cartnet_gemm_pack_b(src.data(), dst.data(), Ks.data(), Ns.data(), sk.data(), sn.data(), (int32_t)src.size(), st));
+      RUN(cartnet_gemm_pack_b(src.data(), dst.data(), Ks.data(), Ns.data(), sk.data(), sn.data(), (int32_t)src.size(), sw));
     else
-      RUN(cartnet_gemm_split_b(src.data(), dst.data(), Ks.data(), Ns.data(), sk.data(), sn.data(), (int32_t)src.size(), st));
+      RUN(cartnet_gemm_split_b(src.data(), dst.data(), Ks.data(), Ns.data(), sk.data(), sn.data(), (int32_t)src.size(), sw));
   }
+  hipEvent_t weights_ready = S.mark_side();
+  FORK();      // the atom branch below writes status bits: after the layout build has reset the word
 
   const bool half = m.half_storage != 0 && m.gemm_precision == 2;
   CN_CHECK(!m.half_storage || (m.gemm_precision == 2 && !w.groups && D % 256 == 0),
@@ -481,6 +539,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
   // ---- encoder, edges (cartnet.py:159)
   RUN(cartnet_edge_features(b.cart_dist, b.cart_dir, m.rbf_means, m.rbf_betas, b.E, m.R, m.invariant, m.radius,
                             m.env_radius, w.feat, w.ldf, w.env, st));
+  MAIN_WAITS(weights_ready);
   {
     CartnetGemmArgs a = gemm_args(E, 2 * D, w.ldf, w.ldf, 2 * D, 2 * D);
     a.A[0] = w.feat; a.B[0] = w.edge0T; a.C[0] = w.he_pre; a.bias[0] = P.edge0_b; a.b_kstrided = 1;
@@ -495,19 +554,36 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     RUN(cartnet_gemm(&a, st));
   }
   // ---- encoder, atoms (cartnet.py:145-154); out-of-table atomic numbers / batch ids are clamped and reported in `status`
+  // (side stream; in stream order behind the weight images it reads)
   if (plain) {   // cartnet.py:150-151: the single row of Embedding(1, D) for every atom, no atom MLP
     RUN(cartnet_node_embed(nullptr, nullptr, nullptr, P.embedding, nullptr, nullptr, nullptr, N, D, 1, b.Bg, status,
-                           w.xenc, st));
+                           w.xenc, sw));
   } else {
     RUN(cartnet_node_embed(m.atom_types ? b.z : nullptr, m.use_temperature ? b.batch : nullptr,
                            m.use_temperature ? b.temperature : nullptr, m.atom_types ? P.embedding : nullptr,
                            m.use_temperature ? P.temp_w : nullptr, m.use_temperature ? P.temp_b : nullptr,
-                           m.use_temperature ? nullptr : P.enc_bias, N, 2 * D, m.n_types, b.Bg, status, w.x0, st));
+                           m.use_temperature ? nullptr : P.enc_bias, N, 2 * D, m.n_types, b.Bg, status, w.x0, sw));
     CartnetGemmArgs a = gemm_args(N, D, 2 * D, 2 * D, D, D);
     a.A[0] = w.x0; a.B[0] = w.atomT; a.C[0] = w.xenc; a.cpre[0] = w.xa_pre; a.bias[0] = P.atom_b;
     a.b_kstrided = 1; a.a_act = 1; a.out_act = 1; a.b_split[0] = w.i_atom;
-    RUN(cartnet_gemm(&a, st));
+    RUN(cartnet_gemm(&a, sw));
   }
+  // node-side halves of a layer's first Linears: Pn = [gate_i | aggr_i | gate_j | aggr_j]
+  auto node_terms = [&](int l, const float* x, void* s_) -> int {
+    const CartnetLayerParams& q = P.layer[l];
+    CartnetGemmArgs a = gemm_args(N, D, D, D, D, 4 * D);
+    a.ngroups = 4; a.b_kstrided = 1;
+    const float* Bt[4] = {w.gate0T[l], w.aggr0T[l], w.gate0T[l] + (size_t)D * D, w.aggr0T[l] + (size_t)D * D};
+    const size_t blk = img_blk(m);
+    for (int g = 0; g < 4; ++g) {
+      a.A[g] = x; a.B[g] = Bt[g]; a.C[g] = w.Pn + (size_t)g * D;
+      if (w.i_pn[l]) a.b_split[g] = w.i_pn[l] + g * blk;
+    }
+    a.bias[0] = q.gate0_b; a.bias[1] = q.aggr0_b;
+    return cartnet_gemm(&a, s_);
+  };
+  RUN(node_terms(0, w.xenc, sw));
+  hipEvent_t atoms_ready = S.mark_side();
 
   // BatchNorm statistics from partial column sums; with CartnetModel.bn_allreduce (sync-BatchNorm) the sums of all ranks
   const bool sync_bn = training && m.bn_allreduce != nullptr;
@@ -530,18 +606,8 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     const CartnetLayerParams& q = P.layer[l];
     float* x_next = (l == L - 1) ? x_out : w.xl[l];
     float* e_next = (l == L - 1) ? e_out : w.el[l];
-    {  // node-side halves of the first Linears: Pn = [gate_i | aggr_i | gate_j | aggr_j]
-      CartnetGemmArgs a = gemm_args(N, D, D, D, D, 4 * D);
-      a.ngroups = 4; a.b_kstrided = 1;
-      const float* Bt[4] = {w.gate0T[l], w.aggr0T[l], w.gate0T[l] + (size_t)D * D, w.aggr0T[l] + (size_t)D * D};
-      const size_t blk = img_blk(m);
-      for (int g = 0; g < 4; ++g) {
-        a.A[g] = x; a.B[g] = Bt[g]; a.C[g] = w.Pn + (size_t)g * D;
-        if (w.i_pn[l]) a.b_split[g] = w.i_pn[l] + g * blk;
-      }
-      a.bias[0] = q.gate0_b; a.bias[1] = q.aggr0_b;
-      RUN(cartnet_gemm(&a, st));
-    }
+    if (l == 0) MAIN_WAITS(atoms_ready);      // x, Pn of layer 0 (and the status bits of the atom branch)
+    else RUN(node_terms(l, x, st));
     {  // pre = e W1e^T + Pn_i[tgt] + Pn_j[src]
       CartnetGemmArgs a = gemm_args(E, D, D, D, D, 2 * D);
       a.ngroups = 2; a.b_kstrided = 1;
@@ -589,47 +655,10 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
   } else {
     RUN(cartnet_scalar_head_fwd(w.hid, P.head2_w, P.head2_b, b.graph_ptr, b.Bg, H, pred, st));
   }
+#undef FORK
+#undef MAIN_WAITS
   return 0;
 }
-
-namespace {
-// Events that order the weight-gradient stream against the main stream (created once per thread, timing disabled).
-struct EventPool {
-  std::vector<hipEvent_t> ev;
-  size_t next = 0;
-  hipEvent_t get() {
-    if (next == ev.size()) {
-      hipEvent_t e;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-      ev.push_back(e);
-    }
-    return ev[next++];
-  }
-};
-thread_local EventPool g_events;
-
-struct Streams {
-  hipStream_t main, side;
-  bool dual;
-  // after(main) -> side waits; returns 0 on success
-  int fork() {
-    if (!dual) return 0;
-    hipEvent_t e = g_events.get();
-    if (!e || hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return 2;
-    return 0;
-  }
-  hipEvent_t mark_side() {
-    if (!dual) return nullptr;
-    hipEvent_t e = g_events.get();
-    if (!e || hipEventRecord(e, side) != hipSuccess) return nullptr;
-    return e;
-  }
-  int main_waits(hipEvent_t e) {
-    if (!dual || !e) return 0;
-    return hipStreamWaitEvent(main, e, 0) == hipSuccess ? 0 : 2;
-  }
-};
-}  // namespace
 
 // Two streams: the MAIN stream carries the chain of activation gradients (dx, de from layer to layer); everything that
 // only produces parameter gradients -- the weight-gradient GEMMs with their split-K reductions and the bias-gradient
@@ -914,27 +943,36 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     a.b_split[0] = w.i_edge2_b;
     a.colsum[0] = w.cs_misc[2];
     RUN(cartnet_gemm(&a, st));       // dhe = d(he_pre)
-    FORK();
+    // The first edge Linear's gradients stay on the MAIN stream (they need dhe, and the main stream has nothing else of
+    // weight left): the weight-gradient stream still holds layer 0's products and dW2 of the encoder at this point, and
+    // queueing these behind them left the main stream idle for the last ~0.8 ms of the step (r03 timeline).
     double* parts[1] = {w.cs_misc[2]};
     float* outs[1] = {G.edge0_b};
-    RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_e, 2 * D, sw));
+    RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_e, 2 * D, st));
     const float* dY2[1] = {w.dhe};
     const float* X2[1] = {w.feat};
     float* o2[1] = {G.edge0_w};
+    // (the split-K slabs of this product must not be the ones the weight-gradient stream is using: w.slabs2)
+    Work w2 = w;
+    w2.slabs = w.slabs2;
+    static const bool dw0_main = [] { const char* e = getenv("CARTNET_DW0_MAIN"); return !e || atoi(e) != 0; }();   // A/B switch
+    void* st0 = st;
+    if (!dw0_main) { FORK(); st = sw; }
     if (m.gemm_precision >= 1 && w.i_edge0) {
       // bf16 kernels want 256-wide column tiles: compute the transpose, featT . dhe = dW0^T [ldf, 2D] (rows kf.. are the
       // zero pad columns of feat), and write its first kf rows transposed into the gradient
       const float* fT[1] = {w.feat};
       const float* dh[1] = {w.dhe};
       float* oT[1] = {w.e0wT};
-      RUN(wgrad(fT, w.ldf, dh, 2 * D, oT, 2 * D, b.E, w.ldf, 2 * D, 1, false, w, sw));
+      RUN(wgrad(fT, w.ldf, dh, 2 * D, oT, 2 * D, b.E, w.ldf, 2 * D, 1, false, w2, st));
       const float* tsrc[1] = {w.e0wT};
       float* tdst[1] = {G.edge0_w};
       const int32_t trows[1] = {w.kf}, tcols[1] = {2 * D}, tlds[1] = {2 * D}, tldd[1] = {w.kf};
-      RUN(cartnet_transpose(tsrc, tdst, trows, tcols, tlds, tldd, 1, sw));
+      RUN(cartnet_transpose(tsrc, tdst, trows, tcols, tlds, tldd, 1, st));
     } else {
-      RUN(wgrad(dY2, 2 * D, X2, w.ldf, o2, w.kf, b.E, 2 * D, w.kf, 1, false, w, sw));
+      RUN(wgrad(dY2, 2 * D, X2, w.ldf, o2, w.kf, b.E, 2 * D, w.kf, 1, false, w2, st));
     }
+    st = st0;
   }
   if (plain) {   // every atom read the same learned row: its gradient is the column sum of dx over the atoms
     double* parts[1] = {w.pa};

@@ -239,7 +239,7 @@ PROTOTYPES = {
     "cartnet_profile_gemm_read": (C.c_int, [C.POINTER(GemmProfile), C.c_int32]),
     "cartnet_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "cartnet_model_forward": (C.c_int, [C.POINTER(Model), C.POINTER(BatchDesc), C.c_void_p, C.c_size_t, C.c_int32,
-                                        C.c_int32, c_f32p, c_f32p, c_f32p, c_i32p, c_stream]),
+                                        C.c_int32, c_f32p, c_f32p, c_f32p, c_i32p, c_stream, c_stream]),
     "cartnet_model_backward": (C.c_int, [C.POINTER(Model), C.POINTER(BatchDesc), C.c_void_p, C.c_size_t, C.c_int32,
                                          c_f32p, c_f32p, C.POINTER(Params), c_stream, c_stream]),
     "cartnet_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, C.c_float,

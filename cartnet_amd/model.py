@@ -196,7 +196,8 @@ class _CartNetFunction(torch.autograd.Function):
         status = torch.empty(1, dtype=torch.int32, device=dev)
         _l.check(lib.cartnet_model_forward(C.byref(md), C.byref(bd), ws.data_ptr(), nbytes, int(training),
                                            int(need_grad), pred.data_ptr(), x_out.data_ptr(), e_store.data_ptr(),
-                                           status.data_ptr(), _l.stream_ptr()), "cartnet_model_forward")
+                                           status.data_ptr(), _l.stream_ptr(), model._aux_stream_ptr(dev)),
+                 "cartnet_model_forward")
         _raise_callback_error(sync_cb)
         if model.validate_graph:
             ops.raise_on_graph_status(int(status.item()))

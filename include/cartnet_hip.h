@@ -366,7 +366,7 @@ int cartnet_node_nparts(int32_t N);
 int cartnet_node_embed_bwd(const int64_t* batch, const float* temperature, const float* dx0, int32_t N, int32_t C,
                            int32_t Bg, double* parts_w, double* parts_b, void* stream);
 
-/* Stable counting sort of N items by key in [0, nkeys), nkeys <= 1024: items with key k are
+/* Stable counting sort of N items by key in [0, nkeys), nkeys <= 512: items with key k are
  * perm[ptr[k] .. ptr[k+1]) in ascending item order.  A key outside the range is clamped into it (perm is always a full
  * permutation of 0..N-1) and reported: status[0] |= 16. */
 int cartnet_sort_by_key(const int64_t* keys, int32_t N, int32_t nkeys, int32_t* perm, int32_t* ptr, int32_t* status,
@@ -621,10 +621,14 @@ size_t cartnet_workspace_bytes(const CartnetModel* model, int32_t N, int64_t E, 
                                int32_t need_backward);
 /* pred [M,3,3] (Cholesky head) or [Bg] (scalar head); x_out [N,D] and e_out [E,D] receive the final node / edge
  * features (what the reference leaves in batch.x / batch.edge_attr).  status[0] (device int32) reports graph-layout
- * problems (cartnet_csr_build bits).  need_backward = 0 lets the layers reuse one set of activation buffers. */
+ * problems (cartnet_csr_build bits).  need_backward = 0 lets the layers reuse one set of activation buffers.
+ * aux_stream (optional second hipStream_t, may be NULL): the work that does not depend on the graph (weight transposes
+ * and DMA images) and the atom branch of the encoder with the first layer's node terms are enqueued there, next to
+ * the layout build and the edge encoder on `stream`; ordered with events, joined before the first layer, so the
+ * caller sees single-stream semantics on `stream`. */
 int cartnet_model_forward(const CartnetModel* model, const CartnetBatch* batch, void* workspace, size_t workspace_bytes,
                           int32_t training, int32_t need_backward, float* pred, float* x_out, float* e_out,
-                          int32_t* status, void* stream);
+                          int32_t* status, void* stream, void* aux_stream);
 /* dpred: gradient of the loss w.r.t. pred.  grads: where each parameter's gradient is written (every non-NULL
  * parameter of the model must have a destination).  Consumes the workspace of the matching forward call.
  * aux_stream (optional second hipStream_t): when given, the parameter-gradient work (weight-gradient GEMMs, split-K

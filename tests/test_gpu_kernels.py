@@ -810,3 +810,32 @@ def test_gemm_half_storage_is_refused_where_no_kernel_reads_it(ops):
         ops.gemm(_bf(X), W.t().contiguous(), C_, b_kstrided=True, b_split=ops.pack_b([W.t()]))
     with pytest.raises(RuntimeError, match="half"):      # no weight image
         ops.gemm(_bf(X), W.t().contiguous(), C_, b_kstrided=True, precision=2)
+
+
+@pytest.mark.parametrize("N,nkeys", [(0, 5), (1, 1), (63, 3), (64, 119), (65, 119), (1023, 7), (12416, 119), (40000, 512)])
+def test_sort_by_key_is_a_stable_counting_sort(ops, N, nkeys):
+    """cartnet_sort_by_key (16 waves, ballot ranking): equal keys keep their input order at every size, incl. ranges
+    that end inside a 64-item chunk, an empty input, a single key, and out-of-table keys (clamped and reported)."""
+    g = torch.Generator().manual_seed(N + nkeys)
+    z = torch.randint(0, nkeys, (N,), generator=g)
+    if N > 3:
+        z[::7] = z[0]                                  # long runs of one key across chunk and wave boundaries
+    perm, zptr, status = ops.sort_by_key(z.to(dev()), nkeys)
+    assert int(status.item()) == 0
+    assert torch.equal(perm[:N].cpu().long(), torch.argsort(z, stable=True))
+    assert torch.equal(zptr.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long),
+                                                    torch.cumsum(torch.bincount(z, minlength=nkeys), 0)]))
+    if N > 10:
+        bad = z.clone()
+        bad[3], bad[N - 2] = -1, nkeys + 4
+        perm, zptr, status = ops.sort_by_key(bad.to(dev()), nkeys)
+        assert int(status.item()) == 16
+        assert torch.equal(perm[:N].cpu().long(), torch.argsort(bad.clamp(0, nkeys - 1), stable=True))
+
+
+def test_colsum_finalize_f32_matches_fp64_column_sums(ops):
+    for nparts, N in [(1, 5), (31, 33), (256, 904), (300, 1000)]:
+        parts = rnd(nparts, N, seed=nparts)
+        out = torch.full((N,), float("nan"), device=dev())
+        ops.colsum_finalize(parts.contiguous().view(-1), nparts, out)
+        assert rel_err(out, parts.double().sum(0)) < 1e-6
