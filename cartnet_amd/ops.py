@@ -212,18 +212,22 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
     _l.check(lib.cartnet_gemm(C.byref(args), _l.stream_ptr()), "cartnet_gemm")
 
 
-def pack_b(mats: Sequence[Tensor]) -> list:
+def pack_b(mats: Sequence[Tensor], outs: Optional[Sequence[Tensor]] = None) -> list:
     """fp32 images (cartnet_gemm_pack_b) of k-strided GEMM operands for precision-0 calls; see split_b."""
-    return split_b(mats, _fp32=True)
+    return split_b(mats, _fp32=True, outs=outs)
 
 
-def split_b(mats: Sequence[Tensor], _fp32: bool = False) -> list:
+def split_b(mats: Sequence[Tensor], _fp32: bool = False, outs: Optional[Sequence[Tensor]] = None) -> list:
     """bf16x3 pre-split images (cartnet_gemm_split_b) of k-strided GEMM operands: each entry is a 2-D fp32 view
-    B [K, N] with arbitrary strides (``W.t()`` of a weight W [out, in] gives the forward operand)."""
+    B [K, N] with arbitrary strides (``W.t()`` of a weight W [out, in] gives the forward operand).  ``outs``: image
+    buffers of an earlier call to refill in place (one launch per 80 matrices for any number of them)."""
     lib = _l.load()
     fn_bytes = lib.cartnet_gemm_pack_b_bytes if _fp32 else lib.cartnet_gemm_split_b_bytes
     fn = lib.cartnet_gemm_pack_b if _fp32 else lib.cartnet_gemm_split_b
     mats = list(mats)
+    given = list(outs) if outs is not None else None
+    if given is not None and len(given) != len(mats):
+        raise ValueError("split_b: one output buffer per matrix")
     outs = []
     n = len(mats)
     src = (C.c_void_p * n)()
@@ -236,7 +240,12 @@ def split_b(mats: Sequence[Tensor], _fp32: bool = False) -> list:
         nbytes = int(fn_bytes(K, N))
         if nbytes == 0:
             raise ValueError(f"split_b[{i}]: K={K} must be a multiple of 16 and N={N} of 256")
-        out = torch.empty(nbytes, dtype=torch.uint8, device=m.device)
+        if given is not None:
+            out = given[i]
+            if out.dtype != torch.uint8 or not out.is_cuda or not out.is_contiguous() or out.numel() < nbytes:
+                raise ValueError(f"split_b outs[{i}]: expected a contiguous uint8 CUDA tensor of {nbytes} bytes")
+        else:
+            out = torch.empty(nbytes, dtype=torch.uint8, device=m.device)
         outs.append(out)
         src[i], dst[i] = m.data_ptr(), out.data_ptr()
         Ks[i], Ns[i], sk[i], sn[i] = K, N, int(m.stride(0)), int(m.stride(1))
@@ -677,16 +686,27 @@ def scalar_head_bwd(hid, w2, graph_ptr, batch, dout, dhid, parts) -> None:
                                                _l.stream_ptr()), "cartnet_scalar_head_bwd")
 
 
-def transpose(srcs: Sequence[Tensor]) -> list:
-    """Returns contiguous transposes of 2-D fp32 views (up to 8 matrices per launch)."""
+def transpose(srcs: Sequence[Tensor], outs: Optional[Sequence[Tensor]] = None) -> list:
+    """Returns contiguous transposes of 2-D fp32 views (up to 40 matrices per launch); ``outs``: contiguous [cols, rows]
+    tensors to refill in place."""
+    given = list(outs) if outs is not None else None
     outs = []
     srcs = list(srcs)
-    for i in range(0, len(srcs), 8):
-        chunk = srcs[i:i + 8]
+    if given is not None and len(given) != len(srcs):
+        raise ValueError("transpose: one output per matrix")
+    for i in range(0, len(srcs), 40):
+        chunk = srcs[i:i + 40]
         dsts = []
-        for t in chunk:
+        for j, t in enumerate(chunk):
             _f32_2d(t, "transpose src")
-            dsts.append(torch.empty((t.shape[1], t.shape[0]), dtype=torch.float32, device=t.device))
+            if given is not None:
+                d = given[i + j]
+                if not (d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and
+                        tuple(d.shape) == (t.shape[1], t.shape[0])):
+                    raise ValueError("transpose outs: expected a contiguous fp32 CUDA tensor of the transposed shape")
+                dsts.append(d)
+            else:
+                dsts.append(torch.empty((t.shape[1], t.shape[0]), dtype=torch.float32, device=t.device))
         n = len(chunk)
         I32 = C.c_int32 * n
         _l.check(_l.load().cartnet_transpose(
