@@ -13,7 +13,7 @@ gen = torch.Generator().manual_seed(7)
 sizes = torch.randint(2, 21, (64,), generator=gen).tolist()
 base = Batch.from_data_list([make_crystal(5000 + i, n, adp=False) for i, n in enumerate(sizes)]).to(dev)
 model = CartNet(256, 64, 4, temperature=False, cholesky=False).to(dev).train()
-model.gemm_precision = 1
+model.gemm_precision = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 opt = FlatAdam(model, lr=1e-3)
 def fresh():
     b = base.clone(); b.num_graphs = base.num_graphs; b._cartnet_layout = None; b._cartnet_mask_index = None
