@@ -216,11 +216,13 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
   const int wm = wid / S::WGN, wn = wid % S::WGN;
   const int li = lane & 31, lh = lane >> 5;
   const int tiles_n = p.N / F32_BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  int bx, by;
+  cn_splitk_block_map(bx, by);     // tiles of one K-chunk on one XCD (gemm_kernel.h)
+  const int tile_m = bx / tiles_n, tile_n = bx % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * F32_BN;
   const int g = blockIdx.z;
-  const int split = fl.split0 + blockIdx.y;
-  const int kbeg = fl.k_lo + blockIdx.y * fl.kchunk;
+  const int split = fl.split0 + by;
+  const int kbeg = fl.k_lo + by * fl.kchunk;
   const int kend = min(fl.k_hi, kbeg + fl.kchunk);
   const int nsteps = (kend - kbeg) / BK;
 

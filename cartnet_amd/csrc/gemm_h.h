@@ -347,11 +347,13 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_htn_kernel(const CartnetG
   const int wm = wid / S::WGN, wn = wid % S::WGN;
   const int li = lane & 31, lh = lane >> 5;
   const int tiles_n = p.N / X3_BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  int bx, by;
+  cn_splitk_block_map(bx, by);     // tiles of one K-chunk on one XCD (gemm_kernel.h)
+  const int tile_m = bx / tiles_n, tile_n = bx % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * X3_BN;
   const int g = blockIdx.z;
-  const int split = fl.split0 + blockIdx.y;
-  const int kbeg = fl.k_lo + blockIdx.y * fl.kchunk;
+  const int split = fl.split0 + by;
+  const int kbeg = fl.k_lo + by * fl.kchunk;
   const int kend = min(fl.k_hi, kbeg + fl.kchunk);
   // every K-step of the slab, also a ragged last one: rows past K are read from row K-1 (in bounds) and the A rows
   // among them are zeroed on their way into LDS, so they add nothing (the fp32 kernel that takes the < 16-row tail of

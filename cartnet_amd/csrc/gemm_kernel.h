@@ -444,6 +444,23 @@ __device__ __forceinline__ void epilogue_wide(const CartnetGemmArgs& p, f32x16 (
   }
 }
 
+// Block -> (tile, K-chunk) map of the split-K weight-gradient kernels (grid: x = tiles, y = K-chunks, z = groups).  The
+// tiles of one K-chunk read the same rows of one operand (M = 256: two row tiles share the whole B chunk).  Workgroups
+// go to the 8 XCDs round-robin in dispatch order (x fastest, then y), so neighbours in x never share an L2 and the shared
+// chunk used to come from beyond the L2 once per tile (PMC, round 3: 1155 MB fetched per edge-sized fp32 launch against
+// 726 MB of operands; 793 MB with this map).  The tiles of a K-chunk sit 8 dispatch slots apart: same XCD, microseconds
+// apart.  Chunks past the last multiple of 8 keep the plain order.
+__device__ __forceinline__ void cn_splitk_block_map(int& bx, int& by) {
+  bx = blockIdx.x;
+  by = blockIdx.y;
+  const int T = gridDim.x, Y = gridDim.y, L = bx + T * by, full = (Y >> 3) * 8 * T;
+  if (T > 1 && L < full) {
+    const int chunk = L / (8 * T), r = L - chunk * 8 * T;
+    by = chunk * 8 + (r & 7);
+    bx = r >> 3;
+  }
+}
+
 // Block -> (tile, group) map for grouped launches without split-K.  Workgroups go to the 8 XCDs round-robin in
 // dispatch order (x fastest, then z), and groups of one row tile read the same A rows (layer GEMM1: both MLPs read e;
 // node projections: four products of x): the groups of a tile are placed 8 dispatch slots apart -- same XCD, same
