@@ -30,7 +30,7 @@ __global__ __launch_bounds__(NTHREADS, 6) void cn_gemm_f32nn128_kernel(const Car
   const int li = lane & 31, lh = lane >> 5;
   const int tiles_n = p.N / W128_BN;
   int bx, g;
-  cn_block_map(bx, g);
+  cn_block_map(bx, g, tiles_n);
   const int tile_m = bx / tiles_n, tile_n = bx % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * W128_BN;
   const int nsteps = p.K / BK;

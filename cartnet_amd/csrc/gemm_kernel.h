@@ -444,6 +444,12 @@ __device__ __forceinline__ void epilogue_wide(const CartnetGemmArgs& p, f32x16 (
   }
 }
 
+// The same with several column tiles per row tile (N = 512: two 256-wide tiles; the 128-wide kernel at N = 256): the
+// column tiles of a row tile read the same A rows as its groups do, so all `tiles_n x groups` workgroups of a row tile
+// go 8 dispatch slots apart (PMC, round 3: layer GEMM 1 on the 128-wide kernel fetched e twice, 548 MB per launch
+// against 181 MB of e + the node-term gathers).  bx = tile_m * tiles_n + tile_n as in the plain order.
+__device__ __forceinline__ void cn_block_map(int& bx, int& g, int tiles_n);
+
 // Block -> (tile, K-chunk) map of the split-K weight-gradient kernels (grid: x = tiles, y = K-chunks, z = groups).  The
 // tiles of one K-chunk read the same rows of one operand (M = 256: two row tiles share the whole B chunk).  Workgroups
 // go to the 8 XCDs round-robin in dispatch order (x fastest, then y), so neighbours in x never share an L2 and the shared
@@ -483,6 +489,29 @@ __device__ __forceinline__ void cn_block_map(int& bx, int& g) {
     g = r / rem;
     bx = X8 + r % rem;
   }
+}
+
+__device__ __forceinline__ void cn_block_map(int& bx, int& g, int tiles_n) {
+  if (tiles_n <= 1 || gridDim.y != 1) {
+    cn_block_map(bx, g);
+    return;
+  }
+  const int X = gridDim.x, G = gridDim.z;
+  const int TM = X / tiles_n, S = tiles_n * G;      // row tiles; workgroups sharing one row tile's A rows
+  const int L = blockIdx.x + X * blockIdx.z;
+  const int TM8 = TM & ~7;
+  int tile_m, sub;
+  if (L < TM8 * S) {
+    const int chunk = L / (8 * S), w = L - chunk * 8 * S;
+    tile_m = chunk * 8 + (w & 7);
+    sub = w >> 3;
+  } else {
+    const int r = L - TM8 * S, rem = TM - TM8;
+    tile_m = TM8 + r % rem;
+    sub = r / rem;
+  }
+  g = sub / tiles_n;
+  bx = tile_m * tiles_n + sub % tiles_n;
 }
 
 // FAST: every tile of the launch is full, K is a whole number of K-steps and rows are 16-byte aligned -> the operand

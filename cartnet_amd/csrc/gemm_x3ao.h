@@ -23,7 +23,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_actout_kernel(const 
   const int li = lane & 31, lh = lane >> 5;
   const int tiles_n = p.N / X3_BN;
   int bx, g;
-  cn_block_map(bx, g);
+  cn_block_map(bx, g, tiles_n);
   const int tile_m = bx / tiles_n, tile_n = bx % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * X3_BN;
   const int nk = p.K / BK;
