@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void cn_csc_build_kernel(const int* __restrict
 // every item with a serial scan over the preceding items of its 1024-chunk: 420 us for 12,416 atoms, alone on the
 // weight-gradient stream.  Dynamic LDS: (SORT_WAVES + 1) * nkeys ints.
 constexpr int SORT_WAVES = 16;
+constexpr int SORT_BATCH = 8;      // 64-item chunks whose key loads are in flight together
 
 __device__ __forceinline__ int cn_sort_key(const int64_t* __restrict__ keys, int i, int nkeys, int* status) {
   long long k = keys[i];
@@ -144,7 +145,19 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void cn_sort_by_key_kernel(const i
   const int i0 = min(N, w * per), i1 = min(N, i0 + per);
   for (int i = tid; i < SORT_WAVES * nkeys; i += 64 * SORT_WAVES) cnt[i] = 0;
   __syncthreads();
-  for (int i = i0 + lane; i < i1; i += 64) atomicAdd(&cnt[w * nkeys + cn_sort_key(keys, i, nkeys, status)], 1);
+  // (key loads in batches of SORT_BATCH chunks: the loads of a batch are independent, so a wave pays the memory latency
+  //  once per batch instead of once per 64 items -- under a co-running GEMM that latency is microseconds)
+  for (int c0 = i0; c0 < i1; c0 += 64 * SORT_BATCH) {
+    int key[SORT_BATCH];
+#pragma unroll
+    for (int u = 0; u < SORT_BATCH; ++u) {
+      const int i = c0 + 64 * u + lane;
+      key[u] = i < i1 ? cn_sort_key(keys, i, nkeys, status) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < SORT_BATCH; ++u)
+      if (key[u] >= 0) atomicAdd(&cnt[w * nkeys + key[u]], 1);
+  }
   __syncthreads();
   for (int k = tid; k < nkeys; k += 64 * SORT_WAVES) {     // per key: counts -> offsets of the waves inside the key
     int run = 0;
@@ -168,21 +181,30 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void cn_sort_by_key_kernel(const i
   }
   __syncthreads();
   volatile int* vcnt = cnt;     // lane `leader` writes what all lanes of the wave read in the next round
-  for (int c0 = i0; c0 < i1; c0 += 64) {
-    const int i = c0 + lane;
-    const bool valid = i < i1;
-    const int key = valid ? cn_sort_key(keys, i, nkeys, nullptr) : -1;
-    unsigned long long todo = __ballot(valid);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int k0 = __shfl(key, leader);
-      const unsigned long long same = __ballot(valid && key == k0);
-      const int off = vcnt[w * nkeys + k0];
-      if (valid && key == k0) perm[base[k0] + off + __popcll(same & ((1ull << lane) - 1ull))] = i;
-      __builtin_amdgcn_wave_barrier();
-      if (lane == leader) vcnt[w * nkeys + k0] = off + __popcll(same);
-      __builtin_amdgcn_wave_barrier();
-      todo &= ~same;
+  for (int b0 = i0; b0 < i1; b0 += 64 * SORT_BATCH) {
+    int keyb[SORT_BATCH];
+#pragma unroll
+    for (int u = 0; u < SORT_BATCH; ++u) {
+      const int i = b0 + 64 * u + lane;
+      keyb[u] = i < i1 ? cn_sort_key(keys, i, nkeys, nullptr) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < SORT_BATCH; ++u) {
+      const int i = b0 + 64 * u + lane;
+      const int key = keyb[u];
+      const bool valid = key >= 0;
+      unsigned long long todo = __ballot(valid);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k0 = __shfl(key, leader);
+        const unsigned long long same = __ballot(valid && key == k0);
+        const int off = vcnt[w * nkeys + k0];
+        if (valid && key == k0) perm[base[k0] + off + __popcll(same & ((1ull << lane) - 1ull))] = i;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == leader) vcnt[w * nkeys + k0] = off + __popcll(same);
+        __builtin_amdgcn_wave_barrier();
+        todo &= ~same;
+      }
     }
   }
 }
@@ -212,6 +234,30 @@ extern "C" int cartnet_sort_by_key(const int64_t* keys, int32_t N, int32_t nkeys
   hipLaunchKernelGGL(cn_sort_by_key_kernel, dim3(1), dim3(64 * SORT_WAVES), sizeof(int) * (SORT_WAVES + 1) * nkeys, st, keys, N,
                      nkeys, perm, ptr, status);
   CN_LAUNCH_CHECK("cartnet_sort_by_key");
+  return 0;
+}
+
+extern "C" int cartnet_csc_build(const int32_t* src32, const int32_t* rowptr, const int64_t* graph_ptr, int32_t Bg, int32_t N,
+                                 int64_t E, int32_t* colptr, int32_t* perm, int32_t* status, void* stream) {
+  CN_CHECK(E >= 0 && N >= 0 && E < 2147483647LL, "cartnet_csc_build: bad sizes");
+  CN_CHECK(src32 && rowptr && colptr && perm && status, "cartnet_csc_build: null pointer");
+  CN_CHECK(graph_ptr == nullptr || Bg >= 1, "cartnet_csc_build: Bg=%d", Bg);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  ZeroJobs z;
+  z.p[0] = colptr; z.n[0] = (long long)N + 1;
+  z.p[1] = perm;   z.n[1] = (long long)E;
+  z.p[2] = nullptr; z.n[2] = 0;
+  z.p[3] = nullptr; z.n[3] = 0;
+  long long most = z.n[0] > z.n[1] ? z.n[0] : z.n[1];
+  int zb = (int)((most + 1023) / 1024);
+  if (zb > 1024) zb = 1024;
+  if (zb < 1) zb = 1;
+  hipLaunchKernelGGL(cn_zero_ints_kernel, dim3(zb, 2), dim3(256), 0, st, z);
+  CN_LAUNCH_CHECK("cartnet_csc_build/zero");
+  const int ng = graph_ptr ? Bg : 1;
+  hipLaunchKernelGGL(cn_csc_build_kernel, dim3(ng), dim3(256), 0, st, src32, rowptr, graph_ptr, ng, N, (int)E, colptr, perm,
+                     status);
+  CN_LAUNCH_CHECK("cartnet_csc_build");
   return 0;
 }
 

@@ -157,7 +157,8 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
   // power- and HBM-limited and 1.8 GB of extra writes cost more than the cheaper weight-gradient kernel returns.
   // CARTNET_ACT_OUT=0: off.
   static const bool act_out_on = [] { const char* e = getenv("CARTNET_ACT_OUT"); return !e || atoi(e) != 0; }();
-  if (need_bwd && act_out_on && m.gemm_precision == 0 && D % 256 == 0) {
+  static const bool act_out_x3 = [] { const char* e = getenv("CARTNET_ACT_OUT_X3"); return e && atoi(e) != 0; }();   // A/B switch
+  if (need_bwd && act_out_on && (m.gemm_precision == 0 || (act_out_x3 && m.gemm_precision == 1)) && D % 256 == 0) {
     for (int l = 0; l < L; ++l) w.act[l] = c.take<float>(En * 2 * D);
     w.he_act = c.take<float>(En * 2 * D);
   }
@@ -446,8 +447,11 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
 #define FORK() do { if (S.fork() != 0) { cartnet_set_error("cartnet_model_forward: stream fork failed"); return 2; } } while (0)
 #define MAIN_WAITS(ev) do { if (S.main_waits(ev) != 0) { cartnet_set_error("cartnet_model_forward: stream wait failed"); return 2; } } while (0)
   FORK();      // the side stream starts after whatever the caller queued (the optimiser step that wrote the weights)
-  RUN(cartnet_csr_build(b.edge_index, b.E, N, b.graph_ptr, b.Bg, w.src32, w.tgt32, w.rowptr, w.colptr, w.perm, status,
-                        st));
+  // (the CSC permutation -- one workgroup per crystal, only backward reads it -- goes to the second stream when there is one)
+  // (an inference pass -- need_backward = 0 -- does not build it at all)
+  const bool want_csc = need_backward != 0, csc_aside = S.dual && want_csc;
+  RUN(cartnet_csr_build(b.edge_index, b.E, N, b.graph_ptr, b.Bg, w.src32, w.tgt32, w.rowptr,
+                        (want_csc && !csc_aside) ? w.colptr : nullptr, (want_csc && !csc_aside) ? w.perm : nullptr, status, st));
   if (w.groups) RUN(cartnet_group_ptrs(b.graph_ptr, b.Bg, m.bn_group_size, w.rowptr, w.G, w.node_gptr, w.edge_gptr, st));
   // weights -> [in, out]   (side stream)
   {
@@ -531,7 +535,9 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       RUN(cartnet_gemm_split_b(src.data(), dst.data(), Ks.data(), Ns.data(), sk.data(), sn.data(), (int32_t)src.size(), sw));
   }
   hipEvent_t weights_ready = S.mark_side();
-  FORK();      // the atom branch below writes status bits: after the layout build has reset the word
+  FORK();      // the atom branch and the CSC build below write status bits: after the layout build has reset the word
+  if (csc_aside)
+    RUN(cartnet_csc_build(w.src32, w.rowptr, b.graph_ptr, b.Bg, N, b.E, w.colptr, w.perm, status, sw));
 
   const bool half = m.half_storage != 0 && m.gemm_precision == 2;
   CN_CHECK(!m.half_storage || (m.gemm_precision == 2 && !w.groups && D % 256 == 0),

@@ -151,6 +151,8 @@ PROTOTYPES = {
     "cartnet_colsum_finalize_f32": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_stream]),
     "cartnet_csr_build": (C.c_int, [c_i64p, C.c_int64, C.c_int32, c_i64p, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p,
                                     c_i32p, c_i32p, c_stream]),
+    "cartnet_csc_build": (C.c_int, [c_i32p, c_i32p, c_i64p, C.c_int32, C.c_int32, C.c_int64, c_i32p, c_i32p, c_i32p,
+                                    c_stream]),
     "cartnet_edge_features": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float,
                                         C.c_float, c_f32p, C.c_int32, c_f32p, c_stream]),
     "cartnet_node_embed": (C.c_int, [c_i64p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32,

@@ -337,6 +337,12 @@ int cartnet_colsum_finalize_f32(const float* parts, int32_t nparts, int32_t N, f
 int cartnet_csr_build(const int64_t* edge_index, int64_t E, int32_t N, const int64_t* graph_ptr, int32_t Bg,
                       int32_t* src32, int32_t* tgt32, int32_t* rowptr, int32_t* colptr, int32_t* perm,
                       int32_t* status, void* stream);
+/* The CSC half of cartnet_csr_build on its own (colptr [N+1], perm [E]: the stable permutation of the edges by source),
+ * from the src32 / rowptr a cartnet_csr_build call with colptr = perm = NULL produced: only backward reads it, so
+ * cartnet_model_forward queues it on its second stream.  ORs the same status bits (4, 8) into `status`, which the
+ * csr call must have reset first (stream order). */
+int cartnet_csc_build(const int32_t* src32, const int32_t* rowptr, const int64_t* graph_ptr, int32_t Bg, int32_t N,
+                      int64_t E, int32_t* colptr, int32_t* perm, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Cartesian edge encoding (models/cartnet.py:159 + models/utils.py:56-61,87-91):
