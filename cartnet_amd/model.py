@@ -222,16 +222,23 @@ class _CartNetFunction(torch.autograd.Function):
         if dpred is None:
             raise RuntimeError("CartNet backward: the loss does not depend on the prediction")
         dpred = dpred.contiguous()
-        G = _GradBuffer(model, dpred.device)
-        gd = _l.Params()
-        _fill_params(gd, G, model.num_layers)
+        sink = model._flat_grad
+        cache = model.__dict__.get("_grad_cache")
+        if sink is not None and cache is not None and cache[0].flat.device == dpred.device and \
+                cache[0].flat.numel() == sink.numel():
+            G, gd = cache              # reused: its content is added to the sink below, in stream order, before the next use
+        else:
+            G = _GradBuffer(model, dpred.device)
+            gd = _l.Params()
+            _fill_params(gd, G, model.num_layers)
+            if sink is not None and sink.numel() == G.flat.numel():
+                model.__dict__["_grad_cache"] = (G, gd)
         aux = model._aux_stream_ptr(dpred.device)
         _l.check(lib.cartnet_model_backward(C.byref(md), C.byref(bd), ws.data_ptr(), nbytes, int(training),
                                             dpred.data_ptr(), x_out.data_ptr(), C.byref(gd), _l.stream_ptr(), aux),
                  "cartnet_model_backward")
         for k in keep:
             _raise_callback_error(k if isinstance(k, _l.ALLREDUCE_FN) else None)
-        sink = model._flat_grad
         if sink is not None and sink.numel() == G.flat.numel():
             sink.add_(G.flat)              # one accumulation into the optimiser's flat gradient buffer
             return (None, None, None) + (None,) * len(model._param_names)
@@ -314,7 +321,23 @@ class CartNet(nn.Module):
         self._flat_grad = None          # set by cartnet_amd.optim.FlatAdam: gradients are accumulated here directly
 
     def _model_desc(self, P: Dict[str, torch.Tensor]) -> "_l.Model":
-        """CartnetModel struct pointing at the current parameters / buffers (reference state_dict layout)."""
+        """CartnetModel struct pointing at the current parameters / buffers (reference state_dict layout).  Cached while
+        every parameter / buffer address and every switch it encodes are what they were (the optimiser updates in place):
+        filling ~120 ctypes fields costs 0.1 ms, a tenth of the host time of a step at configs[2] shapes."""
+        B = self._buffers_dict()
+        key = (tuple(t.data_ptr() for t in P.values()), tuple(t.data_ptr() for t in B.values()),
+               int(self.gemm_precision), int(self.bn_group_size), bool(self.half_storage),
+               tuple(bool(l.use_envelope) for l in self.layers), float(self.layers[0].envelope_radius))
+        cached = self.__dict__.get("_md_cache")
+        if cached is not None and cached[0] == key:
+            cached[1].bn_allreduce = _l.ALLREDUCE_FN()         # per-call field: reset to NULL
+            cached[1].bn_allreduce_user = None
+            return cached[1]
+        md = self._model_desc_build(P)
+        self.__dict__["_md_cache"] = (key, md)
+        return md
+
+    def _model_desc_build(self, P: Dict[str, torch.Tensor]) -> "_l.Model":
         enc = self.encoder
         md = _l.Model()
         md.D, md.R, md.L = self.dim_in, enc.rbf.num_rbf, self.num_layers
