@@ -73,6 +73,9 @@ class ComformerConv_edge(nn.Module):
         self.bn_att, self.bn = nn.BatchNorm1d(c), nn.BatchNorm1d(c)
 
 
+import os as _os
+_KEEP_ACT = _os.environ.get("CARTNET_ICF_ACT_OUT", "0") != "0"      # off: measured twice (r2, r3), no gain -- see _Attention.forward
+_SIDE_BRANCHES = _os.environ.get("CARTNET_ICF_SIDE_BRANCH", "1") != "0"    # A/B switch, see _side_branch
 _GEMM_PRECISION = [0]     # CartnetGemmArgs.precision of the running forward / backward (set from model.gemm_precision)
 
 
@@ -239,6 +242,39 @@ def _wgrad(dY: List[torch.Tensor], X: List[torch.Tensor], outs: List[torch.Tenso
         t.record_stream(side)
 
 
+class _side_branch:
+    """``with _side_branch(inputs) as sb:`` runs a branch of backward that nothing on the main chain waits for (until a
+    later ``_join_wgrads``) on the weight-gradient stream: the stream first waits for what the main stream has queued,
+    the tensors the branch reads are marked as in use there, and ``sb.keep(t)`` marks a result that a later main-stream
+    kernel reads.  Without a second stream it is a no-op context."""
+
+    def __init__(self, inputs):
+        self.inputs = [t for t in inputs if t is not None]
+        self.side = _SIDE["stream"] if (_SIDE["on"] and _SIDE_BRANCHES) else None
+        self.ctx = None
+
+    def __enter__(self):
+        if self.side is not None:
+            self.main = torch.cuda.current_stream()
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def keep(self, *tensors):
+        if self.side is not None:
+            for t in tensors:
+                t.record_stream(self.main)         # allocated on the side stream, read on the main one after the join
+        return tensors[0] if len(tensors) == 1 else tensors
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.ctx.__exit__(*exc)
+            for t in self.inputs:
+                t.record_stream(self.side)
+        return False
+
+
 def _join_wgrads():
     """The main stream waits for every weight gradient queued so far."""
     if _SIDE["stream"] is not None and _SIDE["on"]:
@@ -282,9 +318,15 @@ class _Attention:
                  gather_i=[term_i[:, :C], term_i[:, C:]], gather_j=[term_j[:, :C], term_j[:, C:]], tgt=idx_i, src=idx_j)
         keyb = _e((R, 2 * C), dev)      # key' in the first half (second half unused: groups share a leading dim)
         gs = _e((R, 2 * C), dev)        # [alpha | msg]
+        # Optional (CARTNET_ICF_ACT_OUT=1): keep silu(pr) (written by this GEMM on its way into LDS, a_act_out) so that the
+        # second Linears' weight gradients read a plain operand and run on the all-DMA kernel.  Measured in rounds 2 and 3:
+        # no gain (36.5-36.7 vs 36.2-36.4 ms) -- the cheaper product sits on the weight-gradient stream, which has slack,
+        # while the costlier forward GEMM sits on the critical chain.
+        act = _e((R, 2 * C), dev) if (_KEEP_ACT and _GEMM_PRECISION[0] == 0 and C % 256 == 0) else None
         _gemm([pr[:, :C], pr[:, C:]], [P[pre + ".key_update.2.weight"], P[pre + ".lin_msg_update.2.weight"]],
                  [keyb[:, :C], gs[:, C:]], a_act=True,
-                 bias=[P[pre + ".key_update.2.bias"], P[pre + ".lin_msg_update.2.bias"]])
+                 bias=[P[pre + ".key_update.2.bias"], P[pre + ".lin_msg_update.2.bias"]],
+                 **({"a_act_out": [act[:, :C], act[:, C:]]} if act is not None else {}))
         npart = ops.segment_nparts(S)
         ps, pq = _parts(npart * C, dev), _parts(npart * C, dev)
         scale = 1.0 / math.sqrt(C)
@@ -296,7 +338,7 @@ class _Attention:
         gp = ops.gate_nparts(S)
         ops.gate_scatter_fwd(gs, None, None, seg_layout, mr1, P[pre + ".bn_att.weight"], P[pre + ".bn_att.bias"], None,
                              aggr, _parts(gp * C, dev), _parts(gp * C, dev))
-        sv.update(pr=pr, keyb=keyb, gs=gs, mr1=mr1, aggr=aggr)
+        sv.update(pr=pr, keyb=keyb, gs=gs, mr1=mr1, aggr=aggr, act=act)
         return aggr
 
     @staticmethod
@@ -322,8 +364,13 @@ class _Attention:
         G[pre + ".key_update.2.bias"] = _e((C,), dev)
         ops.colsum(gs[:, :C], G[pre + ".key_update.2.bias"])
         G[pre + ".key_update.2.weight"], G[pre + ".lin_msg_update.2.weight"] = _e((C, C), dev), _e((C, C), dev)
-        _wgrad([gs[:, :C], gs[:, C:]], [pr[:, :C], pr[:, C:]],
-               [G[pre + ".key_update.2.weight"], G[pre + ".lin_msg_update.2.weight"]], b_act=True)
+        act = sv.get("act")
+        if act is not None:
+            _wgrad([gs[:, :C], gs[:, C:]], [act[:, :C], act[:, C:]],
+                   [G[pre + ".key_update.2.weight"], G[pre + ".lin_msg_update.2.weight"]])
+        else:
+            _wgrad([gs[:, :C], gs[:, C:]], [pr[:, :C], pr[:, C:]],
+                   [G[pre + ".key_update.2.weight"], G[pre + ".lin_msg_update.2.weight"]], b_act=True)
         tiles = ops.gemm_tiles_m(R)
         csk, csm = _parts(tiles * C, dev), _parts(tiles * C, dev)
         dpr = _e((R, 2 * C), dev)       # not in place over pr: the weight-gradient stream may still be reading silu(pr)
@@ -584,8 +631,8 @@ class _IComformerFunction(torch.autograd.Function):
                      b_kstrided=True, segments=True, resid=resid)
             return d_in
 
-        def conv_bwd(l, dy):
-            """Returns (dx, de) of att_layers[l]."""
+        def conv_bwd(l, dy, de_acc=None):
+            """Returns (dx, de) of att_layers[l]; ``de_acc`` (optional [E, C]) is added to de in the GEMM's epilogue."""
             p = f"att_layers.{l}"
             s = sv.pop(p)
             x_in, e_in, QKV, ea = s["x"], s["e"], s["QKV"], s["ea"]
@@ -599,18 +646,22 @@ class _IComformerFunction(torch.autograd.Function):
             dQKV = _e((N, 3 * C), dev)
             dpre, dW1k, dW1m = _Attention.backward(P, G, p, daggr, QKV[:, :C], ea, lay, E, training, s, dQKV[:, :C])
             W1k, W1m = P[p + ".key_update.0.weight"], P[p + ".lin_msg_update.0.weight"]
-            # lin_edge: d(ea) = dpre @ W1[:, 2C:], then into e
-            dea = _e((E, C), dev)
-            tiles = ops.gemm_tiles_m(E)
-            cs = _parts(tiles * C, dev)
-            _gemm([dpre[:, :C], dpre[:, C:]], [W1k[:, 2 * C:], W1m[:, 2 * C:]], dea, b_kstrided=True, segments=True,
-                     colsum=cs)
-            G[p + ".lin_edge.bias"] = _e((C,), dev)
-            ops.colsum_finalize(cs, tiles, G[p + ".lin_edge.bias"])
-            G[p + ".lin_edge.weight"] = _e((C, C), dev)
-            _wgrad([dea], [e_in], [G[p + ".lin_edge.weight"]])
-            de = _e((E, C), dev)
-            _gemm(dea, P[p + ".lin_edge.weight"], de, b_kstrided=True)
+            # lin_edge: d(ea) = dpre @ W1[:, 2C:], then into e.  Nothing on the chain of atom gradients reads de before
+            # the edge layer's backward (or the end), so this branch -- two edge-sized products -- runs on the
+            # weight-gradient stream, which has the slack (round 3: main queue 34.7 of 35.4 ms busy, second queue 19.1)
+            with _side_branch([dpre, e_in, de_acc]) as sb:
+                dea = _e((E, C), dev)
+                tiles = ops.gemm_tiles_m(E)
+                cs = _parts(tiles * C, dev)
+                _gemm([dpre[:, :C], dpre[:, C:]], [W1k[:, 2 * C:], W1m[:, 2 * C:]], dea, b_kstrided=True, segments=True,
+                         colsum=cs)
+                G[p + ".lin_edge.bias"] = _e((C,), dev)
+                ops.colsum_finalize(cs, tiles, G[p + ".lin_edge.bias"])
+                G[p + ".lin_edge.weight"] = _e((C, C), dev)
+                _wgrad_now([dea], [e_in], [G[p + ".lin_edge.weight"]])
+                de = _e((E, C), dev)
+                _gemm(dea, P[p + ".lin_edge.weight"], de, b_kstrided=True, resid=de_acc)
+                sb.keep(de, G[p + ".lin_edge.bias"], G[p + ".lin_edge.weight"])
             # node terms: reduce dpre over incoming (target) / outgoing (source) edges
             dKPi, dKPj = _e((N, 2 * C), dev), _e((N, 2 * C), dev)
             ops.segment_sum(dpre, lay.rowptr, None, dKPi)
@@ -644,13 +695,16 @@ class _IComformerFunction(torch.autograd.Function):
             dpre, dW1k, dW1m = _Attention.backward(P, G, p, daggr, QKV[:, :C], exy, seg3, 3 * E, training, s,
                                                    dQKV[:, :C])
             W1k, W1m = P[p + ".key_update.0.weight"], P[p + ".lin_msg_update.0.weight"]
-            # angle branch: d(exy) -> lin_edge (no bias) -> dNA
-            dexy = _e((3 * E, C), dev)
-            _gemm([dpre[:, :C], dpre[:, C:]], [W1k[:, 2 * C:], W1m[:, 2 * C:]], dexy, b_kstrided=True, segments=True)
-            G[p + ".lin_edge.weight"] = _e((C, C), dev)
-            _wgrad([dexy], [sv["NA"]], [G[p + ".lin_edge.weight"]])
-            dNA = _e((3 * E, C), dev)
-            _gemm(dexy, P[p + ".lin_edge.weight"], dNA, b_kstrided=True)
+            # angle branch: d(exy) -> lin_edge (no bias) -> dNA; only the RBF backward at the very end reads dNA, so the
+            # two 3E-row products run on the weight-gradient stream
+            with _side_branch([dpre, sv["NA"]]) as sb:
+                dexy = _e((3 * E, C), dev)
+                _gemm([dpre[:, :C], dpre[:, C:]], [W1k[:, 2 * C:], W1m[:, 2 * C:]], dexy, b_kstrided=True, segments=True)
+                G[p + ".lin_edge.weight"] = _e((C, C), dev)
+                _wgrad_now([dexy], [sv["NA"]], [G[p + ".lin_edge.weight"]])
+                dNA = _e((3 * E, C), dev)
+                _gemm(dexy, P[p + ".lin_edge.weight"], dNA, b_kstrided=True)
+                sb.keep(dNA, G[p + ".lin_edge.weight"])
             # per-edge term (sum over the three lattice vectors) and per-(crystal, lattice vector) term
             dKa = _e((E, 2 * C), dev)
             ops.segment_sum(dpre, seg3.rowptr, None, dKa)
@@ -751,22 +805,19 @@ class _IComformerFunction(torch.autograd.Function):
             # ---- eComformer: att 2, att 1, equivariant update, att 0; the edge features are shared by all of them
             de_tot = None
             for l in (2, 1):
-                dx, de_l = conv_bwd(l, dx)
-                de_tot = add_e(de_tot, de_l)
+                dx, de_tot = conv_bwd(l, dx, de_tot)          # accumulated in the lin_edge backward's epilogue
             dx, de_q = equi_bwd(dx)
+            _join_wgrads()                                    # de_tot was produced on the weight-gradient stream
             de_tot = add_e(de_tot, de_q)
-            dx, de0 = conv_bwd(0, dx)
-            de_tot = add_e(de_tot, de0)
+            dx, de_tot = conv_bwd(0, dx, de_tot)
         else:
             # ---- layers in reverse: att 3, 2, 1 (all read the updated edge features), edge layer, att 0
             de_new = None
             for l in (3, 2, 1):
-                dx, de_l = conv_bwd(l, dx)
-                de_new = add_e(de_new, de_l)
+                dx, de_new = conv_bwd(l, dx, de_new)          # accumulated in the lin_edge backward's epilogue
+            _join_wgrads()                                    # de_new was produced on the weight-gradient stream
             de_old, dNLt, dNA = conv_edge_bwd(de_new)
-            dx, de0 = conv_bwd(0, dx)
-            de_tot = _e((E, C), dev)
-            ops.eltwise(2, de_old, de0, de_tot)
+            dx, de_tot = conv_bwd(0, dx, de_old)
 
         # ---- RBF branches: out = softplus(pre), pre = rbf @ W^T + b ; rbf.1 is shared by the distance and the
         #      lattice-length features, so its gradients add up
@@ -779,6 +830,7 @@ class _IComformerFunction(torch.autograd.Function):
             ops.colsum(dpre, gb)
             return gw, gb
 
+        _join_wgrads()                                        # de_tot / dNA come from the weight-gradient stream
         gw1, gb1 = rbf_bwd("rbf_e", de_tot)
         if sv["equi_model"]:
             G["rbf.1.weight"], G["rbf.1.bias"] = gw1, gb1
