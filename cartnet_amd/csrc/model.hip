@@ -589,6 +589,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     return cartnet_gemm(&a, s_);
   };
   RUN(node_terms(0, w.xenc, sw));
+  if (m.cholesky) RUN(cartnet_mask_index(b.non_h_mask, N, w.idx, nullptr, sw));   // graph-only: off the head's critical path
   hipEvent_t atoms_ready = S.mark_side();
 
   // BatchNorm statistics from partial column sums; with CartnetModel.bn_allreduce (sync-BatchNorm) the sums of all ranks
@@ -656,7 +657,6 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     RUN(cartnet_gemm(&a, st));
   }
   if (m.cholesky) {
-    RUN(cartnet_mask_index(b.non_h_mask, N, w.idx, nullptr, st));
     RUN(cartnet_cholesky_head_fwd(w.hid, w.idx, P.head2_w, P.head2_b, N, H, w.p6, pred, st));
   } else {
     RUN(cartnet_scalar_head_fwd(w.hid, P.head2_w, P.head2_b, b.graph_ptr, b.Bg, H, pred, st));

@@ -88,3 +88,7 @@ timeit("enc dW2: dY^T X, M=256 N=512", lambda: ops.gemm(e, pre, slab1, a_kstride
 slab0 = torch.empty(256*2*D, 80, device=dev)
 timeit("enc dW0: dhe^T feat, M=512 N=80, split-K 256", lambda: ops.gemm(pre, feat, slab0, a_kstrided=True, b_kstrided=True, splitk=256,
        precision=prec), 2.0*E*80*2*D)
+# fixed cost per tile: the same output [E, 512] from K = 16 .. 256 (one K-step .. sixteen)
+for K_ in (16, 32, 80, 128, 256):
+    fk = rnd(E, K_); WkT = rnd(K_, 2*D, sc=0.05); imgk = make([WkT])
+    timeit(f"thin: K={K_} N=512, no bias", lambda: ops.gemm(fk, WkT, out2, b_kstrided=True, b_split=imgk, precision=prec), 2.0*E*K_*2*D)
