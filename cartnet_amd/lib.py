@@ -287,7 +287,15 @@ def check(rc: int, what: str = "") -> None:
         raise CartnetHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr() -> int:
+    """hipStream_t of torch's current stream on the current device.  Through torch's raw accessor when it exists (0.3 us
+    against ~9 us for `torch.cuda.current_stream().cuda_stream`, which builds a Stream object and resolves the device
+    three times -- with several hundred wrapper calls per iComformer step that was 3 ms of host time per step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
