@@ -223,6 +223,11 @@ def _split_k(K, tiles):
 
 
 _SIDE: Dict[str, Optional[torch.cuda.Stream]] = {"stream": None, "on": True}   # weight-gradient stream of the running backward
+# Tensors the second stream reads or writes are kept ALIVE until the streams are joined at the end of backward (a list of
+# references) instead of being marked with `record_stream`: a marked tensor's block is freed through an event the caching
+# allocator then polls on every later allocation -- torch.empty cost 21 us apiece in backward, 7 ms of host time per step.
+# A block that is never returned before the join cannot be handed out while the other stream still uses it.
+_KEEP: list = []
 
 
 def _wgrad(dY: List[torch.Tensor], X: List[torch.Tensor], outs: List[torch.Tensor], b_act=False):
@@ -231,15 +236,16 @@ def _wgrad(dY: List[torch.Tensor], X: List[torch.Tensor], outs: List[torch.Tenso
     Nothing inside backward reads a weight gradient (``_join_wgrads`` covers the one exception), so the product and its
     slab reduction are queued on a second stream, next to the chain of activation gradients -- what
     cartnet_model_backward does for CartNet.  Operands are never written again after this call (the callers keep
-    in-place updates in front of it) and are marked as in use by the side stream for the caching allocator."""
+    in-place updates in front of it) and are kept alive until the streams join (``_KEEP``)."""
     side = _SIDE["stream"] if _SIDE["on"] else None
     if side is None:
         return _wgrad_now(dY, X, outs, b_act)
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         _wgrad_now(dY, X, outs, b_act)
-    for t in list(dY) + list(X) + list(outs):
-        t.record_stream(side)
+    _KEEP.extend(dY)
+    _KEEP.extend(X)
+    _KEEP.extend(outs)
 
 
 class _side_branch:
@@ -263,15 +269,13 @@ class _side_branch:
 
     def keep(self, *tensors):
         if self.side is not None:
-            for t in tensors:
-                t.record_stream(self.main)         # allocated on the side stream, read on the main one after the join
+            _KEEP.extend(tensors)                  # allocated on the side stream, read on the main one after the join
         return tensors[0] if len(tensors) == 1 else tensors
 
     def __exit__(self, *exc):
         if self.side is not None:
             self.ctx.__exit__(*exc)
-            for t in self.inputs:
-                t.record_stream(self.side)
+            _KEEP.extend(self.inputs)
         return False
 
 
@@ -580,6 +584,7 @@ class _IComformerFunction(torch.autograd.Function):
         _GEMM_PRECISION[0] = ctx.gemm_precision
         ctx.sv = None
         P, model, lay = sv["P"], sv["model"], sv["lay"]
+        _KEEP.clear()
         _SIDE["on"] = bool(getattr(model, "overlap_weight_gradients", True))
         if _SIDE["on"] and (_SIDE["stream"] is None or _SIDE["stream"].device != dpred.device):
             _SIDE["stream"] = torch.cuda.Stream(device=dpred.device)
@@ -852,6 +857,7 @@ class _IComformerFunction(torch.autograd.Function):
         G["embedding.weight"] = _e((N_ATOM_TYPES, C), dev)
         ops.segment_sum_long(dx, zptr, zperm, N, G["embedding.weight"])
         _join_wgrads()          # autograd accumulates the gradients on this stream
+        _KEEP.clear()           # the streams are joined: what the second stream used may go back to the allocator
         sink = getattr(model, "_flat_grad", None)
         if sink is not None:
             # the optimiser's flat gradient buffer: one concatenation + one add instead of ~130 per-parameter adds
