@@ -453,10 +453,25 @@ def main():
                 model(bx)
             torch.cuda.synchronize()
             dte = time.perf_counter() - t1
-        model.train()
         eval_fwd = {"value": round(args.graphs * args.steps / dte, 2), "unit": "graphs/s",
                     "ms_per_batch": round(1e3 * dte / args.steps, 3),
                     "note": "forward only, eval mode (running BatchNorm statistics), torch.no_grad: nothing kept for backward"}
+        if args.precision == 0 and not args.no_x3_pass:      # the same pass with bf16x3 products (same parity budget)
+            model.gemm_precision = 1
+            with torch.no_grad():
+                for _ in range(2):
+                    model(fresh())
+                evb = [fresh() for _ in range(args.steps)]
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for bx in evb:
+                    model(bx)
+                torch.cuda.synchronize()
+                dte3 = time.perf_counter() - t1
+            model.gemm_precision = 0
+            eval_fwd["bf16x3_ms_per_batch"] = round(1e3 * dte3 / args.steps, 3)
+            eval_fwd["bf16x3_value"] = round(args.graphs * args.steps / dte3, 2)
+        model.train()
 
     graphs_total = args.graphs * world * args.steps
     value = graphs_total / dt
