@@ -394,7 +394,7 @@ class _IComformerFunction(torch.autograd.Function):
     def forward(ctx, model: "iComformer", batch, training: bool, *params):
         P: Dict[str, torch.Tensor] = dict(zip(model._param_names, params))
         B: Dict[str, torch.Tensor] = dict(model.named_buffers())
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = bool(getattr(model, "_grad_mode", True)) and any(ctx.needs_input_grad)
         ctx.gemm_precision = int(model.gemm_precision)
         _GEMM_PRECISION[0] = ctx.gemm_precision
         _begin_forward(model, P, ctx.gemm_precision)
@@ -896,6 +896,7 @@ class iComformer(nn.Module):
         params = [p for _, p in self.named_parameters()]
         if not params[0].is_cuda:
             raise RuntimeError("cartnet_amd.iComformer runs only on an AMD GPU (HIP kernels); there is no CPU fallback")
+        self._grad_mode = torch.is_grad_enabled()       # read by _IComformerFunction.forward (grad mode is off in there)
         pred, x = _IComformerFunction.apply(self, data, self.training, *params)
         data.x = x
         return pred, data.y
@@ -952,6 +953,7 @@ class eComformer(nn.Module):
         params = [p for _, p in self.named_parameters()]
         if not params[0].is_cuda:
             raise RuntimeError("cartnet_amd.eComformer runs only on an AMD GPU (HIP kernels); there is no CPU fallback")
+        self._grad_mode = torch.is_grad_enabled()       # read by _IComformerFunction.forward (grad mode is off in there)
         pred, x = _IComformerFunction.apply(self, data, self.training, *params)
         data.x = x
         return pred, data.y

@@ -63,7 +63,7 @@ struct Work {
   float *act[CARTNET_MAX_LAYERS], *he_act;
   // backward transients
   float *dhid, *head_parts, *head_tot, *dx[2], *de[2], *daggr, *sums1, *sums2, *dPn[2], *dpre[2], *dhe, *dx0, *seg_tmp,
-      *slabs, *slabs2, *e0wT;
+      *slabs, *slabs2, *e0wT, *gate_bnd;
   double *pa, *pb, *pc[2], *pd[2], *cs_misc[4];
   size_t slab_floats;
   int gparts, nparts_n, tiles_e, tiles_n;
@@ -122,6 +122,7 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
   w.xenc = c.take<float>(Nn * D);
   float* xping[2] = {nullptr, nullptr};
   float* eping[2] = {nullptr, nullptr};
+  if (!need_bwd) w.gate_bnd = c.take<float>(cartnet_gate_gemm_eval_workspace((int64_t)En, D) / sizeof(float) + 4);   // inference fusion
   if (!need_bwd) {
     xping[0] = c.take<float>(Nn * D);
     xping[1] = c.take<float>(Nn * D);
@@ -536,6 +537,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
   }
   hipEvent_t weights_ready = S.mark_side();
   FORK();      // the atom branch and the CSC build below write status bits: after the layout build has reset the word
+  if (m.cholesky) RUN(cartnet_mask_index(b.non_h_mask, N, w.idx, nullptr, sw));   // graph-only: off the head's critical path
   if (csc_aside)
     RUN(cartnet_csc_build(w.src32, w.rowptr, b.graph_ptr, b.Bg, N, b.E, w.colptr, w.perm, status, sw));
 
@@ -589,7 +591,6 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     return cartnet_gemm(&a, s_);
   };
   RUN(node_terms(0, w.xenc, sw));
-  if (m.cholesky) RUN(cartnet_mask_index(b.non_h_mask, N, w.idx, nullptr, sw));   // graph-only: off the head's critical path
   hipEvent_t atoms_ready = S.mark_side();
 
   // BatchNorm statistics from partial column sums; with CartnetModel.bn_allreduce (sync-BatchNorm) the sums of all ranks
@@ -625,6 +626,29 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       a.ldg = 4 * D; a.tgt = w.tgt32; a.src = w.src32;
       if (w.i_pre[l]) { a.b_split[0] = w.i_pre[l]; a.b_split[1] = w.i_pre[l] + img_blk(m); }
       RUN(cartnet_gemm(&a, st));
+    }
+    // Inference (eval-mode BatchNorm, nothing kept for backward, fp32 MFMA): the second Linears, the gate, the per-target
+    // sums and the edge residual are ONE kernel -- gs never reaches memory (csrc/gemm_f32gate.hip)
+    static const bool eval_fuse_on = [] { const char* e_ = getenv("CARTNET_EVAL_FUSE"); return !e_ || atoi(e_) != 0; }();
+    // (BatchNorm groups change nothing in eval mode -- every group's row of mean_rstd holds the running statistics)
+    if (eval_fuse_on && !training && !need_backward && m.gemm_precision == 0 && !half && D % 256 == 0 && w.i_gs[l] &&
+        w.gate_bnd && E > 0) {
+      RUN(bn_stats(w.cs, w.cq, w.tiles_e, b.E, m.buf[l].norm_mean, m.buf[l].norm_var, m.buf[l].norm_nbt, w.mr1[l], 1));
+      CartnetGateGemmArgs ga;
+      memset(&ga, 0, sizeof(ga));
+      ga.pre = w.pre[l]; ga.ldp = 2 * D;
+      ga.img_gate = w.i_gs[l]; ga.img_aggr = w.i_gs[l] + img_blk(m);
+      ga.bias_gate = q.gate2_b; ga.bias_aggr = q.aggr2_b;
+      ga.mean_rstd = w.mr1[l]; ga.gamma = q.norm_w; ga.beta = q.norm_b;
+      ga.env = m.use_envelope[l] ? w.env : nullptr;
+      ga.e_in = e; ga.e_out = e_next; ga.tgt = w.tgt32; ga.rowptr = w.rowptr; ga.aggr = w.aggr[l]; ga.bnd = w.gate_bnd;
+      ga.E = b.E; ga.N = N; ga.D = D;
+      RUN(cartnet_gate_gemm_eval(&ga, st));
+      RUN(bn_stats(w.ps, w.pq, w.gparts, N, m.buf[l].norm2_mean, m.buf[l].norm2_var, m.buf[l].norm2_nbt, w.mr2[l], 0));
+      RUN(cartnet_node_update_fwd(w.aggr[l], x, w.mr2[l], q.norm2_w, q.norm2_b, N, D, x_next, w.groups, st));
+      x = x_next;
+      e = e_next;
+      continue;
     }
     {  // gs = silu(pre) W2^T + b2, BatchNorm statistics of the gate half
       CartnetGemmArgs a = gemm_args(E, D, D, 2 * D, D, 2 * D);

@@ -25,6 +25,15 @@ c_stream = C.c_void_p
 c_groups = C.c_void_p       # const CartnetGroups* (None = one BatchNorm group: the whole batch)
 
 
+class GateGemmArgs(C.Structure):
+    """CartnetGateGemmArgs (include/cartnet_hip.h)."""
+    _fields_ = [("pre", C.c_void_p), ("ldp", C.c_int32), ("img_gate", C.c_void_p), ("img_aggr", C.c_void_p),
+                ("bias_gate", C.c_void_p), ("bias_aggr", C.c_void_p), ("mean_rstd", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("env", C.c_void_p), ("e_in", C.c_void_p), ("e_out", C.c_void_p),
+                ("tgt", C.c_void_p), ("rowptr", C.c_void_p), ("aggr", C.c_void_p), ("bnd", C.c_void_p),
+                ("E", C.c_int64), ("N", C.c_int32), ("D", C.c_int32)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [
         ("A", C.c_void_p * MAX_GROUPS), ("B", C.c_void_p * MAX_GROUPS), ("C", C.c_void_p * MAX_GROUPS),
@@ -126,6 +135,8 @@ PROTOTYPES = {
     "cartnet_abi_version": (C.c_int, []),
     "cartnet_abi_struct_sizes": (C.c_int, [C.POINTER(C.c_size_t), C.c_int32]),
     "cartnet_gemm": (C.c_int, [C.POINTER(GemmArgs), c_stream]),
+    "cartnet_gate_gemm_eval_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "cartnet_gate_gemm_eval": (C.c_int, [C.POINTER(GateGemmArgs), c_stream]),
     "cartnet_gemm_split_b_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "cartnet_gemm_split_b": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32,

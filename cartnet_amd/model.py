@@ -138,7 +138,9 @@ class _CartNetFunction(torch.autograd.Function):
     def forward(ctx, model: "CartNet", batch, training: bool, *params):
         lib = _l.load()
         dev = params[0].device
-        need_grad = any(ctx.needs_input_grad)   # False under no_grad / eval loops: nothing is kept for backward
+        # (under torch.no_grad() the flags of ctx.needs_input_grad still mirror requires_grad, and inside a Function's forward
+        #  the grad mode is always off: the module's forward() records the caller's grad mode in model._grad_mode)
+        need_grad = bool(getattr(model, "_grad_mode", True)) and any(ctx.needs_input_grad)   # False in eval loops: nothing is kept for backward
         z = batch.x
         if not (torch.is_tensor(z) and z.dtype == torch.int64 and z.dim() == 1):
             raise ValueError("batch.x must hold int64 atomic numbers [N] (forward overwrites it with features; "
@@ -450,6 +452,7 @@ class CartNet(nn.Module):
         if not params[0].is_cuda:
             raise RuntimeError("cartnet_amd.CartNet runs only on an AMD GPU (HIP kernels); move the model and the "
                                "batch to 'cuda' -- there is no CPU fallback")
+        self._grad_mode = torch.is_grad_enabled()       # read by _CartNetFunction.forward (grad mode is off in there)
         pred, x, e = _CartNetFunction.apply(self, batch, self.training, *params)
         batch.x = x
         batch.edge_attr = e

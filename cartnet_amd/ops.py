@@ -515,6 +515,43 @@ def gate_scatter_fwd(gs, e_in, env, layout: GraphLayout, mean_rstd, gamma, beta,
              "cartnet_gate_scatter_fwd")
 
 
+def gate_gemm_eval(pre: Tensor, img_gate: Tensor, img_aggr: Tensor, bias_gate: Tensor, bias_aggr: Tensor, mean_rstd: Tensor,
+                   gamma: Tensor, beta: Tensor, env: Optional[Tensor], e_in: Tensor, layout: GraphLayout, e_out: Tensor,
+                   aggr: Tensor) -> None:
+    """Inference-mode fusion of a layer's second Linears with the gate (cartnet_gate_gemm_eval): pre [E, 2D] -> e_out
+    [E, D] = e_in + sigma and aggr [N, D] = per-target sums of sigma * sender; the images come from ``pack_b([W2g.t(),
+    W2a.t()])``; mean_rstd [2D] holds the edge BatchNorm's running mean and 1 / sqrt(running_var + eps)."""
+    lib = _l.load()
+    E, N = layout.E, layout.N
+    D = int(aggr.shape[1])
+    _edge_rows(pre, E, 2 * D, "gate_gemm_eval pre")
+    _edge_rows(e_in, E, D, "gate_gemm_eval e_in")
+    _edge_rows(e_out, E, D, "gate_gemm_eval e_out")
+    _edge_rows(aggr, N, D, "gate_gemm_eval aggr")
+    for name, t in (("bias_gate", bias_gate), ("bias_aggr", bias_aggr), ("gamma", gamma), ("beta", beta)):
+        _vec(t, D, "gate_gemm_eval " + name)
+    _vec(mean_rstd, 2 * D, "gate_gemm_eval mean_rstd")
+    _vec(env, E, "gate_gemm_eval env")
+    need = int(lib.cartnet_gemm_pack_b_bytes(D, D))
+    for name, t in (("img_gate", img_gate), ("img_aggr", img_aggr)):
+        if need == 0 or t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous() or t.numel() < need:
+            raise ValueError(f"gate_gemm_eval {name}: expected a contiguous uint8 CUDA tensor of {need} bytes (pack_b)")
+    if D % 256 != 0:
+        raise ValueError("gate_gemm_eval: D must be a multiple of 256")
+    bnd = torch.empty(max(1, int(lib.cartnet_gate_gemm_eval_workspace(E, D)) // 4), dtype=torch.float32, device=aggr.device)
+    a = _l.GateGemmArgs()
+    a.pre, a.ldp = pre.data_ptr(), _ld(pre)
+    a.img_gate, a.img_aggr = img_gate.data_ptr(), img_aggr.data_ptr()
+    a.bias_gate, a.bias_aggr = bias_gate.data_ptr(), bias_aggr.data_ptr()
+    a.mean_rstd, a.gamma, a.beta = mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    a.env = _l.ptr(env)
+    a.e_in, a.e_out = e_in.data_ptr(), e_out.data_ptr()
+    a.tgt, a.rowptr = layout.tgt.data_ptr(), layout.rowptr.data_ptr()
+    a.aggr, a.bnd = aggr.data_ptr(), bnd.data_ptr()
+    a.E, a.N, a.D = E, N, D
+    _l.check(lib.cartnet_gate_gemm_eval(C.byref(a), _l.stream_ptr()), "cartnet_gate_gemm_eval")
+
+
 def gate_scatter_bwd_stats(gs, de_out, daggr, env, layout: GraphLayout, mean_rstd, gamma, beta, parts_a,
                            parts_b) -> None:
     E, N = layout.E, layout.N

@@ -623,6 +623,32 @@ typedef struct CartnetBatch {
   int64_t E;
 } CartnetBatch;
 
+/* Inference-mode fusion of a layer's second Linears with the gate (reference models/cartnet.py:230-262 in eval mode, where
+ * the edge BatchNorm uses its running statistics): g = silu(pre[:, :D]) W2g^T + b, s = silu(pre[:, D:]) W2a^T + b,
+ * sigma = env * sigmoid(gamma (g - mean) rstd + beta), e_out = e_in + sigma, aggr[t] = sum over the edges of target t of
+ * sigma * s (edge order; edges sorted by target) -- gs [E, 2D] never reaches memory.  fp32 MFMA; D a multiple of 256;
+ * img_*: cartnet_gemm_pack_b images of the [K = D, N = D] operands W2^T; bnd: cartnet_gate_gemm_eval_workspace(E, D)
+ * bytes; aggr rows of atoms without edges are set to zero.  Two launches (product + boundary fix-up), no atomics. */
+typedef struct CartnetGateGemmArgs {
+  const float* pre;                      /* [E, >= 2D] pre-activations [gate | sender], row stride ldp */
+  int32_t ldp;
+  const void *img_gate, *img_aggr;
+  const float *bias_gate, *bias_aggr;    /* [D] */
+  const float* mean_rstd;                /* [2D]: mean | rstd of the edge BatchNorm */
+  const float *gamma, *beta;             /* [D] */
+  const float* env;                      /* [E] envelope or NULL */
+  const float* e_in;                     /* [E, D] */
+  float* e_out;                          /* [E, D] */
+  const int32_t* tgt;                    /* [E] ascending */
+  const int32_t* rowptr;                 /* [N + 1] */
+  float* aggr;                           /* [N, D] */
+  float* bnd;                            /* workspace */
+  int64_t E;
+  int32_t N, D;
+} CartnetGateGemmArgs;
+size_t cartnet_gate_gemm_eval_workspace(int64_t E, int32_t D);
+int cartnet_gate_gemm_eval(const CartnetGateGemmArgs* args, void* stream);
+
 size_t cartnet_workspace_bytes(const CartnetModel* model, int32_t N, int64_t E, int32_t Bg, int32_t M,
                                int32_t need_backward);
 /* pred [M,3,3] (Cholesky head) or [Bg] (scalar head); x_out [N,D] and e_out [E,D] receive the final node / edge
