@@ -235,3 +235,39 @@ def test_bench_self_launch_builds_the_torchrun_child(monkeypatch):
     assert cmd[-5:] == ["--gpus", "4", "--steps", "3", "--share-gpu"] and cmd[-6].endswith("bench.py")
     assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["CARTNET_DIST_BACKEND"] == "gloo"
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_telemetry_reads_a_sysfs_tree(tmp_path, monkeypatch):
+    """cartnet_amd.telemetry against a fake amdgpu sysfs directory (the layout of profiles/r03_sysfs_probe.txt): starred DPM
+    level, hwmon power / cap / labelled temperatures, missing files -> None, the sampler's min / mean / max."""
+    from cartnet_amd import telemetry as tele
+    d = tmp_path / "card"
+    h = d / "hwmon" / "hwmon4"
+    h.mkdir(parents=True)
+    (d / "pp_dpm_sclk").write_text("S: 108Mhz\n0: 500Mhz\n1: 2400Mhz *\n")
+    (d / "pp_dpm_mclk").write_text("0: 2000Mhz *\n")
+    (h / "power1_input").write_text("1265000000\n")
+    (h / "power1_cap").write_text("1400000000\n")
+    (h / "temp2_input").write_text("53000\n")
+    (h / "temp2_label").write_text("junction\n")
+    (h / "temp3_input").write_text("47000\n")
+    (h / "temp3_label").write_text("mem\n")
+    (h / "freq1_input").write_text("2374000000\n")
+    (h / "freq1_label").write_text("sclk\n")
+    monkeypatch.setattr(tele, "_DIR_CACHE", {0: str(d)})
+    s = tele.read(0)
+    assert s["sclk_mhz"] == 2400 and s["mclk_mhz"] == 2000 and s["power_w"] == 1265.0 and s["power_cap_w"] == 1400.0
+    assert s["temp_c"] == {"junction": 53.0, "mem": 47.0}
+    c = tele.compact(s)
+    assert c["junction_c"] == 53.0 and c["mem_c"] == 47.0 and c["edge_c"] is None
+    (d / "pp_dpm_sclk").unlink()                              # falls back to hwmon freq1_input
+    assert tele.read(0)["sclk_mhz"] == 2374
+    smp = tele.Sampler(0, period=0.005).start()
+    import time
+    time.sleep(0.03)
+    out = smp.stop()
+    assert out["samples"] >= 2 and out["power_w"]["max"] == 1265.0 and out["junction_c_max"] == 53.0
+    monkeypatch.setattr(tele, "_DIR_CACHE", {0: None})
+    empty = tele.read(0)
+    assert empty["sclk_mhz"] is None and empty["temp_c"] == {}
+    assert tele._active_level_mhz("0: 500Mhz\n1: 2400Mhz") is None
