@@ -148,14 +148,15 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
   };
 
   if (nsteps > 0) {
-    f32x4 r0, r1;
-    a_issue(r0, 0);
+    // all of the pipeline head's loads in ONE memory round trip (K-step 0 into a third register set, 1 and 2 into the ring)
+    f32x4 r0, r1, rt;
+    a_issue(rt, 0);
     b_issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0) :: "memory");
-    a_store(r0, 0);
     if (nsteps > 1) a_issue(r1, 1);
     if (nsteps > 2) a_issue(r0, 2);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(r0), "+v"(r1) :: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(rt) :: "memory");
+    a_store(rt, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     int u = 0;
