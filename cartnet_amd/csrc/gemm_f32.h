@@ -159,6 +159,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    CN_STAMP_BEGIN();
     int u = 0;
     for (; u + 4 < nsteps; u += 2) {        // both steps satisfy u + 3 < nsteps
       step_full(std::integral_constant<int, 0>{}, u, r1);
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
       step(std::integral_constant<int, 0>{}, u, r1);
       if (u + 1 < nsteps) step(std::integral_constant<int, 1>{}, u + 1, r0);
     }
+    CN_STAMP_END();
   }
   // epilogue (shared with gemm_kernel.h)
   const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |

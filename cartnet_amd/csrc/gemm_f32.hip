@@ -82,3 +82,10 @@ extern "C" int cartnet_gemm_pack_b(const float* const* src, void* const* dst, co
   }
   return 0;
 }
+
+#ifdef CN_CLOCK_STAMP
+// diagnostic build: copies this translation unit's stamp buffer out (4096 pairs of 64-bit counters)
+extern "C" int cartnet_debug_clock_f32(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cn_gemm::cn_clock_dbg), sizeof(unsigned long long) * 2 * 4096);
+}
+#endif

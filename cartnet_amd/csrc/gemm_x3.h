@@ -29,8 +29,8 @@ constexpr int X3_BUF_BYTES = X3_A_BYTES + X3_B_BYTES;     // 36 KB; two buffers 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
-template <int KIND_RT>
-__device__ __forceinline__ void x3_epilogue(const CartnetGemmArgs& p, f32x16 (&acc)[2][2], int g, int row0, int col0,
+template <int KIND_RT, class ACC>
+__device__ __forceinline__ void x3_epilogue(const CartnetGemmArgs& p, ACC& acc, int g, int row0, int col0,
                                             int tile_m, int wm, int wn, int lane, int tid, float* smem) {
   const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
                    (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);
@@ -284,6 +284,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    CN_STAMP_BEGIN();
     int u = 0;
     if constexpr (!ONE) {
       for (; u + 4 < nsteps; u += 2) {        // both steps satisfy u + 3 < nsteps
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
       step(std::integral_constant<int, 0>{}, u, r1);
       if (u + 1 < nsteps) step(std::integral_constant<int, 1>{}, u + 1, r0);
     }
+    CN_STAMP_END();
   }
   x3_epilogue<0>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem);
 }

@@ -5,6 +5,11 @@ namespace cn_gemm {
 
 void launch_x3nn(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st) {
   const bool one = fl.x3 == 2;   // precision 2: plain bf16 operands, one MFMA product
+  static const bool shape16 = [] { const char* e = getenv("CARTNET_X3_SHAPE"); return !e || atoi(e) != 32; }();
+  if (!one && shape16) {
+    launch_x3nn16(a_act, a, fl, grid, st);
+    return;
+  }
   if (a_act) {
     if (one) hipLaunchKernelGGL((cn_gemm_x3nn_kernel<true, true>), grid, dim3(NTHREADS), 0, st, a, fl);
     else hipLaunchKernelGGL((cn_gemm_x3nn_kernel<true, false>), grid, dim3(NTHREADS), 0, st, a, fl);
@@ -101,3 +106,10 @@ extern "C" int cartnet_gemm_split_b(const float* const* src, void* const* dst, c
   }
   return 0;
 }
+
+#ifdef CN_CLOCK_STAMP
+// diagnostic build: copies this translation unit's stamp buffer out (4096 pairs of 64-bit counters)
+extern "C" int cartnet_debug_clock_x3(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cn_gemm::cn_clock_dbg), sizeof(unsigned long long) * 2 * 4096);
+}
+#endif

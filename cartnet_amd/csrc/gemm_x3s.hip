@@ -1,0 +1,18 @@
+// Instantiations of the 16x16x32-shape bf16x3 activation x weight kernel (gemm_x3s.h), own translation unit.
+#include "gemm_x3s.h"
+
+namespace cn_gemm {
+
+void launch_x3nn16(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st) {
+  if (a_act) hipLaunchKernelGGL((cn_gemm_x3nn16_kernel<true>), grid, dim3(NTHREADS), 0, st, a, fl);
+  else hipLaunchKernelGGL((cn_gemm_x3nn16_kernel<false>), grid, dim3(NTHREADS), 0, st, a, fl);
+}
+
+}  // namespace cn_gemm
+
+#ifdef CN_CLOCK_STAMP
+// diagnostic build: copies this translation unit's stamp buffer out (4096 pairs of 64-bit counters)
+extern "C" int cartnet_debug_clock_x3s(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cn_gemm::cn_clock_dbg), sizeof(unsigned long long) * 2 * 4096);
+}
+#endif

@@ -206,7 +206,12 @@ def test_gemm_writes_the_activated_operand(ops, precision, M, K, N, groups):
     ops.gemm(Xs, Bt, Cs, b_kstrided=True, a_act=True, bias=bs, b_split=imgs, a_act_out=Hs, precision=precision,
              colsum=[cs[0]] + [None] * (groups - 1))
     for g in range(groups):
-        assert torch.equal(Cs[g], C0[g]), g
+        if precision == 1:
+            # bf16x3: the plain launch runs on the 16x16x32 MFMA shape (csrc/gemm_x3s.h), the one with the by-product on
+            # the 32x32x16 kernel -- the same six products per element in another summation order
+            assert rel_err(Cs[g], C0[g].double()) < 2e-6, g
+        else:
+            assert torch.equal(Cs[g], C0[g]), g
         ref = silu64(Xs[g].double())
         assert rel_err(Hs[g], ref) < 1e-6, g
     assert bool((H[:, groups * K:] == -7.0).all())
