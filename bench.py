@@ -361,6 +361,7 @@ def main():
             step(bx)
         cdist.barrier()
         torch.cuda.synchronize()
+        sampler3 = tele.Sampler(local, period=0.005).start() if rank == 0 else None
         t1 = time.perf_counter()
         for bx in extra[2:]:
             loss3 = step(bx)
@@ -368,10 +369,14 @@ def main():
         cdist.barrier()
         torch.cuda.synchronize()
         dt3 = cdist.max_over_ranks(time.perf_counter() - t1, dev)
+        tel3 = sampler3.stop() if sampler3 is not None else None
         model.gemm_precision = 0
         if torch.isfinite(loss3):
             x3 = {"value": round(args.graphs * world * args.steps / dt3, 2), "unit": "graphs/s",
                   "ms_per_step": round(1e3 * dt3 / args.steps, 3),
+                  # the bf16x3 products are bound by the clock the chip holds under dense bf16 matrix work (in-kernel:
+                  # 1.53-1.70 GHz against 2.3 GHz under the fp32 MFMA loop, profiles/r03_exp_x3_power.md)
+                  "telemetry_during": tel3,
                   "note": "same step with gemm_precision=1: every fp32 product rebuilt from six bf16 MFMA products "
                           "(operands split exactly into three bf16 pieces), fp32 accumulate; same 1e-5 parity tests"}
 
