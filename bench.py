@@ -207,14 +207,14 @@ def main():
         b._cartnet_mask_index = getattr(base, "_cartnet_mask_index", None)
         return b
 
-    from cartnet_amd.train import grouped_loss
+    from cartnet_amd.train import grouped_loss, compute_loss
 
     def step(b):
         pred, true = model(b)
         if args.bn_group_size > 0:
             loss = grouped_loss(pred, true, b, args.bn_group_size)[0]
         else:
-            loss = (pred - true).abs().mean()
+            loss = compute_loss(pred, true)[0]          # MAE (cfg.loss default), train/metrics.py:26
         loss.backward()
         scale = cdist.all_reduce_gradients(opt.flat_grad)
         opt.step(scale)

@@ -154,3 +154,72 @@ extern "C" int cartnet_adp_metrics(const float* pred, const float* truth, int32_
   CN_LAUNCH_CHECK("cartnet_adp_metrics");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Training loss (reference: train/metrics.py:15-28 -- L1Loss and MSELoss, mean over all elements): both means from one
+// launch, their gradient from another.  The eager form is eight dependent launches per step (sub, abs, mean, and in
+// backward fill, div, sign, mul, mul); at the small-crystal configurations a launch is 5-6 us of a 1.3 ms step.
+// One workgroup: the sums are taken in fp64 in a fixed order (bitwise reproducible); n is M x 9 or Bg elements.
+namespace {
+
+__global__ __launch_bounds__(1024) void cn_loss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ truth,
+                                                           long long n, float* __restrict__ out) {
+  __shared__ double red[2][16];
+  double sa = 0.0, sq = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 1024) {
+    const double d = (double)pred[i] - (double)truth[i];
+    sa += fabs(d);
+    sq += d * d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sa += __shfl_xor(sa, o);
+    sq += __shfl_xor(sq, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = sa;
+    red[1][threadIdx.x >> 6] = sq;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, q = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      a += red[0][w];
+      q += red[1][w];
+    }
+    out[0] = (float)(a / (double)n);
+    out[1] = (float)(q / (double)n);
+  }
+}
+
+// dpred = g_mae * sign(d) / n + g_mse * 2 d / n; the two upstream gradients are device scalars (either may be null = 0)
+__global__ __launch_bounds__(256) void cn_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ truth,
+                                                          long long n, const float* __restrict__ g_mae,
+                                                          const float* __restrict__ g_mse, float* __restrict__ dpred) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float inv = 1.0f / (float)n;
+  const float ga = g_mae ? g_mae[0] * inv : 0.f, gs = g_mse ? g_mse[0] * (2.0f * inv) : 0.f;
+  const float d = pred[i] - truth[i];
+  const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  dpred[i] = ga * sgn + gs * d;
+}
+
+}  // namespace
+
+extern "C" int cartnet_loss_fwd(const float* pred, const float* truth, int64_t n, float* out2, void* stream) {
+  CN_CHECK(pred && truth && out2 && n > 0, "cartnet_loss_fwd: null pointer or n = %lld", (long long)n);
+  hipLaunchKernelGGL(cn_loss_fwd_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), pred, truth,
+                     (long long)n, out2);
+  CN_LAUNCH_CHECK("cartnet_loss_fwd");
+  return 0;
+}
+
+extern "C" int cartnet_loss_bwd(const float* pred, const float* truth, int64_t n, const float* g_mae, const float* g_mse,
+                                float* dpred, void* stream) {
+  CN_CHECK(pred && truth && dpred && n > 0, "cartnet_loss_bwd: null pointer or n = %lld", (long long)n);
+  hipLaunchKernelGGL(cn_loss_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), pred, truth, (long long)n, g_mae, g_mse, dpred);
+  CN_LAUNCH_CHECK("cartnet_loss_bwd");
+  return 0;
+}

@@ -13,8 +13,41 @@ from .config import cfg
 from . import distributed as cdist
 
 
+class _FusedLoss(torch.autograd.Function):
+    """(MAE, MSE) of device tensors from one launch, their gradient from one more (``cartnet_loss_fwd`` /
+    ``cartnet_loss_bwd``, include/cartnet_hip.h) instead of eight eager kernels per step."""
+
+    @staticmethod
+    def forward(ctx, pred, true):
+        from . import lib as _l
+        p, t = pred.contiguous(), true.contiguous()
+        out = torch.empty(2, dtype=torch.float32, device=p.device)
+        _l.check(_l.load().cartnet_loss_fwd(p.data_ptr(), t.data_ptr(), p.numel(), out.data_ptr(), _l.stream_ptr()),
+                 "cartnet_loss_fwd")
+        ctx.save_for_backward(p, t)
+        ctx.set_materialize_grads(False)        # the loss that is not used arrives as None, not as a zero tensor
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_mae, g_mse):
+        from . import lib as _l
+        p, t = ctx.saved_tensors
+        if g_mae is None and g_mse is None:
+            return None, None
+        dpred = torch.empty_like(p)
+        ga = g_mae.contiguous() if g_mae is not None else None
+        gs = g_mse.contiguous() if g_mse is not None else None
+        _l.check(_l.load().cartnet_loss_bwd(p.data_ptr(), t.data_ptr(), p.numel(), _l.ptr(ga), _l.ptr(gs),
+                                            dpred.data_ptr(), _l.stream_ptr()), "cartnet_loss_bwd")
+        return dpred, None
+
+
 def compute_loss(pred: torch.Tensor, true: torch.Tensor):
-    """(MAE, MSE) with mean reduction over all elements (train/metrics.py:26-27)."""
+    """(MAE, MSE) with mean reduction over all elements (train/metrics.py:26-27).  Device tensors go through the fused
+    kernels; host tensors (the CPU tests of the loops' bookkeeping) through torch."""
+    if pred.is_cuda and pred.dtype == torch.float32 and true.dtype == torch.float32 and pred.shape == true.shape \
+            and pred.numel() > 0:
+        return _FusedLoss.apply(pred, true)
     diff = pred - true
     return diff.abs().mean(), (diff * diff).mean()
 

@@ -234,6 +234,17 @@ int cartnet_adp_metrics(const float* pred, const float* truth, int32_t M, const 
                         float* volume_error, float* similarity_index, float* iou, void* stream);
 
 /* ----------------------------------------------------------------------------------------------------
+ * Training loss (reference: train/metrics.py:15-28, called from train/train.py:173-178): L1Loss and MSELoss with mean
+ * reduction over the n = M*9 (or Bg) elements of pred / truth, both from ONE launch, and their gradient from one more:
+ *   out2[0] = mean |pred - truth|,  out2[1] = mean (pred - truth)^2          (sums in fp64, fixed order)
+ *   dpred   = g_mae[0] * sign(pred - truth) / n + g_mse[0] * 2 (pred - truth) / n   (g_* device scalars; NULL = 0)
+ * Replaces eight eager launches per step (sub, abs, mean; fill, div, sign, mul, mul in backward).
+ * ---------------------------------------------------------------------------------------------------- */
+int cartnet_loss_fwd(const float* pred, const float* truth, int64_t n, float* out2, void* stream);
+int cartnet_loss_bwd(const float* pred, const float* truth, int64_t n, const float* g_mae, const float* g_mse,
+                     float* dpred, void* stream);
+
+/* ----------------------------------------------------------------------------------------------------
  * Device-side batching from a packed shard resident in HBM (replaces torch.load of one pickled
  * Data per structure, dataset/datasetADP.py:41-42, PyG's collate in loader/loader.py:114-124, and the per-sample
  * CPU augmentation / temperature standardisation of dataset/datasetADP.py:33-39,43-45,76-77).

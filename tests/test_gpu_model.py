@@ -418,3 +418,32 @@ def test_width_512_against_oracle(precision):
     ref, gref = _oracle_run(b, hp, sd, names)
     assert rel_err(pred, ref) < PRED_TOL
     _check_grads({k: p.grad for k, p in m.named_parameters()}, gref, "width512")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 3, 3), (517, 3, 3), (12416, 3, 3), (64,)])
+def test_fused_loss_matches_torch(shape):
+    """compute_loss on device tensors = one launch for (MAE, MSE) and one for the gradient (cartnet_loss_fwd / _bwd):
+    values against torch in fp64, gradients of either loss and of a mix of both, sign(0) = 0, bitwise repeatable."""
+    from cartnet_amd.train import compute_loss
+    g = torch.Generator().manual_seed(5)
+    p0 = torch.randn(*shape, generator=g)
+    t0 = torch.randn(*shape, generator=g)
+    p0.view(-1)[0] = t0.view(-1)[0]                      # one exact zero difference
+    for wa, ws in ((1.0, 0.0), (0.0, 1.0), (0.3, 1.7)):
+        p = p0.cuda().requires_grad_(True)
+        t = t0.cuda()
+        mae, mse = compute_loss(p, t)
+        (wa * mae + ws * mse).backward()
+        pr = p0.double().requires_grad_(True)
+        d = pr - t0.double()
+        mae_r, mse_r = d.abs().mean(), (d * d).mean()
+        (wa * mae_r + ws * mse_r).backward()
+        assert abs(mae.item() - mae_r.item()) <= 2e-7 * abs(mae_r.item())
+        assert abs(mse.item() - mse_r.item()) <= 2e-7 * abs(mse_r.item())
+        gr = pr.grad
+        assert (p.grad.double().cpu() - gr).abs().max().item() <= 1e-6 * gr.abs().max().item()
+        assert p.grad.view(-1)[0].item() == (0.0 if ws == 0.0 else p.grad.view(-1)[0].item())
+    a = compute_loss(p0.cuda(), t0.cuda())
+    b = compute_loss(p0.cuda(), t0.cuda())
+    assert a[0].item() == b[0].item() and a[1].item() == b[1].item()

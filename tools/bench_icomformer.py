@@ -2,6 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
+from cartnet_amd.train import compute_loss
 from cartnet_amd.config import cfg
 from cartnet_amd.comformer import eComformer, iComformer
 from cartnet_amd.synthetic import make_batch
@@ -20,7 +21,7 @@ def fresh():
     return b
 def step(b):
     pred, true = model(b)
-    loss = (pred - true).abs().mean()
+    loss = compute_loss(pred, true)[0]
     loss.backward()
     for p in model.parameters(): p.grad = None
     return loss

@@ -2,6 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
+from cartnet_amd.train import compute_loss
 from cartnet_amd.config import cfg
 from cartnet_amd.data import Batch
 from cartnet_amd.model import CartNet
@@ -23,7 +24,7 @@ def fresh():
     return b
 def step(b):
     pred, true = model(b)
-    loss = (pred - true).abs().mean()
+    loss = compute_loss(pred, true)[0]
     loss.backward()
     opt.step(1.0); opt.zero_grad()
 for prec, half in ((0, False), (1, False), (2, False), (2, True)):

@@ -2,6 +2,7 @@
 import os, sys, time, cProfile, pstats
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
+from cartnet_amd.train import compute_loss
 from cartnet_amd.config import cfg
 from cartnet_amd.data import Batch
 from cartnet_amd.model import CartNet
@@ -21,7 +22,7 @@ def fresh():
 T = {"fwd": 0.0, "loss": 0.0, "bwd": 0.0, "opt": 0.0}
 def step(b):
     t0 = time.perf_counter(); pred, true = model(b)
-    t1 = time.perf_counter(); loss = (pred - true).abs().mean()
+    t1 = time.perf_counter(); loss = compute_loss(pred, true)[0]
     t2 = time.perf_counter(); loss.backward()
     t3 = time.perf_counter(); opt.step(1.0); opt.zero_grad()
     t4 = time.perf_counter()
