@@ -24,6 +24,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
   __shared__ __attribute__((aligned(16))) float smem[2 * F32_BUF_BYTES / 4];
   char* lds = reinterpret_cast<char*>(smem);
 
+  CN_PHASE(0);
+  CN_PHASE_ID();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,7 +117,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
     asm volatile("" ::: "memory");
   };
   // steady state (u + 3 < nsteps): fragments of both k-groups first, then the MFMA chain with the staging of the next
-  // tiles in its shadow
+  // tiles in its shadow.  (Round 3, measured with in-kernel stamps -- tools/exp_phases.py, profiles/r03_exp_phases.md --
+  // and NOT adopted: the barrier in the middle of the chain with the next step's first fragments read behind it, and
+  // the two waves of a SIMD staging at different places of the chain.  Neither moves a launch.)
   auto step_full = [&](auto cur_c, int u, f32x4& r) {
     constexpr int CUR = decltype(cur_c)::value;
     frags(CUR, 0);
@@ -160,6 +164,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     CN_STAMP_BEGIN();
+    CN_PHASE(1);
     int u = 0;
     for (; u + 4 < nsteps; u += 2) {        // both steps satisfy u + 3 < nsteps
       step_full(std::integral_constant<int, 0>{}, u, r1);
@@ -170,6 +175,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
       if (u + 1 < nsteps) step(std::integral_constant<int, 1>{}, u + 1, r0);
     }
     CN_STAMP_END();
+    CN_PHASE(2);
   }
   // epilogue (shared with gemm_kernel.h)
   const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
@@ -187,6 +193,11 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
     default: CN_EPIW(-1); break;
   }
 #undef CN_EPIW
+#ifdef CN_PHASE_STAMP
+  CN_PHASE(3);                                             // last store issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CN_PHASE(4);                                             // ... and acknowledged
+#endif
 }
 
 }  // namespace cn_gemm

@@ -145,6 +145,27 @@ static __device__ unsigned long long cn_clock_dbg[2 * 4096];
 #define CN_STAMP_BEGIN()
 #define CN_STAMP_END()
 #endif
+// Second diagnostic (-DCN_PHASE_STAMP, tools/exp_phases.py): per workgroup of the fp32 activation x weight kernel the
+// 100 MHz time at entry, main-loop start, main-loop end, last store issued and all stores acknowledged, with the
+// hardware id of the CU it ran on -- the life of every workgroup on every CU of one launch.
+#ifdef CN_PHASE_STAMP
+static __device__ unsigned long long cn_phase_dbg[8192 * 8];
+#define CN_PHASE(slot)                                                                                         \
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) {   /* wave 0, a scalar branch */                 \
+    const unsigned cn_lin = blockIdx.x + gridDim.x * blockIdx.z;                                               \
+    if (cn_lin < 8192) cn_phase_dbg[cn_lin * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();                   \
+  }
+#define CN_PHASE_ID()                                                                                          \
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) {                                                 \
+    const unsigned cn_hw = __builtin_amdgcn_s_getreg((4 | (0 << 6) | (31 << 11)));   /* HW_REG_HW_ID, 32 bits */  \
+    const unsigned cn_xcc = __builtin_amdgcn_s_getreg((20 | (0 << 6) | (31 << 11))); /* HW_REG_XCC_ID */         \
+    const unsigned cn_lin = blockIdx.x + gridDim.x * blockIdx.z;                                               \
+    if (cn_lin < 8192) cn_phase_dbg[cn_lin * 8 + 5] = ((unsigned long long)cn_xcc << 32) | cn_hw;              \
+  }
+#else
+#define CN_PHASE(slot)
+#define CN_PHASE_ID()
+#endif
 
 struct Split3 {
   bf16x4 h, m, l;
@@ -459,6 +480,20 @@ __device__ __forceinline__ void epilogue_wide(const CartnetGemmArgs& p, ACC& acc
 #pragma unroll
     for (int b = 0; b < S::TN; ++b) {
       const int gcol = col0 + wn * S::WN + b * 32 + c4 * 4;
+#ifdef CN_EPI_RAW      /* diagnostic: same stores, same addresses, no transpose and no operands (WRONG values) */
+      if constexpr (!MF16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (grow[i] < p.M)
+            stv4(C + (size_t)grow[i] * p.ldc + gcol,
+                 f32x4{acc[a][b][4 * i], acc[a][b][4 * i + 1], acc[a][b][4 * i + 2], acc[a][b][4 * i + 3]});
+#ifdef CN_PHASE_STAMP
+        if (a == 0 && b == 0) { CN_PHASE(6); }
+        if (a == 0 && b == S::TN - 1) { CN_PHASE(7); }
+#endif
+        continue;
+      }
+#endif
       acc_block_to_scr(acc, a, b, scr, lane, SCR_LD);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -482,6 +517,10 @@ __device__ __forceinline__ void epilogue_wide(const CartnetGemmArgs& p, ACC& acc
         stv4(C + (size_t)grow[i] * p.ldc + gcol, v);
       }
       __builtin_amdgcn_wave_barrier();
+#ifdef CN_PHASE_STAMP
+      if (a == 0 && b == 0) { CN_PHASE(6); }
+      if (a == 0 && b == S::TN - 1) { CN_PHASE(7); }
+#endif
     }
   }
   if (SUM1 || SUM2) {
