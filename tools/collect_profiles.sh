@@ -15,6 +15,8 @@ python3 "$ROOT/bench.py" --steps 20 --warmup 5 > "$OUT/bench_default.json" 2> "$
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-recipe-pass --sustain-seconds 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err" &&
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$ROOT/bench.py" $PMC_ARGS > "$OUT/fetch.json" 2> "$OUT/fetch.err" &&
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$ROOT/bench.py" $PMC_ARGS > "$OUT/write.json" 2> "$OUT/write.err" &&
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_x3" -- python3 "$ROOT/bench.py" $PMC_ARGS --precision 1 > "$OUT/fetch_x3.json" 2> "$OUT/fetch_x3.err" &&
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_x3" -- python3 "$ROOT/bench.py" $PMC_ARGS --precision 1 > "$OUT/write_x3.json" 2> "$OUT/write_x3.err" &&
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/mfma" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-recipe-pass --no-calibration --sustain-seconds 0 > "$OUT/mfma.json" 2> "$OUT/mfma.err"
 echo "exit $?"
 # keep what is published small: stats + counter CSVs only

@@ -5,6 +5,8 @@ WRITE_SIZE (KB) is taken as is.  Output: JSON keyed by kernel name, averages ove
 profiled process (since round 2 the PMC passes run fp32 steps only, `bench.py --no-x3-pass`: 1 warm-up + 2 timed;
 a process that also ran the bf16x3 pass is recognised by its x3 kernels and labelled accordingly).
 Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+                                    [<fetch csv of a --precision 1 run> <write csv of a --precision 1 run>]
+With the last two (passes over bf16x3 steps only) the output gains variants["x3"], "kernels_x3" and "per_step_x3".
 """
 import csv, json, sys, collections
 
@@ -27,9 +29,9 @@ def short(name):
     return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
 
 
-def main():
-    f, fc = per_kernel(sys.argv[1], "FETCH_SIZE")
-    w, wc = per_kernel(sys.argv[2], "WRITE_SIZE")
+def analyse(fpath, wpath, verbose=True):
+    f, fc = per_kernel(fpath, "FETCH_SIZE")
+    w, wc = per_kernel(wpath, "WRITE_SIZE")
     out = {"_about": __doc__.strip()}
     rows = []
     for k in f:
@@ -55,6 +57,14 @@ def main():
         else:
             m3 = re.match(r"cn_gemm::cn_gemm_f32(nn|tn)_kernel<(\w+)>", name)
             m2 = re.match(r"cn_gemm::cn_gemm_x3(nn|tn)_kernel<(\w+), (\w+)>", name)
+            m5 = re.match(r"cn_gemm::cn_gemm_x3nn16_kernel<(\w+)>", name)      # gemm_x3s.h: 16x16x32 MFMA shape
+            if m5:
+                key = "nn256" + ("+silu(A)" if m5.group(1) == "true" else "")
+                v = variants["x3"].setdefault(key, {"launches_profiled": 0, "fetch": 0.0, "write": 0.0})
+                v["launches_profiled"] += n
+                v["fetch"] += fetch * n
+                v["write"] += write * n
+                continue
             m4 = re.match(r"cn_gemm::cn_gemm_f32nn128_kernel<(\w+)>", name)
             if m4 or name == "cn_gemm::cn_gemm_f32nn_actout_kernel":
                 key = ("nn128" + ("+silu(A)" if m4.group(1) == "true" else "")) if m4 else "nn256+silu(A)+out"
@@ -85,14 +95,15 @@ def main():
                                    "write_bytes_per_launch": int(v["write"] / n),
                                    "hbm_bytes_per_launch": int((v["fetch"] + v["write"]) / n)}
     # the activation x weight kernels again, edge-sized launches only (the N-row node projections share the kernel)
-    fb, fbc = per_kernel(sys.argv[1], "FETCH_SIZE", BIG_GRID)
-    wb, wbc = per_kernel(sys.argv[2], "WRITE_SIZE", BIG_GRID)
+    fb, fbc = per_kernel(fpath, "FETCH_SIZE", BIG_GRID)
+    wb, wbc = per_kernel(wpath, "WRITE_SIZE", BIG_GRID)
     for k in fb:
         name = short(k)
         for pat, mode, key in ((r"cn_gemm::cn_gemm_f32nn_kernel<false>", "fp32", "nn256"),
                                (r"cn_gemm::cn_gemm_f32nn128_kernel<false>", "fp32", "nn128"),
                                (r"cn_gemm::cn_gemm_f32tn_kernel<false>", "fp32", "tn256"),
-                               (r"cn_gemm::cn_gemm_x3nn_kernel<false, false>", "x3", "nn256")):
+                               (r"cn_gemm::cn_gemm_x3nn_kernel<false, false>", "x3", "nn256"),
+                               (r"cn_gemm::cn_gemm_x3nn16_kernel<false>", "x3", "nn256")):
             if name == pat and key in variants[mode]:
                 n = fbc[k]
                 variants[mode][key]["hbm_bytes_per_launch_edge_rows"] = int(
@@ -106,14 +117,14 @@ def main():
                  if r["Counter_Name"] == counter and short(r["Kernel_Name"]) == kernel]
         rows_.sort()
         return [v for _, v in rows_]
-    tnk = "cn_gemm::cn_gemm_f32tn_kernel<false>"
-    fd, wd = per_dispatch(sys.argv[1], "FETCH_SIZE", tnk), per_dispatch(sys.argv[2], "WRITE_SIZE", tnk)
-    if fd and len(fd) == len(wd) and "tn256" in variants["fp32"]:
-        big = [i for i, v in enumerate(fd) if 2.0 * 1024.0 * v >= 4.0e8]
-        if big:
-            variants["fp32"]["tn256"]["hbm_bytes_per_launch_edge_rows"] = int(
-                sum(2.0 * 1024.0 * fd[i] + 1024.0 * wd[i] for i in big) / len(big))
-            variants["fp32"]["tn256"]["launches_profiled_edge_rows"] = len(big)
+    for tnk, mode in (("cn_gemm::cn_gemm_f32tn_kernel<false>", "fp32"), ("cn_gemm::cn_gemm_x3tn_kernel<false, false>", "x3")):
+        fd, wd = per_dispatch(fpath, "FETCH_SIZE", tnk), per_dispatch(wpath, "WRITE_SIZE", tnk)
+        if fd and len(fd) == len(wd) and "tn256" in variants[mode]:
+            big = [i for i, v in enumerate(fd) if 2.0 * 1024.0 * v >= 4.0e8]
+            if big:
+                variants[mode]["tn256"]["hbm_bytes_per_launch_edge_rows"] = int(
+                    sum(2.0 * 1024.0 * fd[i] + 1024.0 * wd[i] for i in big) / len(big))
+                variants[mode]["tn256"]["launches_profiled_edge_rows"] = len(big)
     out["variants"] = variants
     # whole-step traffic: every dispatch of the profiled process / number of optimiser steps in it (cn_adam_kernel)
     steps = max(1, max((fc[k] for k in f if "adam" in k), default=1))
@@ -124,9 +135,21 @@ def main():
                        "note": "fabric-side bytes (Infinity-Cache hits included) per optimiser step, averaged over the "
                                + ("fp32 and bf16x3" if any("x3" in k for k in f) else "fp32-MFMA") +
                                " steps of the profiled bench process"}
+    if verbose:
+        for _, k, n, fetch, write in rows[:16]:
+            print(f"{short(k)[:70]:70s} n={n:4d} fetch {fetch/1e6:8.1f} MB write {write/1e6:8.1f} MB")
+    return out
+
+
+def main():
+    out = analyse(sys.argv[1], sys.argv[2])
+    if len(sys.argv) > 5:
+        x = analyse(sys.argv[4], sys.argv[5], verbose=False)
+        out["variants"]["x3"] = x["variants"]["x3"]
+        out["per_step_x3"] = x["per_step"]
+        out["per_step_x3"]["note"] = "the same for bf16x3 steps (bench.py --precision 1 under the same two PMC passes)"
+        out["kernels_x3"] = {k: v for k, v in x.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
-    for _, k, n, fetch, write in rows[:16]:
-        print(f"{short(k)[:70]:70s} n={n:4d} fetch {fetch/1e6:8.1f} MB write {write/1e6:8.1f} MB")
 
 
 if __name__ == "__main__":

@@ -13,8 +13,15 @@ shutil.copy(fetch, os.path.join(dst, f"{tag}_pmc_fetch_size.csv"))
 shutil.copy(write, os.path.join(dst, f"{tag}_pmc_write_size.csv"))
 shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, f"{tag}_bench_n1_under_rocprof.json"))
 shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, f"{tag}_bench_n1.json"))
+fetch3 = glob.glob(os.path.join(src, "fetch_x3", "*", "*_counter_collection.csv"))
+write3 = glob.glob(os.path.join(src, "write_x3", "*", "*_counter_collection.csv"))
+extra = []
+if fetch3 and write3:        # the same two passes over bf16x3 steps (bench.py --precision 1)
+    shutil.copy(fetch3[0], os.path.join(dst, f"{tag}_pmc_fetch_size_x3.csv"))
+    shutil.copy(write3[0], os.path.join(dst, f"{tag}_pmc_write_size_x3.csv"))
+    extra = [fetch3[0], write3[0]]
 subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), fetch, write,
-                os.path.join(dst, "traffic.json")], check=True, stdout=subprocess.DEVNULL)
+                os.path.join(dst, "traffic.json"), *extra], check=True, stdout=subprocess.DEVNULL)
 mfma_csv = glob.glob(os.path.join(src, "mfma", "*", "*_counter_collection.csv"))
 mfma_table = ""
 if mfma_csv:
