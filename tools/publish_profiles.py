@@ -53,7 +53,9 @@ Files: `{tag}_bench_n1_kernel_stats.csv` (raw per-kernel stats), `{tag}_bench_n1
 
 The profiled process runs, in this order: 13 fp32-MFMA training steps on two streams (3 warm-up + 10 timed), 3 single-stream fp32 steps (the `roofline.isolated` pass),
 12 bf16x3 steps (2 + 10, the `bf16x3` object of the bench line) and the eval-forward pass; kernel names tell the GEMM families apart (`cn_gemm_f32nn / f32nn128 / f32nn_actout / f32tn_kernel`,
-`cn_gemm_kernel<..., 0>` = fp32 MFMA; `cn_gemm_x3nn / x3tn_kernel` = bf16x3).
+`cn_gemm_kernel<..., 0>` = fp32 MFMA; `cn_gemm_x3nn16 / x3nn / x3tn_kernel` = bf16x3).
+Counted HBM traffic per optimiser step: {traffic['per_step']['hbm_bytes'] / 1e9:.1f} GB at fp32, {traffic.get('per_step_x3', {}).get('hbm_bytes', float('nan')) / 1e9:.1f} GB at bf16x3
+(`{tag}_pmc_fetch_size_x3.csv` / `{tag}_pmc_write_size_x3.csv`: the same two passes with `--precision 1`; `traffic.json` -> `variants.x3`, `kernels_x3`, `per_step_x3`).
 
 Bench line under the profiler: {under['value']} graphs/s, {under['ms_per_step']} ms/step (bf16x3 pass: {under['bf16x3']['value']} graphs/s, {under['bf16x3']['ms_per_step']} ms/step).
 Un-profiled: {plain['value']} graphs/s, {plain['ms_per_step']} ms/step; sustained {plain.get('sustained', {}).get('value')} graphs/s over {plain.get('sustained', {}).get('seconds')} s; bf16x3 pass {plain['bf16x3']['value']} graphs/s, {plain['bf16x3']['ms_per_step']} ms/step; cpu_baseline {plain['cpu_baseline']['value']} graphs/s on {plain['cpu_baseline']['cores']} threads.
