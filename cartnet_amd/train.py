@@ -4,6 +4,7 @@ with a flush on the last iteration, optimiser + scheduler step at the boundary. 
 the loops return plain numbers (graphs/s is what this build reports)."""
 from __future__ import annotations
 
+import os
 import time
 from typing import Callable, Optional
 
@@ -11,6 +12,9 @@ import torch
 
 from .config import cfg
 from . import distributed as cdist
+
+
+_FUSED_LOSS = os.environ.get("CARTNET_FUSED_LOSS", "1") != "0"      # A/B switch (README)
 
 
 class _FusedLoss(torch.autograd.Function):
@@ -45,7 +49,7 @@ class _FusedLoss(torch.autograd.Function):
 def compute_loss(pred: torch.Tensor, true: torch.Tensor):
     """(MAE, MSE) with mean reduction over all elements (train/metrics.py:26-27).  Device tensors go through the fused
     kernels; host tensors (the CPU tests of the loops' bookkeeping) through torch."""
-    if pred.is_cuda and pred.dtype == torch.float32 and true.dtype == torch.float32 and pred.shape == true.shape \
+    if _FUSED_LOSS and pred.is_cuda and pred.dtype == torch.float32 and true.dtype == torch.float32 and pred.shape == true.shape \
             and pred.numel() > 0:
         return _FusedLoss.apply(pred, true)
     diff = pred - true
