@@ -271,3 +271,26 @@ def test_telemetry_reads_a_sysfs_tree(tmp_path, monkeypatch):
     empty = tele.read(0)
     assert empty["sclk_mhz"] is None and empty["temp_c"] == {}
     assert tele._active_level_mhz("0: 500Mhz\n1: 2400Mhz") is None
+
+
+def test_traffic_json_is_what_the_committed_pmc_passes_give():
+    """profiles/traffic.json (bench.py's `roofline.traffic`, DESIGN.md's bytes per step) is DERIVED data: recompute it
+    from the committed rocprofv3 counter CSVs with tools/pmc_traffic.py and compare -- fp32 and bf16x3 steps."""
+    import importlib.util, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    need = [os.path.join(prof, f"r03_pmc_{k}.csv") for k in ("fetch_size", "write_size", "fetch_size_x3", "write_size_x3")]
+    if not all(os.path.exists(f) for f in need):
+        pytest.skip("counter CSVs of this round are not in the tree")
+    spec = importlib.util.spec_from_file_location("pmc_traffic", os.path.join(root, "tools", "pmc_traffic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ref = json.load(open(os.path.join(prof, "traffic.json")))
+    out = mod.analyse(need[0], need[1], verbose=False)
+    x3 = mod.analyse(need[2], need[3], verbose=False)
+    assert out["per_step"]["hbm_bytes"] == ref["per_step"]["hbm_bytes"]
+    assert x3["per_step"]["hbm_bytes"] == ref["per_step_x3"]["hbm_bytes"]
+    assert out["variants"]["fp32"]["tn256"] == ref["variants"]["fp32"]["tn256"]
+    assert x3["variants"]["x3"]["nn256"] == ref["variants"]["x3"]["nn256"]
+    # the gfx950 correction is in: fetched bytes are the counter (KB) x 1024 x 2
+    assert ref["per_step"]["fetch_bytes"] > ref["per_step"]["write_bytes"] > 0
