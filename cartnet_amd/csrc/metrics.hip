@@ -159,14 +159,19 @@ extern "C" int cartnet_adp_metrics(const float* pred, const float* truth, int32_
 // Training loss (reference: train/metrics.py:15-28 -- L1Loss and MSELoss, mean over all elements): both means from one
 // launch, their gradient from another.  The eager form is eight dependent launches per step (sub, abs, mean, and in
 // backward fill, div, sign, mul, mul); at the small-crystal configurations a launch is 5-6 us of a 1.3 ms step.
-// One workgroup: the sums are taken in fp64 in a fixed order (bitwise reproducible); n is M x 9 or Bg elements.
+// Two small launches forward (up to 64 slices, then one wave adds them -- one workgroup alone took 30 us for the 111k
+// elements of the benchmark batch), one backward; fp64 sums in a fixed order (bitwise reproducible).
 namespace {
 
-__global__ __launch_bounds__(1024) void cn_loss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ truth,
-                                                           long long n, float* __restrict__ out) {
-  __shared__ double red[2][16];
+constexpr int LOSS_MAX_PARTS = 64;
+
+// stage 1: up to 64 workgroups, each a contiguous slice, fp64 sums in a fixed order -> parts[2][nparts]
+__global__ __launch_bounds__(256) void cn_loss_partial_kernel(const float* __restrict__ pred, const float* __restrict__ truth,
+                                                              long long n, int nparts, double* __restrict__ parts) {
+  __shared__ double red[2][4];
+  const long long per = (n + nparts - 1) / nparts, lo = (long long)blockIdx.x * per, hi = min(n, lo + per);
   double sa = 0.0, sq = 0.0;
-  for (long long i = threadIdx.x; i < n; i += 1024) {
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const double d = (double)pred[i] - (double)truth[i];
     sa += fabs(d);
     sq += d * d;
@@ -182,13 +187,18 @@ __global__ __launch_bounds__(1024) void cn_loss_fwd_kernel(const float* __restri
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double a = 0.0, q = 0.0;
-    for (int w = 0; w < 16; ++w) {
-      a += red[0][w];
-      q += red[1][w];
-    }
-    out[0] = (float)(a / (double)n);
-    out[1] = (float)(q / (double)n);
+    parts[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    parts[nparts + blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// stage 2: one wave adds the partial sums in order
+__global__ __launch_bounds__(64) void cn_loss_finalize_kernel(const double* __restrict__ parts, int nparts, long long n,
+                                                              float* __restrict__ out) {
+  if (threadIdx.x < 2) {
+    double s = 0.0;
+    for (int k = 0; k < nparts; ++k) s += parts[threadIdx.x * nparts + k];
+    out[threadIdx.x] = (float)(s / (double)n);
   }
 }
 
@@ -207,9 +217,18 @@ __global__ __launch_bounds__(256) void cn_loss_bwd_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int cartnet_loss_fwd(const float* pred, const float* truth, int64_t n, float* out2, void* stream) {
-  CN_CHECK(pred && truth && out2 && n > 0, "cartnet_loss_fwd: null pointer or n = %lld", (long long)n);
-  hipLaunchKernelGGL(cn_loss_fwd_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), pred, truth,
+extern "C" int32_t cartnet_loss_nparts(int64_t n) {
+  const long long want = (n + 4095) / 4096;
+  return (int32_t)(want < 1 ? 1 : (want > LOSS_MAX_PARTS ? LOSS_MAX_PARTS : want));
+}
+
+extern "C" int cartnet_loss_fwd(const float* pred, const float* truth, int64_t n, double* parts, float* out2,
+                                void* stream) {
+  CN_CHECK(pred && truth && parts && out2 && n > 0, "cartnet_loss_fwd: null pointer or n = %lld", (long long)n);
+  const int nparts = cartnet_loss_nparts(n);
+  hipLaunchKernelGGL(cn_loss_partial_kernel, dim3(nparts), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pred,
+                     truth, (long long)n, nparts, parts);
+  hipLaunchKernelGGL(cn_loss_finalize_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), parts, nparts,
                      (long long)n, out2);
   CN_LAUNCH_CHECK("cartnet_loss_fwd");
   return 0;

@@ -18,7 +18,7 @@ _FUSED_LOSS = os.environ.get("CARTNET_FUSED_LOSS", "1") != "0"      # A/B switch
 
 
 class _FusedLoss(torch.autograd.Function):
-    """(MAE, MSE) of device tensors from one launch, their gradient from one more (``cartnet_loss_fwd`` /
+    """(MAE, MSE) of device tensors from two small launches, their gradient from one more (``cartnet_loss_fwd`` /
     ``cartnet_loss_bwd``, include/cartnet_hip.h) instead of eight eager kernels per step."""
 
     @staticmethod
@@ -26,8 +26,10 @@ class _FusedLoss(torch.autograd.Function):
         from . import lib as _l
         p, t = pred.contiguous(), true.contiguous()
         out = torch.empty(2, dtype=torch.float32, device=p.device)
-        _l.check(_l.load().cartnet_loss_fwd(p.data_ptr(), t.data_ptr(), p.numel(), out.data_ptr(), _l.stream_ptr()),
-                 "cartnet_loss_fwd")
+        lib = _l.load()
+        parts = torch.empty(2 * int(lib.cartnet_loss_nparts(p.numel())), dtype=torch.float64, device=p.device)
+        _l.check(lib.cartnet_loss_fwd(p.data_ptr(), t.data_ptr(), p.numel(), parts.data_ptr(), out.data_ptr(),
+                                      _l.stream_ptr()), "cartnet_loss_fwd")
         ctx.save_for_backward(p, t)
         ctx.set_materialize_grads(False)        # the loss that is not used arrives as None, not as a zero tensor
         return out[0], out[1]

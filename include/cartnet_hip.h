@@ -235,12 +235,14 @@ int cartnet_adp_metrics(const float* pred, const float* truth, int32_t M, const 
 
 /* ----------------------------------------------------------------------------------------------------
  * Training loss (reference: train/metrics.py:15-28, called from train/train.py:173-178): L1Loss and MSELoss with mean
- * reduction over the n = M*9 (or Bg) elements of pred / truth, both from ONE launch, and their gradient from one more:
+ * reduction over the n = M*9 (or Bg) elements of pred / truth, both from one pair of small launches (slices, then
+ * their sum), and their gradient from one more:
  *   out2[0] = mean |pred - truth|,  out2[1] = mean (pred - truth)^2          (sums in fp64, fixed order)
  *   dpred   = g_mae[0] * sign(pred - truth) / n + g_mse[0] * 2 (pred - truth) / n   (g_* device scalars; NULL = 0)
- * Replaces eight eager launches per step (sub, abs, mean; fill, div, sign, mul, mul in backward).
+ * Replaces eight eager launches per step (sub, abs, mean; fill, div, sign, mul, mul in backward) by three.
  * ---------------------------------------------------------------------------------------------------- */
-int cartnet_loss_fwd(const float* pred, const float* truth, int64_t n, float* out2, void* stream);
+int32_t cartnet_loss_nparts(int64_t n);      /* parts: workspace of 2 * cartnet_loss_nparts(n) doubles */
+int cartnet_loss_fwd(const float* pred, const float* truth, int64_t n, double* parts, float* out2, void* stream);
 int cartnet_loss_bwd(const float* pred, const float* truth, int64_t n, const float* g_mae, const float* g_mse,
                      float* dpred, void* stream);
 
