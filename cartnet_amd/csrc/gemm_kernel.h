@@ -496,15 +496,29 @@ __device__ __forceinline__ void epilogue_wide(const CartnetGemmArgs& p, ACC& acc
 #endif
       acc_block_to_scr(acc, a, b, scr, lane, SCR_LD);
       __builtin_amdgcn_wave_barrier();
+      // The two epilogues with ONE operand row per output row and nothing else (residual: dE; `silu'`: dpre) load the
+      // block's four operand rows together before its first store: loads and stores retire through one in-order
+      // counter, so a row that loads its operand after the previous row's store waits for that store's acknowledgement
+      // too -- four load + store round trips in a row per block (profiles/r03_exp_phases.md; -1.3 % / -1 % per launch).
+      // The forms with more operands or statistics spill when they do the same (measured), so they keep the row loop.
+      constexpr bool BATCH = KIND == 2 || KIND == 4;
+      f32x4 op[4];
+      if constexpr (BATCH) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int gr = min(grow[i], p.M - 1);            // rows past M load row M - 1 and are dropped below
+          op[i] = (KIND == 2) ? ldv4(resid + (size_t)gr * p.ldr + gcol) : ldv4(dact + (size_t)gr * p.ldd + gcol);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         f32x4 v = ldv4(scr + (rsub + 8 * i) * SCR_LD + c4 * 4);
         if (grow[i] >= p.M) continue;
         v += bias4[b];
         if (GATHER) v += ldv4(gi + (size_t)ti[i] * p.ldg + gcol) + ldv4(gj + (size_t)sj[i] * p.ldg + gcol);
-        if (RESID) v += ldv4(resid + (size_t)grow[i] * p.ldr + gcol);
+        if (RESID) v += BATCH ? op[i] : ldv4(resid + (size_t)grow[i] * p.ldr + gcol);
         if (DACT) {
-          const f32x4 d = ldv4(dact + (size_t)grow[i] * p.ldd + gcol);
+          const f32x4 d = BATCH ? op[i] : ldv4(dact + (size_t)grow[i] * p.ldd + gcol);
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] *= fast_dsilu(d[q]);
         }
