@@ -501,6 +501,34 @@ __device__ __forceinline__ void epilogue_wide(const CartnetGemmArgs& p, ACC& acc
       // counter, so a row that loads its operand after the previous row's store waits for that store's acknowledgement
       // too -- four load + store round trips in a row per block (profiles/r03_exp_phases.md; -1.3 % / -1 % per launch).
       // The forms with more operands or statistics spill when they do the same (measured), so they keep the row loop.
+      // The store-only forms (plain, and the one with BatchNorm statistics, which are taken before this loop) read the
+      // block's four rows into four register sets and issue its four stores back to back: the compiler puts
+      // s_waitcnt vmcnt(0) in front of any write to a register a store in flight has read from, and with ONE set
+      // recycled row by row that was a wait for the previous row's store to be ACKNOWLEDGED on every row (1-2 us next
+      // to a busy partner workgroup: profiles/r03_exp_phases.md); now it is one wait per block.  Same-box A B A B:
+      // K = 80 / 128 launches -4 %, K = 256 -0.5 % (fp32) and -1...-2 % (bf16x3); the training step within noise.
+      constexpr bool SETS = KIND == 0 || KIND == 16;
+      if constexpr (SETS) {
+        f32x4 vv[4];
+        float* ptr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          vv[i] = ldv4(scr + (rsub + 8 * i) * SCR_LD + c4 * 4) + bias4[b];
+          ptr[i] = C + (size_t)min(grow[i], p.M - 1) * p.ldc + gcol;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (grow[i] < p.M) stv4(ptr[i], vv[i]);
+        // values and addresses stay in their own registers until the last store of the block has been issued
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(vv[i]), "v"(ptr[i]));
+        __builtin_amdgcn_wave_barrier();
+#ifdef CN_PHASE_STAMP
+        if (a == 0 && b == 0) { CN_PHASE(6); }
+        if (a == 0 && b == S::TN - 1) { CN_PHASE(7); }
+#endif
+        continue;
+      }
       constexpr bool BATCH = KIND == 2 || KIND == 4;
       f32x4 op[4];
       if constexpr (BATCH) {
