@@ -206,17 +206,36 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32gate_kernel(const Gate
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       smem[(wm * S::WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * GATE_LD + wn * S::WN + li] = accg[a][r];
-  __syncthreads();
-  {  // e_out = e_in + sigma: a row of the tile is 512 B = 32 lanes x 16 B; a wave instruction covers two rows
+  {  // e_out = e_in + sigma: a row of the tile is 512 B = 32 lanes x 16 B; a wave instruction covers two rows.
+    // All eight e_in rows of a thread are loaded first -- behind the barrier they fly across -- and the eight stores go
+    // out back to back from eight register sets (the gate accumulators are dead by now): loads and stores retire
+    // through one in-order counter, and a row-by-row loop waits for every store's acknowledgement (r03_exp_phases.md).
     const int c4 = (tid & 31) * 4, rsub = tid >> 5;         // 16 row slots
+    constexpr int HALF = BM / 32;                           // 4 rows at a time: 8 spill the accumulators
+    f32x4 ein[HALF];
+    __builtin_amdgcn_sched_barrier(0);                      // not above the sigma stores: their registers are these
 #pragma unroll
-    for (int i = 0; i < BM / 16; ++i) {
-      const int rl = rsub + 16 * i;
-      if (rl < nrows) {
-        const size_t off = (size_t)(row0 + rl) * p.D + col0 + c4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&smem[rl * GATE_LD + c4]);
-        v += *reinterpret_cast<const f32x4*>(p.e_in + off);
-        *reinterpret_cast<f32x4*>(p.e_out + off) = v;
+    for (int i = 0; i < HALF; ++i) {
+      const int rl = min(rsub + 16 * i, nrows - 1);         // rows past the end re-read the last one and are not stored
+      ein[i] = *reinterpret_cast<const f32x4*>(p.e_in + (size_t)(row0 + rl) * p.D + col0 + c4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < HALF; ++i)
+        ein[i] += *reinterpret_cast<const f32x4*>(&smem[(rsub + 16 * (h * HALF + i)) * GATE_LD + c4]);
+#pragma unroll
+      for (int i = 0; i < HALF; ++i) {
+        const int rl = rsub + 16 * (h * HALF + i);
+        if (rl < nrows) *reinterpret_cast<f32x4*>(p.e_out + (size_t)(row0 + rl) * p.D + col0 + c4) = ein[i];
+      }
+      if (h == 0) {
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+          const int rl = min(rsub + 16 * (HALF + i), nrows - 1);
+          ein[i] = *reinterpret_cast<const f32x4*>(p.e_in + (size_t)(row0 + rl) * p.D + col0 + c4);
+        }
       }
     }
   }
