@@ -529,6 +529,11 @@ __device__ __forceinline__ void epilogue_wide(const CartnetGemmArgs& p, ACC& acc
 #endif
         continue;
       }
+      // (bf16x3 kernel only, where the epilogue is longer than the partner's main loop and therefore on the critical
+      //  path: the gather form loads its two node-term rows for two output rows at a time -- 279.6 -> 273.7 us per layer
+      //  GEMM 1; the 128-wide fp32 kernel that takes this form at precision 0 has 80 registers and spills with it)
+      constexpr bool BATCH_G = KIND == 1 && MF16;
+      f32x4 og[4];
       constexpr bool BATCH = KIND == 2 || KIND == 4;
       f32x4 op[4];
       if constexpr (BATCH) {
@@ -540,10 +545,21 @@ __device__ __forceinline__ void epilogue_wide(const CartnetGemmArgs& p, ACC& acc
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        if constexpr (BATCH_G) {
+          if ((i & 1) == 0) {
+#pragma unroll
+            for (int k = i; k < i + 2; ++k) {
+              const bool in = grow[k] < p.M;
+              og[2 * (k - i)] = ldv4(gi + (size_t)(in ? ti[k] : 0) * p.ldg + gcol);
+              og[2 * (k - i) + 1] = ldv4(gj + (size_t)(in ? sj[k] : 0) * p.ldg + gcol);
+            }
+          }
+        }
         f32x4 v = ldv4(scr + (rsub + 8 * i) * SCR_LD + c4 * 4);
         if (grow[i] >= p.M) continue;
         v += bias4[b];
-        if (GATHER) v += ldv4(gi + (size_t)ti[i] * p.ldg + gcol) + ldv4(gj + (size_t)sj[i] * p.ldg + gcol);
+        if (GATHER) v += BATCH_G ? og[2 * (i & 1)] + og[2 * (i & 1) + 1]
+                                 : ldv4(gi + (size_t)ti[i] * p.ldg + gcol) + ldv4(gj + (size_t)sj[i] * p.ldg + gcol);
         if (RESID) v += BATCH ? op[i] : ldv4(resid + (size_t)grow[i] * p.ldr + gcol);
         if (DACT) {
           const f32x4 d = BATCH ? op[i] : ldv4(dact + (size_t)grow[i] * p.ldd + gcol);
