@@ -28,6 +28,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn16_kernel(const Cartn
   __shared__ __attribute__((aligned(16))) float smem[2 * X3_BUF_BYTES / 4];
   char* lds = reinterpret_cast<char*>(smem);
 
+  CN_PHASE(0);
+  CN_PHASE_ID();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn16_kernel(const Cartn
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     CN_STAMP_BEGIN();
+    CN_PHASE(1);
     int u = 0;
     for (; u + 4 < nsteps; u += 2) {        // both steps satisfy u + 3 < nsteps
       step_full(std::integral_constant<int, 0>{}, u, r1);
@@ -307,8 +310,14 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn16_kernel(const Cartn
       if (u + 1 < nsteps) step(std::integral_constant<int, 1>{}, u + 1, r0);
     }
     CN_STAMP_END();
+    CN_PHASE(2);
   }
   x3_epilogue<0>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem);
+#ifdef CN_PHASE_STAMP
+  CN_PHASE(3);                                             // last store issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CN_PHASE(4);                                             // ... and acknowledged
+#endif
 }
 
 }  // namespace cn_gemm

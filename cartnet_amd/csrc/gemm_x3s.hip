@@ -16,3 +16,10 @@ extern "C" int cartnet_debug_clock_x3s(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cn_gemm::cn_clock_dbg), sizeof(unsigned long long) * 2 * 4096);
 }
 #endif
+
+#ifdef CN_PHASE_STAMP
+// diagnostic build: the per-workgroup phase stamps of the last launches (8192 x 8 64-bit words)
+extern "C" int cartnet_debug_phase_x3s(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cn_gemm::cn_phase_dbg), sizeof(unsigned long long) * 8 * 8192);
+}
+#endif

@@ -13,7 +13,8 @@ from cartnet_amd import ops, lib as _lib
 
 dev = torch.device("cuda:0")
 L = _lib.load()
-fn = L.cartnet_debug_phase_f32
+PREC = int(os.environ.get("EXP_PRECISION", "0"))          # 1: the bf16x3 kernel (gemm_x3s.o built with -DCN_PHASE_STAMP)
+fn = L.cartnet_debug_phase_x3s if PREC else L.cartnet_debug_phase_f32
 fn.argtypes = [ctypes.c_void_p]
 fn.restype = ctypes.c_int
 g = torch.Generator().manual_seed(0)
@@ -21,9 +22,9 @@ E, D = 177140, 256
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 A = torch.randn(E, K, generator=g).to(dev)
 Ws = [(torch.randn(K, D, generator=g) * 0.05).to(dev) for _ in range(2)]
-imgs = ops.pack_b(Ws)
+imgs = ops.split_b(Ws) if PREC else ops.pack_b(Ws)
 out = torch.empty(E, 2 * D, device=dev)
-run = lambda: ops.gemm([A, A], Ws, [out[:, :D], out[:, D:]], b_kstrided=True, b_split=imgs, precision=0)
+run = lambda: ops.gemm([A, A], Ws, [out[:, :D], out[:, D:]], b_kstrided=True, b_split=imgs, precision=PREC)
 for _ in range(200):
     run()
 torch.cuda.synchronize()
