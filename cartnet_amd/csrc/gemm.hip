@@ -16,6 +16,14 @@ bool use_f32nn128(const CartnetGemmArgs& a) {
   if (mode == 128) return true;
   if (mode == 256) return false;
   if (a.gather_i[0] != nullptr && !a.a_act) return true;
+  // One 256-wide column tile per row tile, one group, one K-segment (iComformer's edge-sized C x C products): 1,384 row
+  // tiles are 2.7 rounds of the 256-wide kernel's 512 resident workgroups but 3.6 of the 128-wide one's 768, whose third
+  // workgroup per CU also keeps two main loops overlapping -- isolated 365 -> 346 us, the iComformer step 36.72 -> 36.52
+  // ms (same-box A B A B, end of round 3).  CartNet's dE products (two folded K-segments) were faster alone too (370.6 ->
+  // 362.5 us) but the training step, where they run next to the weight-gradient products, was not (14.86 -> 14.92 ms):
+  // they stay on the wide kernel.  CARTNET_N256_WIDE=1 keeps the 256-wide kernel for all.
+  static const bool n256_wide = [] { const char* e = getenv("CARTNET_N256_WIDE"); return e && atoi(e) != 0; }();
+  if (!n256_wide && a.N == 256 && a.ngroups == 1 && a.nsegs == 1 && !a.a_act) return true;
   // few row tiles (atom-sized M): 128-wide tiles put twice as many workgroups on the chip (the folded dX product of the
   // node terms, M = 12,416, K = 1024: 97 tiles of 128 x 256 would use 97 of 256 CUs)
   const long long tiles = (long long)((a.M + 127) / 128) * (a.N / 256) * a.ngroups;
