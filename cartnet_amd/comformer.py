@@ -27,6 +27,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import lib as _l
 from .model import BN_EPS, BN_MOMENTUM, Cholesky_head, N_ATOM_TYPES
 
 
@@ -397,6 +398,7 @@ class _IComformerFunction(torch.autograd.Function):
         need_grad = bool(getattr(model, "_grad_mode", True)) and any(ctx.needs_input_grad)
         ctx.gemm_precision = int(model.gemm_precision)
         _GEMM_PRECISION[0] = ctx.gemm_precision
+        _l.load().cartnet_gemm_tile_policy(1)        # grouped C x C products on the 128-wide kernel (include/cartnet_hip.h)
         _begin_forward(model, P, ctx.gemm_precision)
         C = model.dim_in
         dev = params[0].device
@@ -582,6 +584,7 @@ class _IComformerFunction(torch.autograd.Function):
         if sv is None:
             raise RuntimeError("iComformer backward called without saved state")
         _GEMM_PRECISION[0] = ctx.gemm_precision
+        _l.load().cartnet_gemm_tile_policy(1)
         ctx.sv = None
         P, model, lay = sv["P"], sv["model"], sv["lay"]
         _KEEP.clear()

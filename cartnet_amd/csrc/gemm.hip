@@ -11,6 +11,7 @@ thread_local bool g_half_launched = false;
 // GEMM 1) -- the one variant where a third resident workgroup pays: 402 vs 425 us sustained at the benchmark shape, the
 // training step 15.40 vs 15.57 ms (same box, interleaved).  Every other variant is equal or slower on the narrow tile
 // (SiLU on the A operand: -15 %, its prologue runs once per column tile).  CARTNET_F32NN_BN=256 / =128 force one kernel.
+int g_tile_policy = 0;     // cartnet_gemm_tile_policy
 bool use_f32nn128(const CartnetGemmArgs& a) {
   static const int mode = [] { const char* e = getenv("CARTNET_F32NN_BN"); return e ? atoi(e) : 0; }();
   if (mode == 128) return true;
@@ -22,8 +23,11 @@ bool use_f32nn128(const CartnetGemmArgs& a) {
   // ms (same-box A B A B, end of round 3).  CartNet's dE products (two folded K-segments) were faster alone too (370.6 ->
   // 362.5 us) but the training step, where they run next to the weight-gradient products, was not (14.86 -> 14.92 ms):
   // they stay on the wide kernel.  CARTNET_N256_WIDE=1 keeps the 256-wide kernel for all.
+  // Grouped launches of that shape too when the caller asked for it (cartnet_gemm_tile_policy(1): the iComformer host
+  // path, whose step gains another 1.8 %, 36.39 -> 35.74 ms; CartNet's two-group layer products do not, so
+  // cartnet_model_forward / _backward reset the policy to 0).
   static const bool n256_wide = [] { const char* e = getenv("CARTNET_N256_WIDE"); return e && atoi(e) != 0; }();
-  if (!n256_wide && a.N == 256 && a.ngroups == 1 && a.nsegs == 1 && !a.a_act) return true;
+  if (!n256_wide && a.N == 256 && (a.ngroups == 1 || g_tile_policy == 1) && a.nsegs == 1 && !a.a_act) return true;
   // few row tiles (atom-sized M): 128-wide tiles put twice as many workgroups on the chip (the folded dX product of the
   // node terms, M = 12,416, K = 1024: 97 tiles of 128 x 256 would use 97 of 256 CUs)
   const long long tiles = (long long)((a.M + 127) / 128) * (a.N / 256) * a.ngroups;
@@ -226,6 +230,12 @@ std::vector<GemmRecord> g_prof;
 }  // namespace
 
 static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream);
+
+extern "C" int cartnet_gemm_tile_policy(int32_t policy) {
+  CN_CHECK(policy == 0 || policy == 1, "cartnet_gemm_tile_policy: policy must be 0 or 1 (got %d)", policy);
+  cn_gemm::g_tile_policy = policy;
+  return 0;
+}
 
 extern "C" int cartnet_profile_gemm(int32_t enable) {
   if (enable && !g_prof_on) {

@@ -422,6 +422,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
                                      float* x_out, float* e_out, int32_t* status, void* st, void* aux_stream) {
   RUN(check_model(model, batch, "cartnet_model_forward"));
   g_precision = model->gemm_precision;
+  (void)cartnet_gemm_tile_policy(0);      // CartNet's grouped layer products stay on the 256-wide kernel (gemm.hip)
   const CartnetModel& m = *model;
   const CartnetBatch& b = *batch;
   const CartnetParams& P = m.p;
@@ -699,6 +700,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
                                       const CartnetParams* grads, void* stream, void* aux_stream) {
   RUN(check_model(model, batch, "cartnet_model_backward"));
   g_precision = model->gemm_precision;
+  (void)cartnet_gemm_tile_policy(0);      // CartNet's grouped layer products stay on the 256-wide kernel (gemm.hip)
   const CartnetModel& m = *model;
   const CartnetBatch& b = *batch;
   const CartnetParams& P = m.p;

@@ -244,6 +244,7 @@ PROTOTYPES = {
                                              c_stream]),
     "cartnet_neighbor_cap_fill": (C.c_int, [c_i64p, c_i64p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, C.c_int32,
                                             C.c_int64, C.c_int64, c_i64p, c_f32p, c_f32p, c_stream]),
+    "cartnet_gemm_tile_policy": (C.c_int, [C.c_int32]),
     "cartnet_loss_nparts": (C.c_int32, [C.c_int64]),
     "cartnet_loss_fwd": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_void_p, c_f32p, c_stream]),
     "cartnet_loss_bwd": (C.c_int, [c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_stream]),

@@ -308,6 +308,11 @@ typedef struct CartnetGemmProfile {
   double flops;      /* executed: sum of 2*M*N*K*(groups or segments) */
   double ms;
 } CartnetGemmProfile;
+/* Tile-width policy of the fp32 activation x weight products with one 256-wide column tile per row tile (N = 256):
+ * 0 (default; cartnet_model_forward / _backward set it on entry) = single-group launches of that shape go to the
+ * 128-wide kernel, grouped ones stay on the 256-wide one; 1 = grouped ones too (the iComformer host path sets it:
+ * its step is 1.8 % shorter, CartNet's is not).  Process-wide; not for concurrent use from several threads. */
+int cartnet_gemm_tile_policy(int32_t policy);
 int cartnet_profile_gemm(int32_t enable);
 /* Restrict the timing to launches of one variant (the value CartnetGemmProfile.variant reports; < 0: all variants):
  * bench.py prices every variant during its warm-up steps and only the dominant one inside the timed region, so the
