@@ -18,6 +18,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # per-source additions (the reason is at the top of the source file)
 EXTRA_FLAGS = {"radius_graph.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
+if os.environ.get("CARTNET_BUILD_EXPERIMENTAL"):       # experiments kept as a record (csrc/experimental/), never shipped
+    SOURCES.append("experimental/gemm_f32q.hip")
+    FLAGS.append("-DCN_EXPERIMENTAL_Q")
 FLAGS += os.environ.get("CARTNET_HIPCC_EXTRA", "").split()      # e.g. -DCN_SETPRIO=0 for an A/B library (tools/ab_bench.sh)
 
 

@@ -267,40 +267,74 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
                  :: "s"(st + F32T_A_BYTES + (wid + 8) * 1024), "v"(b_voff), "s"(sb + b_half) : "memory", "m0");
   };
 
+  // fragments of one 8-deep k-group: element j of the MFMA chain takes k = kg*8 + 2j + lh; one ds_read2_b32 fetches the
+  // two 32-row (A) / 32-column (B) halves of a wave tile for one k
+  float af[2][2][4], bf[2][2][4];      // [register set = k-group][tile][j]
+  auto frags = [&](int u, int kg) {
+    const float* sA = reinterpret_cast<const float*>(lds + (u % F32T_NSTAGE) * F32T_STAGE);
+    const float* sB = sA + F32T_A_BYTES / 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = kg * 8 + 2 * j + lh;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[kg][a][j] = sA[k * BM + wm * S::WM + a * 32 + li];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float v = sB[k * F32_BN + wn * S::WN + b * 32 + li];
+        bf[kg][b][j] = B_ACT ? fast_silu(v) : v;
+      }
+    }
+  };
+  auto mma16 = [&](int kg) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg][a][j], bf[kg][b][j], acc[a][b], 0, 0, 0);
+  };
+
+  // Software-pipelined around ONE barrier per K-step, placed between the two k-groups of a tile (round 4; the loop the
+  // compiler made of the plain form kept four fragment registers and waited for LDS -- s_waitcnt lgkmcnt(0) -- in front
+  // of every fourth MFMA: 0.78-0.80 of the matrix pipe isolated).  Iteration u (there is a tile u + 1) starts with
+  // k-group 0 of tile u issued to the matrix pipe and k-group 1 in registers:  (1) this wave's three DMA pieces of tile
+  // u + 1 have landed (vmcnt(3): tile u + 2's stay in flight) and its own LDS reads are done; barrier: everybody's have,
+  // so tile u + 1 is published AND the stage of tile u is free.  (2) k-group 0 of tile u + 1 -> the registers the MFMAs
+  // before the barrier consumed; tile u + 3 is DMA'd into tile u's stage (three stages, two and a half K-steps to
+  // land).  (3) 16 MFMAs of k-group 1 of tile u cover the latency of (2).  (4) k-group 1 of tile u + 1, covered by
+  // (5) the 16 MFMAs of k-group 0 of tile u + 1.
   if (nsteps > 0) {
     issue(0);
     if (nsteps > 1) issue(1);
-    for (int u = 0; u < nsteps; ++u) {
-      if (u + 1 < nsteps) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nsteps > 2) issue(2);
+    if (nsteps > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    frags(0, 0);
+    frags(0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16(0);
+    for (int u = 0; u + 1 < nsteps; ++u) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + 2 < nsteps) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (u + 2 < nsteps) issue(u + 2);
-      const float* sA = reinterpret_cast<const float*>(lds + (u % F32T_NSTAGE) * F32T_STAGE);
-      const float* sB = sA + F32T_A_BYTES / 4;
-#pragma unroll
-      for (int kg = 0; kg < 2; ++kg) {
-        float af[2][4], bf[2][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k = kg * 8 + 2 * j + lh;
-#pragma unroll
-          for (int a = 0; a < 2; ++a) af[a][j] = sA[k * BM + wm * S::WM + a * 32 + li];
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const float v = sB[k * F32_BN + wn * S::WN + b * 32 + li];
-            bf[b][j] = B_ACT ? fast_silu(v) : v;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
-      }
+      frags(u + 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + 3 < nsteps) issue(u + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma16(1);
+      __builtin_amdgcn_sched_barrier(0);
+      frags(u + 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma16(0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    mma16(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // the epilogue reuses the LDS
     asm volatile("" ::: "memory");

@@ -396,11 +396,12 @@ __device__ __forceinline__ void acc_block_to_scr(const f32x4 (&acc)[TM][TN], int
       for (int r = 0; r < 4; ++r) scr[(16 * ta + 4 * lq + r) * ld + 16 * tb + li] = acc[2 * a + ta][2 * b + tb][r];
 }
 
-template <int BN, int KIND, class ACC>
-__device__ __forceinline__ void epilogue_wide(const CartnetGemmArgs& p, ACC& acc,
-                                              int g, int row0, int col0, int tile_m, int wm, int wn, int lane, int tid,
-                                              float* smem, int rt_kind) {
-  using S = Shape<BN>;
+// S: the wave grid (Shape<BN> for the 512-thread kernels, ShapeQ for the 256-thread one of gemm_f32q.h); NT: threads per
+// workgroup.
+template <class S, int BN, int NT, int KIND, class ACC>
+__device__ __forceinline__ void epilogue_wide_s(const CartnetGemmArgs& p, ACC& acc,
+                                                int g, int row0, int col0, int tile_m, int wm, int wn, int lane, int tid,
+                                                float* smem, int rt_kind) {
   constexpr bool MF16 = sizeof(acc[0][0]) == sizeof(f32x4);     // 16x16 tiles
   const int kind = (KIND >= 0) ? KIND : rt_kind;
   const bool GATHER = kind & 1, RESID = kind & 2, DACT = kind & 4, SUM1 = kind & 8, SUM2 = kind & 16,
@@ -624,7 +625,7 @@ __device__ __forceinline__ void epilogue_wide(const CartnetGemmArgs& p, ACC& acc
       }
     }
     __syncthreads();
-    for (int c = tid; c < BN; c += NTHREADS) {
+    for (int c = tid; c < BN; c += NT) {
       const int gcol = col0 + c;
       if (gcol < p.N) {
         double s = 0.0, q = 0.0;
@@ -638,6 +639,13 @@ __device__ __forceinline__ void epilogue_wide(const CartnetGemmArgs& p, ACC& acc
       }
     }
   }
+}
+
+template <int BN, int KIND, class ACC>
+__device__ __forceinline__ void epilogue_wide(const CartnetGemmArgs& p, ACC& acc,
+                                              int g, int row0, int col0, int tile_m, int wm, int wn, int lane, int tid,
+                                              float* smem, int rt_kind) {
+  epilogue_wide_s<Shape<BN>, BN, NTHREADS, KIND>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem, rt_kind);
 }
 
 // The same with several column tiles per row tile (N = 512: two 256-wide tiles; the 128-wide kernel at N = 256): the
@@ -912,6 +920,11 @@ void launch_f32tn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim
 // gemm_f32w128.hip: 128-wide DMA-fed fp32 kernel, chosen by use_f32nn128 (gemm.hip)
 void launch_f32nn128(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
 bool use_f32nn128(const CartnetGemmArgs& a);
+#ifdef CN_EXPERIMENTAL_Q
+// experimental/gemm_f32q.hip (not in the product build): 128 x 128 tiles on 256-thread workgroups, four per CU
+void launch_f32nnq(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
+bool use_f32nnq(const CartnetGemmArgs& a);
+#endif
 // gemm_f32ao.hip: the a_act form of the 256-wide kernel that also writes silu(A) (CartnetGemmArgs.a_act_out)
 void launch_f32nn_actout(const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
 // gemm_x3s.hip: the bf16x3 activation x weight kernel on the 16x16x32 MFMA shape (the default at precision 1;
@@ -971,6 +984,9 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
         for (int i = 0; i < nptr; ++i) prepacked = prepacked && a.b_split[i] != nullptr;
         if (prepacked) {
           if (A_ACT && a.a_act_out[0]) launch_f32nn_actout(a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
+#ifdef CN_EXPERIMENTAL_Q
+          else if (use_f32nnq(a)) launch_f32nnq(A_ACT, a, fl, dim3(nm * tiles_n * 2, ns, a.ngroups), st);
+#endif
           else if (use_f32nn128(a)) launch_f32nn128(A_ACT, a, fl, dim3(nm * tiles_n * 2, ns, a.ngroups), st);
           else launch_f32nn(A_ACT, a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
           return;

@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcartnet_hip.so")
+# CARTNET_LIB (tools only): a diagnostic / A-B build of the same ABI next to the product library (tools/build_variant.sh)
+LIB_PATH = os.environ.get("CARTNET_LIB") or os.path.join(_HERE, "libcartnet_hip.so")
 MAX_GROUPS = 4
 
 _lib: Optional[C.CDLL] = None
@@ -292,6 +293,9 @@ def load() -> C.CDLL:
         if C.sizeof(cls) != sz:
             raise CartnetHipError(f"{LIB_PATH}: sizeof({cls.__name__}) is {sz} in the library, {C.sizeof(cls)} in "
                                   "cartnet_amd/lib.py -- rebuild the library (python -m cartnet_amd.build)")
+    # experiment builds only (CARTNET_BUILD_EXPERIMENTAL=1, csrc/experimental/): CARTNET_Q selects the quad kernel
+    if os.environ.get("CARTNET_Q") and hasattr(lib, "cartnet_gemm_experimental_q"):
+        lib.cartnet_gemm_experimental_q(int(os.environ["CARTNET_Q"]))
     _lib = lib
     return lib
 

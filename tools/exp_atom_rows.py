@@ -33,7 +33,14 @@ def sustained(fn, seconds=1.0):
 
 
 segs = [X4[:, i * D:(i + 1) * D] for i in range(4)]
+xin = rnd(M, D)
+Wn = [rnd(D, D) * 0.05 for _ in range(4)]
+img_n = ops.pack_b(Wn)
+Pn = torch.empty(M, 4 * D, device=dev)
+bn2 = [rnd(D), rnd(D), None, None]
+Wh = rnd(D, D // 2) * 0.05
 cases = {
+    "node terms forward (4 groups, K=N=256), image": lambda: ops.gemm([xin] * 4, Wn, [Pn[:, i * D:(i + 1) * D] for i in range(4)], b_kstrided=True, b_split=img_n, bias=bn2),
     "dX of node terms (4 segments, K=1024), image": lambda: ops.gemm(segs, W4, out, b_kstrided=True, segments=True, resid=resid, b_split_folded=fold),
     "dX of node terms (4 segments, K=1024), no image": lambda: ops.gemm(segs, W4, out, b_kstrided=True, segments=True, resid=resid),
     "atom encoder (K=512, silu in/out), image": lambda: ops.gemm(x, Wa, out, b_kstrided=True, a_act=True, out_act=True, b_split=img_a),
@@ -41,6 +48,6 @@ cases = {
     "atom encoder backward (N=512), image": lambda: ops.gemm(out, Wb, out2, b_kstrided=True, dact=x, b_split=img_b),
     "atom encoder backward (N=512), no image": lambda: ops.gemm(out, Wb, out2, b_kstrided=True, dact=x),
 }
-print("CARTNET_F32NN_BN =", os.environ.get("CARTNET_F32NN_BN"))
+print("CARTNET_F32NN_BN =", os.environ.get("CARTNET_F32NN_BN"), " CARTNET_Q =", os.environ.get("CARTNET_Q"))
 for name, fn in cases.items():
     print(f"  {name:52s} {sustained(fn):7.1f} us")

@@ -14,7 +14,8 @@ from cartnet_amd import ops, lib as _lib
 dev = torch.device("cuda:0")
 L = _lib.load()
 PREC = int(os.environ.get("EXP_PRECISION", "0"))          # 1: the bf16x3 kernel (gemm_x3s.o built with -DCN_PHASE_STAMP)
-fn = L.cartnet_debug_phase_x3s if PREC else L.cartnet_debug_phase_f32
+QUAD = os.environ.get("CARTNET_Q", "0") != "0"            # round 4: the four-workgroups-per-CU kernel (gemm_f32q.o stamped)
+fn = L.cartnet_debug_phase_x3s if PREC else (L.cartnet_debug_phase_f32q if QUAD else L.cartnet_debug_phase_f32)
 fn.argtypes = [ctypes.c_void_p]
 fn.restype = ctypes.c_int
 g = torch.Generator().manual_seed(0)
@@ -38,7 +39,7 @@ print(f"K = {K}: {1e3 * e0.elapsed_time(e1) / 20:.1f} us per launch (with the st
 buf = np.zeros(8192 * 8, dtype=np.uint64)
 assert fn(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 s = buf.reshape(8192, 8)
-n = 2 * ((E + 127) // 128)
+n = (4 if QUAD else 2) * ((E + 127) // 128)
 s = s[:n].astype(np.int64)
 t0 = s[:, 0].min()
 ent, l0, l1, si, sd = [(s[:, i] - t0) * 0.01 for i in range(5)]        # us since the first workgroup's entry
@@ -58,8 +59,8 @@ for q in (10, 50, 90):
 span = sd.max()
 res = 0.05
 T = int(span / res) + 2
-occ_hist = np.zeros(4)
-alive_hist = np.zeros(4)
+occ_hist = np.zeros(6)
+alive_hist = np.zeros(6)
 gaps = []
 for c in set(cu.tolist()):
     idx = np.where(cu == c)[0]
@@ -68,20 +69,20 @@ for c in set(cu.tolist()):
     for i in idx:
         loops[int(l0[i] / res):int(l1[i] / res)] += 1
         alive[int(ent[i] / res):int(sd[i] / res)] += 1
-    for k in range(4):
+    for k in range(6):
         occ_hist[k] += (loops[:int(span / res)] == k).sum()
         alive_hist[k] += (alive[:int(span / res)] == k).sum()
     # successor gap: sort by entry; a workgroup's entry minus the latest exit before it among the CU's workgroups
     order = idx[np.argsort(ent[idx])]
     exits = np.sort(sd[idx])
-    for i in order[2:]:                       # the first two fill the empty CU
+    for i in order[(4 if QUAD else 2):]:                       # the first two fill the empty CU
         prev = exits[exits <= ent[i] + 1e-9]
         if len(prev):
             gaps.append(ent[i] - prev.max())
 occ_hist /= occ_hist.sum()
 alive_hist /= alive_hist.sum()
-print("share of CU-time with k workgroups INSIDE THEIR MAIN LOOP: " + "  ".join(f"k={k}: {occ_hist[k]:.3f}" for k in range(4)))
-print("share of CU-time with k workgroups RESIDENT (entry .. stores acknowledged): " + "  ".join(f"k={k}: {alive_hist[k]:.3f}" for k in range(4)))
+print("share of CU-time with k workgroups INSIDE THEIR MAIN LOOP: " + "  ".join(f"k={k}: {occ_hist[k]:.3f}" for k in range(6)))
+print("share of CU-time with k workgroups RESIDENT (entry .. stores acknowledged): " + "  ".join(f"k={k}: {alive_hist[k]:.3f}" for k in range(6)))
 gaps = np.array(gaps)
 print(f"gap between a workgroup's last acknowledged store and the next entry on the same CU: median {np.median(gaps):.2f} us, "
       f"p10 {np.percentile(gaps, 10):.2f}, p90 {np.percentile(gaps, 90):.2f} ({len(gaps)} successions)")
@@ -91,3 +92,14 @@ idx = np.where(cu == c)[0]
 print(f"CU {c}: (entry, loop start, loop end, last store, acknowledged) us")
 for i in idx[np.argsort(ent[idx])]:
     print(f"   wg {i:5d}: {ent[i]:7.2f} {l0[i]:7.2f} {l1[i]:7.2f} {si[i]:7.2f} {sd[i]:7.2f}")
+
+if QUAD and hasattr(L, "cartnet_debug_phase2_f32q"):
+    f2 = L.cartnet_debug_phase2_f32q
+    f2.argtypes = [ctypes.c_void_p]
+    f2.restype = ctypes.c_int
+    b2 = np.zeros(8192 * 4, dtype=np.uint64)
+    assert f2(b2.ctypes.data_as(ctypes.c_void_p)) == 0
+    q = b2.reshape(8192, 4)[:n].astype(np.float64) / (K // 16)
+    print("wave 0, shader cycles per K-step (median / p10 / p90 over workgroups): "
+          + "  ".join(f"{nm} {np.median(q[:, i]):.0f} / {np.percentile(q[:, i], 10):.0f} / {np.percentile(q[:, i], 90):.0f}"
+                      for i, nm in enumerate(("whole loop", "wait for the DMA", "barrier"))))
