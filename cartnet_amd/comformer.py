@@ -171,6 +171,7 @@ def _gemm(A, B, C_out, **kw):
     W^T with its pre-split image (cartnet_gemm_split_b, once per weight per step): that is the form the bf16 kernels
     implement."""
     prec = _GEMM_PRECISION[0]
+    kw.setdefault("tile_policy", 1)   # grouped C x C products on the 128-wide fp32 kernel (CartnetGemmArgs.tile_policy)
     fp32_img = prec == 0      # precision 0: fp32 rows packed for the DMA-fed fp32-MFMA kernel (cartnet_gemm_pack_b)
     if not kw.get("b_kstrided", False) and not kw.get("a_kstrided", False) and kw.get("splitk", 1) == 1:
         Bs = list(B) if isinstance(B, (list, tuple)) else [B]
@@ -398,7 +399,6 @@ class _IComformerFunction(torch.autograd.Function):
         need_grad = bool(getattr(model, "_grad_mode", True)) and any(ctx.needs_input_grad)
         ctx.gemm_precision = int(model.gemm_precision)
         _GEMM_PRECISION[0] = ctx.gemm_precision
-        _l.load().cartnet_gemm_tile_policy(1)        # grouped C x C products on the 128-wide kernel (include/cartnet_hip.h)
         _begin_forward(model, P, ctx.gemm_precision)
         C = model.dim_in
         dev = params[0].device
@@ -584,10 +584,12 @@ class _IComformerFunction(torch.autograd.Function):
         if sv is None:
             raise RuntimeError("iComformer backward called without saved state")
         _GEMM_PRECISION[0] = ctx.gemm_precision
-        _l.load().cartnet_gemm_tile_policy(1)
         ctx.sv = None
         P, model, lay = sv["P"], sv["model"], sv["lay"]
-        _KEEP.clear()
+        if _KEEP:                   # a previous backward raised before its join: the side stream may still read these
+            if _SIDE["stream"] is not None:
+                torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+            _KEEP.clear()
         _SIDE["on"] = bool(getattr(model, "overlap_weight_gradients", True))
         if _SIDE["on"] and (_SIDE["stream"] is None or _SIDE["stream"].device != dpred.device):
             _SIDE["stream"] = torch.cuda.Stream(device=dpred.device)

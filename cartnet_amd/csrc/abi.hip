@@ -12,7 +12,7 @@ void cartnet_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cartnet_last_error(void) { return g_err; }
-extern "C" int cartnet_abi_version(void) { return 6; }
+extern "C" int cartnet_abi_version(void) { return 7; }
 
 // sizeof of the structs that cross the ABI, in the order of the header: a binding in another language (ctypes here)
 // compares them with its own mirrors at load time instead of finding a layout mismatch as a GPU fault.
@@ -20,7 +20,7 @@ extern "C" int cartnet_abi_struct_sizes(size_t* out, int32_t capacity) {
   const size_t sizes[] = {sizeof(CartnetGemmArgs), sizeof(CartnetShard),       sizeof(CartnetCollated),
                           sizeof(CartnetGemmProfile), sizeof(CartnetGroups),   sizeof(CartnetLayerParams),
                           sizeof(CartnetLayerBuffers), sizeof(CartnetParams),  sizeof(CartnetModel),
-                          sizeof(CartnetBatch)};
+                          sizeof(CartnetBatch),        sizeof(CartnetGateGemmArgs)};
   const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
   for (int i = 0; i < n && i < capacity; ++i) out[i] = sizes[i];
   return n;

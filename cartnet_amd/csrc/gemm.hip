@@ -10,24 +10,20 @@ thread_local bool g_half_launched = false;
 // per CU), or the 128-wide one (gemm_f32w128.h, three per CU) for the launches with the node-term gather epilogue (layer
 // GEMM 1) -- the one variant where a third resident workgroup pays: 402 vs 425 us sustained at the benchmark shape, the
 // training step 15.40 vs 15.57 ms (same box, interleaved).  Every other variant is equal or slower on the narrow tile
-// (SiLU on the A operand: -15 %, its prologue runs once per column tile).  CARTNET_F32NN_BN=256 / =128 force one kernel.
-int g_tile_policy = 0;     // cartnet_gemm_tile_policy
+// (SiLU on the A operand: -15 %, its prologue runs once per column tile).
 bool use_f32nn128(const CartnetGemmArgs& a) {
-  static const int mode = [] { const char* e = getenv("CARTNET_F32NN_BN"); return e ? atoi(e) : 0; }();
-  if (mode == 128) return true;
-  if (mode == 256) return false;
+  if (a.tile_policy == 128) return true;
+  if (a.tile_policy == 256) return false;
   if (a.gather_i[0] != nullptr && !a.a_act) return true;
   // One 256-wide column tile per row tile, one group, one K-segment (iComformer's edge-sized C x C products): 1,384 row
   // tiles are 2.7 rounds of the 256-wide kernel's 512 resident workgroups but 3.6 of the 128-wide one's 768, whose third
   // workgroup per CU also keeps two main loops overlapping -- isolated 365 -> 346 us, the iComformer step 36.72 -> 36.52
   // ms (same-box A B A B, end of round 3).  CartNet's dE products (two folded K-segments) were faster alone too (370.6 ->
   // 362.5 us) but the training step, where they run next to the weight-gradient products, was not (14.86 -> 14.92 ms):
-  // they stay on the wide kernel.  CARTNET_N256_WIDE=1 keeps the 256-wide kernel for all.
-  // Grouped launches of that shape too when the caller asked for it (cartnet_gemm_tile_policy(1): the iComformer host
-  // path, whose step gains another 1.8 %, 36.39 -> 35.74 ms; CartNet's two-group layer products do not, so
-  // cartnet_model_forward / _backward reset the policy to 0).
-  static const bool n256_wide = [] { const char* e = getenv("CARTNET_N256_WIDE"); return e && atoi(e) != 0; }();
-  if (!n256_wide && a.N == 256 && (a.ngroups == 1 || g_tile_policy == 1) && a.nsegs == 1 && !a.a_act) return true;
+  // they stay on the wide kernel.  Grouped launches of that shape too when the caller asks for it per call
+  // (CartnetGemmArgs.tile_policy = 1: the iComformer path, whose step gains another 1.8 %, 36.39 -> 35.74 ms; CartNet's
+  // two-group layer products do not).
+  if (a.N == 256 && (a.ngroups == 1 || a.tile_policy == 1) && a.nsegs == 1 && !a.a_act) return true;
   // few row tiles (atom-sized M): 128-wide tiles put twice as many workgroups on the chip (the folded dX product of the
   // node terms, M = 12,416, K = 1024: 97 tiles of 128 x 256 would use 97 of 256 CUs)
   const long long tiles = (long long)((a.M + 127) / 128) * (a.N / 256) * a.ngroups;
@@ -231,12 +227,6 @@ std::vector<GemmRecord> g_prof;
 
 static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream);
 
-extern "C" int cartnet_gemm_tile_policy(int32_t policy) {
-  CN_CHECK(policy == 0 || policy == 1, "cartnet_gemm_tile_policy: policy must be 0 or 1 (got %d)", policy);
-  cn_gemm::g_tile_policy = policy;
-  return 0;
-}
-
 extern "C" int cartnet_profile_gemm(int32_t enable) {
   if (enable && !g_prof_on) {
     for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -342,6 +332,9 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
   fl.wide = epilogue_rows_aligned(a) ? 1 : 0;
   CN_CHECK(a.precision >= 0 && a.precision <= 2, "cartnet_gemm: precision=%d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = bf16)",
            a.precision);
+  CN_CHECK(a.tile_policy == 0 || a.tile_policy == 1 || a.tile_policy == 128 || a.tile_policy == 256,
+           "cartnet_gemm: tile_policy=%d (0 = automatic, 1 = narrow tiles for grouped N = 256 products too, 128 / 256 = force)",
+           a.tile_policy);
   // Few row tiles (atom-sized M, small batches): 128 x 256 tiles would leave most of the 256 CUs idle and the launch
   // would last one tile's latency (16+ K-steps of a full tile); narrower column tiles (the general kernel's 128- and
   // 64-wide forms, exact fp32) spread the same work over 2-4x as many workgroups.  Not at precision 2 (the bf16 kernels

@@ -927,8 +927,8 @@ bool use_f32nnq(const CartnetGemmArgs& a);
 #endif
 // gemm_f32ao.hip: the a_act form of the 256-wide kernel that also writes silu(A) (CartnetGemmArgs.a_act_out)
 void launch_f32nn_actout(const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
-// gemm_x3s.hip: the bf16x3 activation x weight kernel on the 16x16x32 MFMA shape (the default at precision 1;
-// CARTNET_X3_SHAPE=32 keeps the 32x32x16 kernel of gemm_x3.h)
+// gemm_x3s.hip: the bf16x3 activation x weight kernel on the 16x16x32 MFMA shape (precision 1; the 32x32x16 kernel of
+// gemm_x3.h serves precision 2, one MFMA product per block)
 void launch_x3nn16(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
 // gemm_x3ao.hip: the same for the pre-split bf16x3 / bf16 kernel
 void launch_x3nn_actout(const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);

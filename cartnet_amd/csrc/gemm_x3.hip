@@ -5,18 +5,12 @@ namespace cn_gemm {
 
 void launch_x3nn(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st) {
   const bool one = fl.x3 == 2;   // precision 2: plain bf16 operands, one MFMA product
-  static const bool shape16 = [] { const char* e = getenv("CARTNET_X3_SHAPE"); return !e || atoi(e) != 32; }();
-  if (!one && shape16) {
+  if (!one) {      // precision 1: the six piece products on the 16x16x32 MFMA shape (gemm_x3s.h; round 3: -1...-4 % per launch)
     launch_x3nn16(a_act, a, fl, grid, st);
     return;
   }
-  if (a_act) {
-    if (one) hipLaunchKernelGGL((cn_gemm_x3nn_kernel<true, true>), grid, dim3(NTHREADS), 0, st, a, fl);
-    else hipLaunchKernelGGL((cn_gemm_x3nn_kernel<true, false>), grid, dim3(NTHREADS), 0, st, a, fl);
-  } else {
-    if (one) hipLaunchKernelGGL((cn_gemm_x3nn_kernel<false, true>), grid, dim3(NTHREADS), 0, st, a, fl);
-    else hipLaunchKernelGGL((cn_gemm_x3nn_kernel<false, false>), grid, dim3(NTHREADS), 0, st, a, fl);
-  }
+  if (a_act) hipLaunchKernelGGL((cn_gemm_x3nn_kernel<true, true>), grid, dim3(NTHREADS), 0, st, a, fl);
+  else hipLaunchKernelGGL((cn_gemm_x3nn_kernel<false, true>), grid, dim3(NTHREADS), 0, st, a, fl);
 }
 
 void launch_x3tn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st) {

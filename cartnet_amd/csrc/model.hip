@@ -156,10 +156,8 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
   // weight gradients dW2 = dY^T silu(pre) read a plain operand and run on the all-DMA kernel (step 15.26 vs 15.43 ms,
   // same box, interleaved).  Not at precision 1 / 2: there the step got SLOWER (11.74 vs 11.56 ms) -- the bf16 step is
   // power- and HBM-limited and 1.8 GB of extra writes cost more than the cheaper weight-gradient kernel returns.
-  // CARTNET_ACT_OUT=0: off.
-  static const bool act_out_on = [] { const char* e = getenv("CARTNET_ACT_OUT"); return !e || atoi(e) != 0; }();
-  static const bool act_out_x3 = [] { const char* e = getenv("CARTNET_ACT_OUT_X3"); return e && atoi(e) != 0; }();   // A/B switch
-  if (need_bwd && act_out_on && (m.gemm_precision == 0 || (act_out_x3 && m.gemm_precision == 1)) && D % 256 == 0) {
+  // (Re-measured at bf16x3 in round 3: 11.04-11.09 vs 10.87-10.96 ms, slower again.)
+  if (need_bwd && m.gemm_precision == 0 && D % 256 == 0) {
     for (int l = 0; l < L; ++l) w.act[l] = c.take<float>(En * 2 * D);
     w.he_act = c.take<float>(En * 2 * D);
   }
@@ -422,7 +420,6 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
                                      float* x_out, float* e_out, int32_t* status, void* st, void* aux_stream) {
   RUN(check_model(model, batch, "cartnet_model_forward"));
   g_precision = model->gemm_precision;
-  (void)cartnet_gemm_tile_policy(0);      // CartNet's grouped layer products stay on the 256-wide kernel (gemm.hip)
   const CartnetModel& m = *model;
   const CartnetBatch& b = *batch;
   const CartnetParams& P = m.p;
@@ -442,8 +439,6 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
   // next to the layout build and the edge encoder; the main stream waits for them where it needs them and the two
   // streams are joined before the call returns.
   g_events.next = 0;
-  static const bool fwd_aux_on = [] { const char* e = getenv("CARTNET_FWD_AUX"); return !e || atoi(e) != 0; }();   // A/B switch
-  if (!fwd_aux_on) aux_stream = nullptr;
   Streams S{(hipStream_t)st, aux_stream ? (hipStream_t)aux_stream : (hipStream_t)st, aux_stream != nullptr && aux_stream != st};
   void* sw = (void*)S.side;
 #define FORK() do { if (S.fork() != 0) { cartnet_set_error("cartnet_model_forward: stream fork failed"); return 2; } } while (0)
@@ -630,9 +625,8 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     }
     // Inference (eval-mode BatchNorm, nothing kept for backward, fp32 MFMA): the second Linears, the gate, the per-target
     // sums and the edge residual are ONE kernel -- gs never reaches memory (csrc/gemm_f32gate.hip)
-    static const bool eval_fuse_on = [] { const char* e_ = getenv("CARTNET_EVAL_FUSE"); return !e_ || atoi(e_) != 0; }();
     // (BatchNorm groups change nothing in eval mode -- every group's row of mean_rstd holds the running statistics)
-    if (eval_fuse_on && !training && !need_backward && m.gemm_precision == 0 && !half && D % 256 == 0 && w.i_gs[l] &&
+    if (!training && !need_backward && m.gemm_precision == 0 && !half && D % 256 == 0 && w.i_gs[l] &&
         w.gate_bnd && E > 0) {
       RUN(bn_stats(w.cs, w.cq, w.tiles_e, b.E, m.buf[l].norm_mean, m.buf[l].norm_var, m.buf[l].norm_nbt, w.mr1[l], 1));
       CartnetGateGemmArgs ga;
@@ -700,7 +694,6 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
                                       const CartnetParams* grads, void* stream, void* aux_stream) {
   RUN(check_model(model, batch, "cartnet_model_backward"));
   g_precision = model->gemm_precision;
-  (void)cartnet_gemm_tile_policy(0);      // CartNet's grouped layer products stay on the 256-wide kernel (gemm.hip)
   const CartnetModel& m = *model;
   const CartnetBatch& b = *batch;
   const CartnetParams& P = m.p;
@@ -764,8 +757,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
   float* dx_other = w.dx[1];
   float* de = nullptr;   // the head does not read the edge features
   int de_slot = 0;
-  static const int pairs_env = [] { const char* e = getenv("CARTNET_BWD_PAIRS"); return e ? atoi(e) : -1; }();
-  const bool pairs = pairs_env >= 0 ? pairs_env != 0 : m.gemm_precision >= 1;
+  const bool pairs = m.gemm_precision >= 1;
   hipEvent_t side_done[CARTNET_MAX_LAYERS + 2];
   for (int i = 0; i < CARTNET_MAX_LAYERS + 2; ++i) side_done[i] = nullptr;
 
@@ -987,9 +979,6 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     // (the split-K slabs of this product must not be the ones the weight-gradient stream is using: w.slabs2)
     Work w2 = w;
     w2.slabs = w.slabs2;
-    static const bool dw0_main = [] { const char* e = getenv("CARTNET_DW0_MAIN"); return !e || atoi(e) != 0; }();   // A/B switch
-    void* st0 = st;
-    if (!dw0_main) { FORK(); st = sw; }
     if (m.gemm_precision >= 1 && w.i_edge0) {
       // bf16 kernels want 256-wide column tiles: compute the transpose, featT . dhe = dW0^T [ldf, 2D] (rows kf.. are the
       // zero pad columns of feat), and write its first kf rows transposed into the gradient
@@ -1004,7 +993,6 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     } else {
       RUN(wgrad(dY2, 2 * D, X2, w.ldf, o2, w.kf, b.E, 2 * D, w.kf, 1, false, w2, st));
     }
-    st = st0;
   }
   if (plain) {   // every atom read the same learned row: its gradient is the column sum of dx over the atoms
     double* parts[1] = {w.pa};

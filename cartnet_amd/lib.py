@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CARTNET_LIB (tools only): a diagnostic / A-B build of the same ABI next to the product library (tools/build_variant.sh)
 LIB_PATH = os.environ.get("CARTNET_LIB") or os.path.join(_HERE, "libcartnet_hip.so")
 MAX_GROUPS = 4
+ABI_VERSION = 7          # cartnet_abi_version() of the library this binding mirrors (include/cartnet_hip.h)
 
 _lib: Optional[C.CDLL] = None
 
@@ -52,6 +53,7 @@ class GemmArgs(C.Structure):
         ("b_split", C.c_void_p * MAX_GROUPS), ("b_split_folded", C.c_void_p),
         ("a_act_out", C.c_void_p * MAX_GROUPS),
         ("a_half", C.c_int32), ("b_half", C.c_int32), ("c_half", C.c_int32), ("dact_half", C.c_int32),
+        ("tile_policy", C.c_int32),
     ]
 
 
@@ -245,7 +247,6 @@ PROTOTYPES = {
                                              c_stream]),
     "cartnet_neighbor_cap_fill": (C.c_int, [c_i64p, c_i64p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, C.c_int32,
                                             C.c_int64, C.c_int64, c_i64p, c_f32p, c_f32p, c_stream]),
-    "cartnet_gemm_tile_policy": (C.c_int, [C.c_int32]),
     "cartnet_loss_nparts": (C.c_int32, [C.c_int64]),
     "cartnet_loss_fwd": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_void_p, c_f32p, c_stream]),
     "cartnet_loss_bwd": (C.c_int, [c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_stream]),
@@ -284,7 +285,11 @@ def load() -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     # the ctypes mirrors above must have the C layouts: a mismatch would otherwise show up as a device fault
-    mirrors = [GemmArgs, Shard, Collated, GemmProfile, Groups, LayerParams, LayerBuffers, Params, Model, BatchDesc]
+    if lib.cartnet_abi_version() != ABI_VERSION:
+        raise CartnetHipError(f"{LIB_PATH}: ABI version {lib.cartnet_abi_version()}, this binding is written for "
+                              f"{ABI_VERSION} -- rebuild the library (python -m cartnet_amd.build)")
+    mirrors = [GemmArgs, Shard, Collated, GemmProfile, Groups, LayerParams, LayerBuffers, Params, Model, BatchDesc,
+               GateGemmArgs]
     sizes = (C.c_size_t * 16)()
     n = lib.cartnet_abi_struct_sizes(sizes, 16)
     if n != len(mirrors):

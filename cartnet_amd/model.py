@@ -331,12 +331,14 @@ class CartNet(nn.Module):
                int(self.gemm_precision), int(self.bn_group_size), bool(self.half_storage),
                tuple(bool(l.use_envelope) for l in self.layers), float(self.layers[0].envelope_radius))
         cached = self.__dict__.get("_md_cache")
-        if cached is not None and cached[0] == key:
-            cached[1].bn_allreduce = _l.ALLREDUCE_FN()         # per-call field: reset to NULL
-            cached[1].bn_allreduce_user = None
-            return cached[1]
-        md = self._model_desc_build(P)
-        self.__dict__["_md_cache"] = (key, md)
+        if cached is None or cached[0] != key:
+            cached = (key, self._model_desc_build(P))
+            self.__dict__["_md_cache"] = cached
+        # the cache is a TEMPLATE: every forward gets its own copy, which ctx.saved then owns -- the per-call fields
+        # (bn_allreduce: bound to THIS call's workspace, NULL for an eval forward) must not change under a backward
+        # that is still to run (two training forwards, then two backwards; an eval forward in between)
+        md = _l.Model()
+        C.memmove(C.byref(md), C.byref(cached[1]), C.sizeof(md))
         return md
 
     def _model_desc_build(self, P: Dict[str, torch.Tensor]) -> "_l.Model":

@@ -77,7 +77,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
          a_kstrided: bool = False, b_kstrided: bool = False, a_act: bool = False, b_act: bool = False,
          out_act: bool = False, segments: bool = False, bias=None, gather_i=None, gather_j=None, tgt=None, src=None,
          resid=None, dact=None, cpre=None, colsum=None, colsq=None, splitk: int = 1, precision: int = 0,
-         b_split=None, b_split_folded=None, a_act_out=None) -> None:
+         b_split=None, b_split_folded=None, a_act_out=None, tile_policy: int = 0) -> None:
     """C[g] = epilogue(sum_s opA(A[s]) @ opB(B[s])) on the fp32 matrix cores (see include/cartnet_hip.h).
 
     A / B / C_out: one tensor or a list.  With ``segments=False`` the lists are independent problems (groups) of
@@ -85,6 +85,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
     Shapes: A [M,K] (or [K,M] if a_kstrided), B [N,K] (or [K,N] if b_kstrided), C [M,N]
     (for splitk > 1: C is [splitk*M, N] contiguous slabs).
     ``a_act_out`` (with ``a_act`` and ``b_split`` at precision 0): tensors shaped and strided like A that receive silu(A).
+    ``tile_policy``: CartnetGemmArgs.tile_policy (0 automatic; 1 narrow tiles for grouped N = 256 products too; 128 / 256 force).
     """
     lib = _l.load()
     A, B, C_out = _aslist(A, 1), _aslist(B, 1), _aslist(C_out, 1)
@@ -128,6 +129,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
     args.a_kstrided, args.b_kstrided = int(a_kstrided), int(b_kstrided)
     args.a_act, args.b_act, args.out_act = int(a_act), int(b_act), int(out_act)
     args.precision = int(precision)
+    args.tile_policy = int(tile_policy)
     args.a_half, args.b_half, args.c_half = int(is_half(A, "A")), int(is_half(B, "B")), int(is_half(C_out, "C"))
     for i in range(nptr):
         args.A[i] = A[i].data_ptr()

@@ -8,7 +8,13 @@
  *     row-major with an explicit leading dimension in elements; indices are int32 on the device
  *     (cartnet_csr_build converts the int64 edge_index of the PyG API once per batch);
  *   - `stream` is a hipStream_t passed as void*; kernels are only enqueued, no host synchronisation, no
- *     allocation, no global state -> safe to capture in a hipGraph;
+ *     allocation -> safe to capture in a hipGraph;
+ *   - state: the library reads NO environment variable and keeps no tunable global.  Every choice a caller can make
+ *     is a field of CartnetGemmArgs / CartnetModel.  What it does keep is per THREAD: the message behind
+ *     cartnet_last_error(), and, inside cartnet_model_forward / _backward, a pool of hipEvent_t (created once per
+ *     thread, disable-timing, reused by every call of that thread to order its two streams) -- so two host threads
+ *     may drive two models concurrently, one thread must not interleave two calls.  The one process-global is the
+ *     opt-in launch timer (cartnet_profile_gemm*), off unless bench.py switches it on;
  *   - return value 0 = ok, non-zero = error; cartnet_last_error() returns a thread-local message.
  *   - shapes are validated on the host before launch (a bad shape returns an error, it never launches).
  */
@@ -27,8 +33,10 @@ extern "C" {
 const char* cartnet_last_error(void);
 int cartnet_abi_version(void);
 /* sizeof of every struct below, in header order (CartnetGemmArgs, CartnetShard, CartnetCollated, CartnetGemmProfile,
- * CartnetGroups, CartnetLayerParams, CartnetLayerBuffers, CartnetParams, CartnetModel, CartnetBatch); returns the
- * number of structs.  A binding checks its mirrors against these when it loads the library. */
+ * CartnetGroups, CartnetLayerParams, CartnetLayerBuffers, CartnetParams, CartnetModel, CartnetBatch,
+ * CartnetGateGemmArgs); returns the number of structs.  A binding checks its mirrors against these when it loads the
+ * library, and cartnet_abi_version() against the version it was written for (7: tile_policy in CartnetGemmArgs,
+ * aux_stream in cartnet_model_forward, CartnetGateGemmArgs in the size table; cartnet_gemm_tile_policy() is gone). */
 int cartnet_abi_struct_sizes(size_t* out, int32_t capacity);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -104,6 +112,11 @@ typedef struct CartnetGemmArgs {
                           stay in ELEMENTS).  Honoured by the half-storage kernels (csrc/gemm_h.h): activation x weight
                           products with a pre-split weight image (b_split) and weight gradients (both operands
                           k-strided); every other launch with one of these flags set is refused. */
+  int32_t tile_policy; /* column-tile width of the DMA-fed fp32 activation x weight kernels (precision 0, b_split given).
+                          0: the library's choice per launch (128 x 256 tiles on two workgroups per CU; 128 x 128 on three
+                          for the node-term gather epilogue, for single-group N = 256 products and for launches with few
+                          tiles).  1: grouped N = 256 products take the narrow tile too (the iComformer path: -1.8 % per
+                          step; CartNet's two-group layer products lose).  128 / 256: force one kernel (A/B runs). */
 } CartnetGemmArgs;
 
 int cartnet_gemm(const CartnetGemmArgs* args, void* stream);
@@ -298,7 +311,8 @@ int cartnet_collate(const CartnetShard* shard, const int64_t* sel, const int64_t
                     const int64_t* out_edge_ptr, const int64_t* out_y_ptr, int32_t B, int64_t N, int64_t E, int64_t M,
                     const float* rot, float temp_mean, float temp_std, const CartnetCollated* out, void* stream);
 
-/* Opt-in timing of cartnet_gemm launches (the only process-global state in the library; used by bench.py):
+/* Opt-in timing of cartnet_gemm launches (the only PROCESS-global state in the library; used by bench.py, off by default
+ * and not for concurrent use from several threads):
  * while enabled, every cartnet_gemm call -- also those issued inside cartnet_model_forward/backward -- is bracketed
  * by HIP events on its launch stream.  cartnet_profile_gemm_read waits for the events and returns per-variant totals
  * (variant: bit0 a_kstrided, bit1 b_kstrided, bit2 a_act, bit3 b_act, bits 4.. = tile width / 64). */
@@ -308,11 +322,6 @@ typedef struct CartnetGemmProfile {
   double flops;      /* executed: sum of 2*M*N*K*(groups or segments) */
   double ms;
 } CartnetGemmProfile;
-/* Tile-width policy of the fp32 activation x weight products with one 256-wide column tile per row tile (N = 256):
- * 0 (default; cartnet_model_forward / _backward set it on entry) = single-group launches of that shape go to the
- * 128-wide kernel, grouped ones stay on the 256-wide one; 1 = grouped ones too (the iComformer host path sets it:
- * its step is 1.8 % shorter, CartNet's is not).  Process-wide; not for concurrent use from several threads. */
-int cartnet_gemm_tile_policy(int32_t policy);
 int cartnet_profile_gemm(int32_t enable);
 /* Restrict the timing to launches of one variant (the value CartnetGemmProfile.variant reports; < 0: all variants):
  * bench.py prices every variant during its warm-up steps and only the dominant one inside the timed region, so the

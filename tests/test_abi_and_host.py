@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(cdll, name), f"{name} is declared in include/cartnet_hip.h but not exported"
     # the ctypes prototypes cover exactly the declared set
     assert sorted(lib.PROTOTYPES) == declared
-    assert lib.load().cartnet_abi_version() == 6
+    assert lib.load().cartnet_abi_version() == 7 == lib.ABI_VERSION
 
 
 def test_ctypes_mirrors_have_the_c_struct_layouts():
@@ -38,10 +38,10 @@ def test_ctypes_mirrors_have_the_c_struct_layouts():
     sizes = (ctypes.c_size_t * 16)()
     n = l.cartnet_abi_struct_sizes(sizes, 16)
     mirrors = [lib.GemmArgs, lib.Shard, lib.Collated, lib.GemmProfile, lib.Groups, lib.LayerParams, lib.LayerBuffers,
-               lib.Params, lib.Model, lib.BatchDesc]
+               lib.Params, lib.Model, lib.BatchDesc, lib.GateGemmArgs]
     assert n == len(mirrors)
     assert [ctypes.sizeof(m) for m in mirrors] == list(sizes[:n])
-    assert lib.GemmArgs.dact_half.offset + 4 == ctypes.sizeof(lib.GemmArgs)                         # last field
+    assert lib.GemmArgs.tile_policy.offset + 8 == ctypes.sizeof(lib.GemmArgs)                       # last field + tail padding
     assert lib.Model.half_storage.offset + 8 == ctypes.sizeof(lib.Model)                             # last field + tail padding
 
 

@@ -1,7 +1,9 @@
 #!/bin/bash
 # Same-binary A/B on ONE GPU box: the training step with and without an environment switch (boxes of the pool differ by
 # +-2 %, more than most kernel changes are worth).  usage: bash tools/ab_env.sh VAR [VALUE]   ->  A = VAR unset, B = VAR=VALUE (default 1)
-VAR=${1:-CARTNET_ACT_OUT}
+# (The C library reads no environment variable since round 4: this serves Python-side switches such as CARTNET_FUSED_LOSS;
+#  library variants are compared with tools/build_variant.sh + tools/ab_lib.sh.)
+VAR=${1:-CARTNET_FUSED_LOSS}
 VAL=${2:-1}
 for v in A B A B; do
   if [ $v = B ]; then export $VAR=$VAL; else unset $VAR; fi

@@ -48,6 +48,6 @@ cases = {
     "atom encoder backward (N=512), image": lambda: ops.gemm(out, Wb, out2, b_kstrided=True, dact=x, b_split=img_b),
     "atom encoder backward (N=512), no image": lambda: ops.gemm(out, Wb, out2, b_kstrided=True, dact=x),
 }
-print("CARTNET_F32NN_BN =", os.environ.get("CARTNET_F32NN_BN"), " CARTNET_Q =", os.environ.get("CARTNET_Q"))
+print("CARTNET_Q =", os.environ.get("CARTNET_Q"), "(experimental builds only)")
 for name, fn in cases.items():
     print(f"  {name:52s} {sustained(fn):7.1f} us")
