@@ -22,6 +22,12 @@ Extra objects on the line:
                 stretch and at its end -- so a slow box can be told from a slow build
   calibration   the box's own ceiling for the GEMM kernel: 50 back-to-back launches of the plain two-group layer product
                 (E rows, K = N = 256) on cn_gemm_f32nn_kernel, alone on the chip, as TFLOP/s and fraction of 157.3
+  jarvis_bf16   BASELINE configs[2] (scripts/train_cartnet_jarvis.sh shapes: batch 64, Scalar_head, no temperature; 64
+                crystals of 2-20 atoms), bf16 operands + bf16 storage: >= 20 timed steps after warm-up
+  icomformer    BASELINE configs[4] (models/comformer.py:115-132, D = 256) on the headline's 64 x 194-atom batch, fp32
+  ragged        the headline model on a ragged batch (64 crystals of 64-324 atoms), fp32
+                (the three carry ms_per_step, host_enqueue_ms_per_step, whole_step_frac and telemetry like the headline)
+``--no-telemetry`` starts no sampler thread (tools and profiler runs); every pass samples at the same period.
 """
 from __future__ import annotations
 
@@ -116,6 +122,52 @@ def cpu_baseline(seconds_budget: float = 12.0, which: str = "cartnet"):
                       f"step on 1 thread"}
 
 
+def _csrc_digest() -> str:
+    """sha256 over the kernel sources: profiles/traffic.json records the digest of the build its PMC passes measured, so
+    the bench line can say whether the constant it quotes belongs to THIS build (there is no .git on the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cartnet_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode())
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def timed_pass(step, fresh, warm: int, steps: int, graphs: int, sampler_factory, peak_tflops: float, ops, world: int = 1):
+    """Warm-up, one extra step with the GEMM launch timer on (FLOPs per step), then `steps` timed steps bracketed by
+    synchronises: {ms_per_step, host_enqueue_ms_per_step, value, whole_step_frac, telemetry}."""
+    bs = [fresh() for _ in range(warm + 1 + steps)]
+    for b in bs[:warm]:
+        step(b)
+    torch.cuda.synchronize()
+    ops.profile_gemm(True)
+    step(bs[warm])
+    torch.cuda.synchronize()
+    ops.profile_gemm(False)
+    gflop = sum(v["flops"] for v in ops.profile_gemm_read().values())
+    sampler = sampler_factory()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in bs[warm + 1:]:
+        loss = step(b)
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tel = sampler.stop() if sampler is not None else None
+    if not torch.isfinite(loss):
+        return None
+    out = {"value": round(graphs * world * steps / dt, 2), "unit": "graphs/s", "steps": steps, "warmup": warm,
+           "ms_per_step": round(1e3 * dt / steps, 3), "host_enqueue_ms_per_step": round(1e3 * t_enq / steps, 3),
+           "gemm_flops_per_step": int(gflop),
+           "whole_step_frac": round(gflop / (dt / steps) / 1e12 / peak_tflops, 4), "peak_tflops": peak_tflops}
+    if tel is not None:
+        out["telemetry_during"] = tel
+    return out
+
+
 def self_launch(args) -> int:
     """``python bench.py --gpus N`` without an outer launcher: start the N ranks as a CHILD torch.distributed.run (never
     an exec, and before this process has made any GPU call), pass the child's output through and return its exit code."""
@@ -159,6 +211,11 @@ def main():
     ap.add_argument("--no-calibration", action="store_true", help="skip the isolated plain-GEMM calibration launches")
     ap.add_argument("--sustain-seconds", type=float, default=6.0,
                     help="length of the sustained stretch after the timed region (0 disables; N = 1 only)")
+    ap.add_argument("--no-telemetry", action="store_true",
+                    help="no sysfs sampler thread during any pass (the before / after snapshots stay)")
+    ap.add_argument("--no-subconfigs", action="store_true",
+                    help="skip the jarvis_bf16 / icomformer / ragged passes (BASELINE configs[2], [4] and the ragged batch)")
+    ap.add_argument("--sub-steps", type=int, default=20, help="timed steps of each of those passes (after 5 warm-up steps)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -209,14 +266,23 @@ def main():
 
     from cartnet_amd.train import grouped_loss, compute_loss
 
+    # more than one rank (or CARTNET_DIST_FORCE): the gradient all-reduce goes out in buckets under backward (GradSync)
+    gsync = cdist.GradSync(opt.flat_grad, measure=True) if (cdist._active() and not icf) else None
+
     def step(b):
         pred, true = model(b)
         if args.bn_group_size > 0:
             loss = grouped_loss(pred, true, b, args.bn_group_size)[0]
         else:
             loss = compute_loss(pred, true)[0]          # MAE (cfg.loss default), train/metrics.py:26
-        loss.backward()
-        scale = cdist.all_reduce_gradients(opt.flat_grad)
+        if gsync is not None:
+            model.grad_sync = gsync
+            loss.backward()
+            model.grad_sync = None
+            scale = gsync.finish()
+        else:
+            loss.backward()
+            scale = cdist.all_reduce_gradients(opt.flat_grad)
         opt.step(scale)
         opt.zero_grad()
         return loss
@@ -244,10 +310,13 @@ def main():
             only = warm_summary[max(warm_summary, key=lambda k: warm_summary[k]["ms"])]["variant"]
     from cartnet_amd import telemetry as tele
     telemetry = {"before_timed": tele.compact(tele.read(local))} if rank == 0 else None
+
+    def new_sampler():          # one period for every pass; None with --no-telemetry or off rank 0
+        return tele.Sampler(local).start() if (rank == 0 and not args.no_telemetry) else None
     cdist.barrier()
     torch.cuda.synchronize()
     ops.profile_gemm(timer, only=only)
-    sampler = tele.Sampler(local).start() if rank == 0 else None
+    sampler = new_sampler()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(batches[args.warmup + i])
@@ -273,7 +342,7 @@ def main():
         n_win = max(1, int(args.sustain_seconds / (est * win) + 0.999))
         pool = [fresh() for _ in range(4)]
         ms = []
-        sampler = tele.Sampler(local).start() if rank == 0 else None
+        sampler = new_sampler()
         cdist.barrier()
         torch.cuda.synchronize()
         ts0 = time.perf_counter()
@@ -289,6 +358,7 @@ def main():
             ms.append(1e3 * (time.perf_counter() - tw) / win)
         if sampler is not None:
             telemetry["during_sustained"] = sampler.stop()
+        if telemetry is not None:
             telemetry["sustained_end"] = tele.compact(tele.read(local))
         cdist.barrier()
         tot = cdist.max_over_ranks(time.perf_counter() - ts0, dev)
@@ -333,7 +403,7 @@ def main():
             cal()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        sampler = tele.Sampler(local, period=0.005).start() if rank == 0 else None
+        sampler = new_sampler()
         ev0.record()
         for _ in range(50):
             cal()
@@ -361,7 +431,7 @@ def main():
             step(bx)
         cdist.barrier()
         torch.cuda.synchronize()
-        sampler3 = tele.Sampler(local, period=0.005).start() if rank == 0 else None
+        sampler3 = new_sampler()
         t1 = time.perf_counter()
         for bx in extra[2:]:
             loss3 = step(bx)
@@ -478,6 +548,69 @@ def main():
             eval_fwd["bf16x3_value"] = round(args.graphs * args.steps / dte3, 2)
         model.train()
 
+    # BASELINE configs[2] / configs[4] and the ragged batch, driver-timed: compact sub-objects with the
+    # same bracketing as the headline (warm-up, then >= 20 steps between two synchronises), single rank only
+    sub_cfg = {}
+    if world == 1 and not args.no_subconfigs and not icf and args.precision == 0 and args.bn_group_size == 0:
+        from cartnet_amd.data import Batch
+        from cartnet_amd.synthetic import make_crystal, make_batch
+
+        def clone_of(b0):
+            def f():
+                b = b0.clone()
+                b.num_graphs = b0.num_graphs
+                b._cartnet_layout = None
+                b._cartnet_mask_index = None
+                return b
+            return f
+
+        def train_step_of(mdl, optim):
+            def f(b):
+                pred, true = mdl(b)
+                loss = compute_loss(pred, true)[0]
+                loss.backward()
+                optim.step(cdist.all_reduce_gradients(optim.flat_grad))
+                optim.zero_grad()
+                return loss
+            return f
+        # (i) configs[2]: scripts/train_cartnet_jarvis.sh:5-6 -- batch 64, accumulation 1, Scalar_head (models/cartnet.py:
+        # 323-327), no temperature (main.py:183); the reference does not state graph sizes: 2-20 atoms
+        gen = torch.Generator().manual_seed(7)
+        sizes = torch.randint(2, 21, (64,), generator=gen).tolist()
+        jb = Batch.from_data_list([make_crystal(5000 + i, n, adp=False) for i, n in enumerate(sizes)]).to(dev)
+        jm = CartNet(256, 64, 4, temperature=False, cholesky=False).to(dev).train()
+        jm.gemm_precision, jm.half_storage = 2, True
+        jopt = FlatAdam(jm, lr=1e-3)
+        r = timed_pass(train_step_of(jm, jopt), clone_of(jb), 5, args.sub_steps, 64, new_sampler, 2500.0, ops)
+        if r is not None:
+            r.update({"workload": f"BASELINE configs[2]: CartNet L=4 D=256 Scalar_head, no temperature, 64 crystals of 2-20 "
+                                  f"atoms per step (N={int(jb.x.shape[0])}, E={int(jb.edge_index.shape[1])}), bf16 MFMA "
+                                  "operands, bf16 storage of pre / gs / dpre, fp32 accumulate", "dtype": "bf16"})
+            sub_cfg["jarvis_bf16"] = r
+        del jm, jopt, jb
+        # (ii) configs[4]: iComformer (models/comformer.py:115-132) on the headline's batch, fp32 MFMA
+        from cartnet_amd.comformer import iComformer
+        im = iComformer(256).to(dev).train()
+        im.gemm_precision = 0
+        iopt = FlatAdam(im, lr=1e-3)
+        r = timed_pass(train_step_of(im, iopt), fresh, 5, args.sub_steps, args.graphs, new_sampler,
+                       PEAK_FP32_MFMA_TFLOPS, ops)
+        if r is not None:
+            r.update({"workload": f"BASELINE configs[4]: iComformer D=256 (4 attention layers + edge-update layer, Cholesky "
+                                  f"head) fp32 train step on the headline's batch (N={N}, E={E})", "dtype": "f32"})
+            sub_cfg["icomformer"] = r
+        del im, iopt
+        torch.cuda.empty_cache()
+        # (iii) the headline model on a ragged batch: crystals of 64-324 atoms (uniform, mean 194)
+        rb = make_batch(args.graphs, None, first=300_000).to(dev)
+        r = timed_pass(step, clone_of(rb), 3, args.sub_steps, args.graphs, new_sampler, PEAK_FP32_MFMA_TFLOPS, ops)
+        if r is not None:
+            r.update({"workload": f"headline model and step on {args.graphs} crystals of 64-324 atoms "
+                                  f"(N={int(rb.x.shape[0])}, E={int(rb.edge_index.shape[1])})", "dtype": "f32"})
+            sub_cfg["ragged"] = r
+        del rb
+        torch.cuda.empty_cache()
+
     graphs_total = args.graphs * world * args.steps
     value = graphs_total / dt
     out = {
@@ -509,9 +642,10 @@ def main():
     # formulation (68 MB per 2800-edge crystal, fwd+bwd, perfect fusion) and the bytes the PMC passes
     # counted for one step of this build (profiles/traffic.json), both over the measured step time, against 8 TB/s
     try:
-        per_step = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("per_step", {})
+        tjson = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
-        per_step = {}
+        tjson = {}
+    per_step = tjson.get("per_step", {})
     step_s = dt / args.steps
     alg = 68.0e6 * (E / 2800.0)
     if not icf:
@@ -520,9 +654,20 @@ def main():
                            "algorithmic_frac": round(alg / step_s / 8.0e12, 4),
                            "counted_from": "profiles/traffic.json (committed rocprofv3 PMC passes of the fp32 step; a constant "
                                            "of the build, NOT measured by this run)",
+                           # which build the constant was measured on (tools/collect_profiles.sh stamps both), and whether
+                           # the kernel sources have changed since: a stale constant is visible in the line
+                           "counted_from_commit": tjson.get("commit"),
+                           "counted_from_csrc_digest": tjson.get("csrc_digest"),
+                           "counted_is_stale": (tjson.get("csrc_digest") != _csrc_digest()) if tjson else None,
                            "counted_bytes_per_step": per_step.get("hbm_bytes"),
                            "counted_TBps": round(per_step["hbm_bytes"] / step_s / 1e12, 3) if per_step.get("hbm_bytes") else None,
                            "counted_frac": round(per_step["hbm_bytes"] / step_s / 8.0e12, 4) if per_step.get("hbm_bytes") else None}
+    if world > 1 or cdist._active():
+        out["ranks_seen"] = cdist.ranks_seen(dev)
+        out["allreduce"] = ("bucketed under backward (head, layers L-1..0, encoder: distributed.GradSync)"
+                            if gsync is not None else "one flat all-reduce after backward")
+        out["allreduce_exposed_ms_per_step"] = (round(gsync.exposed_ms(), 4) if gsync is not None and
+                                                gsync.exposed_ms() is not None else None)
     if sustained is not None:
         out["sustained"] = sustained
     if telemetry is not None:
@@ -538,6 +683,7 @@ def main():
         out["reference_recipe_groups_of_4"] = recipe
     if eval_fwd is not None:
         out["eval_forward"] = eval_fwd
+    out.update(sub_cfg)
     if rank == 0:
         summ = timed_summary
         if summ:

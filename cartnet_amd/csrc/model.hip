@@ -775,6 +775,19 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     return cartnet_bn_sync_scale(w.bnrow, D, count, sums, st);
   };
 
+  // Gradient buckets (CartnetModel.grad_ready): every gradient of layer l has been enqueued on one of the two streams by
+  // now (the BatchNorm affine gradients on the main stream before this layer's last fork, everything else on the side
+  // stream) -- a last fork orders the side stream behind the main stream's share, then the caller may queue the bucket's
+  // all-reduce there, under the next layer's kernels.  The head's bucket completes with the deferred side jobs.
+  auto bucket_ready = [&](int l) -> int {
+    if (!m.grad_ready) return 0;
+    FORK();
+    if (l == L - 1)
+      CN_CHECK(m.grad_ready(m.grad_ready_user, L, sw) == 0, "cartnet_model_backward: the grad_ready callback failed (head)");
+    CN_CHECK(m.grad_ready(m.grad_ready_user, l, sw) == 0, "cartnet_model_backward: the grad_ready callback failed (layer %d)", l);
+    return 0;
+  };
+
   // ---- layers, last to first
   for (int l = L - 1; l >= 0; --l) {
     const CartnetLayerParams& q = P.layer[l];
@@ -931,6 +944,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       RUN(side_w1e());
       side_done[l] = S.mark_side();
       if (l == L - 1) RUN(deferred_side_jobs());
+      RUN(bucket_ready(l));
       RUN(main_de_in());
       if (S.main_waits(seg_done) != 0) { cartnet_set_error("cartnet_model_backward: wait failed"); return 2; }
       RUN(main_dx());
@@ -946,6 +960,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       RUN(side_wn());
       side_done[l] = S.mark_side();
       if (l == L - 1) RUN(deferred_side_jobs());
+      RUN(bucket_ready(l));
       RUN(main_dx());
     }
     float* t = dx; dx = dx_other; dx_other = t;
@@ -1026,6 +1041,8 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
   }
   // join: everything queued on the side stream precedes whatever the caller enqueues next on the main stream
   if (S.main_waits(S.mark_side()) != 0) { cartnet_set_error("cartnet_model_backward: stream join failed"); return 2; }
+  if (m.grad_ready)
+    CN_CHECK(m.grad_ready(m.grad_ready_user, L + 1, st) == 0, "cartnet_model_backward: the grad_ready callback failed (encoder)");
 #undef FORK
   return 0;
 }

@@ -104,6 +104,65 @@ def all_reduce_gradients(flat_grad: torch.Tensor) -> float:
     return 1.0 / dist.get_world_size()
 
 
+class GradSync:
+    """The gradient all-reduce in BUCKETS, overlapped with backward (reference accumulation boundary:
+    train/train.py:186-189).  ``cartnet_model_backward`` reports every bucket of the flat gradient buffer (head, layers
+    L-1 .. 0, encoder: CartnetGradReadyFn in include/cartnet_hip.h) on a stream ordered behind the kernels that produced
+    it; ``bucket(lo, hi)`` -- called with that stream current -- queues an asynchronous SUM all-reduce of
+    ``flat_grad[lo:hi]`` (RCCL runs it on its own stream, behind the current one), and backward goes on underneath.
+    ``finish()`` makes the CURRENT stream wait for all of them and returns the 1/world scale for the optimiser, like
+    ``all_reduce_gradients``.  The summed values are the same as one flat all-reduce's (element-wise SUM over ranks;
+    with more than two ranks the transport's summation order may differ between a bucket and the flat buffer in the last
+    bit).  ``exposed_ms()``: GPU time the joining stream spent waiting, averaged over the finish() calls so far."""
+
+    def __init__(self, flat_grad: torch.Tensor, measure: bool = False):
+        self.flat = flat_grad
+        self.works: list = []
+        self.measure = measure and flat_grad.is_cuda
+        self._events: list = []
+        self.buckets_seen = 0
+
+    @property
+    def active(self) -> bool:
+        return _active()
+
+    def bucket(self, lo: int, hi: int) -> None:
+        self.buckets_seen += 1
+        if _active() and hi > lo:
+            self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self) -> float:
+        if not _active():
+            self.works.clear()
+            return 1.0
+        ev = None
+        if self.measure:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        for w in self.works:
+            w.wait()                  # stream-level for RCCL: the current stream waits, the host does not
+        self.works.clear()
+        if ev is not None:
+            ev[1].record()
+            self._events.append(ev)
+        return 1.0 / dist.get_world_size()
+
+    def exposed_ms(self) -> Optional[float]:
+        if not self._events:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._events) / len(self._events)
+
+
+def ranks_seen(device) -> int:
+    """How many ranks the communicator really carries: a SUM all-reduce of one 1 per rank."""
+    if not _active():
+        return 1
+    t = torch.ones(1, dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
 def all_reduce_sum_(t: torch.Tensor) -> None:
     """In-place SUM all-reduce of a (device) tensor, enqueued in the current stream's order; no-op for one rank.
     The sync-BatchNorm exchange of cartnet_amd.model.CartNet (2D+1 doubles per BatchNorm and direction)."""

@@ -97,6 +97,7 @@ class Params(C.Structure):
 
 # CartnetAllReduceFn: int (*)(void* user, double* buf, int64_t count, void* stream)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+GRADREADY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)       # CartnetGradReadyFn(user, bucket, stream)
 
 
 class Model(C.Structure):
@@ -106,7 +107,8 @@ class Model(C.Structure):
                [(n, C.c_float) for n in ("radius", "env_radius", "bn_eps", "bn_momentum")] + \
                [("gemm_precision", C.c_int32), ("bn_group_size", C.c_int32)] + \
                [("rbf_means", C.c_void_p), ("rbf_betas", C.c_void_p), ("p", Params), ("buf", LayerBuffers * MAX_LAYERS),
-                ("bn_allreduce", ALLREDUCE_FN), ("bn_allreduce_user", C.c_void_p), ("half_storage", C.c_int32)]
+                ("bn_allreduce", ALLREDUCE_FN), ("bn_allreduce_user", C.c_void_p), ("half_storage", C.c_int32),
+                ("grad_ready", GRADREADY_FN), ("grad_ready_user", C.c_void_p)]
 
 
 class Groups(C.Structure):

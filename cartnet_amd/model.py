@@ -236,11 +236,23 @@ class _CartNetFunction(torch.autograd.Function):
             if sink is not None and sink.numel() == G.flat.numel():
                 model.__dict__["_grad_cache"] = (G, gd)
         aux = model._aux_stream_ptr(dpred.device)
-        _l.check(lib.cartnet_model_backward(C.byref(md), C.byref(bd), ws.data_ptr(), nbytes, int(training),
-                                            dpred.data_ptr(), x_out.data_ptr(), C.byref(gd), _l.stream_ptr(), aux),
-                 "cartnet_model_backward")
-        for k in keep:
+        # gradient buckets (model.grad_sync: a cartnet_amd.distributed.GradSync armed for THIS backward by the training
+        # loop at an accumulation boundary): as soon as a bucket's kernels are enqueued, its slice is accumulated into the
+        # optimiser's flat buffer and its all-reduce queued -- on the stream the C side names, under the rest of backward
+        sync = getattr(model, "grad_sync", None)
+        bucketed = sync is not None and sink is not None and sink.numel() == G.flat.numel() and sync.flat is sink
+        gr_cb = None
+        if bucketed:
+            gr_cb = _make_grad_ready(model, sync, sink, G.flat)
+            md.grad_ready = gr_cb
+        rc = lib.cartnet_model_backward(C.byref(md), C.byref(bd), ws.data_ptr(), nbytes, int(training),
+                                        dpred.data_ptr(), x_out.data_ptr(), C.byref(gd), _l.stream_ptr(), aux)
+        for k in keep:                     # an exception inside a callback is the cause: raise it, not the C side's echo
             _raise_callback_error(k if isinstance(k, _l.ALLREDUCE_FN) else None)
+        _raise_callback_error(gr_cb)
+        _l.check(rc, "cartnet_model_backward")
+        if bucketed:
+            return (None, None, None) + (None,) * len(model._param_names)
         if sink is not None and sink.numel() == G.flat.numel():
             sink.add_(G.flat)              # one accumulation into the optimiser's flat gradient buffer
             return (None, None, None) + (None,) * len(model._param_names)
@@ -266,6 +278,54 @@ def _make_bn_allreduce(ws: torch.Tensor):
             return 1
 
     fn = _l.ALLREDUCE_FN(cb)
+    fn._cartnet_errors = err
+    return fn
+
+
+def _bucket_ranges(model) -> List[tuple]:
+    """(lo, hi) of every gradient bucket in the flat parameter order: index 0..L-1 = layers, L = head, L+1 = encoder
+    (CartnetGradReadyFn).  named_parameters() lists encoder.*, layers.0.* .. layers.L-1.*, head.* -- contiguous ranges."""
+    cached = model.__dict__.get("_bucket_cache")
+    if cached is not None:
+        return cached
+    L = model.num_layers
+    spans: Dict[int, list] = {}
+    off = 0
+    for n in model._param_names:
+        cnt = 1
+        for d in model._param_shapes[n]:
+            cnt *= d
+        b = int(n.split(".")[1]) if n.startswith("layers.") else (L if n.startswith("head.") else L + 1)
+        sp = spans.setdefault(b, [off, off])
+        if sp[1] != off:
+            raise RuntimeError(f"parameters of bucket {b} are not contiguous in the flat buffer ({n})")
+        sp[1] = off + cnt
+        off += cnt
+    out = [tuple(spans[b]) for b in range(L + 2)]
+    model.__dict__["_bucket_cache"] = out
+    return out
+
+
+def _make_grad_ready(model, sync, sink: torch.Tensor, gflat: torch.Tensor):
+    """CartnetModel.grad_ready for one backward: bucket -> accumulate its slice into the optimiser's flat gradient buffer and
+    hand it to the GradSync, both on the stream the C side passes (ordered behind the kernels that wrote the slice)."""
+    ranges = _bucket_ranges(model)
+    err = []
+
+    def cb(_user, bucket, stream):
+        try:
+            lo, hi = ranges[int(bucket)]
+            # (the caller's stream may be the legacy default stream: a null hipStream_t)
+            ext = torch.cuda.ExternalStream(int(stream), device=sink.device) if stream else torch.cuda.default_stream(sink.device)
+            with torch.cuda.stream(ext):
+                sink[lo:hi].add_(gflat[lo:hi])
+                sync.bucket(lo, hi)
+            return 0
+        except Exception as exc:        # must not propagate through the C frames
+            err.append(exc)
+            return 1
+
+    fn = _l.GRADREADY_FN(cb)
     fn._cartnet_errors = err
     return fn
 
@@ -321,6 +381,7 @@ class CartNet(nn.Module):
         self._param_names = [n for n, _ in self.named_parameters()]
         self._param_shapes = {n: tuple(p.shape) for n, p in self.named_parameters()}
         self._flat_grad = None          # set by cartnet_amd.optim.FlatAdam: gradients are accumulated here directly
+        self.grad_sync = None           # a cartnet_amd.distributed.GradSync armed for the next backward (train_epoch)
 
     def _model_desc(self, P: Dict[str, torch.Tensor]) -> "_l.Model":
         """CartnetModel struct pointing at the current parameters / buffers (reference state_dict layout).  Cached while
@@ -368,6 +429,14 @@ class CartNet(nn.Module):
                                ("norm2_var", "norm2.running_var"), ("norm2_nbt", "norm2.num_batches_tracked")):
                 setattr(bl, field, B[f"layers.{l}.{key}"].data_ptr())
         return md
+
+    def grad_bucket_order(self) -> List[tuple]:
+        """(lo, hi) slices of the flat parameter / gradient buffer in the order cartnet_model_backward reports them
+        (head, layers L-1 .. 0, encoder).  A rank without crystals for a step issues its zero contribution to the
+        bucketed all-reduce in exactly this order (cartnet_amd.train.train_epoch)."""
+        r = _bucket_ranges(self)
+        L = self.num_layers
+        return [r[L]] + [r[l] for l in range(L - 1, -1, -1)] + [r[L + 1]]
 
     _STATUS_DEPTH = 64
 

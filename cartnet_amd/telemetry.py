@@ -157,20 +157,56 @@ def compact(sample: dict) -> dict:
 
 
 class Sampler:
-    """Background thread that samples `read()` every `period` seconds while a stretch of GPU work runs; `stop()`
-    returns mean / min / max of clock and power and the maximum temperatures -- what the card did UNDER the load, which
-    a snapshot taken after the final synchronize cannot show."""
+    """Background thread that samples clock / power / temperature every `period` seconds while a stretch of GPU work
+    runs; `stop()` returns mean / min / max of clock and power and the maximum temperatures -- what the card did UNDER
+    the load, which a snapshot taken after the final synchronize cannot show.
 
-    def __init__(self, device_index: int = 0, period: float = 0.05):
+    Kept light on purpose (the sampler shares the GIL with a ctypes-heavy main thread): the handful of sysfs
+    files it needs (pp_dpm_sclk, pp_dpm_mclk, one hwmon power file, the junction and memory temperatures) are resolved
+    ONCE here -- no glob, no gpu_metrics table, no label lookups per sample -- and every pass of bench.py uses the same
+    period (>= 0.1 s by default).  ``bench.py --no-telemetry`` starts no sampler at all."""
+
+    DEFAULT_PERIOD = 0.1
+
+    def __init__(self, device_index: int = 0, period: Optional[float] = None):
         import threading
-        self.device_index, self.period = device_index, period
+        self.device_index = device_index
+        self.period = self.DEFAULT_PERIOD if period is None else max(float(period), 0.05)
         self.samples = []
         self._stop = threading.Event()
         self._th = threading.Thread(target=self._run, daemon=True)
+        d = device_dir(device_index)
+        self._f_sclk = self._f_mclk = self._f_power = self._f_junction = self._f_mem = None
+        if d is not None:
+            f = os.path.join(d, "pp_dpm_sclk")
+            self._f_sclk = f if os.path.exists(f) else None
+            f = os.path.join(d, "pp_dpm_mclk")
+            self._f_mclk = f if os.path.exists(f) else None
+            for h in sorted(glob.glob(os.path.join(d, "hwmon/hwmon*"))):
+                for name in ("power1_average", "power1_input"):
+                    f = os.path.join(h, name)
+                    if self._f_power is None and os.path.exists(f):
+                        self._f_power = f
+                for f in sorted(glob.glob(os.path.join(h, "temp*_input"))):
+                    label = _read(f.replace("_input", "_label")) or ""
+                    if label == "junction" and self._f_junction is None:
+                        self._f_junction = f
+                    if label == "mem" and self._f_mem is None:
+                        self._f_mem = f
+
+    def _sample(self) -> dict:
+        p = _read_int(self._f_power) if self._f_power else None
+        j = _read_int(self._f_junction) if self._f_junction else None
+        m = _read_int(self._f_mem) if self._f_mem else None
+        return {"sclk_mhz": _active_level_mhz(_read(self._f_sclk)) if self._f_sclk else None,
+                "mclk_mhz": _active_level_mhz(_read(self._f_mclk)) if self._f_mclk else None,
+                "power_w": round(p * 1e-6, 1) if p is not None else None,
+                "junction_c": round(j / 1000.0, 1) if j is not None else None,
+                "mem_c": round(m / 1000.0, 1) if m is not None else None}
 
     def _run(self):
         while not self._stop.is_set():
-            self.samples.append(compact(read(self.device_index)))
+            self.samples.append(self._sample())
             self._stop.wait(self.period)
 
     def start(self) -> "Sampler":
@@ -185,7 +221,7 @@ class Sampler:
             v = [s[key] for s in self.samples if s.get(key) is not None]
             if v:
                 out[key] = {"mean": round(sum(v) / len(v), 1), "min": min(v), "max": max(v)}
-        for key in ("edge_c", "junction_c", "mem_c"):
+        for key in ("junction_c", "mem_c"):
             v = [s[key] for s in self.samples if s.get(key) is not None]
             if v:
                 out[key + "_max"] = max(v)

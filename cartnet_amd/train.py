@@ -103,6 +103,11 @@ def train_epoch(loader, model, optimizer, batch_accumulation: int, scheduler: Op
     micro = 0                                       # micro-batches seen (= iterations unless batches carry groups)
     t0 = time.perf_counter()
     flush = getattr(model, "flush_graph_checks", None)
+    # Multi-rank runs of CartNet: the gradient all-reduce goes out in buckets DURING the backward of the micro-batch that
+    # closes an accumulation window (distributed.GradSync, CartnetGradReadyFn) instead of as one flat call behind it.
+    sync = None
+    if hasattr(optimizer, "flat_grad") and hasattr(model, "grad_bucket_order") and cdist._active():
+        sync = cdist.GradSync(optimizer.flat_grad)
     for it, batch in enumerate(loader):
         if batch is None and getattr(model, "sync_batchnorm", False):
             raise RuntimeError("sync_batchnorm: this rank has no crystals for a step the other ranks run -- every rank "
@@ -119,13 +124,26 @@ def train_epoch(loader, model, optimizer, batch_accumulation: int, scheduler: Op
                 mae, mse = compute_loss(pred, true)
                 micro += 1
             loss = _pick_loss(mae, mse)
-            loss.mean().backward()                  # not divided by the accumulation count (train/train.py:183)
+            boundary = ((it + 1) % batch_accumulation == 0) or (it + 1 == n_iter)
+            if sync is not None and boundary:
+                model.grad_sync = sync              # this backward reports its buckets; their all-reduces overlap it
+            try:
+                loss.mean().backward()              # not divided by the accumulation count (train/train.py:183)
+            finally:
+                if sync is not None:
+                    model.grad_sync = None
             tot_mae += mae.detach()
             graphs += int(batch.num_graphs)
         if ((it + 1) % batch_accumulation == 0) or (it + 1 == n_iter):
             if flush is not None:
                 flush()                             # a malformed batch raises BEFORE its gradient reaches the weights
-            scale = cdist.all_reduce_gradients(optimizer.flat_grad) if hasattr(optimizer, "flat_grad") else 1.0
+            if sync is not None:
+                if batch is None:                   # no crystals this step: the same collectives, in the same order
+                    for lo, hi in model.grad_bucket_order():
+                        sync.bucket(lo, hi)
+                scale = sync.finish()
+            else:
+                scale = cdist.all_reduce_gradients(optimizer.flat_grad) if hasattr(optimizer, "flat_grad") else 1.0
             optimizer.step(scale) if hasattr(optimizer, "flat_grad") else optimizer.step()
             if scheduler is not None:
                 scheduler()

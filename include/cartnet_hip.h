@@ -610,6 +610,13 @@ typedef struct CartnetParams {                  /* used both for parameters (inp
 } CartnetParams;
 
 typedef int (*CartnetAllReduceFn)(void* user, double* buf, int64_t count, void* stream);
+/* Gradient buckets ("all-reduce ... overlapped with the tail of backward"; the reference's accumulation
+ * boundary is train/train.py:186-189).  cartnet_model_backward calls this once per bucket, as soon as every kernel that
+ * writes the bucket's gradients has been ENQUEUED; `stream` is ordered after all of them (the weight-gradient stream
+ * for the layer and head buckets, the caller's stream for the encoder bucket, which completes last), so the callee may
+ * enqueue an all-reduce of that slice there while backward goes on.  bucket: 0..L-1 = layer l (called in the order
+ * L-1 .. 0), L = head (called with layer L-1), L+1 = encoder (last, after the streams have joined). */
+typedef int (*CartnetGradReadyFn)(void* user, int32_t bucket, void* stream);
 
 typedef struct CartnetModel {
   int32_t D, R, L;                              /* dim_in, dim_rbf, num_layers                       */
@@ -635,6 +642,9 @@ typedef struct CartnetModel {
      gradient of a parameter stay fp32).  SURVEY.md 8d config 3: "bf16 storage / fp32 accumulate".  Not with
      bn_group_size (the per-group statistics pass reads gs as fp32). */
   int32_t half_storage;
+  /* optional, cartnet_model_backward only: see CartnetGradReadyFn.  Non-zero return = error. */
+  CartnetGradReadyFn grad_ready;
+  void* grad_ready_user;
 } CartnetModel;
 
 typedef struct CartnetBatch {

@@ -42,7 +42,7 @@ def test_ctypes_mirrors_have_the_c_struct_layouts():
     assert n == len(mirrors)
     assert [ctypes.sizeof(m) for m in mirrors] == list(sizes[:n])
     assert lib.GemmArgs.tile_policy.offset + 8 == ctypes.sizeof(lib.GemmArgs)                       # last field + tail padding
-    assert lib.Model.half_storage.offset + 8 == ctypes.sizeof(lib.Model)                             # last field + tail padding
+    assert lib.Model.grad_ready_user.offset + 8 == ctypes.sizeof(lib.Model)                          # last field
 
 
 def test_host_side_argument_validation_without_gpu():
@@ -262,9 +262,10 @@ def test_telemetry_reads_a_sysfs_tree(tmp_path, monkeypatch):
     assert c["junction_c"] == 53.0 and c["mem_c"] == 47.0 and c["edge_c"] is None
     (d / "pp_dpm_sclk").unlink()                              # falls back to hwmon freq1_input
     assert tele.read(0)["sclk_mhz"] == 2374
-    smp = tele.Sampler(0, period=0.005).start()
+    smp = tele.Sampler(0, period=0.005).start()              # clamped to 0.05 s: one period for every pass, never a busy loop
+    assert smp.period == 0.05
     import time
-    time.sleep(0.03)
+    time.sleep(0.13)
     out = smp.stop()
     assert out["samples"] >= 2 and out["power_w"]["max"] == 1265.0 and out["junction_c_max"] == 53.0
     monkeypatch.setattr(tele, "_DIR_CACHE", {0: None})

@@ -177,3 +177,72 @@ def test_sync_batchnorm_makes_two_shards_equal_to_the_union_batch(tmp_path):
                 assert torch.equal(r["bufs"][k], v), k
             else:
                 assert torch.allclose(r["bufs"][k], v, rtol=1e-5, atol=1e-7), k
+
+
+_BUCKET_CHILD = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from cartnet_amd import distributed as cdist
+from cartnet_amd.config import cfg
+from cartnet_amd.data import Batch
+from cartnet_amd.model import CartNet, make_state_dict
+from cartnet_amd.optim import FlatAdam
+from cartnet_amd.synthetic import make_crystal
+
+rank, world, local = cdist.init_from_env()
+cfg.radius = 5.0
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+m = CartNet(64, 16, 3)
+m.load_state_dict(make_state_dict(64, 16, 3, seed=47))
+m = m.to(dev).train()
+opt = FlatAdam(m, lr=1e-3)
+items = [make_crystal(9900 + 7 * rank + i, 10 + 3 * i + rank) for i in range(3)]      # every rank its own crystals
+out = {}
+for mode in ("flat", "bucketed"):
+    opt.zero_grad()
+    b = Batch.from_data_list(items).to(dev)
+    sync = cdist.GradSync(opt.flat_grad) if mode == "bucketed" else None
+    m.grad_sync = sync
+    pred, true = m(b)
+    (pred - true).abs().mean().backward()
+    m.grad_sync = None
+    scale = sync.finish() if sync is not None else cdist.all_reduce_gradients(opt.flat_grad)
+    torch.cuda.synchronize()
+    out[mode] = opt.flat_grad.cpu().clone()
+    out[mode + "_scale"] = scale
+    if sync is not None:
+        out["buckets"] = sync.buckets_seen
+torch.save(out, os.path.join(sys.argv[2], f"b_w{world}_r{rank}.pt"))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucketed_all_reduce_under_backward_equals_the_flat_one(tmp_path, world):
+    """SURVEY.md 8e: the gradient all-reduce overlapped with backward.  cartnet_model_backward reports every bucket
+    (head, layers L-1..0, encoder) on the weight-gradient stream; distributed.GradSync queues its all-reduce there.  Ranks
+    share the one card and exchange over gloo: the SUM over ranks of every element must be what ONE flat all-reduce after
+    backward gives -- bit for bit with two ranks (a + b has one order); with four the transport may associate the four
+    terms differently for a slice than for the whole buffer, so the bound is one rounding of the sum."""
+    import torch
+    script = tmp_path / "bucket_child.py"
+    script.write_text(_BUCKET_CHILD)
+    env = dict(os.environ, CARTNET_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29550 + world), str(script), ROOT,
+                          str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    outs = [torch.load(tmp_path / f"b_w{world}_r{r}.pt") for r in range(world)]
+    for o in outs:
+        assert o["buckets"] == 3 + 2 and o["flat_scale"] == o["bucketed_scale"] == 1.0 / world
+        assert torch.equal(o["bucketed"], outs[0]["bucketed"])                 # every rank holds the same sum
+        assert o["flat"].abs().max().item() > 0
+        if world == 2:
+            assert torch.equal(o["bucketed"], o["flat"])
+        else:
+            assert (o["bucketed"] - o["flat"]).abs().max().item() <= 2.0 ** -22 * o["flat"].abs().max().item()

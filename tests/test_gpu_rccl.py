@@ -43,6 +43,31 @@ scale = cdist.all_reduce_gradients(opt.flat_grad)          # RCCL all-reduce (SU
 torch.cuda.synchronize()
 assert scale == 1.0
 same = bool(torch.equal(opt.flat_grad, g_before))          # SUM over one rank is the identity, bit for bit
+# the same gradient through the BUCKETED path (CartnetGradReadyFn -> distributed.GradSync): six asynchronous RCCL all-reduces
+# queued from inside cartnet_model_backward on the weight-gradient stream, joined by finish(); bit for bit the flat result
+opt.zero_grad()
+sync = cdist.GradSync(opt.flat_grad, measure=True)
+seen = []
+_ob = sync.bucket
+def _rec(lo, hi):
+    seen.append((int(lo), int(hi)))
+    _ob(lo, hi)
+sync.bucket = _rec
+model.grad_sync = sync
+b2 = make_batch(4, 194, first=31000).to(dev)
+pred2, true2 = model(b2)
+(pred2 - true2).abs().mean().backward()
+model.grad_sync = None
+n_works = len(sync.works)
+scale_b = sync.finish()
+torch.cuda.synchronize()
+bucketed = {"same": bool(torch.equal(opt.flat_grad, g_before)), "scale": scale_b, "works": n_works,
+            "order_ok": seen == [tuple(x) for x in model.grad_bucket_order()],
+            "covers": sorted(seen)[0][0] == 0 and sum(h - l for l, h in seen) == opt.flat_grad.numel() and
+                      all(a[1] == b[0] for a, b in zip(sorted(seen), sorted(seen)[1:])),
+            "exposed_ms": sync.exposed_ms()}
+opt.zero_grad()
+opt.flat_grad.copy_(g_before)
 opt.step(scale)
 cdist.barrier()
 t = cdist.max_over_ranks(3.25, dev)
@@ -77,24 +102,30 @@ cfg.loss = "MAE"
 model.bn_group_size = 4
 items = [make_crystal(33000 + i, 20 + (i % 5)) for i in range(24)]
 loader = DataLoader(items, 8, shuffle=True, seed=1)
-calls = []
-_orig = cdist.all_reduce_gradients
-def _counting(flat):
-    calls.append(int(flat.numel()))
-    return _orig(flat)
-cdist.all_reduce_gradients = _counting
+calls = []                                                 # (elements all-reduced, buckets) per optimiser step
+_GS = cdist.GradSync
+class _Counting(_GS):
+    def bucket(self, lo, hi):
+        self._n = getattr(self, "_n", 0) + (hi - lo)
+        self._k = getattr(self, "_k", 0) + 1
+        super().bucket(lo, hi)
+    def finish(self):
+        calls.append((self._n, self._k))
+        self._n = self._k = 0
+        return super().finish()
+cdist.GradSync = _Counting
 p0 = opt.flat_param.clone()
 stats = train_epoch(loader, model, opt, batch_accumulation=1, device=dev)
-cdist.all_reduce_gradients = _orig
+cdist.GradSync = _GS
 cdist.assert_replicas_in_sync(model)
 model.bn_group_size = 0
-fused = {"steps": len(calls), "graphs": stats["graphs"], "finite": bool(torch.isfinite(opt.flat_param).all()),
+fused = {"steps": len(calls), "per_step": sorted(set(calls)), "graphs": stats["graphs"], "finite": bool(torch.isfinite(opt.flat_param).all()),
          "moved": float((opt.flat_param - p0).abs().max().item()), "mae": stats["mae"]}
 sync_pred = float((preds[0] - preds[1]).abs().max().item() / preds[0].abs().max().item())
 sync_grad = float((grads[0] - grads[1]).abs().max().item() / grads[0].abs().max().item())
 print(json.dumps({"backend": dist.get_backend(), "same": same, "max": t, "moved": moved,
                   "grad_norm": float(g_before.norm().item()), "sync_pred": sync_pred, "sync_grad": sync_grad,
-                  "half_sync_ok": half_ok, "fused": fused}), flush=True)
+                  "half_sync_ok": half_ok, "fused": fused, "bucketed": bucketed}), flush=True)
 dist.destroy_process_group()
 '''
 
@@ -111,8 +142,12 @@ def test_rccl_world_of_one_runs_every_collective_of_the_training_step(tmp_path):
     assert d["backend"] == "nccl" and d["same"] is True and d["max"] == 3.25
     assert d["grad_norm"] > 0 and 0 < d["moved"] <= 1.1e-3            # one Adam step at lr 1e-3 moves each weight by <= lr
     assert d["sync_pred"] <= 1e-6 and d["sync_grad"] <= 1e-5 and d["half_sync_ok"] is True
-    f = d["fused"]                     # three optimiser steps of train_epoch, one RCCL all-reduce each
+    f = d["fused"]                     # three optimiser steps of train_epoch, each all-reducing the whole buffer in 6 buckets
     assert f["steps"] == 3 and f["graphs"] == 24 and f["finite"] and 0 < f["moved"] <= 3.3e-3 and f["mae"] == f["mae"]
+    assert f["per_step"] == [[2498438, 6]]
+    bk = d["bucketed"]                 # head, layers 3..0, encoder: six RCCL all-reduces queued from inside backward
+    assert bk["same"] is True and bk["scale"] == 1.0 and bk["works"] == 6 and bk["order_ok"] and bk["covers"]
+    assert bk["exposed_ms"] is not None and bk["exposed_ms"] >= 0.0
 
 
 def test_bench_starts_its_own_ranks(tmp_path):

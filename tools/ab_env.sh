@@ -7,7 +7,7 @@ VAR=${1:-CARTNET_FUSED_LOSS}
 VAL=${2:-1}
 for v in A B A B; do
   if [ $v = B ]; then export $VAR=$VAL; else unset $VAR; fi
-  python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timer --no-recipe-pass --sustain-seconds 0 > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err
+  python bench.py --no-subconfigs --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timer --no-recipe-pass --sustain-seconds 0 > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err
   python -c "
 import json; d=json.load(open('gpurun_out/ab_$v.json')); print('$v ($VAR=' + ('$VAL' if '$v' == 'B' else 'unset') + ')', d['ms_per_step'], d['value'], d['bf16x3']['ms_per_step'], d['bf16x3']['value'])"
 done

@@ -8,5 +8,5 @@ for v in $A $B $A $B; do
 done
 for v in $A $B $A $B; do
   echo "== $v"
-  CARTNET_LIB=$PWD/$v timeout -k 10 300 python bench.py --steps 30 --warmup 10 --no-x3-pass --no-recipe-pass --no-cpu-baseline --sustain-seconds 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print(d['ms_per_step'], d['value'], 'cal', d['calibration']['avg_launch_us'], 'dominant', r['kernel'][:40], r['avg_launch_us'], r['frac'], 'isolated', r.get('isolated_avg_launch_us'))"
+  CARTNET_LIB=$PWD/$v timeout -k 10 300 python bench.py --no-subconfigs --steps 30 --warmup 10 --no-x3-pass --no-recipe-pass --no-cpu-baseline --sustain-seconds 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print(d['ms_per_step'], d['value'], 'cal', d['calibration']['avg_launch_us'], 'dominant', r['kernel'][:40], r['avg_launch_us'], r['frac'], 'isolated', r.get('isolated_avg_launch_us'))"
 done

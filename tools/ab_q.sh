@@ -19,6 +19,6 @@ fi
 if [ "${STEP:-0}" == "1" ]; then
 for v in 0 1 2 0 1 2; do
   echo "== CARTNET_Q=$v"
-  CARTNET_Q=$v timeout -k 10 300 python bench.py --steps 30 --warmup 10 --no-x3-pass --no-recipe-pass --no-cpu-baseline --sustain-seconds 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['calibration']['avg_launch_us'])"
+  CARTNET_Q=$v timeout -k 10 300 python bench.py --no-subconfigs --steps 30 --warmup 10 --no-x3-pass --no-recipe-pass --no-cpu-baseline --sustain-seconds 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['calibration']['avg_launch_us'])"
 done 2>&1 | tee gpurun_out/q_step.log
 fi

@@ -22,6 +22,19 @@ if fetch3 and write3:        # the same two passes over bf16x3 steps (bench.py -
     extra = [fetch3[0], write3[0]]
 subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), fetch, write,
                 os.path.join(dst, "traffic.json"), *extra], check=True, stdout=subprocess.DEVNULL)
+# provenance of the constant bench.py quotes as path_hbm.counted_*: the commit published from and the digest of the kernel
+# sources the passes ran on (collect_profiles.sh); publishing passes of OTHER sources than the tree's is refused
+sys.path.insert(0, root)
+import bench as _bench
+dig_file = os.path.join(src, "csrc_digest.txt")
+measured = open(dig_file).read().strip() if os.path.exists(dig_file) else None
+if measured != _bench._csrc_digest() and "--force" not in sys.argv:
+    raise SystemExit(f"{src} measured kernel sources {measured}, the tree is at {_bench._csrc_digest()}: re-run "
+                     "tools/collect_profiles.sh on this tree (or pass --force)")
+tj = json.load(open(os.path.join(dst, "traffic.json")))
+tj["csrc_digest"] = measured
+tj["commit"] = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+json.dump(tj, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 mfma_csv = glob.glob(os.path.join(src, "mfma", "*", "*_counter_collection.csv"))
 mfma_table = ""
 if mfma_csv:
