@@ -150,12 +150,25 @@ def timed_pass(step, fresh, warm: int, steps: int, graphs: int, sampler_factory,
     gflop = sum(v["flops"] for v in ops.profile_gemm_read().values())
     sampler = sampler_factory()
     torch.cuda.synchronize()
+    prof = None
+    if os.environ.get("BENCH_PROFILE_SUB"):          # tools: where the host time of a sub-pass goes (stderr)
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
+    import gc
+    gc.collect()               # a generation-2 collection inside a 30 ms host-bound region would double it
+    gc.disable()
     t0 = time.perf_counter()
     for b in bs[warm + 1:]:
         loss = step(b)
     t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(14)
     tel = sampler.stop() if sampler is not None else None
     if not torch.isfinite(loss):
         return None
@@ -581,7 +594,7 @@ def main():
         jm = CartNet(256, 64, 4, temperature=False, cholesky=False).to(dev).train()
         jm.gemm_precision, jm.half_storage = 2, True
         jopt = FlatAdam(jm, lr=1e-3)
-        r = timed_pass(train_step_of(jm, jopt), clone_of(jb), 5, args.sub_steps, 64, new_sampler, 2500.0, ops)
+        r = timed_pass(train_step_of(jm, jopt), clone_of(jb), 5, 5 * args.sub_steps, 64, new_sampler, 2500.0, ops)
         if r is not None:
             r.update({"workload": f"BASELINE configs[2]: CartNet L=4 D=256 Scalar_head, no temperature, 64 crystals of 2-20 "
                                   f"atoms per step (N={int(jb.x.shape[0])}, E={int(jb.edge_index.shape[1])}), bf16 MFMA "
