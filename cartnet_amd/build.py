@@ -16,7 +16,9 @@ LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcartnet_hip.s
 SOURCES = ["abi.hip", "gemm.hip", "gemm_bn256.hip", "gemm_bn128.hip", "gemm_bn64.hip", "gemm_x3.hip", "gemm_x3s.hip", "gemm_f32.hip", "gemm_f32w128.hip", "gemm_f32ao.hip", "gemm_f32gate.hip", "gemm_x3ao.hip", "gemm_h.hip", "graph_ops.hip", "edge_ops.hip", "node_ops.hip", "optim.hip", "model.hip", "comformer_ops.hip", "equi_ops.hip", "radius_graph.hip", "metrics.hip", "collate.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # per-source additions (the reason is at the top of the source file)
-EXTRA_FLAGS = {"radius_graph.hip": ["-ffp-contract=off"]}
+# gemm_f32.hip: cn_gemm_f32tn_kernel declares 4 waves per SIMD to cap its registers at 128 (so that a main-stream GEMM
+# workgroup fits beside it) while its 96 KB of LDS admit one workgroup per CU: the occupancy remark is expected
+EXTRA_FLAGS = {"radius_graph.hip": ["-ffp-contract=off"], "gemm_f32.hip": ["-Wno-pass-failed"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
 if os.environ.get("CARTNET_BUILD_EXPERIMENTAL"):       # experiments kept as a record (csrc/experimental/), never shipped
     SOURCES.append("experimental/gemm_f32q.hip")

@@ -221,7 +221,9 @@ def _parts(n, dev):
 
 
 def _split_k(K, tiles):
-    return int(max(1, min((512 + tiles - 1) // tiles, K // 256)))
+    # 256 workgroups = one per CU, like csrc/model.hip (split_k): the weight-gradient stream must not take both slots of
+    # every CU from the main chain
+    return int(max(1, min((256 + tiles - 1) // tiles, K // 256)))
 
 
 _SIDE: Dict[str, Optional[torch.cuda.Stream]] = {"stream": None, "on": True}   # weight-gradient stream of the running backward

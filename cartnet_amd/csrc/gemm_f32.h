@@ -216,7 +216,12 @@ namespace cn_gemm {
 constexpr int F32T_A_BYTES = BK * BM * 4;          // 8 KB
 constexpr int F32T_B_BYTES = BK * F32_BN * 4;      // 16 KB
 constexpr int F32T_STAGE = F32T_A_BYTES + F32T_B_BYTES;
-constexpr int F32T_NSTAGE = 3;
+// Four stages = 96 KB of LDS: at most ONE of these workgroups per CU, on purpose (model.hip, split_k: the launches share
+// every CU with the kernels of the main stream for the whole of backward; 52 KB stay free for one of theirs).
+#ifndef CN_TN_STAGES
+#define CN_TN_STAGES 4
+#endif
+constexpr int F32T_NSTAGE = CN_TN_STAGES;
 
 template <bool B_ACT>
 __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const CartnetGemmArgs p, const GemmFlags fl) {

@@ -13,6 +13,8 @@ void launch_x3nn(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3
   else hipLaunchKernelGGL((cn_gemm_x3nn_kernel<false, true>), grid, dim3(NTHREADS), 0, st, a, fl);
 }
 
+// (Round 4: padding these to one workgroup per CU, as cn_gemm_f32tn_kernel is by its four stages, measured no gain at
+//  bf16x3 -- 10.48-10.51 vs 10.48 ms -- and a loss with bf16 storage, 6.41 vs 6.34 ms: not done.)
 void launch_x3tn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st) {
   const bool one = fl.x3 == 2;
   if (b_act) {

@@ -24,8 +24,19 @@ struct Carver {
   }
 };
 
+// Split-K of the weight-gradient products: ONE workgroup per CU (256), not two.  Round 4, same-box A B A B: the step
+// 14.63 / 14.92 -> 14.08 / 14.14 ms (fp32), 10.68 -> 10.59 (bf16x3), 6.55 -> 6.32 (bf16 + bf16 storage).  These launches
+// live on the weight-gradient stream for the whole of backward; with 512 long-lived workgroups they took BOTH slots of
+// every CU whenever the main stream's kernel retired, and every kernel of the critical chain -- above all its ~30 small
+// ones -- then waited for a slot (rocprof: 5 us finalisers reading 38 us in-step).  One resident workgroup per CU runs the
+// matrix pipe as well as two (0.97 of it alone, profiles/r03_exp_phases.md) and leaves the other half of every CU's
+// registers to the chain that the step's length depends on.  cn_gemm_f32tn_kernel enforces it with its LDS footprint
+// (four stages = 96 KB: a second one does not fit, gemm_f32.h), which is also one more K-step of prefetch.
+#ifndef CN_WGRAD_TARGET
+#define CN_WGRAD_TARGET 256
+#endif
 inline int split_k(long long K, int tiles) {
-  long long s = (512 + tiles - 1) / tiles;
+  long long s = (CN_WGRAD_TARGET + tiles - 1) / tiles;
   if (s > K / 256) s = K / 256;
   if (s < 1) s = 1;
   return (int)s;
