@@ -26,6 +26,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+import ctypes as C
+
 from . import ops
 from . import lib as _l
 from .model import BN_EPS, BN_MOMENTUM, Cholesky_head, N_ATOM_TYPES
@@ -876,6 +878,118 @@ class _IComformerFunction(torch.autograd.Function):
         return (None, None, None) + tuple(G.get(n) for n in model._param_names)
 
 
+def _fill_icf_params(dst: "_l.IcfParams", T: Dict[str, torch.Tensor]) -> None:
+    """Point a CartnetIcfParams struct at the tensors of a reference-layout name -> tensor mapping."""
+    for field, key in _l.ICF_TOP_KEYS.items():
+        setattr(dst, field, T[key].data_ptr())
+    for l in range(5):
+        conv = dst.att[l] if l < 4 else dst.edge
+        pre = f"att_layers.{l}." if l < 4 else "edge_update_layer."
+        for field, key in _l.ICF_CONV_KEYS.items():
+            t = T.get(pre + key)
+            setattr(conv, field, t.data_ptr() if t is not None else None)       # the edge layer's lin_edge has no bias
+        if l == 4:
+            for i in range(3):
+                conv.key_e_w[i] = T[pre + f"lin_key_e{i + 1}.weight"].data_ptr()
+                conv.key_e_b[i] = T[pre + f"lin_key_e{i + 1}.bias"].data_ptr()
+                conv.value_e_w[i] = T[pre + f"lin_value_e{i + 1}.weight"].data_ptr()
+                conv.value_e_b[i] = T[pre + f"lin_value_e{i + 1}.bias"].data_ptr()
+
+
+class _IcfNativeFunction(torch.autograd.Function):
+    """iComformer forward / backward as ONE call into libcartnet_hip.so each (cartnet_icomformer_forward / _backward,
+    csrc/icomformer.hip): the sequence `_IComformerFunction` issues launch by launch from Python (still the eComformer
+    path), in C++ over one workspace.  ``params`` follow ``model._param_names``."""
+
+    @staticmethod
+    def forward(ctx, model: "iComformer", batch, training: bool, *params):
+        lib = _l.load()
+        P: Dict[str, torch.Tensor] = dict(zip(model._param_names, params))
+        B: Dict[str, torch.Tensor] = dict(model.named_buffers())
+        need_grad = bool(getattr(model, "_grad_mode", True)) and any(ctx.needs_input_grad)
+        C_ = model.dim_in
+        dev = params[0].device
+        z = batch.x
+        if not (torch.is_tensor(z) and z.dtype == torch.int64 and z.dim() == 1):
+            raise ValueError("batch.x must hold int64 atomic numbers [N]")
+        N, E, Bg = int(z.shape[0]), int(batch.edge_index.shape[1]), int(batch.num_graphs)
+        M = int(batch.y.shape[0])
+
+        def dt(t, dtype, numel, name):
+            if not (torch.is_tensor(t) and t.dtype == dtype and t.numel() == numel and t.device == dev):
+                raise ValueError(f"batch.{name}: expected {dtype} with {numel} elements on {dev}")
+            return t.contiguous()
+        keep = [dt(z, torch.int64, N, "x"), dt(batch.batch, torch.int64, N, "batch"),
+                dt(batch.ptr, torch.int64, Bg + 1, "ptr"), dt(batch.edge_index, torch.int64, 2 * E, "edge_index"),
+                dt(batch.cart_dist, torch.float32, E, "cart_dist"), dt(batch.cart_dir, torch.float32, 3 * E, "cart_dir"),
+                dt(batch.temperature, torch.float32, Bg, "temperature"), dt(batch.non_H_mask, torch.bool, N, "non_H_mask"),
+                dt(batch.cell, torch.float32, 9 * Bg, "cell")]
+        bd = _l.BatchDesc()
+        (bd.z, bd.batch, bd.graph_ptr, bd.edge_index, bd.cart_dist, bd.cart_dir, bd.temperature, bd.non_h_mask) = \
+            (t.data_ptr() for t in keep[:8])
+        bd.N, bd.Bg, bd.M, bd.E = N, Bg, M, E
+        for n, t in P.items():
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError(f"parameter {n} must be a contiguous fp32 CUDA tensor")
+        md = _l.IcfModel()
+        md.C, md.n_types, md.gemm_precision = C_, N_ATOM_TYPES, int(model.gemm_precision)
+        md.gamma_rbf, md.gamma_angle = float(model.rbf[0].gamma), float(model.rbf_angle[0].gamma)
+        md.bn_eps, md.bn_momentum = BN_EPS, BN_MOMENTUM
+        md.rbf_centers, md.rbf_angle_centers = B["rbf.0.centers"].data_ptr(), B["rbf_angle.0.centers"].data_ptr()
+        _fill_icf_params(md.p, P)
+        for l in range(5):
+            pre = f"att_layers.{l}." if l < 4 else "edge_update_layer."
+            for which, dst in (("bn", md.att_bn[l] if l < 4 else md.edge_bn),
+                               ("bn_att", md.att_bn_att[l] if l < 4 else md.edge_bn_att)):
+                dst.mean = B[pre + which + ".running_mean"].data_ptr()
+                dst.var = B[pre + which + ".running_var"].data_ptr()
+                dst.nbt = B[pre + which + ".num_batches_tracked"].data_ptr()
+        nbytes = int(lib.cartnet_icomformer_workspace_bytes(C.byref(md), N, E, Bg, M))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        pred = torch.empty((M, 3, 3), dtype=torch.float32, device=dev)
+        x_out = torch.empty((N, C_), dtype=torch.float32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        aux = model._aux_stream_ptr(dev)
+        _l.check(lib.cartnet_icomformer_forward(C.byref(md), C.byref(bd), keep[8].data_ptr(), ws.data_ptr(), nbytes,
+                                                int(training), pred.data_ptr(), x_out.data_ptr(), status.data_ptr(),
+                                                _l.stream_ptr(), aux), "cartnet_icomformer_forward")
+        if model.validate_graph:
+            ops.raise_on_graph_status(int(status.item()))
+        ctx.saved = (model, md, bd, ws, nbytes, keep, x_out, bool(training)) if need_grad else None
+        ctx.mark_non_differentiable(x_out)
+        return pred, x_out
+
+    @staticmethod
+    def backward(ctx, dpred, _dx_unused):
+        if ctx.saved is None:
+            raise RuntimeError("iComformer backward called without saved state")
+        model, md, bd, ws, nbytes, keep, x_out, training = ctx.saved
+        ctx.saved = None
+        lib = _l.load()
+        dpred = dpred.contiguous()
+        dev = dpred.device
+        cache = model.__dict__.get("_grad_cache")
+        if cache is None or cache[0].flat.device != dev:
+            from .model import _GradBuffer
+            G = _GradBuffer(model, dev)
+            G.flat.zero_()                 # lemb / lin_edge_len: declared by the reference, never used -- no gradient
+            gd = _l.IcfParams()
+            _fill_icf_params(gd, G)
+            cache = (G, gd)
+            model.__dict__["_grad_cache"] = cache
+        G, gd = cache
+        _l.check(lib.cartnet_icomformer_backward(C.byref(md), C.byref(bd), ws.data_ptr(), nbytes, int(training),
+                                                 dpred.data_ptr(), x_out.data_ptr(), C.byref(gd), _l.stream_ptr(),
+                                                 model._aux_stream_ptr(dev)), "cartnet_icomformer_backward")
+        sink = getattr(model, "_flat_grad", None)
+        if sink is not None and sink.numel() == G.flat.numel():
+            sink.add_(G.flat)
+            return (None, None, None) + (None,) * len(model._param_names)
+        # (lemb / lin_edge_len: declared by the reference, never used -- no gradient there either)
+        return (None, None, None) + tuple(None if (".lemb." in n or ".lin_edge_len." in n) else G[n].clone()
+                                          for n in model._param_names)
+
+
 class iComformer(nn.Module):
     """iComformer (reference: models/comformer.py:75-132) on the gfx950 kernels.  ``forward(data)`` returns
     ``(pred [M,3,3], data.y)`` and, like the reference, replaces ``data.x`` with the final atom features."""
@@ -898,13 +1012,26 @@ class iComformer(nn.Module):
         self.overlap_weight_gradients = True   # weight-gradient GEMMs on a second stream during backward
         self._flat_grad = None          # set by FlatAdam: backward adds all gradients there in one pass
         self._param_names = [n for n, _ in self.named_parameters()]
+        self._param_shapes = {n: tuple(p.shape) for n, p in self.named_parameters()}
+        self._aux = None
+        # True (default): ONE C-ABI call per direction (csrc/icomformer.hip).  False: the same kernels sequenced from
+        # Python (`_IComformerFunction`, what eComformer uses) -- kept as the cross-check of the C++ sequence
+        self.native_sequence = True
+
+    def _aux_stream_ptr(self, dev):
+        if not getattr(self, "overlap_weight_gradients", True):
+            return None
+        if self._aux is None or self._aux.device != dev:
+            self._aux = torch.cuda.Stream(device=dev)
+        return self._aux.cuda_stream
 
     def forward(self, data):
         params = [p for _, p in self.named_parameters()]
         if not params[0].is_cuda:
             raise RuntimeError("cartnet_amd.iComformer runs only on an AMD GPU (HIP kernels); there is no CPU fallback")
-        self._grad_mode = torch.is_grad_enabled()       # read by _IComformerFunction.forward (grad mode is off in there)
-        pred, x = _IComformerFunction.apply(self, data, self.training, *params)
+        self._grad_mode = torch.is_grad_enabled()       # read by the Function's forward (grad mode is off in there)
+        fn = _IcfNativeFunction if self.native_sequence else _IComformerFunction
+        pred, x = fn.apply(self, data, self.training, *params)
         data.x = x
         return pred, data.y
 

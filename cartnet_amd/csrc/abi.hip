@@ -20,7 +20,8 @@ extern "C" int cartnet_abi_struct_sizes(size_t* out, int32_t capacity) {
   const size_t sizes[] = {sizeof(CartnetGemmArgs), sizeof(CartnetShard),       sizeof(CartnetCollated),
                           sizeof(CartnetGemmProfile), sizeof(CartnetGroups),   sizeof(CartnetLayerParams),
                           sizeof(CartnetLayerBuffers), sizeof(CartnetParams),  sizeof(CartnetModel),
-                          sizeof(CartnetBatch),        sizeof(CartnetGateGemmArgs)};
+                          sizeof(CartnetBatch),        sizeof(CartnetGateGemmArgs),
+                          sizeof(CartnetIcfConv),      sizeof(CartnetIcfParams),    sizeof(CartnetIcfModel)};
   const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
   for (int i = 0; i < n && i < capacity; ++i) out[i] = sizes[i];
   return n;

@@ -2,50 +2,11 @@
 // "Whole-network entry points").  No kernels here -- this file only sequences the launches of the other
 // translation units in the order the reference executes its modules (models/cartnet.py:65-73,142-161,204-274,293-327)
 // and carves every intermediate out of one caller-owned workspace.
-#include "common.h"
-#include <vector>
+#include "model_common.h"
 
 namespace {
+using namespace cn_model;
 
-constexpr int BM_TILE = 128;
-
-inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
-inline int tiles_m(long long M) { return (int)((M + BM_TILE - 1) / BM_TILE); }
-
-struct Carver {
-  char* base;
-  size_t off = 0;
-  template <typename T>
-  T* take(size_t count) {
-    off = align_up(off);
-    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
-    off += count * sizeof(T);
-    return p;
-  }
-};
-
-// Split-K of the weight-gradient products: ONE workgroup per CU (256), not two.  Round 4, same-box A B A B: the step
-// 14.63 / 14.92 -> 14.08 / 14.14 ms (fp32), 10.68 -> 10.59 (bf16x3), 6.55 -> 6.32 (bf16 + bf16 storage).  These launches
-// live on the weight-gradient stream for the whole of backward; with 512 long-lived workgroups they took BOTH slots of
-// every CU whenever the main stream's kernel retired, and every kernel of the critical chain -- above all its ~30 small
-// ones -- then waited for a slot (rocprof: 5 us finalisers reading 38 us in-step).  One resident workgroup per CU runs the
-// matrix pipe as well as two (0.97 of it alone, profiles/r03_exp_phases.md) and leaves the other half of every CU's
-// registers to the chain that the step's length depends on.  cn_gemm_f32tn_kernel enforces it with its LDS footprint
-// (four stages = 96 KB: a second one does not fit, gemm_f32.h), which is also one more K-step of prefetch.
-#ifndef CN_WGRAD_TARGET
-#define CN_WGRAD_TARGET 256
-#endif
-inline int split_k(long long K, int tiles) {
-  long long s = (CN_WGRAD_TARGET + tiles - 1) / tiles;
-  if (s > K / 256) s = K / 256;
-  if (s < 1) s = 1;
-  return (int)s;
-}
-inline int wgrad_tiles(int groups, int M, int N) { return groups * ((M + 127) / 128) * (N > 128 ? (N + 255) / 256 : 1); }
-inline size_t wgrad_slab_floats(int groups, long long K, int M, int N) {
-  const int S = split_k(K, wgrad_tiles(groups, M, N));
-  return S > 1 ? (size_t)groups * S * M * N : 0;
-}
 
 struct Work {
   // graph layout
@@ -307,12 +268,6 @@ inline float* hcol(float* p, size_t elems, bool half) {
 }
 inline const float* hcol(const float* p, size_t elems, bool half) { return hcol(const_cast<float*>(p), elems, half); }
 
-#define RUN(call)            \
-  do {                       \
-    int _rc = (call);        \
-    if (_rc != 0) return _rc; \
-  } while (0)
-
 // outs[g] = dY[g]^T @ (silu?)(X[g]): reduction over `K` rows, split over workgroups, slabs summed in fixed order.
 int wgrad(const float* const* dY, int ldy, const float* const* X, int ldx, float* const* outs, int ldo, long long K,
           int M, int N, int groups, bool b_act, const Work& w, void* st, bool dy_half = false, bool x_half = false) {
@@ -380,42 +335,7 @@ int check_model(const CartnetModel* m, const CartnetBatch* b, const char* who) {
 }  // namespace
 
 namespace {
-// Events that order the weight-gradient stream against the main stream (created once per thread, timing disabled).
-struct EventPool {
-  std::vector<hipEvent_t> ev;
-  size_t next = 0;
-  hipEvent_t get() {
-    if (next == ev.size()) {
-      hipEvent_t e;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-      ev.push_back(e);
-    }
-    return ev[next++];
-  }
-};
 thread_local EventPool g_events;
-
-struct Streams {
-  hipStream_t main, side;
-  bool dual;
-  // after(main) -> side waits; returns 0 on success
-  int fork() {
-    if (!dual) return 0;
-    hipEvent_t e = g_events.get();
-    if (!e || hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return 2;
-    return 0;
-  }
-  hipEvent_t mark_side() {
-    if (!dual) return nullptr;
-    hipEvent_t e = g_events.get();
-    if (!e || hipEventRecord(e, side) != hipSuccess) return nullptr;
-    return e;
-  }
-  int main_waits(hipEvent_t e) {
-    if (!dual || !e) return 0;
-    return hipStreamWaitEvent(main, e, 0) == hipSuccess ? 0 : 2;
-  }
-};
 }  // namespace
 
 extern "C" size_t cartnet_workspace_bytes(const CartnetModel* model, int32_t N, int64_t E, int32_t Bg, int32_t M,
@@ -450,7 +370,8 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
   // next to the layout build and the edge encoder; the main stream waits for them where it needs them and the two
   // streams are joined before the call returns.
   g_events.next = 0;
-  Streams S{(hipStream_t)st, aux_stream ? (hipStream_t)aux_stream : (hipStream_t)st, aux_stream != nullptr && aux_stream != st};
+  Streams S{(hipStream_t)st, aux_stream ? (hipStream_t)aux_stream : (hipStream_t)st, aux_stream != nullptr && aux_stream != st,
+            &g_events};
   void* sw = (void*)S.side;
 #define FORK() do { if (S.fork() != 0) { cartnet_set_error("cartnet_model_forward: stream fork failed"); return 2; } } while (0)
 #define MAIN_WAITS(ev) do { if (S.main_waits(ev) != 0) { cartnet_set_error("cartnet_model_forward: stream wait failed"); return 2; } } while (0)
@@ -723,7 +644,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
   const int E = (int)b.E;
   g_events.next = 0;
   Streams S{(hipStream_t)stream, aux_stream ? (hipStream_t)aux_stream : (hipStream_t)stream,
-            aux_stream != nullptr && aux_stream != stream};
+            aux_stream != nullptr && aux_stream != stream, &g_events};
   void* st = stream;            // main: activation-gradient chain
   void* sw = (void*)S.side;     // side: parameter gradients
 #define FORK() do { if (S.fork() != 0) { cartnet_set_error("cartnet_model_backward: stream fork failed"); return 2; } } while (0)

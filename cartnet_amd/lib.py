@@ -111,6 +111,46 @@ class Model(C.Structure):
                 ("grad_ready", GRADREADY_FN), ("grad_ready_user", C.c_void_p)]
 
 
+_ICF_CONV_FIELDS = ("query_w", "query_b", "key_w", "key_b", "value_w", "value_b", "edge_w", "edge_b", "concate_w",
+                    "concate_b", "key0_w", "key0_b", "key2_w", "key2_b", "msg0_w", "msg0_b", "msg2_w", "msg2_b", "bn_w",
+                    "bn_b", "bn_att_w", "bn_att_b")
+# CartnetIcfConv field -> parameter name below "att_layers.{l}." / "edge_update_layer."
+ICF_CONV_KEYS = {"query_w": "lin_query.weight", "query_b": "lin_query.bias", "key_w": "lin_key.weight", "key_b": "lin_key.bias",
+                 "value_w": "lin_value.weight", "value_b": "lin_value.bias", "edge_w": "lin_edge.weight",
+                 "edge_b": "lin_edge.bias", "concate_w": "lin_concate.weight", "concate_b": "lin_concate.bias",
+                 "key0_w": "key_update.0.weight", "key0_b": "key_update.0.bias", "key2_w": "key_update.2.weight",
+                 "key2_b": "key_update.2.bias", "msg0_w": "lin_msg_update.0.weight", "msg0_b": "lin_msg_update.0.bias",
+                 "msg2_w": "lin_msg_update.2.weight", "msg2_b": "lin_msg_update.2.bias", "bn_w": "bn.weight",
+                 "bn_b": "bn.bias", "bn_att_w": "bn_att.weight", "bn_att_b": "bn_att.bias"}
+ICF_TOP_KEYS = {"embedding": "embedding.weight", "temp_w": "temperature_proj_atom.weight",
+                "temp_b": "temperature_proj_atom.bias", "rbf_w": "rbf.1.weight", "rbf_b": "rbf.1.bias",
+                "rbf_angle_w": "rbf_angle.1.weight", "rbf_angle_b": "rbf_angle.1.bias", "head0_w": "cholesky.MLP.0.weight",
+                "head0_b": "cholesky.MLP.0.bias", "head2_w": "cholesky.MLP.2.weight", "head2_b": "cholesky.MLP.2.bias"}
+
+
+class IcfConv(C.Structure):
+    """CartnetIcfConv (include/cartnet_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in _ICF_CONV_FIELDS] + \
+               [(n, C.c_void_p * 3) for n in ("key_e_w", "key_e_b", "value_e_w", "value_e_b")]
+
+
+class IcfBn(C.Structure):
+    _fields_ = [("mean", C.c_void_p), ("var", C.c_void_p), ("nbt", C.c_void_p)]
+
+
+class IcfParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("embedding", "temp_w", "temp_b", "rbf_w", "rbf_b", "rbf_angle_w", "rbf_angle_b")] + \
+               [("att", IcfConv * 4), ("edge", IcfConv)] + \
+               [(n, C.c_void_p) for n in ("head0_w", "head0_b", "head2_w", "head2_b")]
+
+
+class IcfModel(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("C", "n_types", "gemm_precision", "reserved")] + \
+               [(n, C.c_float) for n in ("gamma_rbf", "gamma_angle", "bn_eps", "bn_momentum")] + \
+               [("rbf_centers", C.c_void_p), ("rbf_angle_centers", C.c_void_p), ("p", IcfParams),
+                ("att_bn", IcfBn * 4), ("att_bn_att", IcfBn * 4), ("edge_bn", IcfBn), ("edge_bn_att", IcfBn)]
+
+
 class Groups(C.Structure):
     """CartnetGroups: BatchNorm groups inside one batch (include/cartnet_hip.h)."""
     _fields_ = [("node_gptr", C.c_void_p), ("edge_gptr", C.c_void_p), ("G", C.c_int32), ("edge_parts", C.c_int32),
@@ -265,6 +305,11 @@ PROTOTYPES = {
                                          c_f32p, c_f32p, C.POINTER(Params), c_stream, c_stream]),
     "cartnet_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_int32, C.c_float, c_stream]),
+    "cartnet_icomformer_workspace_bytes": (C.c_size_t, [C.POINTER(IcfModel), C.c_int32, C.c_int64, C.c_int32, C.c_int32]),
+    "cartnet_icomformer_forward": (C.c_int, [C.POINTER(IcfModel), C.POINTER(BatchDesc), c_f32p, C.c_void_p, C.c_size_t,
+                                             C.c_int32, c_f32p, c_f32p, c_i32p, c_stream, c_stream]),
+    "cartnet_icomformer_backward": (C.c_int, [C.POINTER(IcfModel), C.POINTER(BatchDesc), C.c_void_p, C.c_size_t, C.c_int32,
+                                              c_f32p, c_f32p, C.POINTER(IcfParams), c_stream, c_stream]),
 }
 
 
@@ -291,7 +336,7 @@ def load() -> C.CDLL:
         raise CartnetHipError(f"{LIB_PATH}: ABI version {lib.cartnet_abi_version()}, this binding is written for "
                               f"{ABI_VERSION} -- rebuild the library (python -m cartnet_amd.build)")
     mirrors = [GemmArgs, Shard, Collated, GemmProfile, Groups, LayerParams, LayerBuffers, Params, Model, BatchDesc,
-               GateGemmArgs]
+               GateGemmArgs, IcfConv, IcfParams, IcfModel]
     sizes = (C.c_size_t * 16)()
     n = lib.cartnet_abi_struct_sizes(sizes, 16)
     if n != len(mirrors):

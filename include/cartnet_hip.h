@@ -34,7 +34,7 @@ const char* cartnet_last_error(void);
 int cartnet_abi_version(void);
 /* sizeof of every struct below, in header order (CartnetGemmArgs, CartnetShard, CartnetCollated, CartnetGemmProfile,
  * CartnetGroups, CartnetLayerParams, CartnetLayerBuffers, CartnetParams, CartnetModel, CartnetBatch,
- * CartnetGateGemmArgs); returns the number of structs.  A binding checks its mirrors against these when it loads the
+ * CartnetGateGemmArgs, CartnetIcfConv, CartnetIcfParams, CartnetIcfModel); returns the number of structs.  A binding checks its mirrors against these when it loads the
  * library, and cartnet_abi_version() against the version it was written for (7: tile_policy in CartnetGemmArgs,
  * aux_stream in cartnet_model_forward, CartnetGateGemmArgs in the size table; cartnet_gemm_tile_policy() is gone). */
 int cartnet_abi_struct_sizes(size_t* out, int32_t capacity);
@@ -707,6 +707,63 @@ int cartnet_model_forward(const CartnetModel* model, const CartnetBatch* batch, 
 int cartnet_model_backward(const CartnetModel* model, const CartnetBatch* batch, void* workspace, size_t workspace_bytes,
                            int32_t training, const float* dpred, const float* x_out, const CartnetParams* grads,
                            void* stream, void* aux_stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * iComformer (BASELINE configs[4]; models/comformer.py:75-132, models/comformer_conv.py:21-193) as ONE host call per
+ * direction, like CartNet above: the embeddings and RBF branches, attention layer 0, the edge-update layer on 3E rows
+ * (edge x lattice vector), attention layers 1-3 and the Cholesky head are sequenced here on the kernels of this library;
+ * every weight image / transposed copy of the step is made by two batched launches at the start of forward.
+ * CartnetIcfConv: one ComformerConv (att_layers.l) or the ComformerConv_edge (edge_update_layer: lin_edge has no bias,
+ *   key_e / value_e are lin_key_e{1,2,3} / lin_value_e{1,2,3}; the two parameters the reference declares and never uses,
+ *   lemb and lin_edge_len, have no field and get no gradient).  CartnetIcfParams is used for parameters and gradients.
+ * cell [Bg,9] comes next to the CartnetBatch (comformer.py:118,120 is the only reader); batch->cart_dir is required.
+ * Workspace: cartnet_icomformer_workspace_bytes(...), untouched between forward and backward of a batch.
+ * aux_stream (optional second hipStream_t): graph-independent preparation in forward; weight gradients and the two
+ * branches nothing on the atom-gradient chain waits for (lin_edge backward, the angle branch) in backward; joined before
+ * the calls return.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct CartnetIcfConv {
+  float *query_w, *query_b, *key_w, *key_b, *value_w, *value_b;      /* lin_query / lin_key / lin_value [C,C], [C]      */
+  float *edge_w, *edge_b;                                            /* lin_edge [C,C], [C] (edge layer: bias NULL)      */
+  float *concate_w, *concate_b;                                      /* lin_concate                                      */
+  float *key0_w, *key0_b, *key2_w, *key2_b;                          /* key_update.0 [C,3C] / .2 [C,C]                   */
+  float *msg0_w, *msg0_b, *msg2_w, *msg2_b;                          /* lin_msg_update.0 / .2                            */
+  float *bn_w, *bn_b, *bn_att_w, *bn_att_b;                          /* BatchNorm affine                                 */
+  float *key_e_w[3], *key_e_b[3], *value_e_w[3], *value_e_b[3];      /* edge layer only, else NULL                       */
+} CartnetIcfConv;
+
+typedef struct CartnetIcfBn {            /* running statistics of one BatchNorm1d (updated in training)                */
+  float* mean; float* var; int64_t* nbt;
+} CartnetIcfBn;
+
+typedef struct CartnetIcfParams {
+  float *embedding;                      /* [n_types, C]                                                               */
+  float *temp_w, *temp_b;                /* temperature_proj_atom [C,1], [C]                                           */
+  float *rbf_w, *rbf_b;                  /* rbf.1 [C, bins = C], [C]       (distances and lattice lengths)             */
+  float *rbf_angle_w, *rbf_angle_b;      /* rbf_angle.1                                                                */
+  CartnetIcfConv att[4];
+  CartnetIcfConv edge;
+  float *head0_w, *head0_b, *head2_w, *head2_b;     /* cholesky.MLP.0 [C/2,C], .2 [6,C/2]                             */
+} CartnetIcfParams;
+
+typedef struct CartnetIcfModel {
+  int32_t C, n_types, gemm_precision, reserved;
+  float gamma_rbf, gamma_angle;          /* RBFExpansion gammas (models/utils.py:118-119)                              */
+  float bn_eps, bn_momentum;
+  const float *rbf_centers, *rbf_angle_centers;     /* [C] each                                                       */
+  CartnetIcfParams p;
+  CartnetIcfBn att_bn[4], att_bn_att[4], edge_bn, edge_bn_att;
+} CartnetIcfModel;
+
+size_t cartnet_icomformer_workspace_bytes(const CartnetIcfModel* model, int32_t N, int64_t E, int32_t Bg, int32_t M);
+/* pred [M,3,3]; x_out [N,C] receives the final atom features (what the reference leaves in data.x). */
+int cartnet_icomformer_forward(const CartnetIcfModel* model, const CartnetBatch* batch, const float* cell,
+                               void* workspace, size_t workspace_bytes, int32_t training, float* pred, float* x_out,
+                               int32_t* status, void* stream, void* aux_stream);
+/* x_out: what forward wrote; grads: one destination per parameter (fresh values, not accumulated). */
+int cartnet_icomformer_backward(const CartnetIcfModel* model, const CartnetBatch* batch, void* workspace,
+                                size_t workspace_bytes, int32_t training, const float* dpred, const float* x_out,
+                                const CartnetIcfParams* grads, void* stream, void* aux_stream);
 
 /* Fused Adam step over a flat fp32 parameter buffer (torch.optim.Adam semantics, reference main.py:208):
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr * (m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps).

@@ -38,7 +38,7 @@ def test_ctypes_mirrors_have_the_c_struct_layouts():
     sizes = (ctypes.c_size_t * 16)()
     n = l.cartnet_abi_struct_sizes(sizes, 16)
     mirrors = [lib.GemmArgs, lib.Shard, lib.Collated, lib.GemmProfile, lib.Groups, lib.LayerParams, lib.LayerBuffers,
-               lib.Params, lib.Model, lib.BatchDesc, lib.GateGemmArgs]
+               lib.Params, lib.Model, lib.BatchDesc, lib.GateGemmArgs, lib.IcfConv, lib.IcfParams, lib.IcfModel]
     assert n == len(mirrors)
     assert [ctypes.sizeof(m) for m in mirrors] == list(sizes[:n])
     assert lib.GemmArgs.tile_policy.offset + 8 == ctypes.sizeof(lib.GemmArgs)                       # last field + tail padding

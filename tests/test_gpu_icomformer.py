@@ -139,3 +139,36 @@ def test_properties_at_the_adp_shape(precision):
         assert torch.isfinite(g).all(), k
         assert torch.equal(g, outs[1][1][k]), k
     assert sum(float(g.abs().sum()) for g in outs[0][1].values()) > 0
+
+
+def test_native_sequence_equals_the_python_sequence():
+    """cartnet_icomformer_forward / _backward (csrc/icomformer.hip: one C-ABI call per direction) against the same kernels
+    sequenced launch by launch from Python (`native_sequence = False`, the path eComformer still takes): predictions,
+    every gradient and the BatchNorm buffers, at a golden width (no weight images) and at C = 256 (DMA-fed kernels)."""
+    from cartnet_amd.comformer import iComformer, make_icomformer_state_dict
+    from cartnet_amd.data import Batch
+    from cartnet_amd.synthetic import make_crystal
+    b = Batch.from_data_list([make_crystal(960 + i, 10 + 7 * i) for i in range(3)])
+    for width in (32, 256):
+        sd = make_icomformer_state_dict(width, seed=11)
+        res = []
+        for native in (True, False):
+            m = iComformer(width)
+            m.load_state_dict(sd)
+            m.native_sequence = native
+            m = m.to("cuda:0").train()
+            pred, true = m(_clone(b).to("cuda:0"))
+            (pred - true).abs().mean().backward()
+            res.append((pred.detach(), {k: p.grad for k, p in m.named_parameters()}, m.state_dict()))
+        (p1, g1, s1), (p2, g2, s2) = res
+        assert rel_err(p1, p2) < 2e-6, width
+        gmax = max(float(g.abs().max()) for g in g2.values() if g is not None)
+        for k in g2:
+            assert (g1[k] is None) == (g2[k] is None), k
+            if g2[k] is not None:
+                assert float((g1[k] - g2[k]).abs().max()) <= 5e-6 * gmax, (width, k)
+        for k in s2:
+            if "running" in k:
+                assert rel_err(s1[k], s2[k]) < 1e-6, k
+            elif "num_batches" in k:
+                assert int(s1[k]) == int(s2[k]), k
