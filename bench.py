@@ -148,6 +148,15 @@ def timed_pass(step, fresh, warm: int, steps: int, graphs: int, sampler_factory,
     torch.cuda.synchronize()
     ops.profile_gemm(False)
     gflop = sum(v["flops"] for v in ops.profile_gemm_read().values())
+    # host time to enqueue one step on an IDLE queue (median of 3): over back-to-back steps the host of a C++-sequenced
+    # model runs ahead until the device queue is full and then waits, which is not host work
+    idle = []
+    for b in [fresh() for _ in range(3)]:
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        step(b)
+        idle.append(time.perf_counter() - th)
+    idle.sort()
     sampler = sampler_factory()
     torch.cuda.synchronize()
     prof = None
@@ -173,7 +182,8 @@ def timed_pass(step, fresh, warm: int, steps: int, graphs: int, sampler_factory,
     if not torch.isfinite(loss):
         return None
     out = {"value": round(graphs * world * steps / dt, 2), "unit": "graphs/s", "steps": steps, "warmup": warm,
-           "ms_per_step": round(1e3 * dt / steps, 3), "host_enqueue_ms_per_step": round(1e3 * t_enq / steps, 3),
+           "ms_per_step": round(1e3 * dt / steps, 3), "host_enqueue_ms_per_step": round(1e3 * idle[1], 3),
+           "host_loop_ms_per_step": round(1e3 * t_enq / steps, 3),
            "gemm_flops_per_step": int(gflop),
            "whole_step_frac": round(gflop / (dt / steps) / 1e12 / peak_tflops, 4), "peak_tflops": peak_tflops}
     if tel is not None:

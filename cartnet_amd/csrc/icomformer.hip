@@ -72,6 +72,7 @@ struct IWork {
   float *r_e, *pre_e, *e0, *r_nl, *pre_nl, *NLt, *r_na, *pre_na, *NA;
   // attention layers 0..3 and the edge layer (index 4)
   float *QKV[5], *ea[5], *KPi[4], *KPj[4], *pr[5], *keyb[5], *gs[5], *mr1[5], *aggr[5], *o[5], *mr2[5], *y[5];
+  float* act[5];     // silu(pr), kept by the forward GEMM that activates it (fp32 with images): dW2 then reads a plain operand
   float *KY, *VY, *Ka, *KYb, *bias3;
   // head
   float *hid, *p6;
@@ -124,6 +125,10 @@ IWork icarve(const CartnetIcfModel& m, int N, long long E, int Bg, int M, char* 
     w.ea[l] = c.take<float>(R * C);           // lin_edge output (edge layer: exy)
     if (!edge) { w.KPi[l] = c.take<float>(Nn * 2 * C); w.KPj[l] = c.take<float>(Nn * 2 * C); }
     w.pr[l] = c.take<float>(R * 2 * C); w.keyb[l] = c.take<float>(R * 2 * C); w.gs[l] = c.take<float>(R * 2 * C);
+    // Kept activation.  Rounds 2-3 measured no gain from it on the Python-sequenced path (the cheaper weight gradient sat
+    // on a stream with slack); round 4's trace of the C++ sequence shows the register-staged dY^T silu(X) kernel at 1.36 ms
+    // per launch, 6.8 ms per step, on a side stream the main stream now WAITS for at its joins
+    w.act[l] = (w.use_img && m.gemm_precision == 0) ? c.take<float>(R * 2 * C) : nullptr;
     w.mr1[l] = c.take<float>(2 * C); w.aggr[l] = c.take<float>(S * C); w.o[l] = c.take<float>(S * C);
     w.mr2[l] = c.take<float>(2 * C);
     w.y[l] = (l == 3) ? nullptr : c.take<float>(S * C);     // layer 3 writes the caller's x_out
@@ -343,6 +348,7 @@ int att_forward(const CartnetIcfModel& m, const CartnetIcfConv& P, const Cartnet
     a.A[0] = w.pr[l]; a.A[1] = w.pr[l] + C;
     fwd_operand(a, 0, cw, F_K2, w.use_img); fwd_operand(a, 1, cw, F_M2, w.use_img);
     a.C[0] = w.keyb[l]; a.C[1] = w.gs[l] + C; a.bias[0] = P.key2_b; a.bias[1] = P.msg2_b;
+    if (w.act[l]) { a.a_act_out[0] = w.act[l]; a.a_act_out[1] = w.act[l] + C; }
     RUN(cartnet_gemm(&a, st));
   }
   const float scale = 1.0f / sqrtf((float)C);
@@ -629,7 +635,8 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     const float scale = 1.0f / sqrtf((float)C);
     RUN(cartnet_rowmul_bwd(gs, 2 * C, w.keyb[l], 2 * C, t.q, t.ldq, t.segptr, t.S, C, scale, dq_out, 3 * C, st));  // gs = [dkey | dmsg]
     RUN(colsum(gs, 2 * C, t.R, C, w.pa, g.key2_b, st));
-    RUN(wg({gs, gs + C}, 2 * C, {w.pr[l], w.pr[l] + C}, 2 * C, {g.key2_w, g.msg2_w}, C, t.R, C, C, true));
+    if (w.act[l]) RUN(wg({gs, gs + C}, 2 * C, {w.act[l], w.act[l] + C}, 2 * C, {g.key2_w, g.msg2_w}, C, t.R, C, C, false));
+    else RUN(wg({gs, gs + C}, 2 * C, {w.pr[l], w.pr[l] + C}, 2 * C, {g.key2_w, g.msg2_w}, C, t.R, C, C, true));
     {  // dpr = (gs W2) * silu'(pr), column sums = bias gradients of the first Linears
       CartnetGemmArgs a = gargs(prec, t.R, C, C, 2 * C, C, 2 * C);
       a.ngroups = 2; a.b_kstrided = 1;
