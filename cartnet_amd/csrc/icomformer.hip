@@ -13,7 +13,12 @@
 //   * msg * sigmoid(bn_att(alpha)) + scatter-add = cartnet_gate_scatter_fwd (no envelope, no edge residual);
 //   * softplus(x + bn(lin_concate(out))) = cartnet_softplus_update_fwd;
 //   * the edge layer (comformer_conv.py:156-193) is the same block on 3E rows (edge x lattice vector) in segments of
-//     three; lin_concate is applied after the sum over the three lattice vectors ((sum_i m_i) W^T + 3 b).
+//     three; lin_concate is applied after the sum over the three lattice vectors ((sum_i m_i) W^T + 3 b);
+//   * lin_edge is FOLDED into the row block of key_update.0 / lin_msg_update.0 (round 4): no nonlinearity sits between
+//     ea = e We^T + be and pr = ea W1e^T + ..., so pr = e (W1e We)^T + W1e be + ... with F = W1e We [C, C] and c = W1e be
+//     formed once per step by C x C products.  The row-sized lin_edge product disappears from forward and backward
+//     (d(e) = dpr F directly; dF = dpr^T e is the one row-sized weight gradient; dW1e = dF We^T + db be^T,
+//     dWe = sum W1e^T dF, dbe = sum W1e^T db are C x C): -0.49 of 3.2 TFLOP per step.  Exact in real arithmetic.
 #include "model_common.h"
 
 namespace {
@@ -40,6 +45,13 @@ __global__ void cn_icf_index_kernel(const int* __restrict__ src32, const int64_t
     }
   }
   for (long long g = i0; g <= Bg; g += stride) gedge_ptr[g] = rowptr[(int)graph_ptr[g]];
+}
+
+// out[i, t] += u[i] * v[t]  (C x C block with row stride ldo): the bias part of dW1e = dF We^T + db be^T
+__global__ void cn_icf_rank1_kernel(float* __restrict__ out, int ldo, const float* __restrict__ u, const float* __restrict__ v,
+                                    int C) {
+  const int i = blockIdx.x;
+  for (int t = threadIdx.x; t < C; t += blockDim.x) out[(size_t)i * ldo + t] += u[i] * v[t];
 }
 
 // ---- weight forms of one step -----------------------------------------------------------------------------------------
@@ -71,9 +83,10 @@ struct IWork {
   float *x0, *edge_feat, *nl, *nc;
   float *r_e, *pre_e, *e0, *r_nl, *pre_nl, *NLt, *r_na, *pre_na, *NA;
   // attention layers 0..3 and the edge layer (index 4)
-  float *QKV[5], *ea[5], *KPi[4], *KPj[4], *pr[5], *keyb[5], *gs[5], *mr1[5], *aggr[5], *o[5], *mr2[5], *y[5];
+  float *QKV[5], *KPi[4], *KPj[4], *pr[5], *keyb[5], *gs[5], *mr1[5], *aggr[5], *o[5], *mr2[5], *y[5];
   float* act[5];     // silu(pr), kept by the forward GEMM that activates it (fp32 with images): dW2 then reads a plain operand
   float *KY, *VY, *Ka, *KYb, *bias3;
+  float *Fk[5], *Fm[5], *ck[5], *cm[5], *dFk[5], *dFm[5];    // folded lin_edge (x) W1e per layer: F [C, C], c [C]; gradient temps
   // head
   float *hid, *p6;
   // weights of the step
@@ -86,8 +99,8 @@ struct IWork {
   // backward transients
   float *dhid, *head_parts, *head_tot, *dx_head;
   float *d_o[5], *dres[5], *daggr[5], *dQKV[5], *dpr[5], *sums1[5], *sums2[5];
-  float *dea[4], *de[4], *dKPi[4], *dKPj[4], *dx[4];
-  float *dexy, *dNA, *dKa, *dKYb, *dKY, *dVY, *dNL3, *de_old, *tmpb;
+  float *de[4], *dKPi[4], *dKPj[4], *dx[4];
+  float *dNA, *dKa, *dKYb, *dKY, *dVY, *dNL3, *de_old, *tmpb;
   float *dpre_e, *dpre_nl, *dpre_na, *gw1, *gw2, *gb1, *gb2, *seg_tmp, *dx_emb;
   float *slabs;
   size_t slab_floats;
@@ -122,7 +135,9 @@ IWork icarve(const CartnetIcfModel& m, int N, long long E, int Bg, int M, char* 
     const size_t S = edge ? En : Nn;          // segments (= rows of QKV / aggr / o / y)
     const size_t R = edge ? E3 : En;          // rows of the attention block
     w.QKV[l] = c.take<float>(S * 3 * C);
-    w.ea[l] = c.take<float>(R * C);           // lin_edge output (edge layer: exy)
+    w.Fk[l] = c.take<float>((size_t)C * C); w.Fm[l] = c.take<float>((size_t)C * C);
+    w.ck[l] = c.take<float>(C); w.cm[l] = c.take<float>(C);
+    w.dFk[l] = c.take<float>((size_t)C * C); w.dFm[l] = c.take<float>((size_t)C * C);
     if (!edge) { w.KPi[l] = c.take<float>(Nn * 2 * C); w.KPj[l] = c.take<float>(Nn * 2 * C); }
     w.pr[l] = c.take<float>(R * 2 * C); w.keyb[l] = c.take<float>(R * 2 * C); w.gs[l] = c.take<float>(R * 2 * C);
     // Kept activation.  Rounds 2-3 measured no gain from it on the Python-sequenced path (the cheaper weight gradient sat
@@ -169,11 +184,11 @@ IWork icarve(const CartnetIcfModel& m, int N, long long E, int Bg, int M, char* 
     w.dQKV[l] = c.take<float>(S * 3 * C); w.dpr[l] = c.take<float>(R * 2 * C);
     w.sums1[l] = c.take<float>(2 * C); w.sums2[l] = c.take<float>(2 * C);
     if (!edge) {
-      w.dea[l] = c.take<float>(En * C); w.de[l] = c.take<float>(En * C);
+      w.de[l] = c.take<float>(En * C);
       w.dKPi[l] = c.take<float>(Nn * 2 * C); w.dKPj[l] = c.take<float>(Nn * 2 * C); w.dx[l] = c.take<float>(Nn * C);
     }
   }
-  w.dexy = c.take<float>(E3 * C); w.dNA = c.take<float>(E3 * C); w.dKa = c.take<float>(En * 2 * C);
+  w.dNA = c.take<float>(E3 * C); w.dKa = c.take<float>(En * 2 * C);
   w.dKYb = c.take<float>(B3 * 2 * C); w.dKY = c.take<float>(B3 * C); w.dVY = c.take<float>(B3 * C);
   w.dNL3 = c.take<float>(B3 * C); w.de_old = c.take<float>(En * C); w.tmpb = c.take<float>(C);
   w.dpre_e = c.take<float>(En * C); w.dpre_nl = c.take<float>(B3 * C); w.dpre_na = c.take<float>(E3 * C);
@@ -249,10 +264,12 @@ int check_icf(const CartnetIcfModel* m, const CartnetBatch* b, const char* who) 
 }
 
 // the views of one conv's weights and, with images in use, the requests that build their forms
-void plan_conv(const CartnetIcfConv& q, int C, int prec, bool use_img, ConvW& cw, Jobs& J) {
+void plan_conv(const CartnetIcfConv& q, const float* Fk, const float* Fm, int C, int prec, bool use_img, ConvW& cw, Jobs& J) {
+  // (F_EDGE keeps its slot -- lin_edge itself is no longer applied to rows -- so that the indices stay put; F_K1E / F_M1E
+  //  are the folded matrices F = W1e We)
   const float* W[F_COUNT] = {q.query_w, q.key_w, q.value_w, q.edge_w, q.key0_w, q.msg0_w, q.key0_w + C, q.msg0_w + C,
-                             q.key0_w + 2 * C, q.msg0_w + 2 * C, q.key2_w, q.msg2_w, q.concate_w};
-  const int ld[F_COUNT] = {C, C, C, C, 3 * C, 3 * C, 3 * C, 3 * C, 3 * C, 3 * C, C, C, C};
+                             Fk, Fm, q.key2_w, q.msg2_w, q.concate_w};
+  const int ld[F_COUNT] = {C, C, C, C, 3 * C, 3 * C, 3 * C, 3 * C, C, C, C, C, C};
   for (int f = 0; f < F_COUNT; ++f) { cw.W[f] = W[f]; cw.ldw[f] = ld[f]; }
   if (!use_img) return;
   const size_t ib = img_bytes(prec, C, C);
@@ -263,13 +280,13 @@ void plan_conv(const CartnetIcfConv& q, int C, int prec, bool use_img, ConvW& cw
     J.psrc.push_back(w_); J.pdst.push_back(dst); J.pK.push_back(C); J.pN.push_back(C); J.psk.push_back(ldw); J.psn.push_back(1);
   };
   for (int f = 0; f < F_COUNT; ++f) {
+    if (f == F_EDGE) continue;
     fwd_img(W[f], ld[f], cw.F[f]);
     J.tsrc.push_back(W[f]); J.tdst.push_back(cw.T[f]); J.trows.push_back(C); J.tcols.push_back(C);
     J.tlds.push_back(ld[f]); J.tldd.push_back(C);
   }
   k_img(q.query_w, C, cw.B[B_QKV]); k_img(q.key_w, C, cw.B[B_QKV] + ib); k_img(q.value_w, C, cw.B[B_QKV] + 2 * ib);
-  k_img(q.edge_w, C, cw.B[B_EDGE]);
-  k_img(q.key0_w + 2 * C, 3 * C, cw.B[B_E1]); k_img(q.msg0_w + 2 * C, 3 * C, cw.B[B_E1] + ib);
+  k_img(Fk, C, cw.B[B_E1]); k_img(Fm, C, cw.B[B_E1] + ib);                  // d(rows) = [dpr_k | dpr_m] [Fk; Fm]
   k_img(q.key0_w, 3 * C, cw.B[B_K1I]); k_img(q.msg0_w, 3 * C, cw.B[B_M1I]);
   k_img(q.key2_w, C, cw.B[B_K2]); k_img(q.msg2_w, C, cw.B[B_M2]); k_img(q.concate_w, C, cw.B[B_CAT]);
 }
@@ -330,12 +347,13 @@ struct Att {
 };
 
 int att_forward(const CartnetIcfModel& m, const CartnetIcfConv& P, const CartnetIcfBn& bn_att, const ConvW& cw, const Att& t,
-                int l, IWork& w, int training, void* st) {
+                int l, const float* rows_in, IWork& w, int training, void* st) {
   const int C = m.C, prec = m.gemm_precision;
-  {  // pr = ea W1[:, 2C:]^T + term_i[idx_i] + term_j[idx_j]      (key | msg)
+  {  // pr = rows_in F^T + c + term_i[idx_i] + term_j[idx_j]      (key | msg; F = W1[:, 2C:] We: lin_edge folded in)
     CartnetGemmArgs a = gargs(prec, t.R, C, C, C, C, 2 * C);
     a.ngroups = 2; fwd_form(a, cw, F_K1E, C, w.use_img);
-    a.A[0] = w.ea[l]; a.A[1] = w.ea[l];
+    a.A[0] = rows_in; a.A[1] = rows_in;
+    if (P.edge_b) { a.bias[0] = w.ck[l]; a.bias[1] = w.cm[l]; }
     fwd_operand(a, 0, cw, F_K1E, w.use_img); fwd_operand(a, 1, cw, F_M1E, w.use_img);
     a.C[0] = w.pr[l]; a.C[1] = w.pr[l] + C;
     a.gather_i[0] = t.term_i; a.gather_i[1] = t.term_i + C; a.gather_j[0] = t.term_j; a.gather_j[1] = t.term_j + C;
@@ -384,7 +402,24 @@ extern "C" int cartnet_icomformer_forward(const CartnetIcfModel* model, const Ca
   // ---- weight forms of the step: every transposed copy and every image, two batched launches (side stream)
   Jobs& J = g_jobs;
   J.clear();
-  for (int l = 0; l < 5; ++l) plan_conv(l < 4 ? P.att[l] : P.edge, C, prec, w.use_img, w.cw[l], J);
+  for (int l = 0; l < 5; ++l) {
+    const CartnetIcfConv& q = l < 4 ? P.att[l] : P.edge;
+    {  // F{k,m} = W1{k,m}[:, 2C:] We   (C x C x C each, two groups)
+      CartnetGemmArgs a = gargs(0, C, C, C, 3 * C, C, C);
+      a.ngroups = 2; a.b_kstrided = 1; a.tile_policy = 0;
+      a.A[0] = q.key0_w + 2 * C; a.A[1] = q.msg0_w + 2 * C; a.B[0] = q.edge_w; a.B[1] = q.edge_w;
+      a.C[0] = w.Fk[l]; a.C[1] = w.Fm[l];
+      RUN(cartnet_gemm(&a, sw));
+    }
+    if (q.edge_b) {   // c{k,m} = W1{k,m}[:, 2C:] be   (one row times W^T)
+      CartnetGemmArgs a = gargs(0, 1, C, C, C, 3 * C, C);
+      a.ngroups = 2; a.tile_policy = 0;
+      a.A[0] = q.edge_b; a.A[1] = q.edge_b; a.B[0] = q.key0_w + 2 * C; a.B[1] = q.msg0_w + 2 * C;
+      a.C[0] = w.ck[l]; a.C[1] = w.cm[l];
+      RUN(cartnet_gemm(&a, sw));
+    }
+    plan_conv(q, w.Fk[l], w.Fm[l], C, prec, w.use_img, w.cw[l], J);
+  }
   if (w.use_img) {
     for (int i = 0; i < 2; ++i) {
       const float* W_ = i ? P.rbf_angle_w : P.rbf_w;
@@ -439,12 +474,6 @@ extern "C" int cartnet_icomformer_forward(const CartnetIcfModel* model, const Ca
       a.bias[0] = q.query_b; a.bias[1] = q.key_b; a.bias[2] = q.value_b;
       RUN(cartnet_gemm(&a, st));
     }
-    {  // ea = lin_edge(e)
-      CartnetGemmArgs a = gargs(prec, E, C, C, C, C, C);
-      fwd_form(a, cw, F_EDGE, C, w.use_img);
-      a.A[0] = e; a.C[0] = w.ea[l]; a.bias[0] = q.edge_b; fwd_operand(a, 0, cw, F_EDGE, w.use_img);
-      RUN(cartnet_gemm(&a, st));
-    }
     {  // node terms of key_update.0 / lin_msg_update.0: KPi = [k W1k_i^T + b | v W1m_i^T + b], KPj = [k W1k_j^T | v W1m_j^T]
       CartnetGemmArgs a = gargs(prec, N, C, C, 3 * C, C, 2 * C);
       a.ngroups = 4; fwd_form(a, cw, F_K1I, C, w.use_img);
@@ -457,7 +486,7 @@ extern "C" int cartnet_icomformer_forward(const CartnetIcfModel* model, const Ca
       RUN(cartnet_gemm(&a, st));
     }
     Att t{E, N, w.rowptr, w.tgt32, w.src32, w.KPi[l], w.KPj[l], w.QKV[l], 3 * C, (long long)b.E, w.gp_n, w.sp_n};
-    RUN(att_forward(m, q, m.att_bn_att[l], cw, t, l, w, training, st));
+    RUN(att_forward(m, q, m.att_bn_att[l], cw, t, l, e, w, training, st));
     {  // o = lin_concate(aggr) with the BatchNorm statistics over atoms
       CartnetGemmArgs a = gargs(prec, N, C, C, C, C, C);
       fwd_form(a, cw, F_CAT, C, w.use_img);
@@ -491,12 +520,6 @@ extern "C" int cartnet_icomformer_forward(const CartnetIcfModel* model, const Ca
       }
       RUN(cartnet_gemm(&a, st));
     }
-    {  // exy = lin_edge(NA)  (no bias)
-      CartnetGemmArgs a = gargs(prec, 3 * E, C, C, C, C, C);
-      fwd_form(a, cw, F_EDGE, C, w.use_img);
-      a.A[0] = w.NA; a.C[0] = w.ea[l]; fwd_operand(a, 0, cw, F_EDGE, w.use_img);
-      RUN(cartnet_gemm(&a, st));
-    }
     {  // per-edge term
       CartnetGemmArgs a = gargs(prec, E, C, C, 3 * C, C, 2 * C);
       a.ngroups = 2; fwd_form(a, cw, F_K1I, C, w.use_img);
@@ -512,7 +535,7 @@ extern "C" int cartnet_icomformer_forward(const CartnetIcfModel* model, const Ca
       RUN(cartnet_gemm(&a, st));
     }
     Att t{3 * E, E, w.ptr3, w.idx_edge, w.idx_gl, w.Ka, w.KYb, w.QKV[l], 3 * C, 3LL * b.E, w.gp_e, w.sp_e};
-    RUN(att_forward(m, q, m.edge_bn_att, cw, t, l, w, training, st));
+    RUN(att_forward(m, q, m.edge_bn_att, cw, t, l, w.NA, w, training, st));
     RUN(cartnet_eltwise(3, q.concate_b, nullptr, w.bias3, 1, C, C, 0, C, 3.0f, st));
     {
       CartnetGemmArgs a = gargs(prec, E, C, C, C, C, C);
@@ -562,7 +585,7 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
   const int E = (int)b.E;
   for (int l = 0; l < 5; ++l) {        // the views (the forms themselves were built by forward and are still in the workspace)
     Jobs dummy;
-    plan_conv(l < 4 ? P.att[l] : P.edge, C, prec, false, w.cw[l], dummy);
+    plan_conv(l < 4 ? P.att[l] : P.edge, w.Fk[l], w.Fm[l], C, prec, false, w.cw[l], dummy);
   }
   g_icf_events.next = 0;
   Streams S{(hipStream_t)stream, aux_stream ? (hipStream_t)aux_stream : (hipStream_t)stream,
@@ -649,7 +672,54 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
       float* outs[2] = {g.key0_b, g.msg0_b};
       RUN(cartnet_colsum_finalize(parts, outs, 2, tiles_m(t.R), C, st));
     }
-    return wg({w.dpr[l], w.dpr[l] + C}, 2 * C, {w.ea[l], w.ea[l]}, C, {g.key0_w + 2 * C, g.msg0_w + 2 * C}, 3 * C, t.R, C, C);
+    return 0;
+  };
+
+  // The folded lin_edge: d(rows) = [dpr_k | dpr_m] [Fk; Fm] (+ resid), dF = dpr^T rows (the one row-sized weight gradient),
+  // then the C x C chain rule back to W1[:, 2C:], We and be.  All on the side stream.
+  auto fold_backward = [&](int l, const CartnetIcfConv& q, const CartnetIcfConv& g, const float* rows_in, long long R,
+                           float* d_rows, const float* resid) -> int {
+    const ConvW& cw = w.cw[l];
+    float* dpr = w.dpr[l];
+    FORK();
+    {
+      CartnetGemmArgs a = gargs(prec, (int)R, C, C, 2 * C, C, C);
+      a.nsegs = 2; a.b_kstrided = 1;
+      a.A[0] = dpr; a.A[1] = dpr + C; a.B[0] = w.Fk[l]; a.B[1] = w.Fm[l]; a.C[0] = d_rows; a.resid[0] = resid; a.ldr = C;
+      if (w.use_img) a.b_split_folded = cw.B[B_E1];
+      RUN(cartnet_gemm(&a, sw));
+    }
+    {
+      const float* dY[2] = {dpr, dpr + C};
+      const float* X[2] = {rows_in, rows_in};
+      float* o[2] = {w.dFk[l], w.dFm[l]};
+      RUN(iwgrad(prec, dY, 2 * C, X, C, o, C, R, C, C, 2, false, w, sw));
+    }
+    {  // dW1{k,m}[:, 2C:] = dF We^T
+      CartnetGemmArgs a = gargs(0, C, C, C, C, C, 3 * C);
+      a.ngroups = 2; a.tile_policy = 0;
+      a.A[0] = w.dFk[l]; a.A[1] = w.dFm[l]; a.B[0] = q.edge_w; a.B[1] = q.edge_w;
+      a.C[0] = g.key0_w + 2 * C; a.C[1] = g.msg0_w + 2 * C;
+      RUN(cartnet_gemm(&a, sw));
+    }
+    if (q.edge_b) {   // ... + db be^T  (db = the bias gradients of the first Linears, already summed on the main stream)
+      hipLaunchKernelGGL(cn_icf_rank1_kernel, dim3(C), dim3(256), 0, (hipStream_t)sw, g.key0_w + 2 * C, 3 * C, g.key0_b, q.edge_b, C);
+      hipLaunchKernelGGL(cn_icf_rank1_kernel, dim3(C), dim3(256), 0, (hipStream_t)sw, g.msg0_w + 2 * C, 3 * C, g.msg0_b, q.edge_b, C);
+      CN_LAUNCH_CHECK("cartnet_icomformer_backward (rank-1 update)");
+    }
+    {  // dWe = W1k[:, 2C:]^T dFk + W1m[:, 2C:]^T dFm
+      CartnetGemmArgs a = gargs(0, C, C, C, 3 * C, C, C);
+      a.nsegs = 2; a.a_kstrided = 1; a.b_kstrided = 1; a.tile_policy = 0;
+      a.A[0] = q.key0_w + 2 * C; a.A[1] = q.msg0_w + 2 * C; a.B[0] = w.dFk[l]; a.B[1] = w.dFm[l]; a.C[0] = g.edge_w;
+      RUN(cartnet_gemm(&a, sw));
+    }
+    if (q.edge_b) {   // dbe = W1k[:, 2C:]^T db_k + W1m[:, 2C:]^T db_m   (a row times W)
+      CartnetGemmArgs a = gargs(0, 1, C, C, C, 3 * C, C);
+      a.nsegs = 2; a.b_kstrided = 1; a.tile_policy = 0;
+      a.A[0] = g.key0_b; a.A[1] = g.msg0_b; a.B[0] = q.key0_w + 2 * C; a.B[1] = q.msg0_w + 2 * C; a.C[0] = g.edge_b;
+      RUN(cartnet_gemm(&a, sw));
+    }
+    return 0;
   };
 
   // d(inp) + resid of the query / key / value Linears that share the input `inp`
@@ -680,23 +750,9 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     Att t{E, N, w.rowptr, w.tgt32, w.src32, w.KPi[l], w.KPj[l], w.QKV[l], 3 * C, (long long)b.E, w.gp_n, w.sp_n};
     RUN(att_backward(l, q, g, t, w.daggr[l], w.dQKV[l]));
     float* dpr = w.dpr[l];
-    {  // lin_edge branch: nothing on the chain of atom gradients reads de before the edge layer's backward (or the end)
-      FORK();
-      CartnetGemmArgs a = gargs(prec, E, C, C, 2 * C, 3 * C, C);
-      a.nsegs = 2; a.b_kstrided = 1;
-      a.A[0] = dpr; a.A[1] = dpr + C; a.B[0] = q.key0_w + 2 * C; a.B[1] = q.msg0_w + 2 * C; a.C[0] = w.dea[l];
-      a.colsum[0] = w.cs_side;
-      if (w.use_img) a.b_split_folded = cw.B[B_E1];
-      RUN(cartnet_gemm(&a, sw));
-      double* parts[1] = {w.cs_side};
-      float* outs[1] = {g.edge_b};
-      RUN(cartnet_colsum_finalize(parts, outs, 1, w.tiles_e, C, sw));
-      const float* dY[1] = {w.dea[l]};
-      const float* X[1] = {e_in};
-      float* o[1] = {g.edge_w};
-      RUN(iwgrad(prec, dY, C, X, C, o, C, b.E, C, C, 1, false, w, sw));
-      RUN(dgemm(w.dea[l], C, q.edge_w, C, w.use_img ? cw.B[B_EDGE] : nullptr, w.de[l], C, b.E, C, C, de_acc, C, sw));
-    }
+    // lin_edge (folded into the row block): nothing on the chain of atom gradients reads de before the edge layer's
+    // backward (or the end), so d(e) and the C x C gradients run on the side stream
+    RUN(fold_backward(l, q, g, e_in, b.E, w.de[l], de_acc));
     // node terms: reduce dpr over incoming (target) / outgoing (source) edges
     RUN(cartnet_segment_sum(dpr, 2 * C, w.rowptr, nullptr, N, 2 * C, w.dKPi[l], 2 * C, st));
     RUN(cartnet_segment_sum(dpr, 2 * C, w.colptr, w.perm, N, 2 * C, w.dKPj[l], 2 * C, st));
@@ -728,19 +784,8 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     Att t{3 * E, E, w.ptr3, w.idx_edge, w.idx_gl, w.Ka, w.KYb, w.QKV[l], 3 * C, 3LL * b.E, w.gp_e, w.sp_e};
     RUN(att_backward(l, q, g, t, w.daggr[l], w.dQKV[l]));
     float* dpr = w.dpr[l];
-    {  // angle branch: d(exy) -> lin_edge (no bias) -> dNA; only the RBF backward at the very end reads dNA
-      FORK();
-      CartnetGemmArgs a = gargs(prec, 3 * E, C, C, 2 * C, 3 * C, C);
-      a.nsegs = 2; a.b_kstrided = 1;
-      a.A[0] = dpr; a.A[1] = dpr + C; a.B[0] = q.key0_w + 2 * C; a.B[1] = q.msg0_w + 2 * C; a.C[0] = w.dexy;
-      if (w.use_img) a.b_split_folded = cw.B[B_E1];
-      RUN(cartnet_gemm(&a, sw));
-      const float* dY[1] = {w.dexy};
-      const float* X[1] = {w.NA};
-      float* o[1] = {g.edge_w};
-      RUN(iwgrad(prec, dY, C, X, C, o, C, 3LL * b.E, C, C, 1, false, w, sw));
-      RUN(dgemm(w.dexy, C, q.edge_w, C, w.use_img ? cw.B[B_EDGE] : nullptr, w.dNA, C, 3LL * b.E, C, C, nullptr, 0, sw));
-    }
+    // angle branch (lin_edge folded, no bias): only the RBF backward at the very end reads dNA
+    RUN(fold_backward(l, q, g, w.NA, 3LL * b.E, w.dNA, nullptr));
     // per-edge term (sum over the three lattice vectors) and per-(crystal, lattice vector) term
     RUN(cartnet_segment_sum(dpr, 2 * C, w.ptr3, nullptr, E, 2 * C, w.dKa, 2 * C, st));
     for (int i = 0; i < 3; ++i)

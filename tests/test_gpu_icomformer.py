@@ -161,12 +161,15 @@ def test_native_sequence_equals_the_python_sequence():
             (pred - true).abs().mean().backward()
             res.append((pred.detach(), {k: p.grad for k, p in m.named_parameters()}, m.state_dict()))
         (p1, g1, s1), (p2, g2, s2) = res
-        assert rel_err(p1, p2) < 2e-6, width
+        assert rel_err(p1, p2) < 5e-6, width
         gmax = max(float(g.abs().max()) for g in g2.values() if g is not None)
         for k in g2:
             assert (g1[k] is None) == (g2[k] is None), k
             if g2[k] is not None:
-                assert float((g1[k] - g2[k]).abs().max()) <= 5e-6 * gmax, (width, k)
+                # (the C++ sequence folds lin_edge into the row block of the first Linears: another summation order; biases
+                #  in front of a training-mode BatchNorm have true gradient 0 and carry only rounding noise -- the budget
+                #  is the one every gradient has against the reference, tests/test_gpu_model.py)
+                assert float((g1[k] - g2[k]).abs().max()) <= 3e-5 * gmax, (width, k)
         for k in s2:
             if "running" in k:
                 assert rel_err(s1[k], s2[k]) < 1e-6, k
