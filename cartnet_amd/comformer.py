@@ -2,8 +2,10 @@
 
 Drop-in for ``models/comformer.py:iComformer`` of the reference (same constructor, ``forward(data) -> (pred, true)``,
 ``state_dict`` keys incl. the two parameters the reference declares but never uses, ``lemb`` and ``lin_edge_len``).
-The sub-modules only hold parameters; forward and backward are sequences of libcartnet_hip.so kernels issued from
-``_IComformerFunction`` (this path is orchestrated from Python -- it is a parity case, not the benchmarked path).
+The sub-modules only hold parameters.  iComformer's forward and backward are ONE call into libcartnet_hip.so each
+(``_IcfNativeFunction`` -> cartnet_icomformer_forward / _backward, csrc/icomformer.hip: round 4); the same kernels
+sequenced launch by launch from Python (``_IComformerFunction``) remain as eComformer's path and as the cross-check of the
+C++ sequence (``model.native_sequence = False``).
 
 Mapping onto the kernels (C = dim_in, heads = 1):
   * every Linear = ``cartnet_gemm``; ``key_update`` / ``lin_msg_update`` on ``cat[k_i, k_j, e]`` use the same algebraic
