@@ -253,7 +253,14 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_hnn_kernel(const CartnetG
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                    :: "s"(dst + j * 8192), "v"(b_voff), "s"(src + j * 8192) : "memory", "m0");
   };
+  auto b_issue_slot = [&](int v, int slot) {     // ring slot of x3_one_deep_loop
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds_b + x3_one_slot(slot)), "v"(b_voff), "s"(b_base(v) + wid * 1024) : "memory", "m0");
+  };
   bf16x8 ah[2], am[2], al[2], bh, bm, bl;
+  auto frag_b_slot = [&](int slot, int b) {
+    bh = *reinterpret_cast<const bf16x8*>(lds + x3_one_slot(slot) + X3_A_BYTES + x3_offset(wn * S::WN + b * 32 + li, lh));
+  };
   auto frag_a = [&](int buf) {
     const char* cA = lds + buf * X3_BUF_BYTES;
 #pragma unroll
@@ -313,7 +320,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_hnn_kernel(const CartnetG
     asm volatile("" ::: "memory");
   };
 
-  if (nsteps > 0) {
+  if constexpr (CN_ONE_DEEP) {
+    x3_one_deep_loop<RA>(nsteps, a_issue, a_store, b_issue_slot, frag_a, frag_b_slot, mma);
+  } else if (nsteps > 0) {
     RA r0, r1;
     a_issue(r0, 0);
     b_issue(0, 0);

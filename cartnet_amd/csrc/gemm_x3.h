@@ -49,6 +49,84 @@ __device__ __forceinline__ void x3_epilogue(const CartnetGemmArgs& p, ACC& acc, 
 #undef CN_EPIW
 }
 
+// K-loop of the precision-2 kernels ("ONE": plain bf16 operands, only the first of the three planes of every LDS
+// buffer is in use).  The loop above gives a B tile's DMA one K-step to land, and at precision 2 a K-step is four
+// MFMAs per wave -- the step IS the DMA's latency (~1.2 us; a 156-workgroup, K = 256 product of configs[2] takes 20 us).
+// Here the two unused B planes of both buffers are ring slots: slot s = plane s/2 of buffer s%2, the B tile of K-step v
+// lives in slot v%4 and is issued THREE steps ahead; A tiles wait in four register sets, loaded FOUR steps before the
+// step that writes them to LDS.  Same LDS footprint, same products in the same order (bit-identical results).
+// Memory operations retire in issue order; per step the order is B(u+3), A(u+5), so at the end of step u the ones that
+// may still fly are A(u+3), B(u+2), A(u+4), B(u+3), A(u+5) -- each counted only if it exists.
+#ifndef CN_ONE_DEEP
+#define CN_ONE_DEEP 1
+#endif
+__device__ __forceinline__ void x3_wait_all_but(int n) {
+  switch (n) {
+    case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+  }
+}
+__device__ __forceinline__ unsigned x3_one_slot(int s) { return (s & 1) * X3_BUF_BYTES + (s >> 1) * X3_B_PLANE; }
+
+template <class RA, class AIssue, class AStore, class BIssue, class FragA, class FragB, class Mma>
+__device__ __forceinline__ void x3_one_deep_loop(const int n, AIssue&& a_issue, AStore&& a_store, BIssue&& b_issue_slot,
+                                                 FragA&& frag_a, FragB&& frag_b_slot, Mma&& mma) {
+  RA r0, r1, r2, r3;
+  auto in_flight = [&](int u) {
+    return (u + 3 < n ? 2 : 0) + (u + 2 < n ? 1 : 0) + (u + 4 < n ? 1 : 0) + (u + 5 < n ? 1 : 0);
+  };
+  // r holds the A tile of step u+1 on entry and receives the load of step u+5
+  auto step = [&](auto u4_c, int u, RA& r) {
+    constexpr int U4 = decltype(u4_c)::value;
+    constexpr int CUR = U4 & 1;
+    frag_a(CUR);
+    __builtin_amdgcn_sched_barrier(0);
+    if (u + 1 < n) a_store(r, CUR ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (u + 3 < n) b_issue_slot(u + 3, (U4 + 3) & 3);
+    if (u + 5 < n) a_issue(r, u + 5);
+    __builtin_amdgcn_sched_barrier(0);
+    frag_b_slot(U4, 0);
+    mma(0);
+    frag_b_slot(U4, 1);
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+    x3_wait_all_but(in_flight(u));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  if (n <= 0) return;
+  // head: the order of the steps -3, -2, -1 that never ran.  A product shorter than four K-steps re-reads its last tile
+  // into the registers / slots nobody will use, so that ONE wait with a fixed count covers every length (a wait per
+  // length would make the compiler merge the register sets after it -- with copies of registers still in flight).
+  const int last = n - 1;
+  a_issue(r0, 0);
+  a_issue(r1, min(1, last));
+  b_issue_slot(0, 0);
+  a_issue(r2, min(2, last));
+  b_issue_slot(min(1, last), 1);
+  a_issue(r3, min(3, last));
+  b_issue_slot(min(2, last), 2);
+  asm volatile("s_waitcnt vmcnt(4)" : "+v"(r0), "+v"(r1) :: "memory");     // A(0), A(1), B(0) have landed
+  a_store(r0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if (n > 4) a_issue(r0, 4);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  for (int u = 0; u < n; u += 4) {
+    step(std::integral_constant<int, 0>{}, u, r1);
+    if (u + 1 < n) step(std::integral_constant<int, 1>{}, u + 1, r2);
+    if (u + 2 < n) step(std::integral_constant<int, 2>{}, u + 2, r3);
+    if (u + 3 < n) step(std::integral_constant<int, 3>{}, u + 3, r0);
+  }
+}
+
+
 // C[g] = epilogue(sum_s (silu?)(A[s]) @ B[s]), A fp32 [M, K] row-major (k-contiguous), B given pre-split
 // (p.b_split[s]: image written by cartnet_gemm_split_b for the [K, N] operand).  Requirements (checked on the host):
 // nsegs == 1, K % 16 == 0, N % 256 == 0, A rows 16-byte aligned and M * lda * 4 < 2^32, every epilogue operand
@@ -134,7 +212,14 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                    :: "s"(dst + j * 8192), "v"(b_voff), "s"(src + j * 8192) : "memory", "m0");
   };
+  auto b_issue_slot = [&](int v, int slot) {     // precision 2: ring slot of x3_one_deep_loop
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds_b + x3_one_slot(slot)), "v"(b_voff), "s"(b_base(v) + wid * 1024) : "memory", "m0");
+  };
   bf16x8 ah[2], am[2], al[2], bh, bm, bl;
+  auto frag_b_slot = [&](int slot, int b) {
+    bh = *reinterpret_cast<const bf16x8*>(lds + x3_one_slot(slot) + X3_A_BYTES + x3_offset(wn * S::WN + b * 32 + li, lh));
+  };
   auto frag_a = [&](int buf) {
     const char* cA = lds + buf * X3_BUF_BYTES;
 #pragma unroll
@@ -272,7 +357,11 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
 #undef CN_MMA
 #undef CN_SB
 
-  if (nsteps > 0) {
+  if constexpr (ONE && CN_ONE_DEEP) {
+    CN_STAMP_BEGIN();
+    x3_one_deep_loop<f32x4>(nsteps, a_issue, a_store, b_issue_slot, frag_a, frag_b_slot, mma);
+    CN_STAMP_END();
+  } else if (nsteps > 0) {
     // all of the pipeline head's loads in ONE memory round trip (K-step 0 into a third register set, 1 and 2 into the ring)
     f32x4 r0, r1, rt;
     a_issue(rt, 0);

@@ -183,6 +183,23 @@ def test_gemm_with_weight_images(ops, precision, M, K, N, groups, act):
         assert rel_err(Cs[g], ref) < TOL, g
 
 
+@pytest.mark.parametrize("act", [False, True])
+@pytest.mark.parametrize("M,pad", [(1, 0), (100, 16), (300, 0), (4000, 16)])
+def test_gemm_plain_bf16_operands_every_pipeline_length(ops, M, pad, act):
+    """Precision 2 through the DMA-fed kernel against fp64 on the bf16-rounded operands (what the MFMA multiplies), for
+    every K-loop length from the pipeline head alone (1-3 K-steps: the head re-reads its last tile) over every phase
+    of the four-slot ring to the steady state: 1e-6, i.e. only the fp32 accumulation differs."""
+    for K in (16, 32, 48, 64, 80, 96, 112, 128, 144, 256, 528):
+        X = rnd(M, K + pad, seed=K)
+        x = X[:, :K]
+        W = rnd(256, K, seed=1, scale=0.1)
+        C = torch.full((M, 256), float("nan"), device=dev())
+        ops.gemm([x], [W.t().contiguous()], [C], b_kstrided=True, a_act=act, b_split=ops.split_b([W.t()]), precision=2)
+        a = silu64(x.double()).float() if act else x
+        ref = a.bfloat16().double() @ W.bfloat16().double().t()
+        assert rel_err(C, ref) < (2e-4 if act else 1e-6), K     # the kernel's own SiLU may round a few operands the other way
+
+
 @pytest.mark.parametrize("precision", [0, 1, 2])
 @pytest.mark.parametrize("M,K,N,groups", [(1, 16, 256, 1), (127, 32, 256, 2), (300, 48, 256, 2), (1000, 80, 512, 1),
                                           (33000, 256, 256, 2), (513, 512, 256, 1)])
