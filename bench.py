@@ -276,6 +276,7 @@ def main():
     if args.half_storage:
         model.half_storage = True
     opt = FlatAdam(model, lr=1e-3)
+    opt.direct_grads = True      # (as train_epoch does: the loss reads the parameters through the model only)
     base = build_batch(args.graphs, 100_000 + rank * args.graphs, args.atoms).to(dev)
     N, E = int(base.x.shape[0]), int(base.edge_index.shape[1])
 
@@ -288,6 +289,7 @@ def main():
         return b
 
     from cartnet_amd.train import grouped_loss, compute_loss
+    from cartnet_amd import train as ctrain
 
     # more than one rank (or CARTNET_DIST_FORCE): the gradient all-reduce goes out in buckets under backward (GradSync)
     gsync = cdist.GradSync(opt.flat_grad, measure=True) if (cdist._active() and not icf) else None
@@ -300,11 +302,11 @@ def main():
             loss = compute_loss(pred, true)[0]          # MAE (cfg.loss default), train/metrics.py:26
         if gsync is not None:
             model.grad_sync = gsync
-            loss.backward()
+            ctrain.backward(loss)
             model.grad_sync = None
             scale = gsync.finish()
         else:
-            loss.backward()
+            ctrain.backward(loss)
             scale = cdist.all_reduce_gradients(opt.flat_grad)
         opt.step(scale)
         opt.zero_grad()
@@ -509,7 +511,7 @@ def main():
         def gstep(b):
             pred, true = model(b)
             loss = grouped_loss(pred, true, b, 4)[0]
-            loss.backward()
+            ctrain.backward(loss)
             scale = cdist.all_reduce_gradients(opt.flat_grad)
             opt.step(scale)
             opt.zero_grad()
@@ -591,7 +593,7 @@ def main():
             def f(b):
                 pred, true = mdl(b)
                 loss = compute_loss(pred, true)[0]
-                loss.backward()
+                ctrain.backward(loss)
                 optim.step(cdist.all_reduce_gradients(optim.flat_grad))
                 optim.zero_grad()
                 return loss
@@ -604,6 +606,7 @@ def main():
         jm = CartNet(256, 64, 4, temperature=False, cholesky=False).to(dev).train()
         jm.gemm_precision, jm.half_storage = 2, True
         jopt = FlatAdam(jm, lr=1e-3)
+        jopt.direct_grads = True
         r = timed_pass(train_step_of(jm, jopt), clone_of(jb), 5, 5 * args.sub_steps, 64, new_sampler, 2500.0, ops)
         if r is not None:
             r.update({"workload": f"BASELINE configs[2]: CartNet L=4 D=256 Scalar_head, no temperature, 64 crystals of 2-20 "

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void cn_segment_sum_kernel(const float* __rest
 // into chunks of LONG_CHUNK rows, one wave per (chunk, 256-column slab), and writes one partial row per run of equal
 // segment id at tmp[first position of the run]; pass 2 adds each segment's partial rows in position order.
 constexpr int LONG_CHUNK = 32;
-constexpr int LONG_BATCH = 8;    // independent row loads in flight per wave
+constexpr int LONG_BATCH = 16;   // independent row loads in flight per wave
 
 __global__ __launch_bounds__(256) void cn_segment_long_pass1_kernel(const float* __restrict__ rows, int ld,
                                                                     const int* __restrict__ ptr,
@@ -284,14 +284,16 @@ __global__ __launch_bounds__(256) void cn_segment_long_pass1_kernel(const float*
     const int chunk = (int)(it / slabs);
     const int c = (int)(it % slabs) * 256 + lane * 4;
     const int p0 = chunk * LONG_CHUNK, p1 = min(total, p0 + LONG_CHUNK);
-    // segment of position p0: largest s with ptr[s] <= p0
-    int lo = 0, hi = nseg;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (ptr[mid] <= p0) lo = mid; else hi = mid;
-    }
-    int seg = lo;
-    while (seg + 1 < nseg && ptr[seg + 1] <= p0) ++seg;
+    // Every memory round trip of this wave is a latency nobody hides when the batch is small (736 atoms: 46 waves on the
+    // whole chip), so: the chunk's row numbers in ONE load (lane i holds position p0 + i), and the segment of position p0
+    // = (number of s with ptr[s] <= p0) - 1, counted by the lanes in one or two loads instead of a binary search's seven.
+    const int my_row = (lane < LONG_CHUNK && p0 + lane < p1) ? (perm ? perm[p0 + lane] : p0 + lane) : 0;
+    int below = 0;
+    for (int s0 = 0; s0 < nseg; s0 += 64) below += (s0 + lane < nseg && ptr[s0 + lane] <= p0) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+    int seg = below > 0 ? below - 1 : 0;
+    int next = ptr[seg + 1];         // first position of the next segment (ptr has nseg + 1 entries)
     int run_start = p0;
     f32x4 acc = {0, 0, 0, 0};
     for (int pb = p0; pb < p1; pb += LONG_BATCH) {
@@ -299,20 +301,23 @@ __global__ __launch_bounds__(256) void cn_segment_long_pass1_kernel(const float*
 #pragma unroll
       for (int u = 0; u < LONG_BATCH; ++u) {   // the loads of a batch are independent; the adds below keep position order
         const int p = pb + u;
+        const int r = __shfl(my_row, (p - p0) & 63);
         v[u] = f32x4{0, 0, 0, 0};
-        if (p < p1 && c < W) v[u] = ld4(rows + (size_t)(perm ? perm[p] : p) * ld + c);
+        if (p < p1 && c < W) v[u] = ld4(rows + (size_t)r * ld + c);
       }
 #pragma unroll
       for (int u = 0; u < LONG_BATCH; ++u) {
         const int p = pb + u;
-        if (p >= p1) break;
-        while (seg + 1 <= nseg && p >= ptr[seg + 1]) {   // p starts a new segment: flush the finished run
-          if (p > run_start && c < W) st4(tmp + (size_t)run_start * W + c, acc);
-          acc = f32x4{0, 0, 0, 0};
-          run_start = p;
-          ++seg;
+        if (p < p1) {
+          while (seg + 1 <= nseg && p >= next) {   // p starts a new segment: flush the finished run
+            if (p > run_start && c < W) st4(tmp + (size_t)run_start * W + c, acc);
+            acc = f32x4{0, 0, 0, 0};
+            run_start = p;
+            ++seg;
+            next = seg + 1 <= nseg ? ptr[seg + 1] : 0x7fffffff;
+          }
+          acc += v[u];
         }
-        acc += v[u];
       }
     }
     if (p1 > run_start && c < W) st4(tmp + (size_t)run_start * W + c, acc);

@@ -258,9 +258,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_hnn_kernel(const CartnetG
                  :: "s"(lds_b + x3_one_slot(slot)), "v"(b_voff), "s"(b_base(v) + wid * 1024) : "memory", "m0");
   };
   bf16x8 ah[2], am[2], al[2], bh, bm, bl;
-  auto frag_b_slot = [&](int slot, int b) {
-    bh = *reinterpret_cast<const bf16x8*>(lds + x3_one_slot(slot) + X3_A_BYTES + x3_offset(wn * S::WN + b * 32 + li, lh));
-  };
   auto frag_a = [&](int buf) {
     const char* cA = lds + buf * X3_BUF_BYTES;
 #pragma unroll
@@ -321,7 +318,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_hnn_kernel(const CartnetG
   };
 
   if constexpr (CN_ONE_DEEP) {
-    x3_one_deep_loop<RA>(nsteps, a_issue, a_store, b_issue_slot, frag_a, frag_b_slot, mma);
+    x3_one_deep_loop<RA>(nsteps, lds, x3_offset(wm * S::WM + li, lh), x3_offset(wn * S::WN + li, lh), acc, a_issue, a_store,
+                         b_issue_slot);
   } else if (nsteps > 0) {
     RA r0, r1;
     a_issue(r0, 0);

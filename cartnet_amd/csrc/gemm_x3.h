@@ -50,13 +50,18 @@ __device__ __forceinline__ void x3_epilogue(const CartnetGemmArgs& p, ACC& acc, 
 }
 
 // K-loop of the precision-2 kernels ("ONE": plain bf16 operands, only the first of the three planes of every LDS
-// buffer is in use).  The loop above gives a B tile's DMA one K-step to land, and at precision 2 a K-step is four
-// MFMAs per wave -- the step IS the DMA's latency (~1.2 us; a 156-workgroup, K = 256 product of configs[2] takes 20 us).
-// Here the two unused B planes of both buffers are ring slots: slot s = plane s/2 of buffer s%2, the B tile of K-step v
-// lives in slot v%4 and is issued THREE steps ahead; A tiles wait in four register sets, loaded FOUR steps before the
-// step that writes them to LDS.  Same LDS footprint, same products in the same order (bit-identical results).
-// Memory operations retire in issue order; per step the order is B(u+3), A(u+5), so at the end of step u the ones that
-// may still fly are A(u+3), B(u+2), A(u+4), B(u+3), A(u+5) -- each counted only if it exists.
+// buffer is in use).  The loop of the three-plane kernel gives a B tile's DMA one K-step to land and reads a step's
+// fragments after that step's barrier; at precision 2 a K-step is four MFMAs per wave, so the step was a chain of
+// latencies (barrier -> LDS reads -> MFMAs -> DMA wait: 240 ns hot, more from HBM) and a 156-workgroup, K = 256 product
+// of configs[2] spent more time in sixteen of them than computing.  Here
+//   * the two unused B planes of both buffers are ring slots (slot s = plane s/2 of buffer s%2): the B tile of K-step v
+//     lives in slot v%4, is issued FOUR steps ahead and has landed two steps before it is multiplied;
+//   * A tiles wait in four register sets, loaded four steps before the step that writes them to LDS (buffer v%2);
+//   * the fragments of step u+1 are read during step u, into a second fragment register set, under step u's MFMAs --
+//     after a barrier a wave starts its MFMA chain at once.
+// Same LDS footprint, same products in the same order per accumulator (bit-identical results).  Memory operations retire
+// in issue order; per step the order is B(u+4), A(u+6), so at the end of step u -- when B(u+2) and A(u+3) must be in --
+// the ones that may still fly are A(u+4), B(u+3), A(u+5), B(u+4), A(u+6), each counted only if it exists.
 #ifndef CN_ONE_DEEP
 #define CN_ONE_DEEP 1
 #endif
@@ -72,60 +77,98 @@ __device__ __forceinline__ void x3_wait_all_but(int n) {
 }
 __device__ __forceinline__ unsigned x3_one_slot(int s) { return (s & 1) * X3_BUF_BYTES + (s >> 1) * X3_B_PLANE; }
 
-template <class RA, class AIssue, class AStore, class BIssue, class FragA, class FragB, class Mma>
-__device__ __forceinline__ void x3_one_deep_loop(const int n, AIssue&& a_issue, AStore&& a_store, BIssue&& b_issue_slot,
-                                                 FragA&& frag_a, FragB&& frag_b_slot, Mma&& mma) {
+// a_frag / b_frag: this lane's byte offset of its first A fragment inside an A buffer / first B fragment inside a B slot
+// (x3_offset of the wave tile's first row; the second 32-row fragment is 1 KB further).
+template <class RA, class AIssue, class AStore, class BIssue>
+__device__ __forceinline__ void x3_one_deep_loop(const int n, const char* lds, const int a_frag, const int b_frag,
+                                                 f32x16 (&acc)[2][2], AIssue&& a_issue, AStore&& a_store,
+                                                 BIssue&& b_issue_slot) {
+  using std::integral_constant;
+  using std::true_type;
+  using std::false_type;
   RA r0, r1, r2, r3;
-  auto in_flight = [&](int u) {
-    return (u + 3 < n ? 2 : 0) + (u + 2 < n ? 1 : 0) + (u + 4 < n ? 1 : 0) + (u + 5 < n ? 1 : 0);
+  bf16x8 fa[2][2], fb[2][2];
+  auto frags = [&](auto set_c, auto slot_c) {      // the fragments of the K-step whose B tile lives in ring slot SLOT
+    constexpr int P = decltype(set_c)::value, SLOT = decltype(slot_c)::value;
+    const char* qa = lds + (SLOT & 1) * X3_BUF_BYTES + a_frag;
+    const char* qb = lds + x3_one_slot(SLOT) + X3_A_BYTES + b_frag;
+    fa[P][0] = *reinterpret_cast<const bf16x8*>(qa);
+    fa[P][1] = *reinterpret_cast<const bf16x8*>(qa + 1024);
+    fb[P][0] = *reinterpret_cast<const bf16x8*>(qb);
+    fb[P][1] = *reinterpret_cast<const bf16x8*>(qb + 1024);
   };
-  // r holds the A tile of step u+1 on entry and receives the load of step u+5
-  auto step = [&](auto u4_c, int u, RA& r) {
+  auto mma = [&](auto set_c) {
+    constexpr int P = decltype(set_c)::value;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[P][a], fb[P][b], acc[a][b], 0, 0, 0);
+  };
+  auto in_flight = [&](int u) {
+    return (u + 4 < n ? 2 : 0) + (u + 3 < n ? 1 : 0) + (u + 5 < n ? 1 : 0) + (u + 6 < n ? 1 : 0);
+  };
+  // r holds the A tile of step u+2 on entry and receives the load of step u+6.  FULL: steady state (u + 6 < n), nothing
+  // conditional and a constant wait (the scalar bookkeeping of the general step costs as much as the step's MFMAs).
+  auto step = [&](auto u4_c, auto full_c, int u, RA& r) {
     constexpr int U4 = decltype(u4_c)::value;
-    constexpr int CUR = U4 & 1;
-    frag_a(CUR);
+    constexpr bool FULL = decltype(full_c)::value;
+    constexpr int P = U4 & 1;
+    mma(integral_constant<int, P>{});
     __builtin_amdgcn_sched_barrier(0);
-    if (u + 1 < n) a_store(r, CUR ^ 1);
+    if (FULL || u + 2 < n) a_store(r, P);
     __builtin_amdgcn_sched_barrier(0);
-    if (u + 3 < n) b_issue_slot(u + 3, (U4 + 3) & 3);
-    if (u + 5 < n) a_issue(r, u + 5);
+    if (FULL || u + 4 < n) b_issue_slot(u + 4, U4);
+    if (FULL || u + 6 < n) a_issue(r, u + 6);
     __builtin_amdgcn_sched_barrier(0);
-    frag_b_slot(U4, 0);
-    mma(0);
-    frag_b_slot(U4, 1);
-    mma(1);
+    if (FULL || u + 1 < n) frags(integral_constant<int, P ^ 1>{}, integral_constant<int, (U4 + 1) & 3>{});
     __builtin_amdgcn_sched_barrier(0);
-    x3_wait_all_but(in_flight(u));
+    if constexpr (FULL) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else x3_wait_all_but(in_flight(u));
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
   if (n <= 0) return;
-  // head: the order of the steps -3, -2, -1 that never ran.  A product shorter than four K-steps re-reads its last tile
-  // into the registers / slots nobody will use, so that ONE wait with a fixed count covers every length (a wait per
-  // length would make the compiler merge the register sets after it -- with copies of registers still in flight).
+  // head.  A product shorter than six K-steps re-reads its last tile into the registers / slots nobody will use, so that
+  // ONE wait with a fixed count covers every length (a wait per length makes the compiler merge the register sets
+  // behind it -- with copies of registers whose loads are still in flight).
   const int last = n - 1;
   a_issue(r0, 0);
   a_issue(r1, min(1, last));
-  b_issue_slot(0, 0);
   a_issue(r2, min(2, last));
+  b_issue_slot(0, 0);
   b_issue_slot(min(1, last), 1);
   a_issue(r3, min(3, last));
   b_issue_slot(min(2, last), 2);
-  asm volatile("s_waitcnt vmcnt(4)" : "+v"(r0), "+v"(r1) :: "memory");     // A(0), A(1), B(0) have landed
+  b_issue_slot(min(3, last), 3);
+  asm volatile("s_waitcnt vmcnt(3)" : "+v"(r0), "+v"(r1) :: "memory");     // A(0), A(1), A(2), B(0), B(1) have landed
   a_store(r0, 0);
+  a_store(r1, 1);
   __builtin_amdgcn_sched_barrier(0);
-  if (n > 4) a_issue(r0, 4);
+  a_issue(r0, min(4, last));
+  a_issue(r1, min(5, last));
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  for (int u = 0; u < n; u += 4) {
-    step(std::integral_constant<int, 0>{}, u, r1);
-    if (u + 1 < n) step(std::integral_constant<int, 1>{}, u + 1, r2);
-    if (u + 2 < n) step(std::integral_constant<int, 2>{}, u + 2, r3);
-    if (u + 3 < n) step(std::integral_constant<int, 3>{}, u + 3, r0);
+  frags(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+  // step 0 overwrites A buffer 0 and ring slot 0: every wave must have these fragments first (in the loop a step's
+  // fragments are read BEFORE the barrier that precedes the overwrite; here they can only be read after one)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  int u = 0;
+  for (; u + 10 <= n; u += 4) {      // u + 3 + 6 < n: four steady-state steps
+    step(integral_constant<int, 0>{}, true_type{}, u, r2);
+    step(integral_constant<int, 1>{}, true_type{}, u + 1, r3);
+    step(integral_constant<int, 2>{}, true_type{}, u + 2, r0);
+    step(integral_constant<int, 3>{}, true_type{}, u + 3, r1);
+  }
+  for (; u < n; u += 4) {
+    step(integral_constant<int, 0>{}, false_type{}, u, r2);
+    if (u + 1 < n) step(integral_constant<int, 1>{}, false_type{}, u + 1, r3);
+    if (u + 2 < n) step(integral_constant<int, 2>{}, false_type{}, u + 2, r0);
+    if (u + 3 < n) step(integral_constant<int, 3>{}, false_type{}, u + 3, r1);
   }
 }
-
 
 // C[g] = epilogue(sum_s (silu?)(A[s]) @ B[s]), A fp32 [M, K] row-major (k-contiguous), B given pre-split
 // (p.b_split[s]: image written by cartnet_gemm_split_b for the [K, N] operand).  Requirements (checked on the host):
@@ -217,9 +260,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
                  :: "s"(lds_b + x3_one_slot(slot)), "v"(b_voff), "s"(b_base(v) + wid * 1024) : "memory", "m0");
   };
   bf16x8 ah[2], am[2], al[2], bh, bm, bl;
-  auto frag_b_slot = [&](int slot, int b) {
-    bh = *reinterpret_cast<const bf16x8*>(lds + x3_one_slot(slot) + X3_A_BYTES + x3_offset(wn * S::WN + b * 32 + li, lh));
-  };
   auto frag_a = [&](int buf) {
     const char* cA = lds + buf * X3_BUF_BYTES;
 #pragma unroll
@@ -359,7 +399,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn_kernel(const Cartnet
 
   if constexpr (ONE && CN_ONE_DEEP) {
     CN_STAMP_BEGIN();
-    x3_one_deep_loop<f32x4>(nsteps, a_issue, a_store, b_issue_slot, frag_a, frag_b_slot, mma);
+    x3_one_deep_loop<f32x4>(nsteps, lds, x3_offset(wm * S::WM + li, lh), x3_offset(wn * S::WN + li, lh), acc, a_issue, a_store,
+                            b_issue_slot);
     CN_STAMP_END();
   } else if (nsteps > 0) {
     // all of the pipeline head's loads in ONE memory round trip (K-step 0 into a third register set, 1 and 2 into the ring)

@@ -676,14 +676,15 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       RUN(cartnet_cholesky_head_bwd(w.hid, w.idx, P.head2_w, w.p6, dpred, N, H, w.dhid, w.head_parts, st));
     else
       RUN(cartnet_scalar_head_bwd(w.hid, P.head2_w, b.graph_ptr, b.batch, dpred, N, b.Bg, H, w.dhid, w.head_parts, st));
-    FORK();
+    hipEvent_t dhid_done = S.mark_main();
+    CartnetGemmArgs a = gemm_args(N, D, H, H, D, D);
+    a.A[0] = w.dhid; a.B[0] = P.head0_w; a.C[0] = w.dx[0]; a.b_kstrided = 1; a.b_split[0] = w.i_head0_b;
+    RUN(cartnet_gemm(&a, st));       // (main stream first: see the host-order note in the layer loop)
+    if (S.side_waits(dhid_done) != 0) { cartnet_set_error("cartnet_model_backward: stream fork failed"); return 2; }
     const float* dY[1] = {w.dhid};
     const float* X[1] = {x_out};
     float* o[1] = {G.head0_w};
     RUN(wgrad(dY, H, X, D, o, D, N, H, D, 1, false, w, sw));
-    CartnetGemmArgs a = gemm_args(N, D, H, H, D, D);
-    a.A[0] = w.dhid; a.B[0] = P.head0_w; a.C[0] = w.dx[0]; a.b_kstrided = 1; a.b_split[0] = w.i_head0_b;
-    RUN(cartnet_gemm(&a, st));
   }
   float* dx = w.dx[0];
   float* dx_other = w.dx[1];
@@ -866,10 +867,15 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     // segment sums + the node-term weight gradients go to the side stream UNDER dE and only dX waits for them.  At fp32 the
     // same order measured no better (15.27 vs 15.18 ms: both streams already saturate the chip).
     if (pairs && S.dual) {
-      FORK();
-      RUN(side_w2());
+      // host order: the main stream's dpre and dE are in its queue before the ten launches of the side stream are made
+      // (configs[2]: they are ~60 us of host time, and the main stream sat idle for them between dpre and dE)
+      hipEvent_t apply_done = S.mark_main();      // gs = [dg | ds] is final
       RUN(main_dpre());
-      FORK();
+      hipEvent_t dpre_done = S.mark_main();
+      RUN(main_de_in());
+      if (S.side_waits(apply_done) != 0) { cartnet_set_error("cartnet_model_backward: stream fork failed"); return 2; }
+      RUN(side_w2());
+      if (S.side_waits(dpre_done) != 0) { cartnet_set_error("cartnet_model_backward: stream fork failed"); return 2; }
       RUN(segsums(sw));
       hipEvent_t seg_done = S.mark_side();
       RUN(side_wn());
@@ -877,7 +883,6 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       side_done[l] = S.mark_side();
       if (l == L - 1) RUN(deferred_side_jobs());
       RUN(bucket_ready(l));
-      RUN(main_de_in());
       if (S.main_waits(seg_done) != 0) { cartnet_set_error("cartnet_model_backward: wait failed"); return 2; }
       RUN(main_dx());
     } else {
@@ -902,18 +907,19 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
 
   // ---- encoder: de = d(e0_pre), dx = d(xa_pre)
   {
-    FORK();
-    const float* dY[1] = {de};
-    const bool kept = w.he_act != nullptr;
-    const float* X[1] = {kept ? w.he_act : w.he_pre};
-    float* o[1] = {G.edge2_w};
-    RUN(wgrad(dY, D, X, 2 * D, o, 2 * D, b.E, D, 2 * D, 1, !kept, w, sw, false, half && !kept));
+    hipEvent_t de_done = S.mark_main();
     CartnetGemmArgs a = gemm_args(E, 2 * D, D, D, 2 * D, 2 * D);
     a.A[0] = de; a.B[0] = P.edge2_w; a.C[0] = w.dhe; a.dact[0] = w.he_pre; a.ldd = 2 * D; a.b_kstrided = 1;
     a.dact_half = half;
     a.b_split[0] = w.i_edge2_b;
     a.colsum[0] = w.cs_misc[2];
     RUN(cartnet_gemm(&a, st));       // dhe = d(he_pre)
+    if (S.side_waits(de_done) != 0) { cartnet_set_error("cartnet_model_backward: stream fork failed"); return 2; }
+    const float* dY[1] = {de};
+    const bool kept = w.he_act != nullptr;
+    const float* X[1] = {kept ? w.he_act : w.he_pre};
+    float* o[1] = {G.edge2_w};
+    RUN(wgrad(dY, D, X, 2 * D, o, 2 * D, b.E, D, 2 * D, 1, !kept, w, sw, false, half && !kept));
     // The first edge Linear's gradients stay on the MAIN stream (they need dhe, and the main stream has nothing else of
     // weight left): the weight-gradient stream still holds layer 0's products and dW2 of the encoder at this point, and
     // queueing these behind them left the main stream idle for the last ~0.8 ms of the step (r03 timeline).

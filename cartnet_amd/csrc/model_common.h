@@ -76,6 +76,19 @@ struct Streams {
     if (!e || hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return 2;
     return 0;
   }
+  // the two halves of fork(), for call sites that put the main stream's next kernels in the queue BEFORE spending host
+  // time on the side stream's launches (a batch of tiny crystals is host-paced: what is enqueued first starts first)
+  hipEvent_t mark_main() {
+    if (!dual) return nullptr;
+    hipEvent_t e = pool->get();
+    if (!e || hipEventRecord(e, main) != hipSuccess) return nullptr;
+    return e;
+  }
+  int side_waits(hipEvent_t e) {
+    if (!dual) return 0;
+    if (!e) return 2;
+    return hipStreamWaitEvent(side, e, 0) == hipSuccess ? 0 : 2;
+  }
   hipEvent_t mark_side() {
     if (!dual) return nullptr;
     hipEvent_t e = pool->get();

@@ -119,10 +119,10 @@ class _GradBuffer(dict):
     """All parameter gradients of one backward pass as views of ONE flat buffer (parameter order), so the hand-off to
     the optimiser's flat gradient buffer is a single add instead of one autograd accumulation per parameter."""
 
-    def __init__(self, model, dev):
+    def __init__(self, model, dev, flat=None):
         super().__init__()
         total = sum(math.prod(sh) if len(sh) else 1 for sh in model._param_shapes.values())
-        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev) if flat is None else flat
         off = 0
         for name, sh in model._param_shapes.items():
             k = math.prod(sh) if len(sh) else 1
@@ -225,8 +225,26 @@ class _CartNetFunction(torch.autograd.Function):
             raise RuntimeError("CartNet backward: the loss does not depend on the prediction")
         dpred = dpred.contiguous()
         sink = model._flat_grad
-        cache = model.__dict__.get("_grad_cache")
-        if sink is not None and cache is not None and cache[0].flat.device == dpred.device and \
+        # The optimiser's flat gradient buffer was zeroed by zero_grad() and nothing has been added since (FlatAdam.fresh):
+        # the C side writes every gradient straight into it -- no staging buffer, no accumulation launch.  A second
+        # backward before the next zero_grad() (gradient accumulation) takes the staging path below.
+        owner = model.__dict__.get("_flat_owner")
+        opt = owner() if owner is not None else None
+        direct = opt is not None and getattr(opt, "fresh", False) and sink is not None and opt.flat_grad is sink and \
+            sink.device == dpred.device
+        cache = model.__dict__.get("_grad_direct" if direct else "_grad_cache")
+        if direct:
+            if cache is None or cache[0].flat is not sink:
+                G = _GradBuffer(model, dpred.device, flat=sink)
+                if G.flat.numel() != sum(v.numel() for v in G.values()):
+                    raise RuntimeError("CartNet backward: the optimiser's flat buffer does not match the parameters")
+                gd = _l.Params()
+                _fill_params(gd, G, model.num_layers)
+                cache = (G, gd)
+                model.__dict__["_grad_direct"] = cache
+            G, gd = cache
+            opt.fresh = False
+        elif sink is not None and cache is not None and cache[0].flat.device == dpred.device and \
                 cache[0].flat.numel() == sink.numel():
             G, gd = cache              # reused: its content is added to the sink below, in stream order, before the next use
         else:
@@ -243,7 +261,7 @@ class _CartNetFunction(torch.autograd.Function):
         bucketed = sync is not None and sink is not None and sink.numel() == G.flat.numel() and sync.flat is sink
         gr_cb = None
         if bucketed:
-            gr_cb = _make_grad_ready(model, sync, sink, G.flat)
+            gr_cb = _make_grad_ready(model, sync, sink, None if direct else G.flat)
             md.grad_ready = gr_cb
         rc = lib.cartnet_model_backward(C.byref(md), C.byref(bd), ws.data_ptr(), nbytes, int(training),
                                         dpred.data_ptr(), x_out.data_ptr(), C.byref(gd), _l.stream_ptr(), aux)
@@ -253,8 +271,12 @@ class _CartNetFunction(torch.autograd.Function):
         _l.check(rc, "cartnet_model_backward")
         if bucketed:
             return (None, None, None) + (None,) * len(model._param_names)
+        if direct:
+            return (None, None, None) + (None,) * len(model._param_names)
         if sink is not None and sink.numel() == G.flat.numel():
             sink.add_(G.flat)              # one accumulation into the optimiser's flat gradient buffer
+            if opt is not None:
+                opt.fresh = False
             return (None, None, None) + (None,) * len(model._param_names)
         return (None, None, None) + tuple(G[name] for name in model._param_names)
 
@@ -318,7 +340,8 @@ def _make_grad_ready(model, sync, sink: torch.Tensor, gflat: torch.Tensor):
             # (the caller's stream may be the legacy default stream: a null hipStream_t)
             ext = torch.cuda.ExternalStream(int(stream), device=sink.device) if stream else torch.cuda.default_stream(sink.device)
             with torch.cuda.stream(ext):
-                sink[lo:hi].add_(gflat[lo:hi])
+                if gflat is not None:          # (None: the kernels wrote the fresh flat buffer itself)
+                    sink[lo:hi].add_(gflat[lo:hi])
                 sync.bucket(lo, hi)
             return 0
         except Exception as exc:        # must not propagate through the C frames
@@ -460,9 +483,19 @@ class CartNet(nn.Module):
                 bad = int(word.item())
             free.append(word)
         word = free.pop()
-        word.copy_(status, non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record()
+        aux = self._aux_stream if self.overlap_weight_gradients else None
+        if aux is not None and aux.device == status.device:
+            # every writer of the word (the layout build on the main stream -- the side stream forked behind it --, the CSC
+            # build and the atom encoder on the side stream) precedes this point of the SIDE stream: copy there, so the
+            # main stream's chain of dependent launches is one short (5 us + a launch gap at configs[2] shapes)
+            status.record_stream(aux)          # (the caching allocator must not hand the word out again before the copy)
+            with torch.cuda.stream(aux):
+                word.copy_(status, non_blocking=True)
+                ev.record()
+        else:
+            word.copy_(status, non_blocking=True)
+            ev.record()
         pending.append([word, ev])
         if bad is not None:
             try:

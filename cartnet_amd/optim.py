@@ -7,6 +7,7 @@ Update rule = torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -36,8 +37,16 @@ class FlatAdam:
                 p.grad = self.flat_grad[off:off + k].view(p.shape)       # autograd accumulates in place into the views
                 off += k
         self.params = params
+        # ``direct_grads`` (off by default; cartnet_amd.train.train_epoch and bench.py switch it on): after zero_grad() the
+        # buffer is ``fresh`` -- all zeros, nothing accumulated since -- and a model whose whole backward is one native call
+        # (CartNet) writes its gradients straight into flat_grad instead of adding a staging buffer to it.  Only valid when
+        # nothing else contributes to the parameters' gradients between zero_grad() and that backward: no loss term that
+        # reads the parameters outside the model (an L2 penalty written into the loss), no hand edits of ``p.grad``.
+        self.direct_grads = False
+        self.fresh = False
         if hasattr(model, "_flat_grad") and len(params) == len(list(model.parameters())):
             model._flat_grad = self.flat_grad     # CartNet.backward adds its gradients here in one pass
+            model.__dict__["_flat_owner"] = weakref.ref(self)
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.step_count = 0
         self.param_groups = [{"lr": self.lr}]     # enough of torch's surface for a scheduler / logger to read lr
@@ -48,6 +57,7 @@ class FlatAdam:
 
     def zero_grad(self) -> None:
         self.flat_grad.zero_()
+        self.fresh = bool(self.direct_grads)
         for p in self.params:                      # re-attach views if a caller reset them to None
             if p.grad is None or p.grad.data_ptr() < self.flat_grad.data_ptr():
                 self._reattach()

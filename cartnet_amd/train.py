@@ -48,6 +48,22 @@ class _FusedLoss(torch.autograd.Function):
         return dpred, None
 
 
+_ONES = {}
+
+
+def backward(loss: torch.Tensor) -> None:
+    """``loss.backward()`` for the scalar loss of a training step with the seed gradient taken from a cached device
+    scalar: autograd's own ``ones_like`` is one more launch on the step's critical chain (6 us of a 1.2 ms step at
+    configs[2] shapes).  A non-scalar loss is reduced with ``mean()`` first, as the reference does (train/train.py:183)."""
+    if loss.dim() != 0:
+        loss = loss.mean()
+    key = (loss.device, loss.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    loss.backward(one)
+
+
 def compute_loss(pred: torch.Tensor, true: torch.Tensor):
     """(MAE, MSE) with mean reduction over all elements (train/metrics.py:26-27).  Device tensors go through the fused
     kernels; host tensors (the CPU tests of the loops' bookkeeping) through torch."""
@@ -96,6 +112,8 @@ def train_epoch(loader, model, optimizer, batch_accumulation: int, scheduler: Op
                 device="cuda:0"):
     """One pass over ``loader`` (train/train.py:148-199).  Returns dict(loss, mae, graphs, seconds)."""
     model.train()
+    if hasattr(optimizer, "direct_grads"):
+        optimizer.direct_grads = True               # the loss below depends on the parameters through the model only
     optimizer.zero_grad()
     n_iter = len(loader)
     tot_mae = torch.zeros((), device=device)
@@ -128,7 +146,7 @@ def train_epoch(loader, model, optimizer, batch_accumulation: int, scheduler: Op
             if sync is not None and boundary:
                 model.grad_sync = sync              # this backward reports its buckets; their all-reduces overlap it
             try:
-                loss.mean().backward()              # not divided by the accumulation count (train/train.py:183)
+                backward(loss)                      # not divided by the accumulation count (train/train.py:183)
             finally:
                 if sync is not None:
                     model.grad_sync = None

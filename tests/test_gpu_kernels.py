@@ -197,7 +197,32 @@ def test_gemm_plain_bf16_operands_every_pipeline_length(ops, M, pad, act):
         ops.gemm([x], [W.t().contiguous()], [C], b_kstrided=True, a_act=act, b_split=ops.split_b([W.t()]), precision=2)
         a = silu64(x.double()).float() if act else x
         ref = a.bfloat16().double() @ W.bfloat16().double().t()
-        assert rel_err(C, ref) < (2e-4 if act else 1e-6), K     # the kernel's own SiLU may round a few operands the other way
+        assert rel_err(C, ref) < (1e-3 if act else 1e-6), K     # the kernel's own SiLU may round a few operands the other way
+
+
+@pytest.mark.parametrize("a_dtype", [torch.float32, torch.bfloat16])
+def test_plain_bf16_products_are_bitwise_repeatable_when_the_chip_is_oversubscribed(ops, a_dtype):
+    """2,768 workgroups (two per CU, five rounds of them): waves of a workgroup drift apart by as much as the barriers
+    allow, which is what exposes a missing one -- a first version of the precision-2 K-loop read its first fragments
+    after the head's barrier and overwrote their buffer in step 0 without a second one, and was wrong in ~1 tile per
+    launch at this size while every small case passed.  Fresh weight images per repetition (first touch from HBM)."""
+    M, K, N, groups = 177140, 256, 256, 2
+    X = rnd(M, groups * K + 16, seed=11).to(a_dtype)
+    Xs = [X[:, g * K:(g + 1) * K] for g in range(groups)]
+    Ws = [rnd(N, K, seed=20 + g, scale=0.1) for g in range(groups)]
+    Bt = [w.t().contiguous() for w in Ws]
+    first = None
+    for rep in range(12):
+        imgs = ops.split_b([w.t() for w in Ws])
+        C = [torch.full((M, N), float("nan"), device=dev()) for _ in range(groups)]
+        ops.gemm(Xs, Bt, C, b_kstrided=True, a_act=True, b_split=imgs, precision=2)
+        if first is None:
+            first = C
+            x = Xs[0][:4096].double()
+            ref = silu64(x).float().bfloat16().double() @ Ws[0].bfloat16().double().t()
+            assert rel_err(C[0][:4096], ref) < 2e-3
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(C, first)), rep
 
 
 @pytest.mark.parametrize("precision", [0, 1, 2])

@@ -307,6 +307,33 @@ def test_jarvis_shapes_scalar_head_all_precisions(precision):
         assert perr < PRED_TOL and gerr < GRAD_TOL, (perr, gerr)
 
 
+def test_gradients_written_straight_into_a_fresh_flat_buffer():
+    """FlatAdam.direct_grads: after zero_grad() the native backward writes the optimiser's flat gradient buffer itself
+    (no staging buffer, no accumulation launch) -- bitwise the staged gradients; a second backward before the next
+    zero_grad() accumulates (the staging path), and the flag is off unless a training loop switches it on."""
+    from cartnet_amd.optim import FlatAdam
+    from cartnet_amd.train import backward, compute_loss
+    b, hp, sd = _jarvis_case(n_graphs=16)
+
+    def grads(direct, twice):
+        m = _model(hp, sd, 0).train()
+        opt = FlatAdam(m, lr=1e-3)
+        assert opt.direct_grads is False
+        opt.direct_grads = direct
+        opt.zero_grad()
+        assert opt.fresh is direct
+        for _ in range(2 if twice else 1):
+            pred, true = m(gu.clone_batch(b).to("cuda:0"))
+            backward(compute_loss(pred, true)[0])
+            assert opt.fresh is False
+        assert all(p.grad.data_ptr() >= opt.flat_grad.data_ptr() for p in m.parameters())
+        return opt.flat_grad.clone()
+
+    staged, direct = grads(False, False), grads(True, False)
+    assert staged.abs().max().item() > 0 and torch.equal(staged, direct)
+    assert torch.equal(grads(False, True), grads(True, True))      # second backward: accumulated in both modes
+
+
 def test_bf16_mode_on_adp_config2_fixture():
     """gemm_precision = 2 on the configs[1]-shaped golden fixture: bf16-level agreement, finite, SPD outputs."""
     z, hp, b, sd = gu.load("config2")

@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
 from cartnet_amd.train import compute_loss
+from cartnet_amd import train as ctrain
 from cartnet_amd.config import cfg
 from cartnet_amd.data import Batch
 from cartnet_amd.model import CartNet
@@ -16,6 +17,7 @@ base = Batch.from_data_list([make_crystal(5000 + i, n, adp=False) for i, n in en
 print("N", base.x.shape[0], "E", base.edge_index.shape[1], flush=True)
 model = CartNet(256, 64, 4, temperature=False, cholesky=False).to(dev).train()
 opt = FlatAdam(model, lr=1e-3)
+opt.direct_grads = True
 if "--no-overlap" in sys.argv:
     model.overlap_weight_gradients = False
 print("weight-gradient stream:", model.overlap_weight_gradients, flush=True)
@@ -25,7 +27,7 @@ def fresh():
 def step(b):
     pred, true = model(b)
     loss = compute_loss(pred, true)[0]
-    loss.backward()
+    ctrain.backward(loss)
     opt.step(1.0); opt.zero_grad()
 for prec, half in ((0, False), (1, False), (2, False), (2, True)):
     model.gemm_precision = prec

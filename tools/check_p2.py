@@ -1,7 +1,8 @@
 """Precision-2 (plain bf16 operand) activation x weight products against fp64, every pipeline length: debugging aid for
 the K-loop of cn_gemm_x3nn_kernel<*, true> / cn_gemm_hnn_kernel (CARTNET_LIB selects the build)."""
 import sys, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from cartnet_amd import ops
 
 dev = "cuda"

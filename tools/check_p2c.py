@@ -1,0 +1,37 @@
+"""Debug: run-to-run bitwise stability of the plain precision-2 launch and of the a_act_out launch (races show up as
+elements that differ between repetitions)."""
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from cartnet_amd import ops
+dev = "cuda"
+def rnd(*s, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*s, generator=g) * scale).to(dev)
+for (M, K, N, groups) in ((33000, 256, 256, 2), (9970, 256, 256, 1), (736, 1024, 256, 1), (177140, 256, 256, 2), (177140, 48, 256, 1), (60000, 1024, 512, 1)):
+    X = rnd(M, groups * K + 16, seed=11)
+    Xs = [X[:, g * K:(g + 1) * K] for g in range(groups)]
+    Ws = [rnd(N, K, seed=20 + g, scale=0.1) for g in range(groups)]
+    bs = [rnd(N, seed=30 + g) for g in range(groups)]
+    Bt = [w.t().contiguous() for w in Ws]
+    H = torch.empty_like(X); Hs = [H[:, g * K:(g + 1) * K] for g in range(groups)]
+    first = {}
+    bad = {"plain": 0, "act_out": 0}
+    for rep in range(60):
+        imgs = ops.split_b([w.t() for w in Ws])         # fresh images: the first touch of B comes from HBM
+        for kind in ("plain", "act_out"):
+            C = [torch.full((M, N), float("nan"), device=dev) for _ in range(groups)]
+            kw = dict(a_act_out=Hs) if kind == "act_out" else {}
+            ops.gemm(Xs, Bt, C, b_kstrided=True, a_act=True, bias=bs, b_split=imgs, precision=2, **kw)
+            if kind not in first:
+                first[kind] = C
+            else:
+                d = sum(int((a != b).sum().item()) for a, b in zip(C, first[kind]))
+                if d:
+                    bad[kind] += 1
+                    if bad[kind] <= 3:
+                        g = 0 if (C[0] != first[kind][0]).any() else 1
+                        ne = (C[g] != first[kind][g]); rows = ne.any(1).nonzero().flatten()
+                        print(f"  {kind} rep {rep}: {d} elements differ, group {g}, rows {rows[:6].tolist()} .. {rows[-1].item()}, "
+                              f"cols {ne[rows[0]].nonzero().flatten()[:6].tolist()}", flush=True)
+    same = all(torch.equal(a, b) for a, b in zip(first["plain"], first["act_out"]))
+    print(f"M {M} K {K} groups {groups}: repetitions that differ from the first: {bad}; plain == act_out: {same}", flush=True)

@@ -16,6 +16,10 @@ base = Batch.from_data_list([make_crystal(5000 + i, n, adp=False) for i, n in en
 model = CartNet(256, 64, 4, temperature=False, cholesky=False).to(dev).train()
 model.gemm_precision = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 opt = FlatAdam(model, lr=1e-3)
+opt.direct_grads = True
+if len(sys.argv) > 2:
+    model.half_storage = bool(int(sys.argv[2]))
+from cartnet_amd import train as ctrain
 def fresh():
     b = base.clone(); b.num_graphs = base.num_graphs; b._cartnet_layout = None; b._cartnet_mask_index = None
     return b
@@ -23,7 +27,7 @@ T = {"fwd": 0.0, "loss": 0.0, "bwd": 0.0, "opt": 0.0}
 def step(b):
     t0 = time.perf_counter(); pred, true = model(b)
     t1 = time.perf_counter(); loss = compute_loss(pred, true)[0]
-    t2 = time.perf_counter(); loss.backward()
+    t2 = time.perf_counter(); ctrain.backward(loss)
     t3 = time.perf_counter(); opt.step(1.0); opt.zero_grad()
     t4 = time.perf_counter()
     T["fwd"] += t1 - t0; T["loss"] += t2 - t1; T["bwd"] += t3 - t2; T["opt"] += t4 - t3
