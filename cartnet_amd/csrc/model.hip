@@ -984,3 +984,22 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
 #undef FORK
   return 0;
 }
+
+#ifdef CN_HOST_PROFILE
+#include <cstdio>
+// Prints and resets the per-line host times of this translation unit's RUN(...) statements (diagnostic build only).
+extern "C" int cartnet_debug_host_profile(int32_t calls) {
+  auto& p = cn_model::host_prof();
+  double tot = 0;
+  for (int i = 0; i < 4096; ++i) tot += p.us[i];
+  std::printf("host time inside RUN(...) statements: %.1f us per call over %d calls\n", tot / calls, calls);
+  for (int i = 0; i < 4096; ++i)
+    if (p.n[i]) {
+      std::printf("  line %4d  %7.1f us/call  x%-4.1f  %.90s\n", i, p.us[i] / calls, (double)p.n[i] / calls, p.what[i]);
+      p.us[i] = 0; p.n[i] = 0;
+    }
+  std::fflush(stdout);
+  return 0;
+}
+#endif
+

@@ -45,11 +45,32 @@ inline size_t wgrad_slab_floats(int groups, long long K, int M, int N) {
   const int S = split_k(K, wgrad_tiles(groups, M, N));
   return S > 1 ? (size_t)groups * S * M * N : 0;
 }
+#ifdef CN_HOST_PROFILE
+// Diagnostic build only (tools/host_profile.py): host time of every RUN(...) statement of the sequencing code, by source
+// line, summed over calls; read and reset through cartnet_debug_host_profile.  The product build has none of this.
+}  // namespace cn_model
+#include <chrono>
+namespace cn_model {
+struct HostProf { double us[4096]; long n[4096]; const char* what[4096]; };
+inline HostProf& host_prof() { static HostProf p{}; return p; }
+#define RUN(call)                                                                                   \
+  do {                                                                                              \
+    const auto _t0 = std::chrono::steady_clock::now();                                              \
+    int _rc = (call);                                                                               \
+    const auto _t1 = std::chrono::steady_clock::now();                                              \
+    auto& _p = cn_model::host_prof();                                                               \
+    _p.us[__LINE__ & 4095] += std::chrono::duration<double, std::micro>(_t1 - _t0).count();         \
+    _p.n[__LINE__ & 4095] += 1;                                                                     \
+    _p.what[__LINE__ & 4095] = #call;                                                               \
+    if (_rc != 0) return _rc;                                                                       \
+  } while (0)
+#else
 #define RUN(call)            \
   do {                       \
     int _rc = (call);        \
     if (_rc != 0) return _rc; \
   } while (0)
+#endif
 
 // Events that order the weight-gradient stream against the main stream (created once per thread, timing disabled).
 struct EventPool {
@@ -65,12 +86,28 @@ struct EventPool {
   }
 };
 
+#ifdef CN_HOST_PROFILE
+struct HostProfScope {
+  int slot; const char* what; std::chrono::steady_clock::time_point t0;
+  HostProfScope(int s, const char* w) : slot(s), what(w), t0(std::chrono::steady_clock::now()) {}
+  ~HostProfScope() {
+    auto& p = host_prof();
+    p.us[slot] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    p.n[slot] += 1; p.what[slot] = what;
+  }
+};
+#define CN_PROF_SCOPE(slot, what) cn_model::HostProfScope _scope(slot, what)
+#else
+#define CN_PROF_SCOPE(slot, what)
+#endif
+
 struct Streams {
   hipStream_t main, side;
   bool dual;
   EventPool* pool;      // the calling thread's pool (thread_local in the translation unit that sequences the call)
   // after(main) -> side waits; returns 0 on success
   int fork() {
+    CN_PROF_SCOPE(4001, "Streams::fork (record + wait)");
     if (!dual) return 0;
     hipEvent_t e = pool->get();
     if (!e || hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return 2;
@@ -79,23 +116,27 @@ struct Streams {
   // the two halves of fork(), for call sites that put the main stream's next kernels in the queue BEFORE spending host
   // time on the side stream's launches (a batch of tiny crystals is host-paced: what is enqueued first starts first)
   hipEvent_t mark_main() {
+    CN_PROF_SCOPE(4002, "Streams::mark_main (record)");
     if (!dual) return nullptr;
     hipEvent_t e = pool->get();
     if (!e || hipEventRecord(e, main) != hipSuccess) return nullptr;
     return e;
   }
   int side_waits(hipEvent_t e) {
+    CN_PROF_SCOPE(4003, "Streams::side_waits (wait)");
     if (!dual) return 0;
     if (!e) return 2;
     return hipStreamWaitEvent(side, e, 0) == hipSuccess ? 0 : 2;
   }
   hipEvent_t mark_side() {
+    CN_PROF_SCOPE(4004, "Streams::mark_side (record)");
     if (!dual) return nullptr;
     hipEvent_t e = pool->get();
     if (!e || hipEventRecord(e, side) != hipSuccess) return nullptr;
     return e;
   }
   int main_waits(hipEvent_t e) {
+    CN_PROF_SCOPE(4005, "Streams::main_waits (wait)");
     if (!dual || !e) return 0;
     return hipStreamWaitEvent(main, e, 0) == hipSuccess ? 0 : 2;
   }

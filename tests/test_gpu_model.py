@@ -334,6 +334,45 @@ def test_gradients_written_straight_into_a_fresh_flat_buffer():
     assert torch.equal(grads(False, True), grads(True, True))      # second backward: accumulated in both modes
 
 
+def test_training_helper_backward_without_the_autograd_engine():
+    """cartnet_amd.train.backward runs the two backward functions of the step's two-node graph itself (no engine hand-off)
+    when the graph is exactly compute_loss(CartNet(batch)) with a FlatAdam attached, and falls back to the engine for
+    anything else; both deliver bitwise the same gradients, for either loss."""
+    from cartnet_amd import train as ctrain
+    from cartnet_amd.optim import FlatAdam
+    b, hp, sd = _jarvis_case(n_graphs=16)
+
+    def grads(which, how):
+        m = _model(hp, sd, 0).train()
+        opt = FlatAdam(m, lr=1e-3)
+        opt.zero_grad()
+        pred, true = m(gu.clone_batch(b).to("cuda:0"))
+        loss = ctrain.compute_loss(pred, true)[which]
+        if how == "engine":
+            loss.backward()
+        elif how == "helper":
+            assert ctrain._two_node_backward(loss, torch.ones((), device="cuda:0"))
+            with pytest.raises(RuntimeError):
+                loss.backward()                  # the activations were consumed: a second backward says so
+        else:                                    # one more term in the loss: not the two-node graph
+            loss = loss + 0.0 * pred.sum()
+            assert not ctrain._two_node_backward(loss, torch.ones((), device="cuda:0"))
+            ctrain.backward(loss)
+        return opt.flat_grad.clone()
+
+    for which in (0, 1):
+        ref = grads(which, "engine")
+        assert ref.abs().max().item() > 0
+        assert torch.equal(grads(which, "helper"), ref)
+        assert torch.equal(grads(which, "other"), ref)
+    m = _model(hp, sd, 0).train()                # no FlatAdam: the parameters' .grad come from the engine
+    pred, true = m(gu.clone_batch(b).to("cuda:0"))
+    loss = ctrain.compute_loss(pred, true)[0]
+    assert not ctrain._two_node_backward(loss, torch.ones((), device="cuda:0"))
+    ctrain.backward(loss)
+    assert all(p.grad is not None for p in m.parameters())
+
+
 def test_bf16_mode_on_adp_config2_fixture():
     """gemm_precision = 2 on the configs[1]-shaped golden fixture: bf16-level agreement, finite, SPD outputs."""
     z, hp, b, sd = gu.load("config2")
