@@ -869,15 +869,15 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     if (pairs && S.dual) {
       // host order: the main stream's dpre and dE are in its queue before the ten launches of the side stream are made
       // (configs[2]: they are ~60 us of host time, and the main stream sat idle for them between dpre and dE)
-      hipEvent_t apply_done = S.mark_main();      // gs = [dg | ds] is final
       RUN(main_dpre());
       hipEvent_t dpre_done = S.mark_main();
       RUN(main_de_in());
-      if (S.side_waits(apply_done) != 0) { cartnet_set_error("cartnet_model_backward: stream fork failed"); return 2; }
-      RUN(side_w2());
+      // side stream: the segment sums FIRST (dX waits for them; behind the second Linears' weight gradients they came
+      // ~15 us after dE was done), then the parameter gradients nobody waits for
       if (S.side_waits(dpre_done) != 0) { cartnet_set_error("cartnet_model_backward: stream fork failed"); return 2; }
       RUN(segsums(sw));
       hipEvent_t seg_done = S.mark_side();
+      RUN(side_w2());
       RUN(side_wn());
       RUN(side_w1e());
       side_done[l] = S.mark_side();
