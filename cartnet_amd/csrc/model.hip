@@ -869,15 +869,23 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     if (pairs && S.dual) {
       // host order: the main stream's dpre and dE are in its queue before the ten launches of the side stream are made
       // (configs[2]: they are ~60 us of host time, and the main stream sat idle for them between dpre and dE)
+      // Side-stream order by batch size (same-box A/B, tools/ab_pairs_order.sh).  Full-size batch: the second Linears'
+      // weight gradients first, under dpre -- they need only gs, and the stream would idle until dpre is done (bf16x3 10.37
+      // vs 10.52 ms).  Small batch (configs[2]): every kernel is one tile's latency and dX waits for the segment sums, which
+      // came ~15 us after dE was done when queued behind those weight gradients (1.20 vs 1.17 ms): segment sums first.
+      const bool seg_first = b.E < 32768;
+      hipEvent_t apply_done = seg_first ? nullptr : S.mark_main();      // gs = [dg | ds] is final
       RUN(main_dpre());
       hipEvent_t dpre_done = S.mark_main();
       RUN(main_de_in());
-      // side stream: the segment sums FIRST (dX waits for them; behind the second Linears' weight gradients they came
-      // ~15 us after dE was done), then the parameter gradients nobody waits for
+      if (!seg_first) {
+        if (S.side_waits(apply_done) != 0) { cartnet_set_error("cartnet_model_backward: stream fork failed"); return 2; }
+        RUN(side_w2());
+      }
       if (S.side_waits(dpre_done) != 0) { cartnet_set_error("cartnet_model_backward: stream fork failed"); return 2; }
       RUN(segsums(sw));
       hipEvent_t seg_done = S.mark_side();
-      RUN(side_w2());
+      if (seg_first) RUN(side_w2());
       RUN(side_wn());
       RUN(side_w1e());
       side_done[l] = S.mark_side();
