@@ -195,13 +195,21 @@ __global__ __launch_bounds__(256) void cn_loss_partial_kernel(const float* __res
 // both stages in one launch when one slice covers the input (n <= 4096: the scalar targets of configs[2], 64 per step):
 // the same sums in the same order as stage 1 + stage 2 with nparts = 1, one launch less on the step's critical chain
 __global__ __launch_bounds__(256) void cn_loss_small_kernel(const float* __restrict__ pred, const float* __restrict__ truth,
-                                                            long long n, float* __restrict__ out) {
+                                                            long long n, float* __restrict__ out,
+                                                            float* __restrict__ unit) {
   __shared__ double red[2][4];
   double sa = 0.0, sq = 0.0;
+  const float inv = 1.0f / (float)n;
   for (long long i = threadIdx.x; i < n; i += 256) {
     const double d = (double)pred[i] - (double)truth[i];
     sa += fabs(d);
     sq += d * d;
+    if (unit) {       // the expressions of cn_loss_bwd_kernel with g_mae[0] = 1, g_mse = NULL and the other way round
+      const float df = pred[i] - truth[i];
+      const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+      unit[i] = (1.0f * inv) * sgn + 0.f * df;
+      unit[n + i] = 0.f * sgn + (1.0f * (2.0f * inv)) * df;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -255,7 +263,7 @@ extern "C" int cartnet_loss_fwd(const float* pred, const float* truth, int64_t n
   const int nparts = cartnet_loss_nparts(n);
   if (nparts == 1) {
     hipLaunchKernelGGL(cn_loss_small_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pred, truth,
-                       (long long)n, out2);
+                       (long long)n, out2, static_cast<float*>(nullptr));
     CN_LAUNCH_CHECK("cartnet_loss_fwd");
     return 0;
   }
@@ -264,6 +272,16 @@ extern "C" int cartnet_loss_fwd(const float* pred, const float* truth, int64_t n
   hipLaunchKernelGGL(cn_loss_finalize_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), parts, nparts,
                      (long long)n, out2);
   CN_LAUNCH_CHECK("cartnet_loss_fwd");
+  return 0;
+}
+
+extern "C" int cartnet_loss_fwd_unit(const float* pred, const float* truth, int64_t n, float* out2, float* unit,
+                                     void* stream) {
+  CN_CHECK(pred && truth && out2 && unit && n > 0, "cartnet_loss_fwd_unit: null pointer or n = %lld", (long long)n);
+  CN_CHECK(cartnet_loss_nparts(n) == 1, "cartnet_loss_fwd_unit: n = %lld is more than one slice (4096 elements)", (long long)n);
+  hipLaunchKernelGGL(cn_loss_small_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pred, truth,
+                     (long long)n, out2, unit);
+  CN_LAUNCH_CHECK("cartnet_loss_fwd_unit");
   return 0;
 }
 

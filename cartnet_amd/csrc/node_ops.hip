@@ -552,7 +552,9 @@ __global__ __launch_bounds__(256) void cn_cholesky_head_bwd_kernel(const float* 
   }
 }
 
-// Scalar head: one wave per crystal, atoms in order.
+// Scalar head: one wave per crystal.  The two halves of the wave take alternate atoms, a lane four columns (16-byte
+// loads; H % 4 == 0 as D % 8 == 0): every load of the crystal is independent of every other and ONE wave reduction closes
+// it -- the atom-at-a-time form (a wave sum per atom) was a chain of one memory round trip per atom, 17 us for 2-20 atoms.
 __global__ __launch_bounds__(64) void cn_scalar_head_fwd_kernel(const float* __restrict__ hid,
                                                                 const float* __restrict__ w2,
                                                                 const float* __restrict__ b2,
@@ -560,23 +562,19 @@ __global__ __launch_bounds__(64) void cn_scalar_head_fwd_kernel(const float* __r
                                                                 float* __restrict__ out) {
   const int g = blockIdx.x, lane = threadIdx.x;
   const int n0 = (int)graph_ptr[g], n1 = (int)graph_ptr[g + 1];
-  float tot = 0.f;
   const float bias = b2[0];
-  // eight atoms' loads in flight, then their sums in atom order (one atom at a time was one memory round trip per atom:
-  // 17 us for the 2-20 atoms of a configs[2] crystal)
-  for (int nb = n0; nb < n1; nb += 8) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      v[j] = 0.f;
-      if (nb + j < n1)
-        for (int c = lane; c < H; c += 64) v[j] += cn_silu(hid[(size_t)(nb + j) * H + c]) * w2[c];
+  const int half = lane >> 5, c4 = (lane & 31) * 4;
+  float acc = 0.f;
+  for (int c = c4; c < H; c += 128) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(w2 + c);
+#pragma unroll 4
+    for (int n = n0 + half; n < n1; n += 2) {
+      const f32x4 h = *reinterpret_cast<const f32x4*>(hid + (size_t)n * H + c);
+      acc += cn_silu(h[0]) * w[0] + cn_silu(h[1]) * w[1] + cn_silu(h[2]) * w[2] + cn_silu(h[3]) * w[3];
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (nb + j < n1) tot += wave_sum(v[j]) + bias;
   }
   const int cnt = n1 - n0;
+  const float tot = wave_sum(acc) + (float)cnt * bias;
   if (lane == 0) out[g] = tot / (float)(cnt > 0 ? cnt : 1);
 }
 

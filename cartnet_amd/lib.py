@@ -292,6 +292,7 @@ PROTOTYPES = {
     "cartnet_loss_nparts": (C.c_int32, [C.c_int64]),
     "cartnet_loss_fwd": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_void_p, c_f32p, c_stream]),
     "cartnet_loss_bwd": (C.c_int, [c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_stream]),
+    "cartnet_loss_fwd_unit": (C.c_int, [c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_stream]),
     "cartnet_adp_metrics": (C.c_int, [c_f32p, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, c_f32p, c_f32p, c_stream]),
     "cartnet_collate": (C.c_int, [C.POINTER(Shard), c_i64p, c_i64p, c_i64p, c_i64p, C.c_int32, C.c_int64, C.c_int64,
                                   C.c_int64, c_f32p, C.c_float, C.c_float, C.POINTER(Collated), c_stream]),

@@ -258,6 +258,12 @@ int32_t cartnet_loss_nparts(int64_t n);      /* parts: workspace of 2 * cartnet_
 int cartnet_loss_fwd(const float* pred, const float* truth, int64_t n, double* parts, float* out2, void* stream);
 int cartnet_loss_bwd(const float* pred, const float* truth, int64_t n, const float* g_mae, const float* g_mse,
                      float* dpred, void* stream);
+/* Small inputs (n <= 4096: the scalar targets of a batch, scripts/train_cartnet_jarvis.sh) in ONE launch, which also
+ * writes the gradients of either loss for an upstream gradient of exactly 1 -- what loss.backward() of a training step
+ * (train/train.py:183) feeds in: unit[0..n) = sign(pred - truth) / n, unit[n..2n) = 2 (pred - truth) / n, bit for bit
+ * what cartnet_loss_bwd writes for g_mae[0] = 1 (resp. g_mse[0] = 1).  The caller that knows its seed is 1 then needs
+ * no backward launch.  out2 as cartnet_loss_fwd. */
+int cartnet_loss_fwd_unit(const float* pred, const float* truth, int64_t n, float* out2, float* unit, void* stream);
 
 /* ----------------------------------------------------------------------------------------------------
  * Device-side batching from a packed shard resident in HBM (replaces torch.load of one pickled
