@@ -242,6 +242,36 @@ def test_bitwise_reproducible_and_graph_order_invariant_at_full_size(precision):
     assert rel_err(g3, g1) < 1e-4
 
 
+@pytest.mark.parametrize("half", [False, True])
+def test_bf16_step_is_bitwise_repeatable_on_the_benchmark_batch(half):
+    """Precision 2 (and bf16 storage) on the whole benchmark batch -- 64 crystals x 194 atoms, ~177k edges, every GEMM a
+    few thousand workgroups: forward + backward twice, bit-identical predictions and gradients.  The small fixtures cannot
+    see a missing barrier in a K-loop (waves of a workgroup only drift apart when the chip is oversubscribed)."""
+    from cartnet_amd.data import Batch
+    from cartnet_amd.model import make_state_dict
+    from cartnet_amd.synthetic import make_crystal
+    items = [make_crystal(900 + g, 194) for g in range(64)]
+    hp = dict(dim_in=256, dim_rbf=64, num_layers=4, radius=5.0, invariant=False, temperature=True,
+              use_envelope=True, atom_types=True, cholesky=True)
+    sd = make_state_dict(256, 64, 4, seed=6)
+    m = _model(hp, sd, 2).train()
+    m.half_storage = half
+
+    def run():
+        b = Batch.from_data_list(items).to("cuda:0")
+        m.zero_grad(set_to_none=True)
+        m.load_state_dict(sd)
+        pred, true = m(b)
+        (pred - true).abs().mean().backward()
+        return pred.detach().clone(), torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+
+    p1, g1 = run()
+    assert torch.isfinite(p1).all() and torch.isfinite(g1).all() and g1.abs().max().item() > 0
+    for _ in range(3):
+        p2, g2 = run()
+        assert torch.equal(p1, p2) and torch.equal(g1, g2)
+
+
 def test_product_path_refuses_cpu_tensors():
     z, hp, b, sd = gu.load("tiny_adp")
     from cartnet_amd.model import CartNet
