@@ -11,7 +11,15 @@ constexpr int NODES_PER_BLOCK = 4;
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+// softplus(x) = max(x, 0) + log1p(exp(-|x|)) on the hardware exp / log (the libm log1pf(expf(x)) made the element-wise
+// softplus passes compute-bound: 2.1 TB/s on the 3E x C angle features against 5.2 TB/s for the other element-wise ops).
+// t = exp(-|x|) is in (0, 1]; below 2^-11 the series t - t^2/2 is exact to fp32 where log(1 + t) would lose t's low bits.
+__device__ __forceinline__ float softplus_f(float x) {
+  if (x > 20.f) return x;        // (as torch.nn.functional.softplus: threshold 20)
+  const float t = __expf(-fabsf(x));
+  const float l = t < 4.8828125e-4f ? t - 0.5f * t * t : __logf(1.0f + t);
+  return fmaxf(x, 0.f) + l;
+}
 
 inline int seg_parts(int S) {
   int b = cn_ceil_div(S, NODES_PER_BLOCK);

@@ -99,7 +99,7 @@ struct IWork {
   // backward transients
   float *dhid, *head_parts, *head_tot, *dx_head;
   float *d_o[5], *dres[5], *daggr[5], *dQKV[5], *dpr[5], *sums1[5], *sums2[5];
-  float *de[4], *dKPi[4], *dKPj[4], *dx[4];
+  float *de[4], *dKP[4], *dx[4];       // dKP [N, 4C] = [d(term_i) key | d(term_j) key | d(term_i) msg | d(term_j) msg]
   float *dNA, *dKa, *dKYb, *dKY, *dVY, *dNL3, *de_old, *tmpb;
   float *dpre_e, *dpre_nl, *dpre_na, *gw1, *gw2, *gb1, *gb2, *seg_tmp, *dx_emb;
   float *slabs;
@@ -161,7 +161,9 @@ IWork icarve(const CartnetIcfModel& m, int N, long long E, int Bg, int M, char* 
     }
     w.cw[l].B[B_QKV] = c.take<char>(3 * ib);
     w.cw[l].B[B_E1] = c.take<char>(2 * ib);
-    for (int k : {B_EDGE, B_K1I, B_M1I, B_K2, B_M2, B_CAT}) w.cw[l].B[k] = c.take<char>(ib);
+    w.cw[l].B[B_K1I] = c.take<char>(2 * ib);      // fold: key0[:, :C], key0[:, C:2C]  (the i and j node blocks)
+    w.cw[l].B[B_M1I] = c.take<char>(2 * ib);      // fold: msg0[:, :C], msg0[:, C:2C]
+    for (int k : {B_EDGE, B_K2, B_M2, B_CAT}) w.cw[l].B[k] = c.take<char>(ib);
   }
   if (w.use_img) {
     w.rbfT = c.take<float>((size_t)C * C); w.rbfaT = c.take<float>((size_t)C * C);
@@ -185,7 +187,7 @@ IWork icarve(const CartnetIcfModel& m, int N, long long E, int Bg, int M, char* 
     w.sums1[l] = c.take<float>(2 * C); w.sums2[l] = c.take<float>(2 * C);
     if (!edge) {
       w.de[l] = c.take<float>(En * C);
-      w.dKPi[l] = c.take<float>(Nn * 2 * C); w.dKPj[l] = c.take<float>(Nn * 2 * C); w.dx[l] = c.take<float>(Nn * C);
+      w.dKP[l] = c.take<float>(Nn * 4 * C); w.dx[l] = c.take<float>(Nn * C);
     }
   }
   w.dNA = c.take<float>(E3 * C); w.dKa = c.take<float>(En * 2 * C);
@@ -288,6 +290,7 @@ void plan_conv(const CartnetIcfConv& q, const float* Fk, const float* Fm, int C,
   k_img(q.query_w, C, cw.B[B_QKV]); k_img(q.key_w, C, cw.B[B_QKV] + ib); k_img(q.value_w, C, cw.B[B_QKV] + 2 * ib);
   k_img(Fk, C, cw.B[B_E1]); k_img(Fm, C, cw.B[B_E1] + ib);                  // d(rows) = [dpr_k | dpr_m] [Fk; Fm]
   k_img(q.key0_w, 3 * C, cw.B[B_K1I]); k_img(q.msg0_w, 3 * C, cw.B[B_M1I]);
+  k_img(q.key0_w + C, 3 * C, cw.B[B_K1I] + ib); k_img(q.msg0_w + C, 3 * C, cw.B[B_M1I] + ib);
   k_img(q.key2_w, C, cw.B[B_K2]); k_img(q.msg2_w, C, cw.B[B_M2]); k_img(q.concate_w, C, cw.B[B_CAT]);
 }
 
@@ -754,17 +757,24 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     // backward (or the end), so d(e) and the C x C gradients run on the side stream
     RUN(fold_backward(l, q, g, e_in, b.E, w.de[l], de_acc));
     // node terms: reduce dpr over incoming (target) / outgoing (source) edges
-    RUN(cartnet_segment_sum(dpr, 2 * C, w.rowptr, nullptr, N, 2 * C, w.dKPi[l], 2 * C, st));
-    RUN(cartnet_segment_sum(dpr, 2 * C, w.colptr, w.perm, N, 2 * C, w.dKPj[l], 2 * C, st));
+    // ... into dKP = [i key | j key | i msg | j msg] (leading dimension 4C): the two K-segments of dk (and of dv) are then
+    // adjacent column blocks, and the sum over them is ONE product over K = 2C on the DMA-fed kernel (b_split_folded) --
+    // as two-segment products without images they ran on the general kernel, 0.2 ms each on the main stream
+    float* dKP = w.dKP[l];
+    RUN(cartnet_segment_sum(dpr, 2 * C, w.rowptr, nullptr, N, C, dKP, 4 * C, st));
+    RUN(cartnet_segment_sum(dpr + C, 2 * C, w.rowptr, nullptr, N, C, dKP + 2 * C, 4 * C, st));
+    RUN(cartnet_segment_sum(dpr, 2 * C, w.colptr, w.perm, N, C, dKP + C, 4 * C, st));
+    RUN(cartnet_segment_sum(dpr + C, 2 * C, w.colptr, w.perm, N, C, dKP + 3 * C, 4 * C, st));
     const float* k = w.QKV[l] + C; const float* v = w.QKV[l] + 2 * C;
-    RUN(wg({w.dKPi[l], w.dKPi[l] + C, w.dKPj[l], w.dKPj[l] + C}, 2 * C, {k, v, k, v}, 3 * C,
+    RUN(wg({dKP, dKP + 2 * C, dKP + C, dKP + 3 * C}, 4 * C, {k, v, k, v}, 3 * C,
            {g.key0_w, g.msg0_w, g.key0_w + C, g.msg0_w + C}, 3 * C, N, C, C));
     for (int km = 0; km < 2; ++km) {   // dk = dKPi_k W1k_i + dKPj_k W1k_j ; dv likewise
-      CartnetGemmArgs a = gargs(prec, N, C, C, 2 * C, 3 * C, 3 * C);
+      CartnetGemmArgs a = gargs(prec, N, C, C, 4 * C, 3 * C, 3 * C);
       a.nsegs = 2; a.b_kstrided = 1;
       const float* W1 = km ? q.msg0_w : q.key0_w;
-      a.A[0] = w.dKPi[l] + km * C; a.A[1] = w.dKPj[l] + km * C; a.B[0] = W1; a.B[1] = W1 + C;
+      a.A[0] = dKP + km * 2 * C; a.A[1] = a.A[0] + C; a.B[0] = W1; a.B[1] = W1 + C;
       a.C[0] = w.dQKV[l] + (1 + km) * C;
+      if (w.use_img && N >= 2048) a.b_split_folded = cw.B[km ? B_M1I : B_K1I];
       RUN(cartnet_gemm(&a, st));
     }
     return linear3_bwd(l, q, g, x_in, N, w.dx[l]);
