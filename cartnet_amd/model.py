@@ -182,6 +182,11 @@ class _CartNetFunction(torch.autograd.Function):
             pred = torch.empty((Bg,), dtype=torch.float32, device=dev)
         bd.N, bd.Bg, bd.M, bd.E = N, Bg, M, E
 
+        # (with a FlatAdam attached only ONE parameter travels through autograd -- enough for backward to be called; the
+        #  gradients go to the optimiser's flat buffer, not back through these inputs: CartNet.forward)
+        ctx.n_params = len(params)
+        if len(params) != len(model._param_names):
+            params = model._params_list()
         md = model._model_desc(dict(zip(model._param_names, params)))
         nbytes = int(lib.cartnet_workspace_bytes(C.byref(md), N, E, Bg, M, int(need_grad)))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -270,14 +275,16 @@ class _CartNetFunction(torch.autograd.Function):
         _raise_callback_error(gr_cb)
         _l.check(rc, "cartnet_model_backward")
         if bucketed:
-            return (None, None, None) + (None,) * len(model._param_names)
+            return (None, None, None) + (None,) * ctx.n_params
         if direct:
-            return (None, None, None) + (None,) * len(model._param_names)
+            return (None, None, None) + (None,) * ctx.n_params
         if sink is not None and sink.numel() == G.flat.numel():
             sink.add_(G.flat)              # one accumulation into the optimiser's flat gradient buffer
             if opt is not None:
                 opt.fresh = False
-            return (None, None, None) + (None,) * len(model._param_names)
+            return (None, None, None) + (None,) * ctx.n_params
+        if ctx.n_params != len(model._param_names):
+            raise RuntimeError("CartNet backward: the optimiser's flat gradient buffer went away between forward and backward")
         return (None, None, None) + tuple(G[name] for name in model._param_names)
 
 
@@ -557,7 +564,12 @@ class CartNet(nn.Module):
             raise RuntimeError("cartnet_amd.CartNet runs only on an AMD GPU (HIP kernels); move the model and the "
                                "batch to 'cuda' -- there is no CPU fallback")
         self._grad_mode = torch.is_grad_enabled()       # read by _CartNetFunction.forward (grad mode is off in there)
-        pred, x, e = _CartNetFunction.apply(self, batch, self.training, *params)
+        if self._flat_grad is not None and self._flat_grad.device == params[0].device and torch.is_grad_enabled():
+            # every gradient goes to the optimiser's flat buffer (FlatAdam): one differentiable input is enough to have
+            # backward called, and 60 fewer arguments through autograd are 0.05 ms of host time per step
+            pred, x, e = _CartNetFunction.apply(self, batch, self.training, params[0])
+        else:
+            pred, x, e = _CartNetFunction.apply(self, batch, self.training, *params)
         batch.x = x
         batch.edge_attr = e
         return pred, batch.y
