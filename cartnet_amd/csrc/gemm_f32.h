@@ -256,7 +256,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
   // DMA pieces of 1 KB: wave w moves A rows 2w, 2w+1 (one piece) and B rows w, w+8 (two pieces)
   const float* a_base = p.A[g] + (size_t)(kbeg + 2 * wid) * p.lda + row0;
   const float* b_base = p.B[g] + (size_t)(kbeg + wid) * p.ldb + col0;
-  const unsigned a_voff = ((unsigned)(lane >> 5) * (unsigned)p.lda + (lane & 31) * 4) * 4u;
+  // ragged last row tile (M % 128 != 0, M % 4 == 0): lanes past M re-read the last four valid columns of their k-row; the
+  // output rows they feed are never stored
+  const int a_col = min(row0 + (lane & 31) * 4, p.M - 4) - row0;
+  const unsigned a_voff = ((unsigned)(lane >> 5) * (unsigned)p.lda + (unsigned)a_col) * 4u;
   const unsigned b_voff = lane * 16;
   const size_t a_step = (size_t)BK * p.lda, b_step = (size_t)BK * p.ldb, b_half = (size_t)8 * p.ldb;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int grow = row0 + wm * S::WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (grow >= p.M) continue;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const int gcol = col0 + wn * S::WN + b * 32 + li;

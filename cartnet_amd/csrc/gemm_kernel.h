@@ -938,6 +938,34 @@ bool launch_htn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 
 inline bool any_half(const CartnetGemmArgs& a) { return a.a_half || a.b_half || a.c_half || a.dact_half; }
 extern thread_local bool g_half_launched;     // set by launch_variant when a half-storage kernel took the launch
 
+// K tail of a split-K weight gradient on the DMA-fed kernels (the < 16 rows behind the last whole K-step) as the LAST slab:
+// out[m, n] = sum_k A[k, m] (silu?)(B[k, n]), a few thousand FMAs per output row.  As a launch of the checked MFMA kernel
+// -- two workgroups with the register and LDS footprint of a GEMM -- it could not share a CU with the resident
+// weight-gradient workgroups (one per CU, 144 VGPRs) and waited for one of them to finish: up to 0.34 ms at the end of the
+// step's main stream.  This one fits anywhere.
+template <bool B_ACT>
+__global__ __launch_bounds__(256) void cn_gemm_tn_tail_kernel(const CartnetGemmArgs p, int k_lo, int split) {
+  const int g = blockIdx.y;
+  const float* __restrict__ A = p.A[g];
+  const float* __restrict__ B = p.B[g];
+  float* __restrict__ C = p.C[g] + (size_t)split * p.M * p.ldc;
+  const unsigned n4 = (unsigned)p.N / 4u, total = (unsigned)p.M * n4;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = k_lo; k < p.K; ++k) {
+      const float a = A[(size_t)k * p.lda + m];
+      f32x4 b = ldv4(B + (size_t)k * p.ldb + n);
+      if (B_ACT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = fast_silu(b[q]);
+      }
+      acc += a * b;
+    }
+    stv4(C + (size_t)m * p.ldc + n, acc);
+  }
+}
+
 template <bool A_KS, bool B_KS, int BN, bool A_ACT, bool B_ACT>
 void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
   const int tiles_n = cn_ceil_div(a.N, BN);
@@ -1001,7 +1029,7 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
   // weight gradients at precision 1 / 2: the transposing-read kernel takes every row tile (also a ragged last one)
   // over the whole K-steps; a K tail (< 16 rows) is one more slab from the checked fp32 kernel
   if constexpr (A_KS && B_KS && BN == 256 && !A_ACT) {
-    // precision 0: the all-DMA fp32 kernel (gemm_f32.h), whole 128-row tiles only
+    // precision 0: the all-DMA fp32 kernel (gemm_f32.h); a ragged last row tile needs M % 4 == 0 (its lanes clamp)
     // (SiLU on the B operand stays on the register-staged kernel at precision 0: applying it to the DMA-fed
     //  fragments costs every wave 32 transcendental pairs per K-step in front of its MFMAs -- measured 15 % slower)
     if (fl.x3 == 2 && any_half(a)) {
@@ -1014,7 +1042,7 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
       }
       return;
     }
-    const bool tn_ok = fl.x3 ? (a.M % 4 == 0) : (a.M % BM == 0 && !B_ACT);
+    const bool tn_ok = a.M % 4 == 0 && (fl.x3 || !B_ACT);
     auto launch_tn = [&](dim3 grid) {
       if (fl.x3) launch_x3tn(B_ACT, a, fl, grid, st);
       else launch_f32tn(B_ACT, a, fl, grid, st);
@@ -1032,7 +1060,11 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
         fl.tile_m0 = 0; fl.split0 = 0; fl.k_lo = 0; fl.k_hi = K16x;
         fl.kchunk = round_up(cn_ceil_div(K16x, nfastx));
         launch_tn(dim3(tiles_mx * tiles_n, nfastx, a.ngroups));
-        if (tailx) launch(std::false_type{}, 0, tiles_mx, nfastx, 1, K16x, a.K, BK);
+        if (tailx) {
+          const long long items = (long long)a.M * (a.N / 4);
+          const int blocks = (int)(items / 256 + 1 > 2048 ? 2048 : items / 256 + 1);
+          hipLaunchKernelGGL((cn_gemm_tn_tail_kernel<B_ACT>), dim3(blocks, a.ngroups), dim3(256), 0, st, a, K16x, nfastx);
+        }
         return;
       }
     }

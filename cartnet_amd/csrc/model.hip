@@ -940,9 +940,11 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     // (the split-K slabs of this product must not be the ones the weight-gradient stream is using: w.slabs2)
     Work w2 = w;
     w2.slabs = w.slabs2;
-    if (m.gemm_precision >= 1 && w.i_edge0) {
-      // bf16 kernels want 256-wide column tiles: compute the transpose, featT . dhe = dW0^T [ldf, 2D] (rows kf.. are the
-      // zero pad columns of feat), and write its first kf rows transposed into the gradient
+    if (w.i_edge0) {
+      // the DMA-fed weight-gradient kernels want 256-wide column tiles: compute the transpose, featT . dhe = dW0^T [ldf, 2D]
+      // (rows kf.. are the zero pad columns of feat; one ragged row tile), and write its first kf rows transposed into the
+      // gradient.  (Round 4: at fp32 too -- as dhe^T . feat with N = kf it ran on the general kernel, 0.7 ms at the END of
+      // the main stream.)
       const float* fT[1] = {w.feat};
       const float* dh[1] = {w.dhe};
       float* oT[1] = {w.e0wT};
