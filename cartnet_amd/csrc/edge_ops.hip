@@ -272,6 +272,10 @@ __global__ __launch_bounds__(256) void cn_segment_sum_kernel(const float* __rest
 constexpr int LONG_CHUNK = 32;
 constexpr int LONG_BATCH = 16;   // independent row loads in flight per wave
 
+// COMPACT: partial rows are numbered instead of sitting at their position -- a run that starts a chunk is row
+// position / LONG_CHUNK, any other run starts its segment and is row nchunks + segment: tmp needs nchunks + nseg rows
+// instead of `total` (cartnet_segment_sum_chunked: per-crystal sums over all edges, where `total` rows would be 1 GB).
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void cn_segment_long_pass1_kernel(const float* __restrict__ rows, int ld,
                                                                     const int* __restrict__ ptr,
                                                                     const int* __restrict__ perm, int nseg, int total,
@@ -295,6 +299,10 @@ __global__ __launch_bounds__(256) void cn_segment_long_pass1_kernel(const float*
     int seg = below > 0 ? below - 1 : 0;
     int next = ptr[seg + 1];         // first position of the next segment (ptr has nseg + 1 entries)
     int run_start = p0;
+    auto slot = [&](int start, int seg_of_run) -> size_t {
+      if (!COMPACT) return (size_t)start;
+      return (size_t)(start % LONG_CHUNK == 0 ? start / LONG_CHUNK : nchunks + seg_of_run);
+    };
     f32x4 acc = {0, 0, 0, 0};
     for (int pb = p0; pb < p1; pb += LONG_BATCH) {
       f32x4 v[LONG_BATCH];
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(256) void cn_segment_long_pass1_kernel(const float*
         const int p = pb + u;
         if (p < p1) {
           while (seg + 1 <= nseg && p >= next) {   // p starts a new segment: flush the finished run
-            if (p > run_start && c < W) st4(tmp + (size_t)run_start * W + c, acc);
+            if (p > run_start && c < W) st4(tmp + slot(run_start, seg) * W + c, acc);
             acc = f32x4{0, 0, 0, 0};
             run_start = p;
             ++seg;
@@ -320,13 +328,14 @@ __global__ __launch_bounds__(256) void cn_segment_long_pass1_kernel(const float*
         }
       }
     }
-    if (p1 > run_start && c < W) st4(tmp + (size_t)run_start * W + c, acc);
+    if (p1 > run_start && c < W) st4(tmp + slot(run_start, seg) * W + c, acc);
   }
 }
 
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void cn_segment_long_pass2_kernel(const float* __restrict__ tmp,
                                                                     const int* __restrict__ ptr, int nseg, int W,
-                                                                    float* __restrict__ out, int ldo) {
+                                                                    float* __restrict__ out, int ldo, int nchunks) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int slabs = (W + 255) / 256;
   for (long long it = (long long)blockIdx.x * NODES_PER_BLOCK + wid; it < (long long)nseg * slabs;
@@ -344,7 +353,8 @@ __global__ __launch_bounds__(256) void cn_segment_long_pass2_kernel(const float*
       for (int u = 0; u < LONG_BATCH; ++u) {
         pos[u] = p;
         if (p < e) {
-          v[u] = ld4(tmp + (size_t)p * W + c);
+          const size_t row = !COMPACT ? (size_t)p : (size_t)(p % LONG_CHUNK == 0 ? p / LONG_CHUNK : nchunks + s);
+          v[u] = ld4(tmp + row * W + c);
           p = (p / LONG_CHUNK + 1) * LONG_CHUNK;
         } else {
           v[u] = f32x4{0, 0, 0, 0};
@@ -529,25 +539,43 @@ extern "C" int cartnet_segment_sum_h(const void* rows_bf16, int32_t ld, const in
   return segment_sum_impl(true, static_cast<const float*>(rows_bf16), ld, ptr, perm, N, W, out, ldo, stream);
 }
 
-extern "C" int cartnet_segment_sum_long(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm,
-                                        int32_t nseg, int32_t total, int32_t W, float* tmp, float* out, int32_t ldo,
-                                        void* stream) {
+template <bool COMPACT>
+static int segment_sum_long_impl(const char* who, const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm,
+                                 int32_t nseg, int32_t total, int32_t W, float* tmp, float* out, int32_t ldo, void* stream) {
   CN_CHECK(nseg >= 1 && total >= 0 && W >= 4 && W % 4 == 0 && ld % 4 == 0 && ldo % 4 == 0 && ld >= W && ldo >= W,
-           "cartnet_segment_sum_long: W=%d ld=%d ldo=%d must be multiples of 4", W, ld, ldo);
-  CN_CHECK((rows || total == 0) && ptr && tmp && out, "cartnet_segment_sum_long: null pointer");
+           "%s: W=%d ld=%d ldo=%d must be multiples of 4", who, W, ld, ldo);
+  CN_CHECK((rows || total == 0) && ptr && tmp && out, "%s: null pointer", who);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int slabs = (W + 255) / 256;
+  const int nchunks = (total + LONG_CHUNK - 1) / LONG_CHUNK;
   if (total > 0) {
-    long long items = (long long)((total + LONG_CHUNK - 1) / LONG_CHUNK) * slabs;
+    long long items = (long long)nchunks * slabs;
     long long blocks = (items + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(cn_segment_long_pass1_kernel, dim3((int)blocks), dim3(256), 0, st, rows, ld, ptr, perm, nseg,
-                       total, W, tmp);
-    CN_LAUNCH_CHECK("cartnet_segment_sum_long/pass1");
+    hipLaunchKernelGGL(cn_segment_long_pass1_kernel<COMPACT>, dim3((int)blocks), dim3(256), 0, st, rows, ld, ptr, perm,
+                       nseg, total, W, tmp);
+    CN_LAUNCH_CHECK(who);
   }
   long long blocks2 = ((long long)nseg * slabs + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;
   if (blocks2 > 4096) blocks2 = 4096;
-  hipLaunchKernelGGL(cn_segment_long_pass2_kernel, dim3((int)blocks2), dim3(256), 0, st, tmp, ptr, nseg, W, out, ldo);
-  CN_LAUNCH_CHECK("cartnet_segment_sum_long/pass2");
+  hipLaunchKernelGGL(cn_segment_long_pass2_kernel<COMPACT>, dim3((int)blocks2), dim3(256), 0, st, tmp, ptr, nseg, W, out,
+                     ldo, nchunks);
+  CN_LAUNCH_CHECK(who);
   return 0;
+}
+
+extern "C" int cartnet_segment_sum_long(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm,
+                                        int32_t nseg, int32_t total, int32_t W, float* tmp, float* out, int32_t ldo,
+                                        void* stream) {
+  return segment_sum_long_impl<false>("cartnet_segment_sum_long", rows, ld, ptr, perm, nseg, total, W, tmp, out, ldo, stream);
+}
+
+extern "C" int32_t cartnet_segment_chunked_rows(int32_t nseg, int32_t total) {
+  return (total + LONG_CHUNK - 1) / LONG_CHUNK + (nseg > 0 ? nseg : 0);
+}
+
+extern "C" int cartnet_segment_sum_chunked(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm,
+                                           int32_t nseg, int32_t total, int32_t W, float* tmp, float* out, int32_t ldo,
+                                           void* stream) {
+  return segment_sum_long_impl<true>("cartnet_segment_sum_chunked", rows, ld, ptr, perm, nseg, total, W, tmp, out, ldo, stream);
 }

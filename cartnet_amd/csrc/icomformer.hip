@@ -26,6 +26,23 @@ using namespace cn_model;
 
 thread_local EventPool g_icf_events;
 
+// out[e, :] = rows[3e, :] + rows[3e + 1, :] + rows[3e + 2, :]   (rows [3E, 4 * cols4] contiguous): the edge layer's per-edge
+// term sums each edge's three lattice-vector rows.  Two edges' worth of columns per 256 threads when cols4 = 128; the
+// thread -> (edge, column) split is done once, outside the loop.
+__global__ __launch_bounds__(256) void cn_icf_sum3_kernel(const float* __restrict__ rows, long long E, int cols4,
+                                                          float* __restrict__ out) {
+  const long long gtid = (long long)blockIdx.x * 256 + threadIdx.x, gsize = (long long)gridDim.x * 256;
+  const long long per = gsize / cols4;                 // edges advanced per round (host: gsize is a multiple of cols4)
+  const int c = (int)(gtid % cols4) * 4;
+  for (long long e = gtid / cols4; e < E; e += per) {
+    const float* r = rows + (size_t)e * 3 * cols4 * 4 + c;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(r);
+    const f32x4 b2 = *reinterpret_cast<const f32x4*>(r + (size_t)cols4 * 4);
+    const f32x4 c2 = *reinterpret_cast<const f32x4*>(r + (size_t)cols4 * 8);
+    *reinterpret_cast<f32x4*>(out + (size_t)e * cols4 * 4 + c) = (a + b2) + c2;
+  }
+}
+
 // ---- small index kernel: rows r = 3 e + i of the edge layer -------------------------------------------------------------
 // idx_edge[r] = e, idx_gl[r] = 3 * crystal(source of e) + i, ptr3[e] = 3 e, gedge_ptr[g] = rowptr[graph_ptr[g]]
 __global__ void cn_icf_index_kernel(const int* __restrict__ src32, const int64_t* __restrict__ batch, long long E,
@@ -101,7 +118,7 @@ struct IWork {
   float *d_o[5], *dres[5], *daggr[5], *dQKV[5], *dpr[5], *sums1[5], *sums2[5];
   float *de[4], *dKP[4], *dx[4];       // dKP [N, 4C] = [d(term_i) key | d(term_j) key | d(term_i) msg | d(term_j) msg]
   float *dNA, *dKa, *dKYb, *dKY, *dVY, *dNL3, *de_old, *tmpb;
-  float *dpre_e, *dpre_nl, *dpre_na, *gw1, *gw2, *gb1, *gb2, *seg_tmp, *dx_emb;
+  float *dpre_e, *dpre_nl, *dpre_na, *gw1, *gw2, *gb1, *gb2, *seg_tmp, *seg_tmp_e, *dx_emb;
   float *slabs;
   size_t slab_floats;
   int tiles_3e, tiles_e, tiles_n, nparts_n, gp_n, gp_e, sp_n, sp_e, sp_3e;
@@ -196,6 +213,7 @@ IWork icarve(const CartnetIcfModel& m, int N, long long E, int Bg, int M, char* 
   w.dpre_e = c.take<float>(En * C); w.dpre_nl = c.take<float>(B3 * C); w.dpre_na = c.take<float>(E3 * C);
   w.gw1 = c.take<float>((size_t)C * C); w.gw2 = c.take<float>((size_t)C * C); w.gb1 = c.take<float>(C); w.gb2 = c.take<float>(C);
   w.seg_tmp = c.take<float>(Nn * C); w.dx_emb = c.take<float>(Nn * C);
+  w.seg_tmp_e = c.take<float>((size_t)cartnet_segment_chunked_rows(Bg, (int)En) * 6 * C);     // per-crystal sums over [E, 6C]
   // split-K slabs of the weight-gradient products (one set per stream order: all of them run on the side stream)
   size_t sl = 0;
   auto slab = [&](int groups, long long K, int Mm, int Nn_) { sl = std::max(sl, wgrad_slab_floats(groups, K, Mm, Nn_)); };
@@ -680,6 +698,9 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
 
   // The folded lin_edge: d(rows) = [dpr_k | dpr_m] [Fk; Fm] (+ resid), dF = dpr^T rows (the one row-sized weight gradient),
   // then the C x C chain rule back to W1[:, 2C:], We and be.  All on the side stream.
+  // rows_ready[l]: d(rows) of layer l is complete on the side stream -- what the main stream waits for where it reads it
+  // (a full join there also waited for the C x C gradient products queued behind it: 1.0 + 1.5 ms of the step)
+  hipEvent_t rows_ready[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   auto fold_backward = [&](int l, const CartnetIcfConv& q, const CartnetIcfConv& g, const float* rows_in, long long R,
                            float* d_rows, const float* resid) -> int {
     const ConvW& cw = w.cw[l];
@@ -691,6 +712,7 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
       a.A[0] = dpr; a.A[1] = dpr + C; a.B[0] = w.Fk[l]; a.B[1] = w.Fm[l]; a.C[0] = d_rows; a.resid[0] = resid; a.ldr = C;
       if (w.use_img) a.b_split_folded = cw.B[B_E1];
       RUN(cartnet_gemm(&a, sw));
+      rows_ready[l] = S.mark_side();
     }
     {
       const float* dY[2] = {dpr, dpr + C};
@@ -797,9 +819,18 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     // angle branch (lin_edge folded, no bias): only the RBF backward at the very end reads dNA
     RUN(fold_backward(l, q, g, w.NA, 3LL * b.E, w.dNA, nullptr));
     // per-edge term (sum over the three lattice vectors) and per-(crystal, lattice vector) term
-    RUN(cartnet_segment_sum(dpr, 2 * C, w.ptr3, nullptr, E, 2 * C, w.dKa, 2 * C, st));
-    for (int i = 0; i < 3; ++i)
-      RUN(cartnet_segment_sum(dpr + (size_t)i * 2 * C, 6 * C, w.gedge_ptr, nullptr, Bg, 2 * C, w.dKYb + (size_t)i * 2 * C, 6 * C, st));
+    // (dpr is [3E, 2C] = [E, 3, 2C]: the per-edge term is the sum of each edge's three rows, the per-(crystal, lattice
+    //  vector) term the sum over the crystal's edges of the [E, 6C] view.  Through cartnet_segment_sum -- one wave per
+    //  segment -- the second was 64 x 2 waves on the whole chip, three times: 3 ms of the step; the first ran at 1.5 TB/s.)
+    if (b.E > 0) {
+      const int cols4 = 2 * C / 4;                      // threads of the grid: a multiple of cols4 (C % 8 == 0 => 256 * cols4)
+      const long long items = (long long)b.E * cols4;
+      long long blocks = std::min<long long>((items + 255) / 256, 16384);
+      blocks = (blocks + cols4 - 1) / cols4 * cols4;
+      hipLaunchKernelGGL(cn_icf_sum3_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)st, dpr, (long long)b.E, cols4, w.dKa);
+      CN_LAUNCH_CHECK("cartnet_icomformer_backward (three-row sums)");
+    }
+    RUN(cartnet_segment_sum_chunked(dpr, 6 * C, w.gedge_ptr, nullptr, Bg, E, 6 * C, w.seg_tmp_e, w.dKYb, 6 * C, st));
     RUN(wg({w.dKa, w.dKa + C}, 2 * C, {w.QKV[l] + C, w.QKV[l] + 2 * C}, 3 * C, {g.key0_w, g.msg0_w}, 3 * C, b.E, C, C));
     RUN(wg({w.dKYb, w.dKYb + C}, 2 * C, {w.KY, w.VY}, C, {g.key0_w + C, g.msg0_w + C}, 3 * C, (long long)Bg * 3, C, C));
     RUN(dgemm(w.dKa, 2 * C, q.key0_w, 3 * C, w.use_img ? cw.B[B_K1I] : nullptr, w.dQKV[l] + C, 3 * C, b.E, C, C, nullptr, 0, st));
@@ -829,11 +860,14 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     dx = w.dx[l];
     de_new = w.de[l];
   }
-  JOIN();                                            // de_new was produced on the side stream
+#define WAIT_ROWS(l) do { if (S.main_waits(rows_ready[l]) != 0) { cartnet_set_error("cartnet_icomformer_backward: stream wait failed"); return 2; } } while (0)
+  WAIT_ROWS(1);                                      // de_new = de[1] (accumulated from layers 3 and 2 on the side stream)
   RUN(conv_edge_bwd(de_new));
   RUN(conv_bwd(0, dx, w.de_old));
   dx = w.dx[0];
-  JOIN();                                            // de[0] / dNA come from the side stream
+  WAIT_ROWS(0);                                      // de[0]
+  WAIT_ROWS(4);                                      // dNA
+#undef WAIT_ROWS
 
   // ---- RBF branches: out = softplus(pre), pre = rbf W^T + b; rbf.1 is shared by the distance and the lattice-length
   //      features, so its gradients add up

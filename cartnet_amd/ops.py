@@ -469,6 +469,24 @@ def segment_sum_long(rows: Tensor, ptr_: Tensor, perm: Optional[Tensor], total: 
                                                 _l.stream_ptr()), "cartnet_segment_sum_long")
 
 
+
+def segment_sum_chunked(rows: Tensor, ptr_: Tensor, perm: Optional[Tensor], total: int, out: Tensor) -> None:
+    """segment_sum_long with numbered partial rows (cartnet_segment_sum_chunked): the workspace is
+    cartnet_segment_chunked_rows(nseg, total) rows instead of ``total`` -- sums over all edges per crystal."""
+    _f32_2d(rows, "segment_sum_chunked rows")
+    _f32_2d(out, "segment_sum_chunked out")
+    nseg, W = out.shape
+    if rows.shape[1] < W or rows.shape[0] < total:
+        raise ValueError("segment_sum_chunked: shape mismatch")
+    _vec(ptr_, nseg + 1, "segment_sum_chunked ptr", torch.int32)
+    if perm is not None:
+        _vec(perm, total, "segment_sum_chunked perm", torch.int32)
+    lib = _l.load()
+    tmp = torch.empty((int(lib.cartnet_segment_chunked_rows(nseg, int(total))), W), dtype=torch.float32, device=rows.device)
+    _l.check(lib.cartnet_segment_sum_chunked(rows.data_ptr(), _ld(rows), ptr_.data_ptr(), _l.ptr(perm), nseg, int(total), W,
+                                             tmp.data_ptr(), out.data_ptr(), _ld(out), _l.stream_ptr()),
+             "cartnet_segment_sum_chunked")
+
 def bn_finalize(parts_sum, parts_sq, nparts: int, count: int, Cc: int, eps: float, momentum: float, training: bool,
                 running_mean, running_var, nbt, mean_rstd: Tensor) -> None:
     _vec(mean_rstd, 2 * Cc, "bn_finalize mean_rstd")

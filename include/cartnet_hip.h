@@ -534,6 +534,14 @@ int cartnet_segment_sum_h(const void* rows_bf16, int32_t ld, const int32_t* ptr,
  * adds its partial rows in position order -- evenly loaded and still bitwise reproducible. */
 int cartnet_segment_sum_long(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t nseg,
                              int32_t total, int32_t W, float* tmp, float* out, int32_t ldo, void* stream);
+/* The same two passes with the partial rows NUMBERED (a run that starts a chunk: position / chunk; any other run starts
+ * its segment: number of chunks + segment) instead of stored at their position: tmp is
+ * [cartnet_segment_chunked_rows(nseg, total), W] instead of [total, W].  For sums over ALL edges per crystal -- iComformer's
+ * per-(crystal, lattice vector) terms, comformer_conv.py:160-170 backward -- where `total` rows would be a gigabyte and
+ * one wave per segment (cartnet_segment_sum) 64 waves on the whole chip. */
+int32_t cartnet_segment_chunked_rows(int32_t nseg, int32_t total);
+int cartnet_segment_sum_chunked(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t nseg,
+                                int32_t total, int32_t W, float* tmp, float* out, int32_t ldo, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Node update (models/cartnet.py:269 norm2, :223 SiLU + residual):  x_out = silu(bn(aggr)) + x_in.

@@ -675,6 +675,31 @@ def test_node_embed_fwd_bwd(ops, N):
     assert rel_err(dbt, b64.grad) < TOL
 
 
+@pytest.mark.parametrize("total,nseg,W,ld", [(1, 1, 4, 4), (31, 3, 256, 256), (32, 1, 512, 1536), (1000, 7, 516, 520),
+                                              (50000, 64, 1536, 1536), (97, 40, 8, 8)])
+def test_segment_sum_chunked_equals_the_long_form_and_torch(ops, total, nseg, W, ld):
+    """cartnet_segment_sum_chunked (numbered partial rows, workspace of chunks + segments rows): bitwise the sums of
+    cartnet_segment_sum_long on the same input -- same chunks, same order -- and torch's index_add_ within rounding; with
+    empty segments, segments that start inside a chunk, a permutation, strided rows."""
+    g = torch.Generator().manual_seed(total + nseg)
+    rows = rnd(total, ld, seed=total)[:, :W]
+    cuts = torch.sort(torch.randint(0, total + 1, (nseg - 1,), generator=g)).values if nseg > 1 else torch.zeros(0, dtype=torch.int64)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), cuts, torch.tensor([total])]).int().to(dev())
+    for use_perm in (False, True):
+        perm = torch.randperm(total, generator=g).int().to(dev()) if use_perm else None
+        a = torch.full((nseg, W), float("nan"), device=dev())
+        b = torch.full((nseg, W), float("nan"), device=dev())
+        ops.segment_sum_chunked(rows, ptr, perm, total, a)
+        ops.segment_sum_long(rows.contiguous(), ptr, perm, total, b)
+        assert torch.equal(a, b)
+        seg = torch.repeat_interleave(torch.arange(nseg), (ptr[1:] - ptr[:-1]).cpu().long())
+        src = rows.double().cpu() if perm is None else rows.double().cpu()[perm.cpu().long()]
+        ref = torch.zeros(nseg, W, dtype=torch.float64).index_add_(0, seg, src)
+        assert rel_err(a, ref) < 1e-5
+    lib = __import__("cartnet_amd.lib", fromlist=["load"]).load()
+    assert int(lib.cartnet_segment_chunked_rows(nseg, total)) == (total + 31) // 32 + nseg
+
+
 @pytest.mark.parametrize("H", [8, 32, 128])
 def test_cholesky_head_fwd_bwd(ops, H):
     from oracle import cartnet_ref as orc
