@@ -222,6 +222,8 @@ struct GemmRecord {
 };
 bool g_prof_on = false;
 int g_prof_only = -1;     // >= 0: only launches of this variant are timed
+int g_prof_every = 1;     // of the launches that qualify, every n-th is timed (cartnet_profile_gemm_every)
+long long g_prof_seen = 0;
 std::vector<GemmRecord> g_prof;
 }  // namespace
 
@@ -238,6 +240,13 @@ extern "C" int cartnet_profile_gemm(int32_t enable) {
 
 extern "C" int cartnet_profile_gemm_only(int32_t variant) {
   g_prof_only = variant;
+  return 0;
+}
+
+extern "C" int cartnet_profile_gemm_every(int32_t n) {
+  CN_CHECK(n >= 1, "cartnet_profile_gemm_every: n=%d must be >= 1", n);
+  g_prof_every = n;
+  g_prof_seen = 0;
   return 0;
 }
 
@@ -280,6 +289,7 @@ extern "C" int cartnet_gemm(const CartnetGemmArgs* args, void* stream) {
   r.variant = (args->a_kstrided ? 1 : 0) | (args->b_kstrided ? 2 : 0) | (args->a_act ? 4 : 0) | (args->b_act ? 8 : 0) |
               (bn << 4) | (streamed >= 32768 ? 256 : 0) | (actout ? 512 : 0) | ((inner > 4080 ? 255 : inner / 16) << 10);
   if (g_prof_only >= 0 && r.variant != g_prof_only) return cartnet_gemm_impl(args, stream);
+  if (g_prof_every > 1 && (g_prof_seen++ % g_prof_every) != 0) return cartnet_gemm_impl(args, stream);
   const int nptr = args->ngroups > 1 ? args->ngroups : args->nsegs;
   r.flops = 2.0 * args->M * args->N * (double)args->K * nptr;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -301,6 +301,7 @@ PROTOTYPES = {
                                   C.c_int64, c_f32p, C.c_float, C.c_float, C.POINTER(Collated), c_stream]),
     "cartnet_profile_gemm": (C.c_int, [C.c_int32]),
     "cartnet_profile_gemm_only": (C.c_int, [C.c_int32]),
+    "cartnet_profile_gemm_every": (C.c_int, [C.c_int32]),
     "cartnet_profile_gemm_read": (C.c_int, [C.POINTER(GemmProfile), C.c_int32]),
     "cartnet_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "cartnet_model_forward": (C.c_int, [C.POINTER(Model), C.POINTER(BatchDesc), C.c_void_p, C.c_size_t, C.c_int32,

@@ -17,10 +17,11 @@ from . import lib as _l
 Tensor = torch.Tensor
 
 
-def profile_gemm(enable: bool, only: Optional[int] = None) -> None:
+def profile_gemm(enable: bool, only: Optional[int] = None, every: int = 1) -> None:
     """Start / stop HIP-event timing of cartnet_gemm launches (see include/cartnet_hip.h); ``only`` restricts it to
-    one variant (the ``variant`` number profile_gemm_read reports)."""
+    one variant (the ``variant`` number profile_gemm_read reports), ``every`` to every n-th qualifying launch."""
     _l.check(_l.load().cartnet_profile_gemm_only(-1 if only is None else int(only)), "cartnet_profile_gemm_only")
+    _l.check(_l.load().cartnet_profile_gemm_every(int(every)), "cartnet_profile_gemm_every")
     _l.check(_l.load().cartnet_profile_gemm(int(enable)), "cartnet_profile_gemm")
 
 

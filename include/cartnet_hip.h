@@ -333,6 +333,10 @@ int cartnet_profile_gemm(int32_t enable);
  * bench.py prices every variant during its warm-up steps and only the dominant one inside the timed region, so the
  * event pairs of the other ~50 launches per step do not sit in the measured steps. */
 int cartnet_profile_gemm_only(int32_t variant);
+/* Of the launches that qualify, time every n-th (n >= 1; resets the count).  An event pair in front of and behind a
+ * launch costs the stream ~4 us; bench.py samples one in four launches of the dominant variant inside its timed region
+ * (four is coprime with the nine such launches of a step, so the sample walks over all of them). */
+int cartnet_profile_gemm_every(int32_t n);
 int cartnet_profile_gemm_read(CartnetGemmProfile* out, int32_t max_entries);
 
 /* For each job j < njobs (<= 4; host arrays of device pointers):
