@@ -82,7 +82,8 @@ def backward(loss: torch.Tensor) -> None:
 
 def _two_node_backward(loss: torch.Tensor, one: torch.Tensor) -> bool:
     """The training step's graph is two nodes, each ONE native call: compute_loss (cartnet_loss_bwd) on the prediction of
-    CartNet (cartnet_model_backward), the parameter gradients going straight to the optimiser's flat buffer.  When the
+    CartNet (cartnet_model_backward) or iComformer (cartnet_icomformer_backward), the parameter gradients going to the
+    optimiser's flat buffer.  When the
     graph is exactly that, run the two backward functions here instead of handing them to the autograd engine (0.15 ms
     of host time per step, a seventh of a configs[2] step).  Anything else -- another loss term, a hook, anomaly mode,
     parameters without a FlatAdam -- returns False and the engine runs as usual."""
@@ -94,7 +95,8 @@ def _two_node_backward(loss: torch.Tensor, one: torch.Tensor) -> bool:
         return False
     net = nxt[0][0]
     saved = getattr(net, "saved", None)
-    if type(net).__name__ != "_CartNetFunctionBackward" or not saved:
+    n_out = {"_CartNetFunctionBackward": 3, "_IcfNativeFunctionBackward": 2}.get(type(net).__name__)   # outputs of the forward
+    if n_out is None or not saved:
         return False
     model = saved[0]
     if getattr(model, "_flat_grad", None) is None or loss._backward_hooks:
@@ -106,7 +108,7 @@ def _two_node_backward(loss: torch.Tensor, one: torch.Tensor) -> bool:
     if k not in (0, 1):
         return False
     dpred = fn.apply(one if k == 0 else None, one if k == 1 else None)[0]
-    out = net.apply(dpred, None, None)
+    out = net.apply(dpred, *([None] * (n_out - 1)))
     if any(g is not None for g in out):     # (cannot happen with a FlatAdam attached: the gradients went to its buffer)
         raise RuntimeError("cartnet_amd.train.backward: the network returned gradients the shortcut does not deliver")
     return True

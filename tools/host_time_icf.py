@@ -8,6 +8,7 @@ from cartnet_amd.comformer import iComformer
 from cartnet_amd.optim import FlatAdam
 from cartnet_amd.synthetic import make_batch
 from cartnet_amd.train import compute_loss
+from cartnet_amd import train as ctrain
 from cartnet_amd.config import cfg
 cfg.radius = 5.0
 dev = torch.device("cuda:0")
@@ -22,7 +23,7 @@ for native in (True, False):
     def step(b):
         pred, true = m(b)
         loss = compute_loss(pred, true)[0]
-        loss.backward()
+        ctrain.backward(loss)
         opt.step(1.0); opt.zero_grad()
     bs = [fresh() for _ in range(12)]
     for b in bs[:4]: step(b)
