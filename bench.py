@@ -142,7 +142,8 @@ TIMED_EVERY = 4      # launches of the dominant GEMM variant between two timed o
 def timed_pass(step, fresh, warm: int, steps: int, graphs: int, sampler_factory, peak_tflops: float, ops, world: int = 1):
     """Warm-up, one extra step with the GEMM launch timer on (FLOPs per step), then `steps` timed steps bracketed by
     synchronises: {ms_per_step, host_enqueue_ms_per_step, value, whole_step_frac, telemetry}."""
-    bs = [fresh() for _ in range(warm + 1 + steps)]
+    spin = 5                   # untimed steps right before the timed loop (see --spinup in main)
+    bs = [fresh() for _ in range(warm + 1 + spin + steps)]
     for b in bs[:warm]:
         step(b)
     torch.cuda.synchronize()
@@ -170,8 +171,11 @@ def timed_pass(step, fresh, warm: int, steps: int, graphs: int, sampler_factory,
     import gc
     gc.collect()               # a generation-2 collection inside a 30 ms host-bound region would double it
     gc.disable()
+    for b in bs[warm + 1:warm + 1 + spin]:
+        step(b)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for b in bs[warm + 1:]:
+    for b in bs[warm + 1 + spin:]:
         loss = step(b)
     t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
