@@ -219,6 +219,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preroll-steps", type=int, default=200,
+                    help="untimed steps before the warm-up steps: the card settles over seconds (see the comment in main)")
     ap.add_argument("--spinup", type=int, default=2,
                     help="untimed steps right before the timed region, after the warm-up's bookkeeping (see the comment there)")
     ap.add_argument("--graphs", type=int, default=64, help="crystals per rank per step")
@@ -331,6 +333,17 @@ def main():
     # event pairs -- ~26 events per step instead of ~130, whose markers cost ~1.5 % of the step.
     timer = not args.no_kernel_timer
     warm_summary, only = {}, None
+    # Pre-roll: the card's power management takes SECONDS to settle once work arrives (profiles/r04_sustained_60s.json:
+    # 16.3 ms per step over the first 100 steps of a stretch, 14.01-14.02 for the 57 s after it; the K = 10 timed steps
+    # of that process read 14.76).  `--preroll-steps` untimed steps (default 200, ~3 s; the same count on every rank) run
+    # before the W warm-up steps, so that W and K mean what they say on a card that has been working.
+    for i in range(args.preroll_steps):
+        b = fresh()
+        b._cartnet_layout = None
+        b._cartnet_mask_index = None
+        step(b)
+        if i % 50 == 49:
+            torch.cuda.synchronize()        # (bounds the allocator's backlog of batches in flight)
     for i in range(args.warmup):
         if timer and i == 1:
             torch.cuda.synchronize()
@@ -664,7 +677,7 @@ def main():
     out = {
         "metric": "graphs/sec (iComformer D=256 on ADP shapes, ~194 atoms/~2.8k edges), forward+backward+Adam" if icf
         else "graphs/sec (CartNet 4x256, ~194 atoms/~2.8k edges), forward+backward+Adam",
-        "value": round(value, 2), "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup": args.spinup,
+        "value": round(value, 2), "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup": args.spinup, "preroll_steps": args.preroll_steps,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if args.precision == 2 else "f32", "data": "synthetic",
         "config": {"workload": (f"BASELINE configs[4]: iComformer D=256 (4 attention layers + edge-update layer, Cholesky "
