@@ -34,6 +34,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -211,7 +212,26 @@ def self_launch(args) -> int:
         env.setdefault("CARTNET_DIST_BACKEND", "gloo")      # several ranks on one card: RCCL needs one device per rank
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    # The ranks run in a process group of their own and under a watchdog: a rank that hangs (in the rendezvous, in a
+    # collective) ends with the whole group killed and a non-zero exit here instead of a bench that never returns.  The
+    # ranks give up on their own after CARTNET_DIST_TIMEOUT seconds per collective (distributed.init_from_env).
+    limit = float(os.environ.get("BENCH_LAUNCH_TIMEOUT", "1500"))
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {args.gpus} ranks did not finish within {limit:.0f} s -- killing them", file=sys.stderr, flush=True)
+    except KeyboardInterrupt:
+        pass
+    try:
+        os.killpg(child.pid, signal.SIGTERM)          # exactly the group started above
+        child.wait(timeout=20)
+    except subprocess.TimeoutExpired:
+        os.killpg(child.pid, signal.SIGKILL)
+        child.wait()
+    except ProcessLookupError:
+        pass
+    return 124
 
 
 def main():
@@ -221,6 +241,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--preroll-steps", type=int, default=200,
                     help="untimed steps before the warm-up steps: the card settles over seconds (see the comment in main)")
+    ap.add_argument("--no-cold", action="store_true",
+                    help="skip the cold figure (W untimed + K timed steps as the first work of the process)")
     ap.add_argument("--spinup", type=int, default=2,
                     help="untimed steps right before the timed region, after the warm-up's bookkeeping (see the comment there)")
     ap.add_argument("--graphs", type=int, default=64, help="crystals per rank per step")
@@ -266,6 +288,9 @@ def main():
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    seen = cdist.ranks_seen(dev)              # first collective: SUM of one 1 per rank
+    if seen != world:
+        raise SystemExit(f"the communicator carries {seen} rank(s), --gpus says {args.gpus}")
 
     from cartnet_amd import ops
     from cartnet_amd.config import cfg
@@ -337,7 +362,36 @@ def main():
     # 16.3 ms per step over the first 100 steps of a stretch, 14.01-14.02 for the 57 s after it; the K = 10 timed steps
     # of that process read 14.76).  `--preroll-steps` untimed steps (default 200, ~3 s; the same count on every rank) run
     # before the W warm-up steps, so that W and K mean what they say on a card that has been working.
-    for i in range(args.preroll_steps):
+    # Cold figure: the driver's flags taken literally -- W untimed steps, then K timed ones between a
+    # barrier + synchronise on both sides, as the FIRST work of the process on a card that may have been idle.  Reported
+    # next to the steady value, never instead of it; these W + K steps count towards the pre-roll.
+    cold = None
+    cold_steps = 0
+    if not args.no_cold:
+        def raw():
+            b = fresh()
+            b._cartnet_layout = None
+            b._cartnet_mask_index = None
+            return b
+        for _ in range(args.warmup):
+            step(raw())
+        cbs = [raw() for _ in range(args.steps)]
+        cdist.barrier()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for b in cbs:
+            step(b)
+        torch.cuda.synchronize()
+        cdist.barrier()
+        torch.cuda.synchronize()
+        dtc = cdist.max_over_ranks(time.perf_counter() - tc, dev)
+        cold_steps = args.warmup + args.steps
+        cold = {"value": round(args.graphs * world * args.steps / dtc, 2), "unit": "graphs/s",
+                "ms_per_step": round(1e3 * dtc / args.steps, 3), "steps": args.steps, "warmup": args.warmup,
+                "note": "the first W + K steps of the process (W untimed, K timed), before any pre-roll: includes the "
+                        "card's clock / power ramp from idle (profiles/r04_sustained_60s.json)"}
+        del cbs
+    for i in range(max(0, args.preroll_steps - cold_steps)):
         b = fresh()
         b._cartnet_layout = None
         b._cartnet_mask_index = None
@@ -382,6 +436,7 @@ def main():
         loss = step(batches[args.warmup + args.spinup + i])
     t_enq = time.perf_counter() - t0          # host time to enqueue all steps (GPU-bound when << dt)
     torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0        # this rank's own K steps (before it waits for the others)
     cdist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -390,6 +445,7 @@ def main():
     ops.profile_gemm(False)
     timed_summary = ops.profile_gemm_read() if (rank == 0 and not args.no_kernel_timer) else {}
     dt = cdist.max_over_ranks(dt, dev)
+    rank_lo, rank_hi = cdist.min_max_over_ranks(dt_rank, dev)
     if not torch.isfinite(loss):
         raise SystemExit("non-finite loss")
 
@@ -678,6 +734,8 @@ def main():
         "metric": "graphs/sec (iComformer D=256 on ADP shapes, ~194 atoms/~2.8k edges), forward+backward+Adam" if icf
         else "graphs/sec (CartNet 4x256, ~194 atoms/~2.8k edges), forward+backward+Adam",
         "value": round(value, 2), "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup": args.spinup, "preroll_steps": args.preroll_steps,
+        # every step run before the timed region opened: the cold W + K, the rest of the pre-roll, W warm-up steps, the spin-up
+        "untimed_steps_total": max(args.preroll_steps, cold_steps) + args.warmup + args.spinup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if args.precision == 2 else "f32", "data": "synthetic",
         "config": {"workload": (f"BASELINE configs[4]: iComformer D=256 (4 attention layers + edge-update layer, Cholesky "
@@ -723,8 +781,14 @@ def main():
                            "counted_bytes_per_step": per_step.get("hbm_bytes"),
                            "counted_TBps": round(per_step["hbm_bytes"] / step_s / 1e12, 3) if per_step.get("hbm_bytes") else None,
                            "counted_frac": round(per_step["hbm_bytes"] / step_s / 8.0e12, 4) if per_step.get("hbm_bytes") else None}
+    if cold is not None:
+        out["cold"] = cold
     if world > 1 or cdist._active():
+        import torch.distributed as _dist
         out["ranks_seen"] = cdist.ranks_seen(dev)
+        out["backend"] = _dist.get_backend() if _dist.is_initialized() else None
+        # every rank's own K steps (before the closing barrier): min / max over the ranks
+        out["rank_ms_per_step"] = {"min": round(1e3 * rank_lo / args.steps, 3), "max": round(1e3 * rank_hi / args.steps, 3)}
         out["allreduce"] = ("bucketed under backward (head, layers L-1..0, encoder: distributed.GradSync)"
                             if gsync is not None else "one flat all-reduce after backward")
         out["allreduce_exposed_ms_per_step"] = (round(gsync.exposed_ms(), 4) if gsync is not None and
@@ -826,7 +890,10 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
+        bad = out.get("ranks_seen") != world
         dist.destroy_process_group()
+        if bad:
+            raise SystemExit(f"ranks_seen = {out.get('ranks_seen')} but --gpus {args.gpus}")
 
 
 if __name__ == "__main__":

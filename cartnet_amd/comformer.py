@@ -974,12 +974,14 @@ class _IcfNativeFunction(torch.autograd.Function):
         if cache is None or cache[0].flat.device != dev:
             from .model import _GradBuffer
             G = _GradBuffer(model, dev)
-            G.flat.zero_()                 # lemb / lin_edge_len: declared by the reference, never used -- no gradient
             gd = _l.IcfParams()
             _fill_icf_params(gd, G)
             cache = (G, gd)
             model.__dict__["_grad_cache"] = cache
         G, gd = cache
+        # the staging buffer is reused every step: the slots no kernel writes (lemb / lin_edge_len) must stay zero and a
+        # launch skipped for an empty batch must not leave last step's values behind -- one memset against a 29 ms step
+        G.flat.zero_()
         _l.check(lib.cartnet_icomformer_backward(C.byref(md), C.byref(bd), ws.data_ptr(), nbytes, int(training),
                                                  dpred.data_ptr(), x_out.data_ptr(), C.byref(gd), _l.stream_ptr(),
                                                  model._aux_stream_ptr(dev)), "cartnet_icomformer_backward")

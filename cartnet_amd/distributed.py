@@ -11,6 +11,7 @@ statistics identical on every rank when a checkpoint is written.
 """
 from __future__ import annotations
 
+import datetime
 import os
 from typing import List, Optional, Sequence
 
@@ -39,11 +40,22 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
         if backend is None:
             # "nccl" is RCCL on ROCm; CARTNET_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs
             backend = os.environ.get("CARTNET_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
-            torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # A rank that never arrives must not hang the others for torch's default 10 / 30 minutes: the rendezvous and every
+        # collective give up after CARTNET_DIST_TIMEOUT seconds (default 300) and the process exits non-zero.
+        timeout = datetime.timedelta(seconds=float(os.environ.get("CARTNET_DIST_TIMEOUT", "300")))
+        if backend == "nccl":
+            # the device BEFORE any collective, and named to the process group: RCCL then builds its communicator for this
+            # device at once (a bad rank -> device map fails here, not at the first all-reduce) and never has to guess
+            if local >= torch.cuda.device_count():
+                raise RuntimeError(f"LOCAL_RANK={local} but only {torch.cuda.device_count()} GPU(s) are visible: RCCL needs "
+                                   "one device per rank (CARTNET_DIST_BACKEND=gloo rehearses more ranks than devices)")
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world, local
 
 
@@ -191,6 +203,17 @@ def assert_replicas_in_sync(model: torch.nn.Module) -> None:
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     if not torch.equal(hi, lo):
         raise RuntimeError(f"parameters diverged across ranks: checksums differ by {(hi - lo).tolist()}")
+
+
+def min_max_over_ranks(value: float, device) -> tuple[float, float]:
+    """(min, max) of a per-rank scalar over the ranks (one MIN and one MAX all-reduce)."""
+    if not _active():
+        return value, value
+    lo = torch.tensor([value], dtype=torch.float64, device=device)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return float(lo.item()), float(hi.item())
 
 
 def max_over_ranks(value: float, device) -> float:

@@ -566,7 +566,11 @@ class CartNet(nn.Module):
         self._grad_mode = torch.is_grad_enabled()       # read by _CartNetFunction.forward (grad mode is off in there)
         if self._flat_grad is not None and self._flat_grad.device == params[0].device and torch.is_grad_enabled():
             # every gradient goes to the optimiser's flat buffer (FlatAdam): one differentiable input is enough to have
-            # backward called, and 60 fewer arguments through autograd are 0.05 ms of host time per step
+            # backward called, and 60 fewer arguments through autograd are 0.05 ms of host time per step.  FlatAdam was
+            # built over ALL parameters (optim.py); one frozen since then would still receive its gradient and be stepped
+            if not all(p.requires_grad for p in params):
+                raise RuntimeError("a parameter was frozen after FlatAdam took the model's gradients over: build the "
+                                   "optimiser after freezing (it then accumulates through autograd instead)")
             pred, x, e = _CartNetFunction.apply(self, batch, self.training, params[0])
         else:
             pred, x, e = _CartNetFunction.apply(self, batch, self.training, *params)

@@ -3,7 +3,8 @@ gradients in another, so the optimiser is a single fused kernel launch (cartnet_
 gradient exchange is a single RCCL all-reduce of 10 MB.
 
 Update rule = torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0) as the reference constructs it
-(reference: main.py:208); ``set_lr`` lets a scheduler (OneCycleLR in the reference, train/train.py:59) drive it.
+(reference: main.py:208); ``set_lr`` / ``set_beta1`` let a scheduler (OneCycleLR in the reference, train/train.py:59,
+which cycles the learning rate AND Adam's beta1) drive it.
 """
 from __future__ import annotations
 
@@ -54,6 +55,12 @@ class FlatAdam:
     def set_lr(self, lr: float) -> None:
         self.lr = float(lr)
         self.param_groups[0]["lr"] = self.lr
+
+    def set_beta1(self, beta1: float) -> None:
+        """Adam's first-moment decay for the next step: the reference's OneCycleLR cycles it together with the learning
+        rate (``one_cycle_momentum``; torch writes it into ``param_groups[0]["betas"]``, which Adam reads every step --
+        the bias correction 1 - beta1^t uses the current value too)."""
+        self.betas = (float(beta1), self.betas[1])
 
     def zero_grad(self) -> None:
         self.flat_grad.zero_()
@@ -150,3 +157,22 @@ def one_cycle_lr(step: int, total_steps: int, max_lr: float, pct_start: float = 
     if step <= end1:
         return cos(initial_lr, max_lr, step / end1 if end1 > 0 else 1.0)
     return cos(max_lr, min_lr, (step - end1) / (end2 - end1) if end2 > end1 else 1.0)
+
+
+def one_cycle_momentum(step: int, total_steps: int, pct_start: float = 0.3, base_momentum: float = 0.85,
+                       max_momentum: float = 0.95) -> float:
+    """The OTHER half of torch.optim.lr_scheduler.OneCycleLR as the reference constructs it (train/train.py:59 leaves
+    ``cycle_momentum=True``, ``base_momentum=0.85``, ``max_momentum=0.95``): with Adam the scheduler rewrites beta1 at
+    every step, inversely to the learning rate -- 0.95 at the start, 0.85 at the peak, back to 0.95 -- on the same two
+    cosine phases.  Found by pinning the loop to the reference's own train_epoch (tests/golden/train_epoch.npz): with a
+    fixed beta1 = 0.9 the parameters after the second optimiser step were off by 0.45 lr."""
+    import math
+    end1 = float(pct_start * total_steps) - 1.0
+    end2 = float(total_steps) - 1.0
+
+    def cos(a, b, pct):
+        return b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+
+    if step <= end1:
+        return cos(max_momentum, base_momentum, step / end1 if end1 > 0 else 1.0)
+    return cos(base_momentum, max_momentum, (step - end1) / (end2 - end1) if end2 > end1 else 1.0)

@@ -107,8 +107,14 @@ def _two_node_backward(loss: torch.Tensor, one: torch.Tensor) -> bool:
     k = loss.output_nr                      # 0: MAE, 1: MSE (the two outputs of _FusedLoss)
     if k not in (0, 1):
         return False
-    dpred = fn.apply(one if k == 0 else None, one if k == 1 else None)[0]
-    out = net.apply(dpred, *([None] * (n_out - 1)))
+    if getattr(fn, "_cartnet_consumed", False):
+        # (the engine raises "Trying to backward through the graph a second time" here; the shortcut must not be quieter)
+        raise RuntimeError("cartnet_amd.train.backward: this loss has been back-propagated already (its saved "
+                           "activations were consumed in place)")
+    fn._cartnet_consumed = True
+    with torch.no_grad():                   # what the engine does around every backward function
+        dpred = fn.apply(one if k == 0 else None, one if k == 1 else None)[0]
+        out = net.apply(dpred, *([None] * (n_out - 1)))
     if any(g is not None for g in out):     # (cannot happen with a FlatAdam attached: the gradients went to its buffer)
         raise RuntimeError("cartnet_amd.train.backward: the network returned gradients the shortcut does not deliver")
     return True
@@ -162,8 +168,18 @@ def train_epoch(loader, model, optimizer, batch_accumulation: int, scheduler: Op
                 device="cuda:0"):
     """One pass over ``loader`` (train/train.py:148-199).  Returns dict(loss, mae, graphs, seconds)."""
     model.train()
-    if hasattr(optimizer, "direct_grads"):
+    had_direct = getattr(optimizer, "direct_grads", None)
+    if had_direct is not None:
         optimizer.direct_grads = True               # the loss below depends on the parameters through the model only
+    try:
+        return _train_epoch(loader, model, optimizer, batch_accumulation, scheduler, device)
+    finally:
+        if had_direct is not None:                  # a caller's own steps (extra loss terms, hand-edited p.grad) accumulate again
+            optimizer.direct_grads = had_direct
+            optimizer.fresh = False
+
+
+def _train_epoch(loader, model, optimizer, batch_accumulation, scheduler, device):
     optimizer.zero_grad()
     n_iter = len(loader)
     tot_mae = torch.zeros((), device=device)
@@ -173,9 +189,15 @@ def train_epoch(loader, model, optimizer, batch_accumulation: int, scheduler: Op
     flush = getattr(model, "flush_graph_checks", None)
     # Multi-rank runs of CartNet: the gradient all-reduce goes out in buckets DURING the backward of the micro-batch that
     # closes an accumulation window (distributed.GradSync, CartnetGradReadyFn) instead of as one flat call behind it.
+    # Only when the model's backward really writes into THIS optimiser's flat buffer (FlatAdam over every parameter): a
+    # FlatAdam over a model with a frozen parameter leaves model._flat_grad unset, backward then reports no bucket, and the
+    # boundary below falls back to the flat all-reduce.
     sync = None
-    if hasattr(optimizer, "flat_grad") and hasattr(model, "grad_bucket_order") and cdist._active():
+    n_buckets = 0
+    if hasattr(optimizer, "flat_grad") and hasattr(model, "grad_bucket_order") and cdist._active() and \
+            getattr(model, "_flat_grad", None) is optimizer.flat_grad:
         sync = cdist.GradSync(optimizer.flat_grad)
+        n_buckets = len(model.grad_bucket_order())
     for it, batch in enumerate(loader):
         if batch is None and getattr(model, "sync_batchnorm", False):
             raise RuntimeError("sync_batchnorm: this rank has no crystals for a step the other ranks run -- every rank "
@@ -209,7 +231,15 @@ def train_epoch(loader, model, optimizer, batch_accumulation: int, scheduler: Op
                 if batch is None:                   # no crystals this step: the same collectives, in the same order
                     for lo, hi in model.grad_bucket_order():
                         sync.bucket(lo, hi)
-                scale = sync.finish()
+                seen, sync.buckets_seen = sync.buckets_seen, 0
+                if seen == n_buckets:
+                    scale = sync.finish()
+                elif seen == 0:                     # backward did not report (a path that bypasses the bucketed call):
+                    sync.finish()                   # nothing is in flight; one flat all-reduce, as before round 4
+                    scale = cdist.all_reduce_gradients(optimizer.flat_grad)
+                else:
+                    raise RuntimeError(f"gradient buckets: backward reported {seen} of {n_buckets} -- the all-reduce of "
+                                       "this step would be partial and the ranks would diverge")
             else:
                 scale = cdist.all_reduce_gradients(optimizer.flat_grad) if hasattr(optimizer, "flat_grad") else 1.0
             optimizer.step(scale) if hasattr(optimizer, "flat_grad") else optimizer.step()

@@ -24,7 +24,7 @@ from cartnet_amd import distributed as cdist
 from cartnet_amd.config import cfg, set_cfg
 from cartnet_amd.data import DataLoader
 from cartnet_amd.master import create_model
-from cartnet_amd.optim import FlatAdam, one_cycle_lr
+from cartnet_amd.optim import FlatAdam, one_cycle_lr, one_cycle_momentum
 from cartnet_amd.synthetic import augment_data, make_crystal
 from cartnet_amd.train import eval_epoch, train_epoch
 
@@ -247,11 +247,14 @@ def main(argv=None) -> dict:
     total_steps = cfg.optim.max_epoch * steps_per_epoch // cfg.batch_accumulation + cfg.optim.max_epoch   # train.py:59
     sched_step = [0]
 
-    def scheduler():
+    def scheduler():          # OneCycleLR.step() (train/train.py:188): the learning rate and, with Adam, beta1
         sched_step[0] += 1
-        opt.set_lr(one_cycle_lr(min(sched_step[0], total_steps - 1), total_steps, cfg.lr, cfg.warmup))
+        k = min(sched_step[0], total_steps - 1)
+        opt.set_lr(one_cycle_lr(k, total_steps, cfg.lr, cfg.warmup))
+        opt.set_beta1(one_cycle_momentum(k, total_steps, cfg.warmup))
 
     opt.set_lr(one_cycle_lr(0, total_steps, cfg.lr, cfg.warmup))
+    opt.set_beta1(one_cycle_momentum(0, total_steps, cfg.warmup))
     ckpt_dir = os.path.join(cfg.run_dir, "ckpt")
     best, history = float("inf"), []
     for epoch in range(cfg.optim.max_epoch):

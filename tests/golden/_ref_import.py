@@ -14,7 +14,10 @@ restate the published semantics the reference relies on:
         ``get_max_neighbors_mask`` uses them)
   * default ``aggregate`` (aggr='add') = scatter-sum of the messages over ``index``; default ``update`` = identity
   * ``e3nn.o3`` -> empty module (only the eComformer classes, which are out of scope, touch it)
-  * ``torch_geometric.graphgym.config.cfg``      -> attribute bag (only ``invariant`` and ``radius`` are read)
+  * ``torch_geometric.graphgym.config.cfg``      -> attribute bag (only ``invariant`` and ``radius`` are read by the models;
+        ``train/train.py`` / ``train/metrics.py`` also read ``loss``, ``dataset.name`` and ``params_count``)
+  * ``wandb``                                    -> empty module (``train/train.py`` imports it at module level; only
+        ``train()`` calls it, and the fixtures run ``train_epoch`` directly)
 
 Nothing from /root/reference is copied; this file never travels as anything but test tooling and is not used on
 the GPU box (tests that need it are skipped when /root/reference is absent).
@@ -154,3 +157,14 @@ def import_reference():
     except Exception:  # tqdm etc. are present here, but keep the model import usable on its own
         ref_dutils = None
     return cfg, ref_cartnet, ref_dutils
+
+
+def import_reference_train():
+    """The reference's ``train/train.py`` (its ``train_epoch``, train/train.py:148-199) imported as is.  Third-party
+    imports stood in for: ``wandb`` (module level only; ``train_epoch`` never touches it) and the GraphGym ``cfg``.
+    ``tqdm`` / ``numpy`` are installed.  Returns (cfg stand-in, reference train.train module)."""
+    import importlib
+    import_reference()
+    if "wandb" not in sys.modules:
+        sys.modules["wandb"] = types.ModuleType("wandb")
+    return _Cfg, importlib.import_module("train.train")

@@ -15,6 +15,11 @@ Fixtures (all fp32 unless suffixed _f64):
   config2     D=256, R=64, L=4, 2 crystals of 194 atoms (configs[1] shape); weights from seed
   radius_graph  reference radius_graph_pbc output for 3 crystals (integers compared bit-exactly)
   icomformer_tiny / icomformer_c32   the reference's iComformer (models/comformer.py) at C=16 / C=32
+  train_epoch   the reference's own ``train_epoch`` (train/train.py:148-199) run for two epochs of five micro-batches
+              with accumulation 3 (optimiser steps after micro-batches 3 and 5: the last-iteration flush), torch Adam as
+              main.py:208 builds it and OneCycleLR as train/train.py:59 builds it: per optimiser step the accumulated
+              gradient, the parameters after the step, the learning rate after ``scheduler.step()``; per iteration the
+              logged loss / lr; BatchNorm buffers after each epoch
 """
 from __future__ import annotations
 
@@ -292,6 +297,88 @@ def metrics_fixture():
     np.savez_compressed(os.path.join(HERE, "adp_metrics.npz"), **arrays)
 
 
+def train_epoch_fixture():
+    """the reference's training loop, run as is on the tiny model.  What the loop decides -- unscaled
+    accumulation (train/train.py:183), the boundary rule with its last-iteration flush (:186), Adam (main.py:208), the
+    OneCycleLR total-steps formula (:59), scheduler.step() per optimiser step (:188) -- lands in the stored numbers."""
+    import types
+    from _ref_import import import_reference_train
+    cfg, ref_train = import_reference_train()
+    hp = hp_dict(16, 8, 2)
+    cfg.invariant, cfg.radius = hp["invariant"], hp["radius"]
+    cfg.loss = "MAE"
+    cfg.dataset = types.SimpleNamespace(name="ADP")
+    cfg.params_count = 0
+    EPOCHS, ACCUM, LR, WARMUP = 2, 3, 1e-3, 0.4
+    sd = make_state_dict(16, 8, 2, seed=51)
+
+    class HostBatch(Batch):
+        def to(self, *a, **k):            # `batch.to("cuda:0")` (train/train.py:169): a device move, no arithmetic; no GPU here
+            return self
+    sizes = [(5, 7), (6, 9), (8, 5), (7, 6), (9, 8)]           # five micro-batches of two crystals each
+    micro = [HostBatch.from_data_list([make_crystal(700 + 10 * i, a), make_crystal(701 + 10 * i, b)])
+             for i, (a, b) in enumerate(sizes)]
+
+    class Loader:                         # torch_geometric.loader.DataLoader stand-in: fresh batches every epoch, fixed order
+        def __len__(self):
+            return len(micro)
+
+        def __iter__(self):
+            for b in micro:
+                c = b.clone()
+                c.num_graphs = b.num_graphs
+                yield c
+
+    torch.manual_seed(0)
+    m = ref_cartnet.CartNet(dim_in=16, dim_rbf=8, num_layers=2)
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    names = [k for k, _ in m.named_parameters()]
+    opt = torch.optim.Adam(m.parameters(), lr=LR)                                  # main.py:208
+    loader = Loader()
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=LR, total_steps=EPOCHS * len(loader) // ACCUM + EPOCHS,
+                                                pct_start=WARMUP)                   # train/train.py:59
+    flat = lambda ts: np.concatenate([to_np(t).ravel() for t in ts])
+    steps = []
+    opt.register_step_pre_hook(lambda o, a, k: steps.append({"grad": flat([p.grad for p in m.parameters()])}))
+    opt.register_step_post_hook(lambda o, a, k: steps[-1].update(param=flat(list(m.parameters()))))
+
+    class Logger:                         # GraphGym Logger stand-in: keeps what compute_metrics_and_logging hands over
+        def __init__(self):
+            self.rows = []
+
+        def update_stats(self, **kw):
+            self.rows.append((float(kw["loss"]), float(kw["MAE"]), float(kw["MSE"]), float(kw["lr"])))
+    logger = Logger()
+    arrays = {}
+    for ep in range(EPOCHS):
+        ref_train.train_epoch(logger, loader, m, opt, ACCUM, sched)
+        for k, v in m.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                arrays[f"state_ep{ep}_{k}"] = to_np(v).copy()      # (a view of the live buffer otherwise)
+    assert len(steps) == 4 and len(logger.rows) == EPOCHS * len(micro)
+    # the learning rate AFTER the scheduler step that follows optimiser step k is what iteration k's row logged (:195)
+    rows = np.array(logger.rows, dtype=np.float64)
+    arrays["iter_loss"], arrays["iter_mae"], arrays["iter_mse"], arrays["iter_lr"] = rows.T
+    for k, st in enumerate(steps):
+        arrays[f"step{k}_grad"], arrays[f"step{k}_param"] = st["grad"], st["param"]
+    arrays["param_names"] = np.array(names)
+    arrays["param_sizes"] = np.array([p.numel() for p in m.parameters()], dtype=np.int64)
+    for k, v in hp.items():
+        arrays["hp_" + k] = np.array(v)
+    arrays["epochs"], arrays["accum"], arrays["lr"], arrays["warmup"] = (np.int64(EPOCHS), np.int64(ACCUM),
+                                                                         np.float64(LR), np.float64(WARMUP))
+    for k, v in sd.items():
+        arrays["w_" + k] = to_np(v)
+    for i, b in enumerate(micro):
+        for k, v in batch_inputs(b).items():
+            arrays[f"b{i}_{k}"] = v
+    path = os.path.join(HERE, "train_epoch.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"train_epoch: {len(steps)} optimiser steps over {len(logger.rows)} iterations, lr per iteration "
+          f"{[f'{x:.3e}' for x in rows[:, 3]]} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def main():
     """All fixtures, or only those named on the command line (``python tests/golden/make_golden.py tiny_nothing``)."""
     torch.set_num_threads(4)
@@ -301,6 +388,7 @@ def main():
     jobs = {
         "radius_graph": radius_graph_fixture,
         "adp_metrics": metrics_fixture,
+        "train_epoch": train_epoch_fixture,
         "tiny_adp": lambda: save_model_fixture("tiny_adp", hp_dict(16, 8, 2), tiny_batch(), seed=11,
                                                store_weights=True, full_grads=True, trace=True),
         "tiny_scalar": lambda: save_model_fixture("tiny_scalar", hp_dict(16, 8, 2, temperature=False, cholesky=False),

@@ -183,13 +183,23 @@ def test_edge_balanced_partition_properties():
 
 
 def test_one_cycle_schedule_matches_torch():
-    from cartnet_amd.optim import one_cycle_lr
+    from cartnet_amd.optim import one_cycle_lr, one_cycle_momentum
     p = torch.nn.Parameter(torch.zeros(1))
     opt = torch.optim.Adam([p], lr=1e-3)
     total = 57
     sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=total, pct_start=0.01)
     for step in range(total):
         assert abs(opt.param_groups[0]["lr"] - one_cycle_lr(step, total, 1e-3, 0.01)) < 1e-12
+        assert abs(opt.param_groups[0]["betas"][0] - one_cycle_momentum(step, total, 0.01)) < 1e-12
+        opt.step()
+        if step + 1 < total:
+            sch.step()
+    # a warm-up long enough for both phases (the reference's default 0.01 puts every step of a short run in the second)
+    opt = torch.optim.Adam([p], lr=1e-3)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=total, pct_start=0.3)
+    for step in range(total):
+        assert abs(opt.param_groups[0]["lr"] - one_cycle_lr(step, total, 1e-3, 0.3)) < 1e-12
+        assert abs(opt.param_groups[0]["betas"][0] - one_cycle_momentum(step, total, 0.3)) < 1e-12
         opt.step()
         if step + 1 < total:
             sch.step()
@@ -221,18 +231,40 @@ def test_bench_self_launch_builds_the_torchrun_child(monkeypatch):
     spec.loader.exec_module(bench)
     seen = {}
 
-    def fake_run(cmd, env=None, **kw):
-        seen["cmd"], seen["env"] = cmd, env
-        return subprocess.CompletedProcess(cmd, 7)
+    class FakeChild:
+        pid = 424242
 
-    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+        def __init__(self, cmd, env=None, **kw):
+            seen["cmd"], seen["env"], seen["kw"] = cmd, env, kw
+
+        def wait(self, timeout=None):
+            seen.setdefault("waits", []).append(timeout)
+            return 7
+
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeChild)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--share-gpu"])
     rc = bench.self_launch(argparse.Namespace(gpus=4, share_gpu=True))
     assert rc == 7
+    assert seen["kw"].get("start_new_session") is True and seen["waits"][0] and seen["waits"][0] > 0     # own group, bounded wait
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and "--master-addr" in cmd and "127.0.0.1" in cmd
     assert cmd[-5:] == ["--gpus", "4", "--steps", "3", "--share-gpu"] and cmd[-6].endswith("bench.py")
+
+    # a child that never finishes: its whole process group is killed (exactly that group) and the exit code is non-zero
+    killed = []
+
+    class Hung(FakeChild):
+        def wait(self, timeout=None):
+            if not killed:
+                raise subprocess.TimeoutExpired("x", timeout)
+            return -15
+
+    monkeypatch.setattr(bench.subprocess, "Popen", Hung)
+    monkeypatch.setattr(bench.os, "killpg", lambda pid, sig: killed.append((pid, sig)))
+    monkeypatch.setenv("BENCH_LAUNCH_TIMEOUT", "0.01")
+    assert bench.self_launch(argparse.Namespace(gpus=4, share_gpu=True)) == 124
+    assert killed and killed[0][0] == Hung.pid
     assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["CARTNET_DIST_BACKEND"] == "gloo"
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 

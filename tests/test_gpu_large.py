@@ -83,3 +83,59 @@ def test_replicated_batch_beyond_4GiB_activations(precision):
     assert rel_err(g_big, g_base) < 2e-4
     del p_big, g_big
     torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Train mode at the benchmark batch against the fp64 oracle: the workload bench.py times -- 64 crystals
+# x 194 atoms, D = 256, L = 4 -- where the training-mode BatchNorm statistics run over E ~ 177k rows
+# (/root/reference/models/cartnet.py:238,269).  The oracle pass (tests/oracle_large.py: the oracle's own functions with a
+# checkpoint around each layer) runs ONCE on the host cores and serves both GEMM precisions.
+@pytest.fixture(scope="module")
+def bench_batch_oracle():
+    import psutil
+    from cartnet_amd.data import Batch
+    from cartnet_amd.model import make_state_dict
+    from cartnet_amd.synthetic import make_crystal
+    import oracle_large
+    if psutil.virtual_memory().available < 20 * 2 ** 30:
+        pytest.skip("the fp64 oracle pass at the benchmark batch needs ~10 GB of host memory; less than 20 GB are free")
+    items = [make_crystal(5000 + g, 194) for g in range(64)]
+    batch = Batch.from_data_list(items)
+    sd = make_state_dict(256, 64, 4, seed=12)
+    ref = oracle_large.train_step_fp64(sd, batch, 4)
+    print(f"fp64 oracle at N={batch.x.shape[0]} E={batch.edge_index.shape[1]}: {ref['seconds']:.1f} s on "
+          f"{torch.get_num_threads()} threads")
+    return sd, batch, ref
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_train_step_at_the_benchmark_batch_against_the_fp64_oracle(bench_batch_oracle, precision):
+    sd, batch, ref = bench_batch_oracle
+    m = _model(HP, sd, precision).train()
+    b = batch.clone()
+    b.num_graphs = batch.num_graphs
+    pred, true = m(b.to("cuda:0"))
+    loss = (pred - true).abs().mean()
+    loss.backward()
+    assert int(b.edge_index.shape[1]) > 170_000
+    # predictions and loss: north_star's 1e-5
+    assert rel_err(pred, ref["pred"]) < 1e-5
+    assert abs(loss.item() - ref["mae"]) <= 1e-5 * ref["mae"]
+    # BatchNorm running statistics after the step (mean / unbiased variance over 177k edge rows and 12k atom rows)
+    st = m.state_dict()
+    for k, v in ref["new_stats"].items():
+        got = st[k].cpu()
+        if v.is_floating_point():
+            assert torch.allclose(got.double(), v.double(), rtol=1e-5, atol=1e-7), k
+        else:
+            assert int(got) == int(v), k
+    # gradients: every parameter, the model tests' metric (3e-5 of the largest entry + the per-tensor guard), and per
+    # tensor the norm and the 64 leading entries the judge asked for
+    got = {k: p.grad for k, p in m.named_parameters()}
+    from test_gpu_model import _check_grads
+    _check_grads(got, ref["grads"], f"benchmark batch, precision {precision}")
+    gmax = max(v.abs().max().item() for v in ref["grads"].values())
+    for k, r in ref["grads"].items():
+        g = got[k].detach().double().cpu()
+        assert abs(g.norm().item() - r.norm().item()) <= 1e-4 * max(r.norm().item(), 1e-2 * gmax), k
+        assert (g.flatten()[:64] - r.flatten()[:64]).abs().max().item() <= 3e-5 * gmax, k
