@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
     const float* __restrict__ gs, const float* __restrict__ e_in, const float* __restrict__ env,
     const int* __restrict__ rowptr, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, int N, int D, float* __restrict__ e_out, float* __restrict__ aggr,
-    double* __restrict__ parts_sum, double* __restrict__ parts_sq, int reverse, const int* __restrict__ node_gptr) {
+    double* __restrict__ parts_sum, double* __restrict__ parts_sq, int reverse, const int* __restrict__ node_gptr,
+    float* __restrict__ bc) {
   __shared__ double red[NODES_PER_BLOCK * 256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int ld = 2 * D;
@@ -94,10 +95,11 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
   for (int c0 = 0; c0 < D; c0 += 256) {
     const int c = c0 + lane * 4;
     const bool active = c < D;
-    f32x4 mean = {0, 0, 0, 0}, scale = {0, 0, 0, 0}, shift = {0, 0, 0, 0};
+    f32x4 mean = {0, 0, 0, 0}, scale = {0, 0, 0, 0}, shift = {0, 0, 0, 0}, rstd = {0, 0, 0, 0};
     if (active) {
       mean = ld4(mean_rstd + c);
-      scale = ld4(mean_rstd + D + c) * ld4(gamma + c);
+      rstd = ld4(mean_rstd + D + c);
+      scale = rstd * ld4(gamma + c);
       shift = ld4(beta + c);
     }
     f64x4 ps = {0, 0, 0, 0}, pq = {0, 0, 0, 0};
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
       const int t = n0 + bx * NODES_PER_BLOCK + wid + (reverse ? nsweeps - 1 - j : j) * stride;
       if (t >= n1) continue;
       const int k0 = rowptr[t], k1 = rowptr[t + 1];
-      f32x4 acc = {0, 0, 0, 0};
+      f32x4 acc = {0, 0, 0, 0}, accb = {0, 0, 0, 0}, accc = {0, 0, 0, 0};
       if (active) {
         // GATE_BATCH edges per round: all row loads of a round are issued before the first use (a round past the end
         // of the segment repeats the last edge and drops it)
@@ -124,13 +126,30 @@ __global__ __launch_bounds__(256) void cn_gate_scatter_fwd_kernel(
           for (int u = 0; u < GATE_BATCH; ++u) {
             if (k + u >= k1) break;
             f32x4 sig;
+            if (bc) {
+              // for the backward pass (cartnet_node_update_bwd_apply_bc): per target, B = sum_e s w and C = sum_e s w ghat with
+              // w = d sigma / d bn = env z (1 - z) -- the daggr share of the BatchNorm-backward sums is then a sum over ATOMS
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sig[q] = ev[u] * cn_sigmoid((g[u][q] - mean[q]) * scale[q] + shift[q]);
+              for (int q = 0; q < 4; ++q) {
+                const float z = cn_sigmoid((g[u][q] - mean[q]) * scale[q] + shift[q]);
+                sig[q] = ev[u] * z;
+                const float sw = sv[u][q] * (sig[q] * (1.0f - z));
+                accb[q] += sw;
+                accc[q] += sw * ((g[u][q] - mean[q]) * rstd[q]);
+              }
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) sig[q] = ev[u] * cn_sigmoid((g[u][q] - mean[q]) * scale[q] + shift[q]);
+            }
             if (e_out) st4(e_out + (size_t)(k + u) * D + c, ei[u] + sig);
             acc += sig * sv[u];
           }
         }
         st4(aggr + (size_t)t * D + c, acc);
+        if (bc) {
+          st4(bc + (size_t)t * ld + c, accb);
+          st4(bc + (size_t)t * ld + D + c, accc);
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -272,6 +291,32 @@ __global__ __launch_bounds__(256) void cn_segment_sum_kernel(const float* __rest
   }
 }
 
+// Per-target sums left unfinished by a GEMM epilogue (CartnetGemmArgs.seg_*, gemm_kernel.h): a wave there owns a run of 64
+// rows and writes the targets that lie inside it; here every other target gets the tail of its first run + the heads of
+// the runs that follow, added in run order.  One wave per (target, 256-column slab), as in the segment-sum kernel.
+__global__ __launch_bounds__(256) void cn_segment_fixup_kernel(const int* __restrict__ rowptr, const float* __restrict__ bnd,
+                                                               int N, int E, int W, float* __restrict__ out, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int chunks = (W + 255) / 256;
+  const long long items = (long long)N * chunks;
+  for (long long it = (long long)blockIdx.x * NODES_PER_BLOCK + wid; it < items; it += (long long)gridDim.x * NODES_PER_BLOCK) {
+    const int t = (int)(it / chunks);
+    const int c = (int)(it % chunks) * 256 + lane * 4;
+    if (c >= W) continue;
+    const int k0 = rowptr[t], k1 = rowptr[t + 1];
+    f32x4 acc = {0, 0, 0, 0};
+    if (k1 > k0) {
+      const int r0 = k0 >> 6, r1 = (k1 - 1) >> 6;
+      const int end0 = min((r0 + 1) << 6, E);
+      if (r0 == r1 && k1 < end0) continue;          // another target starts after it in the same run: the epilogue wrote it
+      acc = ld4(bnd + ((size_t)r0 * 2 + 1) * W + c);
+      for (int r = r0 + 1; r <= r1; ++r) acc += ld4(bnd + ((size_t)r * 2) * W + c);
+    }
+    st4(out + (size_t)t * ldo + c, acc);
+  }
+}
+
 // Long-segment variant (few, very uneven segments, e.g. atoms grouped by element): pass 1 cuts the sorted positions
 // into chunks of LONG_CHUNK rows, one wave per (chunk, 256-column slab), and writes one partial row per run of equal
 // segment id at tmp[first position of the run]; pass 2 adds each segment's partial rows in position order.
@@ -405,7 +450,7 @@ extern "C" int cartnet_gate_scatter_nparts(int32_t N) { return gate_parts(N); }
 static int gate_scatter_fwd_impl(bool half, const float* gs, const float* e_in, const float* env, const int32_t* rowptr,
                                  const float* mean_rstd, const float* gamma, const float* beta, int32_t N,
                                  int32_t D, float* e_out, float* aggr, double* parts_sum, double* parts_sq,
-                                 const CartnetGroups* groups, void* stream) {
+                                 const CartnetGroups* groups, void* stream, float* bc = nullptr) {
   CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_gate_scatter_fwd: D=%d must be a positive multiple of 4", D);
   CN_CHECK(gs && rowptr && mean_rstd && gamma && beta && aggr && parts_sum && parts_sq,
            "cartnet_gate_scatter_fwd: null pointer");
@@ -414,11 +459,11 @@ static int gate_scatter_fwd_impl(bool half, const float* gs, const float* e_in, 
   if (half)
     hipLaunchKernelGGL(cn_gate_scatter_fwd_kernel<true>, cn_group_grid(groups, gate_parts(N), true), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), gs, e_in, env, rowptr, mean_rstd, gamma, beta, N, D,
-                       e_out, aggr, parts_sum, parts_sq, /*reverse=*/1, groups ? groups->node_gptr : nullptr);
+                       e_out, aggr, parts_sum, parts_sq, /*reverse=*/1, groups ? groups->node_gptr : nullptr, bc);
   else
     hipLaunchKernelGGL(cn_gate_scatter_fwd_kernel<false>, cn_group_grid(groups, gate_parts(N), true), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), gs, e_in, env, rowptr, mean_rstd, gamma, beta, N, D,
-                       e_out, aggr, parts_sum, parts_sq, /*reverse=*/1, groups ? groups->node_gptr : nullptr);
+                       e_out, aggr, parts_sum, parts_sq, /*reverse=*/1, groups ? groups->node_gptr : nullptr, bc);
   CN_LAUNCH_CHECK("cartnet_gate_scatter_fwd");
   return 0;
 }
@@ -429,6 +474,14 @@ extern "C" int cartnet_gate_scatter_fwd(const float* gs, const float* e_in, cons
                                         const CartnetGroups* groups, void* stream) {
   return gate_scatter_fwd_impl(false, gs, e_in, env, rowptr, mean_rstd, gamma, beta, N, D, e_out, aggr, parts_sum, parts_sq,
                                groups, stream);
+}
+extern "C" int cartnet_gate_scatter_fwd_bc(const float* gs, const float* e_in, const float* env, const int32_t* rowptr,
+                                           const float* mean_rstd, const float* gamma, const float* beta, int32_t N,
+                                           int32_t D, float* e_out, float* aggr, double* parts_sum, double* parts_sq,
+                                           float* bc, void* stream) {
+  CN_CHECK(bc != nullptr && (reinterpret_cast<uintptr_t>(bc) & 15u) == 0, "cartnet_gate_scatter_fwd_bc: bc must be a 16-byte aligned [N, 2D] buffer");
+  return gate_scatter_fwd_impl(false, gs, e_in, env, rowptr, mean_rstd, gamma, beta, N, D, e_out, aggr, parts_sum, parts_sq,
+                               nullptr, stream, bc);
 }
 extern "C" int cartnet_gate_scatter_fwd_h(const void* gs_bf16, const float* e_in, const float* env, const int32_t* rowptr,
                                           const float* mean_rstd, const float* gamma, const float* beta, int32_t N,
@@ -533,6 +586,21 @@ static int segment_sum_impl(bool half, const float* rows, int32_t ld, const int3
     hipLaunchKernelGGL(cn_segment_sum_kernel<false>, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        rows, ld, ptr, perm, N, W, out, ldo, /*reverse=*/perm ? 1 : 0);
   CN_LAUNCH_CHECK("cartnet_segment_sum");
+  return 0;
+}
+
+extern "C" int cartnet_segment_fixup(const int32_t* rowptr, const float* bnd, int32_t N, int64_t E, int32_t W, float* out,
+                                     int32_t ldo, void* stream) {
+  CN_CHECK(N >= 0 && E >= 0 && E < 2147483647LL && W >= 4 && W % 4 == 0 && ldo % 4 == 0 && ldo >= W,
+           "cartnet_segment_fixup: W=%d ldo=%d must be multiples of 4", W, ldo);
+  if (N == 0) return 0;
+  CN_CHECK(rowptr && bnd && out, "cartnet_segment_fixup: null pointer");
+  long long items = (long long)N * ((W + 255) / 256);
+  long long blocks = (items + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(cn_segment_fixup_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rowptr,
+                     bnd, N, (int)E, W, out, ldo);
+  CN_LAUNCH_CHECK("cartnet_segment_fixup");
   return 0;
 }
 

@@ -197,6 +197,40 @@ static bool f32_image_path(const CartnetGemmArgs& a) {
   return ok;
 }
 
+static int choose_bn(const CartnetGemmArgs& a);
+
+// CartnetGemmArgs.gst_*: the launch reaches cn_gemm_f32nn128_kernel<false, true>, the one kernel that carries the gate
+// statistics epilogue.  (The same predicates the dispatch below and launch_variant apply, in their order.)
+static bool gate_stats_launch_ok(const CartnetGemmArgs& a) {
+  if (!(a.gst_g && a.gst_mean_rstd && a.gst_gamma && a.gst_beta && a.gst_ld >= a.N && a.gst_ld % 4 == 0)) return false;
+  if (!(aligned16(a.gst_g) && aligned16(a.gst_mean_rstd) && aligned16(a.gst_gamma) && aligned16(a.gst_beta))) return false;
+  if (!(a.precision == 0 && a.ngroups == 1 && !a.a_act && !a.b_act && !a.out_act && !a.dact[0] &&
+        !a.gather_i[0] && !a.cpre[0] && !a.bias[0] && a.colsum[0] && a.colsq[0] && !a.a_act_out[0] && a.N == 256))
+    return false;
+  if (!f32_image_path(a) || choose_bn(a) != 256) return false;
+  CartnetGemmArgs f = a;
+  if (segments_fold(a)) { f.K *= f.nsegs; f.nsegs = 1; }
+  return f.nsegs == 1 && cn_gemm::use_f32nn128(f);
+}
+
+// CartnetGemmArgs.seg_*: the launch reaches cn_gemm_f32nn_kernel<false, true> (256-wide tile, epilogue kind 4 | 256).
+static bool segment_sums_launch_ok(const CartnetGemmArgs& a) {
+  if (!(a.seg_bnd && a.tgt && a.seg_ldo >= a.ngroups * a.N && !a.gst_g)) return false;
+  for (int g = 0; g < a.ngroups; ++g)
+    if (!(a.seg_out[g] && a.dact[g] && !a.resid[g] && !a.gather_i[g] && !a.cpre[g] && !a.bias[g] && !a.colsum[g] &&
+          !a.a_act_out[g]))
+      return false;
+  if (!(a.precision == 0 && a.nsegs == 1 && !a.a_act && !a.b_act && !a.out_act && a.N == 256)) return false;
+  if (!f32_image_path(a) || choose_bn(a) != 256) return false;
+  return !cn_gemm::use_f32nn128(a);
+}
+
+extern "C" int cartnet_gemm_segment_sums_ok(const CartnetGemmArgs* args) {
+  return args && segment_sums_launch_ok(*args) ? 1 : 0;
+}
+
+extern "C" int cartnet_gemm_gate_stats_ok(const CartnetGemmArgs* args) { return args && gate_stats_launch_ok(*args) ? 1 : 0; }
+
 // Column-tile width of a launch (see the comment in cartnet_gemm_impl): 256 / 128 / 64 by N, narrower for launches
 // with few tiles.  Shared with the launch timer so that its variant names the kernel family that really runs.
 static int choose_bn(const CartnetGemmArgs& a) {
@@ -334,6 +368,14 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
                    !a.out_act,
                "cartnet_gemm: split-K writes raw partial slabs, no epilogue allowed");
   }
+  CN_CHECK(!a.gst_g || gate_stats_launch_ok(a),
+           "cartnet_gemm: gst_g is set but this launch does not reach the kernel with the gate-statistics epilogue "
+           "(precision 0, N = 256, weight image, one group, colsum + colsq (+ resid) and nothing else, >= 64 row tiles: "
+           "ask cartnet_gemm_gate_stats_ok first)");
+  CN_CHECK(!a.seg_out[0] || segment_sums_launch_ok(a),
+           "cartnet_gemm: seg_out is set but this launch does not reach the kernel with the per-target sums in its epilogue "
+           "(precision 0, N = 256, weight images, dact and nothing else, the 256-wide kernel: ask "
+           "cartnet_gemm_segment_sums_ok first)");
   cn_gemm::GemmFlags fl;
   fl.tile_m0 = 0;
   fl.split0 = 0;

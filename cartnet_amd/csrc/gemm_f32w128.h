@@ -15,7 +15,9 @@ constexpr int W128_BN = 128;
 constexpr int W128_B_BYTES = W128_BN * BK * 4;          // 8 KB per K-step per 128-column tile
 constexpr int W128_BUF_BYTES = F32_A_BYTES + W128_B_BYTES;
 
-template <bool A_ACT>
+// GSTK: the dE product with the gate statistics of the layer below in its epilogue (CartnetGemmArgs.gst_*, epilogue kind
+// 2 | 128) as a kernel of its own, so that the extra epilogue registers cannot disturb the allocation of the other forms.
+template <bool A_ACT, bool GSTK = false>
 __global__ __launch_bounds__(NTHREADS, 6) void cn_gemm_f32nn128_kernel(const CartnetGemmArgs p, const GemmFlags fl) {
   using S = Shape<W128_BN>;
   static_assert(S::TM == 2 && S::TN == 1 && S::WGM == 2 && S::WGN == 4, "wave tile is 64 x 32");
@@ -157,19 +159,26 @@ __global__ __launch_bounds__(NTHREADS, 6) void cn_gemm_f32nn128_kernel(const Car
       if (u + 1 < nsteps) step(std::integral_constant<int, 1>{}, u + 1, r0);
     }
   }
-  const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
-                   (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);
 #define CN_EPIW(K) epilogue_wide<W128_BN, K>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem, kind)
-  switch (kind) {
-    case 0: CN_EPIW(0); break;
-    case 1: CN_EPIW(1); break;
-    case 16: CN_EPIW(16); break;
-    case 96: CN_EPIW(96); break;
-    case 2: CN_EPIW(2); break;
-    case 4: CN_EPIW(4); break;
-    case 12: CN_EPIW(12); break;
-    case 14: CN_EPIW(14); break;
-    default: CN_EPIW(-1); break;
+  if constexpr (GSTK) {
+    // with the edge residual (layers below the last) or without (the last layer: the head does not read the edge features)
+    const int kind = p.resid[g] ? 130 : 128;
+    if (p.resid[g]) CN_EPIW(130);
+    else CN_EPIW(128);
+  } else {
+    const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
+                     (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);
+    switch (kind) {
+      case 0: CN_EPIW(0); break;
+      case 1: CN_EPIW(1); break;
+      case 16: CN_EPIW(16); break;
+      case 96: CN_EPIW(96); break;
+      case 2: CN_EPIW(2); break;
+      case 4: CN_EPIW(4); break;
+      case 12: CN_EPIW(12); break;
+      case 14: CN_EPIW(14); break;
+      default: CN_EPIW(-1); break;
+    }
   }
 #undef CN_EPIW
 }

@@ -30,6 +30,15 @@ struct Work {
   // forward transients
   float* Pn;
   double *cs, *cq, *ps, *pq, *bnrow;   // bnrow [2D + 2]: the summed row of a sync-BatchNorm exchange
+  // Gate BatchNorm-backward sums without a pass over the edges (fp32, one BatchNorm group, no sync-BatchNorm, D = 256):
+  // bc[l] [N, 2D] = per-target sums written by the forward gate kernel; gpa / gpb = partial rows of the two sums -- rows
+  // [0, tiles_e) from the epilogue of the dE product of the layer above, rows [tiles_e, tiles_e + nparts_n) from the node
+  // update's apply pass (include/cartnet_hip.h: cartnet_gate_scatter_fwd_bc).  nullptr = the statistics pass runs.
+  float* bc[CARTNET_MAX_LAYERS];
+  double *gpa, *gpb;
+  // by-target sums of dpre from the dpre product's epilogue (CartnetGemmArgs.seg_*): head / tail rows of every 64-row run,
+  // [2 * ceil(E / 64)][2D]; nullptr = the by-target cartnet_segment_sum pass runs
+  float* seg_bnd;
   // silu(pre) / silu(he_pre), written by the forward GEMMs that activate them (CartnetGemmArgs.a_act_out) for the weight
   // gradients of the second Linears; nullptr = recompute the SiLU in the weight-gradient kernel
   float *act[CARTNET_MAX_LAYERS], *he_act;
@@ -46,6 +55,27 @@ struct Work {
   CartnetGroups grp;
   const CartnetGroups* groups;   // &grp, or nullptr for one group (set by the entry points, not by carve)
 };
+
+// The gate's BatchNorm-backward sums come from the dE epilogue + per-atom sums instead of a statistics pass over gs and
+// de_out (544 MB per layer at the benchmark batch): needs the kernel that carries the epilogue (cartnet_gemm_gate_stats_ok:
+// fp32 MFMA, D = 256 -- the two K-segments of dE fold into one product --, at least 64 row tiles), one BatchNorm group and
+// per-rank statistics.  Training-mode passes only (the callers check `training`).
+inline bool gate_sums_fused(const CartnetModel& m, int G, int tiles_e) {
+#ifdef CN_NO_GATE_FUSE      /* A/B builds only (tools/build_variant.sh): the statistics pass of rounds 1-4 */
+  return false;
+#endif
+  return m.gemm_precision == 0 && m.D == 256 && G == 1 && tiles_e >= 64 && m.half_storage == 0 && m.bn_allreduce == nullptr;
+}
+
+// The by-target sums of dpre (the node halves of the first Linears' gradient, index_select backward of cartnet.py:218) come
+// out of the dpre product's epilogue instead of a segment-sum pass that re-reads dpre (363 MB per layer at the benchmark
+// batch): needs the 256-wide fp32 kernel (cartnet_gemm_segment_sums_ok: D = 256, two groups of at least 100 row tiles).
+inline bool dpre_sums_fused(const CartnetModel& m, int tiles_e) {
+#ifdef CN_NO_SEG_FUSE       /* A/B builds only (tools/build_variant.sh) */
+  return false;
+#endif
+  return m.gemm_precision == 0 && m.D == 256 && 2 * tiles_e >= 200 && m.half_storage == 0;
+}
 
 Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_bwd, char* base, size_t* total) {
   Work w;
@@ -133,6 +163,11 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
     for (int l = 0; l < L; ++l) w.act[l] = c.take<float>(En * 2 * D);
     w.he_act = c.take<float>(En * 2 * D);
   }
+  if (need_bwd && gate_sums_fused(m, w.G, w.tiles_e)) {
+    for (int l = 0; l < L; ++l) w.bc[l] = c.take<float>(Nn * 2 * D);
+    w.gpa = c.take<double>((size_t)(w.tiles_e + w.nparts_n) * D);
+    w.gpb = c.take<double>((size_t)(w.tiles_e + w.nparts_n) * D);
+  }
   w.hid = c.take<float>(Nn * H);
   w.p6 = c.take<float>((size_t)(M > 0 ? M : 1) * 6);
   w.edge0T = c.take<float>((size_t)w.ldf * 2 * D);   // [ldf, 2D]: rows kf.. are zero
@@ -188,6 +223,7 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
       w.dPn[i] = c.take<float>(Nn * 4 * D);
       w.dpre[i] = take_edge2d();
     }
+    if (dpre_sums_fused(m, w.tiles_e)) w.seg_bnd = c.take<float>(((En + 63) / 64) * 2 * 2 * D);
     w.dhe = c.take<float>(En * 2 * D);
     w.dx0 = c.take<float>(Nn * 2 * D);
     w.seg_tmp = c.take<float>(Nn * 2 * D);
@@ -592,9 +628,13 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
     // pass of their own over the gate half of gs (181 MB at the benchmark batch, ~40 us) instead of in the epilogue
     if (w.groups && training) RUN(cartnet_colstats_grouped(w.gs[l], 2 * D, D, w.groups, w.cs, w.cq, st));
     RUN(bn_stats(w.cs, w.cq, w.tiles_e, b.E, m.buf[l].norm_mean, m.buf[l].norm_var, m.buf[l].norm_nbt, w.mr1[l], 1));
-    RUN((half ? cartnet_gate_scatter_fwd_h : cartnet_gate_scatter_fwd_f)(
-        w.gs[l], e, m.use_envelope[l] ? w.env : nullptr, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, N, D, e_next, w.aggr[l],
-        w.ps, w.pq, w.groups, st));
+    if (training && w.bc[l])      // also leaves the per-target sums the backward pass builds its BatchNorm sums from
+      RUN(cartnet_gate_scatter_fwd_bc(w.gs[l], e, m.use_envelope[l] ? w.env : nullptr, w.rowptr, w.mr1[l], q.norm_w, q.norm_b,
+                                      N, D, e_next, w.aggr[l], w.ps, w.pq, w.bc[l], st));
+    else
+      RUN((half ? cartnet_gate_scatter_fwd_h : cartnet_gate_scatter_fwd_f)(
+          w.gs[l], e, m.use_envelope[l] ? w.env : nullptr, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, N, D, e_next, w.aggr[l],
+          w.ps, w.pq, w.groups, st));
     RUN(bn_stats(w.ps, w.pq, w.gparts, N, m.buf[l].norm2_mean, m.buf[l].norm2_var, m.buf[l].norm2_nbt, w.mr2[l], 0));
     RUN(cartnet_node_update_fwd(w.aggr[l], x, w.mr2[l], q.norm2_w, q.norm2_b, N, D, x_next, w.groups, st));
     x = x_next;
@@ -750,12 +790,27 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       float* grads2[2] = {gq.norm2_b, gq.norm2_w};      // the same sums are the BatchNorm affine gradients
       RUN(cartnet_colsum_finalize2(parts, outs, grads2, 2, w.nparts_n, D, st));
     }
+    const bool fused_sums = training && w.bc[l] != nullptr;
+    if (fused_sums) {
+      // sum(dbn), sum(dbn ghat) = the rows the dE epilogue of layer l + 1 left (de_out's share) + the atoms' share, taken
+      // here while daggr is in registers: no statistics pass over gs / de_out
+      double* node_a = w.gpa + (size_t)w.tiles_e * D;
+      double* node_b = w.gpb + (size_t)w.tiles_e * D;
+      RUN(cartnet_node_update_bwd_apply_bc(w.aggr[l], dx, w.mr2[l], q.norm2_w, q.norm2_b, w.sums2, training, N, D, w.daggr,
+                                           w.bc[l], node_a, node_b, st));
+      double* parts[2] = {de ? w.gpa : node_a, de ? w.gpb : node_b};
+      float* outs[2] = {w.sums1, w.sums1 + D};
+      float* grads1[2] = {gq.norm_b, gq.norm_w};
+      RUN(cartnet_colsum_finalize2(parts, outs, grads1, 2, (de ? w.tiles_e : 0) + w.nparts_n, D, st));
+    } else {
     RUN(cartnet_node_update_bwd_apply(w.aggr[l], dx, w.mr2[l], q.norm2_w, q.norm2_b, w.sums2, training, N, D, w.daggr,
                                       w.groups, st));
     // gate * sender aggregation and the edge BatchNorm
     RUN((half ? cartnet_gate_scatter_bwd_stats_h : cartnet_gate_scatter_bwd_stats_f)(
         gs, de, w.daggr, env, w.rowptr, w.mr1[l], q.norm_w, q.norm_b, N, D, w.pa, w.pb, w.groups, st));
-    if (sync_bn) {
+    }
+    if (fused_sums) {
+    } else if (sync_bn) {
       RUN(bn_sums_sync(w.pa, w.pb, w.gparts, b.E, w.sums1, gq.norm_b, gq.norm_w));
     } else if (w.groups) {
       RUN(cartnet_group_sums_finalize(w.pa, w.pb, D, w.groups, 1, w.sums1, gq.norm_b, gq.norm_w, st));
@@ -788,6 +843,12 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       // (no column sums here: the bias gradients of the first Linears are the column sums of dpre over all edges =
       //  the column sums over atoms of its by-target segment sums, 14x fewer rows -- taken from dPn below)
       if (w.i_dpre[l]) { a.b_split[0] = w.i_dpre[l]; a.b_split[1] = w.i_dpre[l] + img_blk(m); }
+      if (w.seg_bnd) {   // by-target sums of dpre (the first half of dPn) from the epilogue; segsums() completes them
+        a.seg_out[0] = dPn; a.seg_out[1] = dPn + D; a.seg_ldo = 4 * D; a.seg_bnd = w.seg_bnd; a.tgt = w.tgt32;
+        CN_CHECK(cartnet_gemm_segment_sums_ok(&a) == 1,
+                 "cartnet_model_backward: the dpre product of layer %d does not take the kernel with the per-target sums "
+                 "(model.hip: dpre_sums_fused is out of step with gemm.hip: segment_sums_launch_ok)", l);
+      }
       return cartnet_gemm(&a, st);
     };
     auto side_w1e = [&]() -> int {   // edge-block weight gradients of the first Linears
@@ -804,6 +865,17 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       a.C[0] = de_in; a.resid[0] = de; a.ldr = D;
       a.b_split_folded = w.i_de[l];
       if (l == 0) { a.dact[0] = w.e0_pre; a.ldd = D; a.colsum[0] = w.cs_misc[0]; }
+      if (l > 0 && training && w.bc[l - 1]) {
+        // de_in of this layer is de_out of layer l - 1: its share of that layer's gate BatchNorm-backward sums, from the
+        // epilogue (gs[l - 1] still holds the forward g: its own backward overwrites it later)
+        a.gst_g = w.gs[l - 1]; a.gst_ld = 2 * D;
+        a.gst_env = m.use_envelope[l - 1] ? w.env : nullptr;
+        a.gst_mean_rstd = w.mr1[l - 1]; a.gst_gamma = P.layer[l - 1].norm_w; a.gst_beta = P.layer[l - 1].norm_b;
+        a.colsum[0] = w.gpa; a.colsq[0] = w.gpb;
+        CN_CHECK(cartnet_gemm_gate_stats_ok(&a) == 1,
+                 "cartnet_model_backward: the dE product of layer %d does not take the gate-statistics kernel (model.hip: "
+                 "gate_sums_fused is out of step with gemm.hip: gate_stats_launch_ok)", l);
+      }
       if (half && D != 256) {
         // the two K-segments only fold into one product at N = 256 (gemm.hip: segments_fold), and no kernel reads bf16
         // K-segments: two single-segment products instead, the second adding onto the first in place (every output
@@ -830,6 +902,8 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     };
     // node-side halves: reduce dpre over each atom's incoming (target) and outgoing (source) edges
     auto segsums = [&](void* s_) -> int {
+      if (w.seg_bnd) RUN(cartnet_segment_fixup(w.rowptr, w.seg_bnd, N, b.E, 2 * D, dPn, 4 * D, s_));
+      else
       RUN((half ? cartnet_segment_sum_h : cartnet_segment_sum_f)(dpre, 2 * D, w.rowptr, nullptr, N, 2 * D, dPn, 4 * D, s_));
       return (half ? cartnet_segment_sum_h : cartnet_segment_sum_f)(dpre, 2 * D, w.colptr, w.perm, N, 2 * D, dPn + 2 * D,
                                                                     4 * D, s_);

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void cn_node_update_bwd_kernel(
     const float* __restrict__ aggr, const float* __restrict__ dx_out, const float* __restrict__ mean_rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums, float inv_count,
     int N, int D, double* __restrict__ parts_a, double* __restrict__ parts_b, float* __restrict__ daggr,
-    const int* __restrict__ node_gptr) {
+    const int* __restrict__ node_gptr, const float* __restrict__ bc) {
   __shared__ double red[NODES_PER_BLOCK * 256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   int gi, bx, n0, n1;
@@ -393,9 +393,19 @@ __global__ __launch_bounds__(256) void cn_node_update_bwd_kernel(
           o[q] = gam[q] * rstd[q] * (dxn - m_a[q] - ahat * m_b[q]);
         }
       }
-      if (MODE == 1) st4(daggr + (size_t)n * D + c, o);
+      if (MODE == 1) {
+        st4(daggr + (size_t)n * D + c, o);
+        if (bc) {   // daggr's share of the gate BatchNorm-backward sums: sum_t daggr[t] B[t], sum_t daggr[t] C[t]
+          const f32x4 bb = ld4(bc + (size_t)n * 2 * D + c), cc = ld4(bc + (size_t)n * 2 * D + D + c);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            pa[q] += (double)(o[q] * bb[q]);
+            pb[q] += (double)(o[q] * cc[q]);
+          }
+        }
+      }
     }
-    if (MODE == 0) {
+    if (MODE == 0 || bc) {
       cn_block_store_parts_row(pa, red, parts_a, D, c, active, wid, lane, prow);
       cn_block_store_parts_row(pb, red, parts_b, D, c, active, wid, lane, prow);
     }
@@ -786,7 +796,7 @@ extern "C" int cartnet_node_update_bwd_stats(const float* aggr, const float* dx_
   CN_CHECK(cn_groups_ok(groups), "cartnet_node_update_bwd_stats: bad groups");
   hipLaunchKernelGGL(cn_node_update_bwd_kernel<0>, cn_group_grid(groups, node_parts(N), false), dim3(256), 0, ST(stream),
                      aggr, dx_out, mean_rstd, gamma, beta, (const float*)nullptr, 0.f, N, D, parts_a, parts_b,
-                     (float*)nullptr, groups ? groups->node_gptr : nullptr);
+                     (float*)nullptr, groups ? groups->node_gptr : nullptr, (const float*)nullptr);
   CN_LAUNCH_CHECK("cartnet_node_update_bwd_stats");
   return 0;
 }
@@ -802,8 +812,23 @@ extern "C" int cartnet_node_update_bwd_apply(const float* aggr, const float* dx_
   const float inv = (training && N > 0) ? (float)(1.0 / (double)N) : 0.f;
   hipLaunchKernelGGL(cn_node_update_bwd_kernel<1>, cn_group_grid(groups, node_parts(N), false), dim3(256), 0, ST(stream),
                      aggr, dx_out, mean_rstd, gamma, beta, sums, inv, N, D, (double*)nullptr, (double*)nullptr, daggr,
-                     groups ? groups->node_gptr : nullptr);
+                     groups ? groups->node_gptr : nullptr, (const float*)nullptr);
   CN_LAUNCH_CHECK("cartnet_node_update_bwd_apply");
+  return 0;
+}
+
+extern "C" int cartnet_node_update_bwd_apply_bc(const float* aggr, const float* dx_out, const float* mean_rstd,
+                                                const float* gamma, const float* beta, const float* sums,
+                                                int32_t training, int32_t N, int32_t D, float* daggr, const float* bc,
+                                                double* parts_a, double* parts_b, void* stream) {
+  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_node_update_bwd_apply_bc: D=%d must be a multiple of 4", D);
+  CN_CHECK(aggr && dx_out && mean_rstd && gamma && beta && sums && daggr && bc && parts_a && parts_b,
+           "cartnet_node_update_bwd_apply_bc: null pointer");
+  const float inv = (training && N > 0) ? (float)(1.0 / (double)N) : 0.f;
+  // (N == 0 still launches: the workgroups write their zero partial rows)
+  hipLaunchKernelGGL(cn_node_update_bwd_kernel<1>, dim3(node_parts(N), 1), dim3(256), 0, ST(stream), aggr, dx_out, mean_rstd,
+                     gamma, beta, sums, inv, N, D, parts_a, parts_b, daggr, (const int*)nullptr, bc);
+  CN_LAUNCH_CHECK("cartnet_node_update_bwd_apply_bc");
   return 0;
 }
 

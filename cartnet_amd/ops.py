@@ -78,7 +78,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
          a_kstrided: bool = False, b_kstrided: bool = False, a_act: bool = False, b_act: bool = False,
          out_act: bool = False, segments: bool = False, bias=None, gather_i=None, gather_j=None, tgt=None, src=None,
          resid=None, dact=None, cpre=None, colsum=None, colsq=None, splitk: int = 1, precision: int = 0,
-         b_split=None, b_split_folded=None, a_act_out=None, tile_policy: int = 0) -> None:
+         b_split=None, b_split_folded=None, a_act_out=None, tile_policy: int = 0, gate_stats=None, seg_sums=None) -> None:
     """C[g] = epilogue(sum_s opA(A[s]) @ opB(B[s])) on the fp32 matrix cores (see include/cartnet_hip.h).
 
     A / B / C_out: one tensor or a list.  With ``segments=False`` the lists are independent problems (groups) of
@@ -87,6 +87,11 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
     (for splitk > 1: C is [splitk*M, N] contiguous slabs).
     ``a_act_out`` (with ``a_act`` and ``b_split`` at precision 0): tensors shaped and strided like A that receive silu(A).
     ``tile_policy``: CartnetGemmArgs.tile_policy (0 automatic; 1 narrow tiles for grouped N = 256 products too; 128 / 256 force).
+    ``gate_stats`` = (g [M, N] (a column block of a wider matrix is fine), env [M] or None, mean_rstd [2N], gamma [N],
+    beta [N]): CartnetGemmArgs.gst_* -- colsum / colsq then receive the partial sums of v w and v w ghat (see the header);
+    raises unless the launch reaches the kernel that carries that epilogue.
+    ``seg_sums`` = (outs: one [n_targets, N] view per group (column blocks of one matrix), bnd [2 * ceil(M/64), ngroups*N],
+    tgt [M] int32 ascending): CartnetGemmArgs.seg_* -- per-target sums of the output rows; finish with ``segment_fixup``.
     """
     lib = _l.load()
     A, B, C_out = _aslist(A, 1), _aslist(B, 1), _aslist(C_out, 1)
@@ -212,7 +217,48 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
                 continue
             _vec(t, tiles_m * N, f"gemm {name}[{g}]", torch.float64)
             getattr(args, field)[g] = t.data_ptr()
+    if gate_stats is not None:
+        gg, genv, gmr, ggam, gbet = gate_stats
+        _f32_2d(gg, "gemm gate_stats g")
+        if tuple(gg.shape) != (M, N):
+            raise ValueError(f"gemm gate_stats g: expected shape {(M, N)}, got {tuple(gg.shape)}")
+        _vec(genv, M, "gemm gate_stats env")
+        _vec(gmr, 2 * N, "gemm gate_stats mean_rstd")
+        _vec(ggam, N, "gemm gate_stats gamma")
+        _vec(gbet, N, "gemm gate_stats beta")
+        args.gst_g, args.gst_ld, args.gst_env = gg.data_ptr(), _ld(gg), _l.ptr(genv)
+        args.gst_mean_rstd, args.gst_gamma, args.gst_beta = gmr.data_ptr(), ggam.data_ptr(), gbet.data_ptr()
+        if not lib.cartnet_gemm_gate_stats_ok(C.byref(args)):
+            raise ValueError("gemm gate_stats: this launch does not reach the kernel with the gate-statistics epilogue "
+                             "(precision 0, N = 256, weight image, resid + colsum + colsq only, >= 64 row tiles)")
+    if seg_sums is not None:
+        souts, sbnd, stgt = seg_sums
+        souts = _aslist(souts, ngroups)
+        if len(souts) != ngroups:
+            raise ValueError(f"gemm seg_sums: expected {ngroups} outputs")
+        for g, t in enumerate(souts):
+            _f32_2d(t, f"gemm seg_sums out[{g}]")
+            if t.shape[1] != N or _ld(t) != _ld(souts[0]):
+                raise ValueError("gemm seg_sums: outputs need N columns and one row stride")
+            args.seg_out[g] = t.data_ptr()
+        _vec(stgt, M, "gemm seg_sums tgt", torch.int32)
+        _vec(sbnd, 2 * ((M + 63) // 64) * ngroups * N, "gemm seg_sums bnd")
+        args.seg_ldo, args.seg_bnd, args.tgt = _ld(souts[0]), sbnd.data_ptr(), stgt.data_ptr()
+        if not lib.cartnet_gemm_segment_sums_ok(C.byref(args)):
+            raise ValueError("gemm seg_sums: this launch does not reach the kernel with the per-target sums in its epilogue "
+                             "(precision 0, N = 256, weight images, dact only, the 256-wide kernel)")
     _l.check(lib.cartnet_gemm(C.byref(args), _l.stream_ptr()), "cartnet_gemm")
+
+
+def segment_fixup(rowptr: Tensor, bnd: Tensor, E: int, out: Tensor) -> None:
+    """cartnet_segment_fixup: completes the per-target sums of a ``gemm(..., seg_sums=...)`` launch.  ``out`` [N, W]: the
+    matrix whose column blocks were that launch's outputs (W = ngroups * N of the launch)."""
+    _f32_2d(out, "segment_fixup out")
+    N, W = out.shape
+    _vec(rowptr, N + 1, "segment_fixup rowptr", torch.int32)
+    _vec(bnd, 2 * ((int(E) + 63) // 64) * W, "segment_fixup bnd")
+    _l.check(_l.load().cartnet_segment_fixup(rowptr.data_ptr(), bnd.data_ptr(), N, int(E), W, out.data_ptr(), _ld(out),
+                                             _l.stream_ptr()), "cartnet_segment_fixup")
 
 
 def pack_b(mats: Sequence[Tensor], outs: Optional[Sequence[Tensor]] = None) -> list:
@@ -512,7 +558,8 @@ def _edge_rows(t: Tensor, E: int, W: int, name: str) -> None:
 
 
 def gate_scatter_fwd(gs, e_in, env, layout: GraphLayout, mean_rstd, gamma, beta, e_out, aggr, parts_sum,
-                     parts_sq) -> None:
+                     parts_sq, bc=None) -> None:
+    """``bc`` [N, 2D] (optional): cartnet_gate_scatter_fwd_bc -- per target also sum s w | sum s w ghat for the backward pass."""
     E, N = layout.E, layout.N
     D = int(aggr.shape[1])
     _edge_rows(gs, E, 2 * D, "gate_scatter_fwd gs")
@@ -529,6 +576,14 @@ def gate_scatter_fwd(gs, e_in, env, layout: GraphLayout, mean_rstd, gamma, beta,
     npart = gate_nparts(N)
     _vec(parts_sum, npart * D, "gate_scatter_fwd parts_sum", torch.float64)
     _vec(parts_sq, npart * D, "gate_scatter_fwd parts_sq", torch.float64)
+    if bc is not None:
+        _edge_rows(bc, N, 2 * D, "gate_scatter_fwd bc")
+        _l.check(_l.load().cartnet_gate_scatter_fwd_bc(gs.data_ptr(), _l.ptr(e_in), _l.ptr(env), layout.rowptr.data_ptr(),
+                                                       mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, D,
+                                                       _l.ptr(e_out), aggr.data_ptr(), parts_sum.data_ptr(),
+                                                       parts_sq.data_ptr(), bc.data_ptr(), _l.stream_ptr()),
+                 "cartnet_gate_scatter_fwd_bc")
+        return
     _l.check(_l.load().cartnet_gate_scatter_fwd(gs.data_ptr(), _l.ptr(e_in), _l.ptr(env), layout.rowptr.data_ptr(),
                                                 mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, D,
                                                 _l.ptr(e_out), aggr.data_ptr(), parts_sum.data_ptr(),
@@ -659,7 +714,10 @@ def node_update_bwd_stats(aggr, dx_out, mean_rstd, gamma, beta, parts_a, parts_b
              "cartnet_node_update_bwd_stats")
 
 
-def node_update_bwd_apply(aggr, dx_out, mean_rstd, gamma, beta, sums, training: bool, daggr) -> None:
+def node_update_bwd_apply(aggr, dx_out, mean_rstd, gamma, beta, sums, training: bool, daggr, bc=None, parts_a=None,
+                          parts_b=None) -> None:
+    """``bc`` [N, 2D] + ``parts_a`` / ``parts_b`` [node_nparts(N), D] fp64: cartnet_node_update_bwd_apply_bc -- also the
+    column partial sums of daggr * bc[:, :D] and daggr * bc[:, D:]."""
     _f32_2d(aggr, "node_update_bwd_apply aggr")
     N, D = aggr.shape
     _edge_rows(aggr, N, D, "aggr")
@@ -669,6 +727,16 @@ def node_update_bwd_apply(aggr, dx_out, mean_rstd, gamma, beta, sums, training: 
     _vec(gamma, D, "gamma")
     _vec(beta, D, "beta")
     _vec(sums, 2 * D, "sums")
+    if bc is not None:
+        _edge_rows(bc, N, 2 * D, "bc")
+        _vec(parts_a, node_nparts(N) * D, "parts_a", torch.float64)
+        _vec(parts_b, node_nparts(N) * D, "parts_b", torch.float64)
+        _l.check(_l.load().cartnet_node_update_bwd_apply_bc(aggr.data_ptr(), dx_out.data_ptr(), mean_rstd.data_ptr(),
+                                                            gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(),
+                                                            int(training), N, D, daggr.data_ptr(), bc.data_ptr(),
+                                                            parts_a.data_ptr(), parts_b.data_ptr(), _l.stream_ptr()),
+                 "cartnet_node_update_bwd_apply_bc")
+        return
     _l.check(_l.load().cartnet_node_update_bwd_apply(aggr.data_ptr(), dx_out.data_ptr(), mean_rstd.data_ptr(),
                                                      gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(),
                                                      int(training), N, D, daggr.data_ptr(), None, _l.stream_ptr()),

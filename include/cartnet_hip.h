@@ -35,7 +35,7 @@ int cartnet_abi_version(void);
 /* sizeof of every struct below, in header order (CartnetGemmArgs, CartnetShard, CartnetCollated, CartnetGemmProfile,
  * CartnetGroups, CartnetLayerParams, CartnetLayerBuffers, CartnetParams, CartnetModel, CartnetBatch,
  * CartnetGateGemmArgs, CartnetIcfConv, CartnetIcfParams, CartnetIcfModel); returns the number of structs.  A binding checks its mirrors against these when it loads the
- * library, and cartnet_abi_version() against the version it was written for (7: tile_policy in CartnetGemmArgs,
+ * library, and cartnet_abi_version() against the version it was written for (8: gst_* in CartnetGemmArgs; 7: tile_policy in CartnetGemmArgs,
  * aux_stream in cartnet_model_forward, CartnetGateGemmArgs in the size table; cartnet_gemm_tile_policy() is gone). */
 int cartnet_abi_struct_sizes(size_t* out, int32_t capacity);
 
@@ -112,6 +112,32 @@ typedef struct CartnetGemmArgs {
                           stay in ELEMENTS).  Honoured by the half-storage kernels (csrc/gemm_h.h): activation x weight
                           products with a pre-split weight image (b_split) and weight gradients (both operands
                           k-strided); every other launch with one of these flags set is refused. */
+  /* Gate statistics in the epilogue (precision 0 with a weight image, ngroups == 1, resid optional, nothing else: the dE
+   * product of CartNet's backward).  v = the value written to C (de_out of the layer BELOW, models/cartnet.py:225).  With
+   * g = gst_g[m*gst_ld + n] (that layer's gate pre-activation, cartnet.py:237), ghat = (g - mean[n]) * rstd[n] with
+   * mean_rstd = [mean | rstd] (2N floats), w = gst_env[m] * s * (1 - s), s = sigmoid(ghat * gamma[n] + beta[n])
+   * (cartnet.py:238-241), the per-column partial sums over this block's rows of  v * w  -> colsum[0][tile_m*N + n]  and
+   * v * w * ghat -> colsq[0][tile_m*N + n] (both must be given): the edge-residual share of the BatchNorm backward's
+   * sum(dbn) and sum(dbn * ghat), taken where de_out is in registers instead of by a pass over gs and de_out.
+   * gst_env may be NULL (no envelope).  Any other launch with gst_g set is refused. */
+  const float* gst_g;
+  const float* gst_env;
+  const float* gst_mean_rstd;
+  const float* gst_gamma;
+  const float* gst_beta;
+  int32_t gst_ld;
+  /* Per-target sums of the output rows in the epilogue (precision 0 with a weight image, N = 256, dact given and nothing
+   * else, enough row tiles for the 256-wide kernel: the dpre product of CartNet's backward).  The M rows are edges sorted
+   * by target (tgt[m] ascending: models/cartnet.py:218 with the reference's edge order, dataset/utils.py:235).  A target
+   * whose rows lie inside one 64-row run (rows 64 r .. 64 r + 63) with another target's first row after them in the same
+   * run gets its column sums written to seg_out[g][tgt * seg_ldo + n]; every run also leaves the sums of its rows before
+   * its first target start ("head") and from its last target start on ("tail") in seg_bnd[(run*2 + 0 / 1) * ngroups*N +
+   * g*N + n] (seg_bnd: 2 * ceil(M/64) * ngroups * N floats), and cartnet_segment_fixup completes the other targets from
+   * those.  Replaces a cartnet_segment_sum pass over C (index_select backward, cartnet.py:218).  Any other launch with
+   * seg_out[0] set is refused (cartnet_gemm_segment_sums_ok). */
+  float* seg_out[CARTNET_MAX_GROUPS];
+  float* seg_bnd;
+  int32_t seg_ldo;
   int32_t tile_policy; /* column-tile width of the DMA-fed fp32 activation x weight kernels (precision 0, b_split given).
                           0: the library's choice per launch (128 x 256 tiles on two workgroups per CU; 128 x 128 on three
                           for the node-term gather epilogue, for single-group N = 256 products and for launches with few
@@ -120,6 +146,17 @@ typedef struct CartnetGemmArgs {
 } CartnetGemmArgs;
 
 int cartnet_gemm(const CartnetGemmArgs* args, void* stream);
+/* 1 if a launch with these arguments (gst_* set) takes the kernel that carries the gate-statistics epilogue; cartnet_gemm
+ * refuses such a launch otherwise.  Host only, no launch. */
+int cartnet_gemm_gate_stats_ok(const CartnetGemmArgs* args);
+/* The same question for seg_out / seg_bnd. */
+int cartnet_gemm_segment_sums_ok(const CartnetGemmArgs* args);
+/* Completes the per-target sums a launch with seg_out left unfinished: for every target t (rows rowptr[t] .. rowptr[t+1]
+ * of the M = E rows) that the epilogue did not write -- its rows cross a 64-row run boundary, or run on to the end of a
+ * run or of the matrix -- out[t, 0:W] = tail of its first run + heads of the following ones (fixed order); targets without
+ * rows get zeros.  W = ngroups * N of that launch (bnd as written by it), out / ldo = seg_out[0] / seg_ldo. */
+int cartnet_segment_fixup(const int32_t* rowptr, const float* bnd, int32_t N, int64_t E, int32_t W, float* out, int32_t ldo,
+                          void* stream);
 
 /* bf16x3 pre-split of a k-strided GEMM operand B [K, N] (element (k, n) = src[k*stride_k + n*stride_n]; a weight
  * W [out, in] used as B = W^T has stride_k = 1, stride_n = ld) into the image cartnet_gemm reads through
@@ -492,6 +529,17 @@ int cartnet_gate_scatter_fwd(const float* gs, const float* e_in, const float* en
                              float* e_out, float* aggr, double* parts_sum, double* parts_sq,
                              const CartnetGroups* groups, void* stream);
 
+/* The same, and per target t also  bc[t, 0:D] = sum_e s w,  bc[t, D:2D] = sum_e s w ghat  with w = env z (1 - z),
+ * z = sigmoid(bn(g)), ghat = (g - mean) rstd, the sums over the edges of row t (bc: [N, 2D] fp32, 16-byte aligned).  With
+ * them the BatchNorm backward of the gate needs no pass over the edges for its two sums (cartnet.py:238 backward):
+ *   sum_e dbn      = sum_e de_out w      + sum_t daggr[t] bc[t, 0:D]
+ *   sum_e dbn ghat = sum_e de_out w ghat + sum_t daggr[t] bc[t, D:2D]
+ * -- the first terms come from the epilogue of the product that writes de_out (CartnetGemmArgs.gst_*), the second from
+ * cartnet_node_update_bwd_apply_bc, which has daggr in registers.  One BatchNorm group only. */
+int cartnet_gate_scatter_fwd_bc(const float* gs, const float* e_in, const float* env, const int32_t* rowptr,
+                                const float* mean_rstd, const float* gamma, const float* beta, int32_t N, int32_t D,
+                                float* e_out, float* aggr, double* parts_sum, double* parts_sq, float* bc, void* stream);
+
 /* de_out may be NULL in both backward passes (last layer: the head does not read the edge features).
  * Backward, pass 1 (statistics): with dm = daggr[tgt], z = sigmoid(bn(g)), dbn = (dm*s + de_out) * env * z(1-z):
  * column partial sums of dbn and dbn * ghat (ghat = (g-mean)*rstd) -> parts_a, parts_b [nparts][D]. */
@@ -562,6 +610,13 @@ int cartnet_node_update_bwd_stats(const float* aggr, const float* dx_out, const 
 int cartnet_node_update_bwd_apply(const float* aggr, const float* dx_out, const float* mean_rstd,
                                   const float* gamma, const float* beta, const float* sums, int32_t training,
                                   int32_t N, int32_t D, float* daggr, const CartnetGroups* groups, void* stream);
+/* The same (one BatchNorm group), and the column partial sums of daggr * bc[:, 0:D] -> parts_a and daggr * bc[:, D:2D] ->
+ * parts_b [cartnet_node_nparts(N)][D] (bc from cartnet_gate_scatter_fwd_bc): the atoms' share of the gate's
+ * BatchNorm-backward sums, taken while daggr is in registers. */
+int cartnet_node_update_bwd_apply_bc(const float* aggr, const float* dx_out, const float* mean_rstd,
+                                     const float* gamma, const float* beta, const float* sums, int32_t training,
+                                     int32_t N, int32_t D, float* daggr, const float* bc, double* parts_a,
+                                     double* parts_b, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Cholesky ADP head (models/cartnet.py:293-305).  hid [N, H] = pre-activation of head.MLP.0 for every atom;

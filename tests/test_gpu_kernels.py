@@ -961,3 +961,146 @@ def test_gate_gemm_eval_matches_the_two_kernel_path(ops, D, degs):
     e2 = torch.empty_like(e_out)
     ops.gate_gemm_eval(pre, imgs[0], imgs[1], bg, ba, mr, gamma, beta, None, e_in, lay, e2, a2)
     assert torch.equal(a2, aggr) and (E == 0 or torch.equal(e2, e_out))
+
+
+@pytest.mark.parametrize("with_env", [True, False])
+def test_gate_backward_sums_without_the_statistics_pass(ops, with_env):
+    """Round 5: sum(dbn) and sum(dbn ghat) of the gate's BatchNorm backward (models/cartnet.py:238) from three places
+    where the operands are in registers anyway -- per-target sums of the forward gate kernel (bc), the node update's
+    apply pass (daggr * bc) and the epilogue of the dE product that writes de_out (CartnetGemmArgs.gst_*) -- against the
+    statistics pass they replace and against the fp64 formula.  D = 256, E >= 64 row tiles: the fused kernel's range."""
+    D = 256
+    ei, ptr = _random_graph_batch(26, 50, 80, 14, seed=77)
+    N, E = int(ptr[-1]), ei.shape[1]
+    assert (E + 127) // 128 >= 64
+    lay = ops.GraphLayout(ei.to(dev()), N, ptr.to(dev()))
+    gs, e_in = rnd(E, 2 * D, seed=1), rnd(E, D, seed=2)
+    env = torch.rand(E, generator=torch.Generator().manual_seed(3)).to(dev()) if with_env else None
+    g64 = gs[:, :D].double().cpu()
+    bmean, brstd = g64.mean(0), torch.rsqrt(g64.var(0, unbiased=False) + 1e-5)
+    mean_rstd = torch.cat([bmean, brstd]).float().to(dev()).contiguous()
+    gamma, beta = rnd(D, seed=6), rnd(D, seed=7)
+    e_out, aggr, aggr2 = (torch.empty(E, D, device=dev()), torch.empty(N, D, device=dev()), torch.empty(N, D, device=dev()))
+    e_out2 = torch.empty(E, D, device=dev())
+    nparts = ops.gate_nparts(N)
+    ps, pq, ps2, pq2 = (torch.zeros(nparts * D, device=dev(), dtype=torch.float64) for _ in range(4))
+    bc = torch.full((N, 2 * D), 7.0, device=dev())
+    ops.gate_scatter_fwd(gs, e_in, env, lay, mean_rstd, gamma, beta, e_out, aggr, ps, pq, bc=bc)
+    ops.gate_scatter_fwd(gs, e_in, env, lay, mean_rstd, gamma, beta, e_out2, aggr2, ps2, pq2)
+    assert torch.equal(e_out, e_out2) and torch.equal(aggr, aggr2) and torch.equal(ps, ps2)      # the old outputs, bit for bit
+    # fp64 formula
+    c = lambda t: t.detach().double().cpu()
+    ev = c(env)[:, None] if with_env else 1.0
+    ghat = (g64 - bmean) * brstd
+    z = torch.sigmoid(ghat * c(gamma) + c(beta))
+    w = ev * z * (1 - z)
+    s64 = c(gs)[:, D:]
+    tgt = ei[1]
+    B_ref = torch.zeros(N, D, dtype=torch.float64).index_add_(0, tgt, s64 * w)
+    C_ref = torch.zeros(N, D, dtype=torch.float64).index_add_(0, tgt, s64 * w * ghat)
+    assert rel_err(bc[:, :D], B_ref) < TOL and rel_err(bc[:, D:], C_ref) < TOL
+    # node share: daggr comes out of the node update's apply pass, which also leaves sum_t daggr[t] bc[t]
+    aggr_in, dx_out = rnd(N, D, seed=11), rnd(N, D, seed=12)
+    mr2 = torch.cat([aggr_in.mean(0), torch.rsqrt(aggr_in.var(0, unbiased=False) + 1e-5)]).contiguous()
+    g2, b2 = rnd(D, seed=13), rnd(D, seed=14)
+    npn = ops.node_nparts(N)
+    pa, pb = (torch.zeros(npn * D, device=dev(), dtype=torch.float64) for _ in range(2))
+    ops.node_update_bwd_stats(aggr_in, dx_out, mr2, g2, b2, pa, pb)
+    sums2 = torch.empty(2 * D, device=dev())
+    ops.colsum_finalize([pa, pb], npn, [sums2[:D], sums2[D:]])
+    daggr, daggr_plain = torch.empty(N, D, device=dev()), torch.empty(N, D, device=dev())
+    na, nb = (torch.full((npn * D,), 5.0, device=dev(), dtype=torch.float64) for _ in range(2))
+    ops.node_update_bwd_apply(aggr_in, dx_out, mr2, g2, b2, sums2, True, daggr, bc=bc, parts_a=na, parts_b=nb)
+    ops.node_update_bwd_apply(aggr_in, dx_out, mr2, g2, b2, sums2, True, daggr_plain)
+    assert torch.equal(daggr, daggr_plain)
+    node_a, node_b = na.view(npn, D).sum(0).cpu(), nb.view(npn, D).sum(0).cpu()
+    assert rel_err(node_a, (c(daggr) * c(bc[:, :D])).sum(0)) < 1e-6
+    assert rel_err(node_b, (c(daggr) * c(bc[:, D:])).sum(0)) < 1e-6
+    # edge share: the dE product de_out = resid + dpre @ [W1; W2] (two folded K-segments of 256) with the epilogue
+    dpre, resid = rnd(E, 2 * D, seed=21, scale=0.3), rnd(E, D, seed=22)
+    W = rnd(2 * D, D, seed=23, scale=0.05)                    # [K = 512, N = 256]: segments W[:256], W[256:]
+    img = ops.pack_b([W[:D], W[D:]])
+    folded = torch.cat([t.view(-1) for t in img]).contiguous()
+    de_out = torch.empty(E, D, device=dev())
+    tiles = ops.gemm_tiles_m(E)
+    ca, cb = (torch.full((tiles * D,), 3.0, device=dev(), dtype=torch.float64) for _ in range(2))
+    ops.gemm([dpre[:, :D], dpre[:, D:]], [W[:D], W[D:]], de_out, segments=True, b_kstrided=True, resid=resid,
+             b_split=img, b_split_folded=folded, colsum=ca, colsq=cb,
+             gate_stats=(gs[:, :D], env, mean_rstd, gamma, beta))
+    de_ref = c(resid) + c(dpre) @ c(W)
+    assert rel_err(de_out, de_ref) < TOL
+    plain = torch.empty(E, D, device=dev())
+    ops.gemm([dpre[:, :D], dpre[:, D:]], [W[:D], W[D:]], plain, segments=True, b_kstrided=True, resid=resid, b_split=img,
+             b_split_folded=folded)
+    assert torch.equal(plain, de_out)                         # the statistics do not touch the product
+    edge_a, edge_b = ca.view(tiles, D).sum(0).cpu(), cb.view(tiles, D).sum(0).cpu()
+    assert rel_err(edge_a, (c(de_out) * w).sum(0)) < 2e-6
+    assert rel_err(edge_b, (c(de_out) * w * ghat).sum(0)) < 2e-6
+    # together == the statistics pass == the formula
+    spa, spb = (torch.zeros(nparts * D, device=dev(), dtype=torch.float64) for _ in range(2))
+    ops.gate_scatter_bwd_stats(gs, de_out, daggr, env, lay, mean_rstd, gamma, beta, spa, spb)
+    old_a, old_b = spa.view(nparts, D).sum(0).cpu(), spb.view(nparts, D).sum(0).cpu()
+    dbn = (c(daggr)[tgt] * s64 + c(de_out)) * w
+    ref_a, ref_b = dbn.sum(0), (dbn * ghat).sum(0)
+    scale_a, scale_b = dbn.abs().sum(0).max().item(), (dbn * ghat).abs().sum(0).max().item()
+    for got_a, got_b in ((edge_a + node_a, edge_b + node_b), (old_a, old_b)):
+        assert (got_a - ref_a).abs().max().item() <= 2e-6 * scale_a
+        assert (got_b - ref_b).abs().max().item() <= 2e-6 * scale_b
+    # a launch that cannot reach the kernel is refused, not silently computed without the sums
+    small = 50 * 128
+    with pytest.raises(ValueError, match="gate-statistics"):
+        ops.gemm([dpre[:small, :D], dpre[:small, D:]], [W[:D], W[D:]], de_out[:small], segments=True, b_kstrided=True,
+                 resid=resid[:small], b_split=img, b_split_folded=folded, colsum=ca[:50 * D], colsq=cb[:50 * D],
+                 gate_stats=(gs[:small, :D], None, mean_rstd, gamma, beta))
+
+
+@pytest.mark.parametrize("pattern", ["random", "long", "aligned", "tail"])
+def test_per_target_sums_from_the_dpre_epilogue(ops, pattern):
+    """Round 5: the by-target segment sums of dpre (index_select backward, models/cartnet.py:218) from the epilogue of the
+    product that writes dpre (CartnetGemmArgs.seg_*) + cartnet_segment_fixup, against cartnet_segment_sum over the written
+    matrix and the fp64 sum.  Degree patterns: random (0..40), targets longer than a 64-row run (70, 130, 200 rows: whole
+    runs without a start), targets that end exactly on run / tile boundaries, and a last target that runs to the end of a
+    ragged last tile.  Integer-valued operands make every sum exact: the comparison with the segment-sum kernel is bitwise."""
+    D = 256
+    g = torch.Generator().manual_seed({"random": 1, "long": 2, "aligned": 3, "tail": 4}[pattern])
+    if pattern == "random":
+        degs = torch.randint(0, 41, (700,), generator=g).tolist()
+    elif pattern == "long":
+        degs = ([70, 3, 130, 0, 0, 200, 1, 64, 63, 65, 128, 2] * 12) + torch.randint(5, 30, (300,), generator=g).tolist()
+    elif pattern == "aligned":
+        degs = ([64] * 10 + [32, 32] * 10 + [16] * 8 + [128] * 4 + [1] * 64 + [63, 1] * 6) * 4
+    else:
+        degs = torch.randint(8, 25, (900,), generator=g).tolist() + [37]
+    ei, ptr = _graph_with_degrees(degs, seed=5)
+    N, E = len(degs), ei.shape[1]
+    assert 2 * ((E + 127) // 128) >= 200, E                      # the 256-wide kernel's range (two groups)
+    if pattern == "tail":
+        assert E % 128 != 0
+    lay = ops.GraphLayout(ei.to(dev()), N, ptr.to(dev()))
+    A = torch.randint(-3, 4, (E, 2 * D), generator=g).float().to(dev())
+    W = [torch.randint(-2, 3, (D, D), generator=g).float().to(dev()) for _ in range(2)]      # [K, N], k-strided
+    pre = torch.zeros(E, 2 * D, device=dev())                    # silu'(0) = 0.5: the epilogue halves every (even) product
+    W = [2.0 * w for w in W]
+    img = ops.pack_b(W)
+    dpre = torch.empty(E, 2 * D, device=dev())
+    dPn = torch.full((N, 4 * D), 9.0, device=dev())
+    bnd = torch.full((2 * ((E + 63) // 64) * 2 * D,), 9.0, device=dev())
+    ops.gemm([A[:, :D], A[:, D:]], W, [dpre[:, :D], dpre[:, D:]], b_kstrided=True, dact=[pre[:, :D], pre[:, D:]], b_split=img,
+             seg_sums=([dPn[:, :D], dPn[:, D:2 * D]], bnd, lay.tgt))
+    ops.segment_fixup(lay.rowptr, bnd, E, dPn[:, :2 * D])
+    plain = torch.empty(E, 2 * D, device=dev())
+    ops.gemm([A[:, :D], A[:, D:]], W, [plain[:, :D], plain[:, D:]], b_kstrided=True, dact=[pre[:, :D], pre[:, D:]], b_split=img)
+    assert torch.equal(plain, dpre)
+    ref = torch.cat([A[:, :D].double().cpu() @ W[0].double().cpu(), A[:, D:].double().cpu() @ W[1].double().cpu()], 1) * 0.5
+    assert torch.equal(dpre.double().cpu(), ref)
+    want = torch.empty(N, 2 * D, device=dev())
+    ops.segment_sum(dpre, lay.rowptr, None, want)
+    seg_ref = torch.zeros(N, 2 * D, dtype=torch.float64).index_add_(0, ei[1], ref)
+    assert torch.equal(want.double().cpu(), seg_ref)
+    assert torch.equal(dPn[:, :2 * D], want)
+    assert bool((dPn[:, 2 * D:] == 9.0).all())                   # the by-source half is not touched
+    # a launch outside the kernel's range is refused
+    with pytest.raises(ValueError, match="per-target sums"):
+        ops.gemm([A[:6400, :D], A[:6400, D:]], W, [dpre[:6400, :D], dpre[:6400, D:]], b_kstrided=True,
+                 dact=[pre[:6400, :D], pre[:6400, D:]], b_split=img,
+                 seg_sums=([dPn[:, :D], dPn[:, D:2 * D]], bnd, lay.tgt))

@@ -53,7 +53,7 @@ def test_two_epochs_against_the_reference_train_epoch():
         return out
 
     mask = tu.well_conditioned(z, 4)
-    assert mask.sum() > 0.2 * mask.size
+    assert mask.sum() >= 500                                    # (most embedding rows belong to absent elements: zero gradient)
     for ep in range(epochs):
         stats = train_epoch(loader(), m, opt, accum, scheduler)
         want = float(np.mean(z["iter_mae"][ep * len(micro):(ep + 1) * len(micro)]))
@@ -76,6 +76,9 @@ def test_two_epochs_against_the_reference_train_epoch():
         assert abs(rec["beta1"] - one_cycle_momentum(s, total, warm)) < 1e-15
         g_ref, p_ref = z[f"step{s}_grad"], z[f"step{s}_param"]
         gmax = np.abs(g_ref).max()
+        dd = np.abs(rec["param"] - p_ref)
+        print(f"step {s}: lr {rec['lr']:.3e} beta1 {rec['beta1']:.4f} grad err {np.abs(rec['grad'] - g_ref).max() / gmax:.2e} "
+              f"param err well-conditioned {dd[mask].max() / rec['lr']:.2e} lr, all {dd.max() / rec['lr']:.2e} lr")
         # accumulated gradient of the window: unscaled sum over its micro-batches.  The first window starts from the
         # fixture's weights (3e-5, the model tests' bound); later ones from parameters that already differ where Adam
         # amplified rounding noise (see train_epoch_utils.well_conditioned), hence the wider bound

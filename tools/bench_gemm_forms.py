@@ -65,6 +65,31 @@ timeit("dE: folded K=512 + residual", lambda: ops.gemm([pre[:, :D], pre[:, D:]],
        b_kstrided=True, segments=True, resid=e, b_split_folded=img_de, precision=prec), F)
 timeit("dE: same, no residual", lambda: ops.gemm([pre[:, :D], pre[:, D:]], [W0g[:, 2*D:], W0a[:, 2*D:]], out1,
        b_kstrided=True, segments=True, b_split_folded=img_de, precision=prec), F)
+# round 5: the two epilogue fusions next to the passes they replace (fp32 only)
+if prec == 0:
+    rowptr = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+    rowptr[1:] = torch.cumsum(torch.bincount(tgt.long(), minlength=N), 0).to(torch.int32)
+    dPn = torch.empty(N, 4*D, device=dev)
+    bnd = torch.empty(2 * ((E + 63) // 64) * 2*D, device=dev)
+    timeit("dpre: x2 * silu'(pre) + per-target sums (seg_*)", lambda: ops.gemm([gs[:, :D], gs[:, D:]], [W2g, W2a], [out2[:, :D], out2[:, D:]],
+           b_kstrided=True, b_split=img_dpre, precision=prec, dact=[pre[:, :D], pre[:, D:]],
+           seg_sums=([dPn[:, :D], dPn[:, D:2*D]], bnd, tgt)), F)
+    timeit("pass: segment_fixup", lambda: ops.segment_fixup(rowptr, bnd, E, dPn[:, :2*D]), F)
+    timeit("pass: segment_sum by target [E, 2D]", lambda: ops.segment_sum(out2, rowptr, None, dPn[:, :2*D]), F)
+    env = torch.rand(E, generator=g).to(dev); mr = torch.cat([rnd(D, sc=0.1), 1.0 + torch.rand(D, generator=g).to(dev)]).contiguous()
+    gam, bet = rnd(D), rnd(D)
+    ca = torch.empty(tiles*D, dtype=torch.float64, device=dev); cb = torch.empty_like(ca)
+    timeit("dE: folded K=512 + residual + gate stats (gst_*)", lambda: ops.gemm([pre[:, :D], pre[:, D:]], [W0g[:, 2*D:], W0a[:, 2*D:]], out1,
+           b_kstrided=True, segments=True, resid=e, b_split_folded=img_de, precision=prec, colsum=ca, colsq=cb,
+           gate_stats=(gs[:, :D], env, mr, gam, bet)), F)
+    class L: pass
+    lay = L(); lay.E, lay.N, lay.rowptr = E, N, rowptr
+    daggr = rnd(N, D); npg = ops.gate_nparts(N)
+    pa = torch.empty(npg*D, dtype=torch.float64, device=dev); pb = torch.empty_like(pa)
+    timeit("pass: gate_scatter_bwd_stats", lambda: ops.gate_scatter_bwd_stats(gs, e, daggr, env, lay, mr, gam, bet, pa, pb), F)
+    aggr = torch.empty(N, D, device=dev); eo = torch.empty(E, D, device=dev); bcb = torch.empty(N, 2*D, device=dev)
+    timeit("pass: gate_scatter_fwd", lambda: ops.gate_scatter_fwd(gs, e, env, lay, mr, gam, bet, eo, aggr, pa, pb), F)
+    timeit("pass: gate_scatter_fwd + bc", lambda: ops.gate_scatter_fwd(gs, e, env, lay, mr, gam, bet, eo, aggr, pa, pb, bc=bcb), F)
 # encoder
 We2 = rnd(D, 2*D, sc=0.05); be2 = rnd(D)
 We2T = T(We2); img_e2 = make([We2T]); img_e2b = make([We2])
