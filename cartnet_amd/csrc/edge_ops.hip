@@ -291,32 +291,6 @@ __global__ __launch_bounds__(256) void cn_segment_sum_kernel(const float* __rest
   }
 }
 
-// Per-target sums left unfinished by a GEMM epilogue (CartnetGemmArgs.seg_*, gemm_kernel.h): a wave there owns a run of 64
-// rows and writes the targets that lie inside it; here every other target gets the tail of its first run + the heads of
-// the runs that follow, added in run order.  One wave per (target, 256-column slab), as in the segment-sum kernel.
-__global__ __launch_bounds__(256) void cn_segment_fixup_kernel(const int* __restrict__ rowptr, const float* __restrict__ bnd,
-                                                               int N, int E, int W, float* __restrict__ out, int ldo) {
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int chunks = (W + 255) / 256;
-  const long long items = (long long)N * chunks;
-  for (long long it = (long long)blockIdx.x * NODES_PER_BLOCK + wid; it < items; it += (long long)gridDim.x * NODES_PER_BLOCK) {
-    const int t = (int)(it / chunks);
-    const int c = (int)(it % chunks) * 256 + lane * 4;
-    if (c >= W) continue;
-    const int k0 = rowptr[t], k1 = rowptr[t + 1];
-    f32x4 acc = {0, 0, 0, 0};
-    if (k1 > k0) {
-      const int r0 = k0 >> 6, r1 = (k1 - 1) >> 6;
-      const int end0 = min((r0 + 1) << 6, E);
-      if (r0 == r1 && k1 < end0) continue;          // another target starts after it in the same run: the epilogue wrote it
-      acc = ld4(bnd + ((size_t)r0 * 2 + 1) * W + c);
-      for (int r = r0 + 1; r <= r1; ++r) acc += ld4(bnd + ((size_t)r * 2) * W + c);
-    }
-    st4(out + (size_t)t * ldo + c, acc);
-  }
-}
-
 // Long-segment variant (few, very uneven segments, e.g. atoms grouped by element): pass 1 cuts the sorted positions
 // into chunks of LONG_CHUNK rows, one wave per (chunk, 256-column slab), and writes one partial row per run of equal
 // segment id at tmp[first position of the run]; pass 2 adds each segment's partial rows in position order.
@@ -586,21 +560,6 @@ static int segment_sum_impl(bool half, const float* rows, int32_t ld, const int3
     hipLaunchKernelGGL(cn_segment_sum_kernel<false>, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        rows, ld, ptr, perm, N, W, out, ldo, /*reverse=*/perm ? 1 : 0);
   CN_LAUNCH_CHECK("cartnet_segment_sum");
-  return 0;
-}
-
-extern "C" int cartnet_segment_fixup(const int32_t* rowptr, const float* bnd, int32_t N, int64_t E, int32_t W, float* out,
-                                     int32_t ldo, void* stream) {
-  CN_CHECK(N >= 0 && E >= 0 && E < 2147483647LL && W >= 4 && W % 4 == 0 && ldo % 4 == 0 && ldo >= W,
-           "cartnet_segment_fixup: W=%d ldo=%d must be multiples of 4", W, ldo);
-  if (N == 0) return 0;
-  CN_CHECK(rowptr && bnd && out, "cartnet_segment_fixup: null pointer");
-  long long items = (long long)N * ((W + 255) / 256);
-  long long blocks = (items + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;
-  if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(cn_segment_fixup_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rowptr,
-                     bnd, N, (int)E, W, out, ldo);
-  CN_LAUNCH_CHECK("cartnet_segment_fixup");
   return 0;
 }
 

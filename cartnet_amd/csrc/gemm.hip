@@ -213,22 +213,6 @@ static bool gate_stats_launch_ok(const CartnetGemmArgs& a) {
   return f.nsegs == 1 && cn_gemm::use_f32nn128(f);
 }
 
-// CartnetGemmArgs.seg_*: the launch reaches cn_gemm_f32nn_kernel<false, true> (256-wide tile, epilogue kind 4 | 256).
-static bool segment_sums_launch_ok(const CartnetGemmArgs& a) {
-  if (!(a.seg_bnd && a.tgt && a.seg_ldo >= a.ngroups * a.N && !a.gst_g)) return false;
-  for (int g = 0; g < a.ngroups; ++g)
-    if (!(a.seg_out[g] && a.dact[g] && !a.resid[g] && !a.gather_i[g] && !a.cpre[g] && !a.bias[g] && !a.colsum[g] &&
-          !a.a_act_out[g]))
-      return false;
-  if (!(a.precision == 0 && a.nsegs == 1 && !a.a_act && !a.b_act && !a.out_act && a.N == 256)) return false;
-  if (!f32_image_path(a) || choose_bn(a) != 256) return false;
-  return !cn_gemm::use_f32nn128(a);
-}
-
-extern "C" int cartnet_gemm_segment_sums_ok(const CartnetGemmArgs* args) {
-  return args && segment_sums_launch_ok(*args) ? 1 : 0;
-}
-
 extern "C" int cartnet_gemm_gate_stats_ok(const CartnetGemmArgs* args) { return args && gate_stats_launch_ok(*args) ? 1 : 0; }
 
 // Column-tile width of a launch (see the comment in cartnet_gemm_impl): 256 / 128 / 64 by N, narrower for launches
@@ -372,10 +356,6 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
            "cartnet_gemm: gst_g is set but this launch does not reach the kernel with the gate-statistics epilogue "
            "(precision 0, N = 256, weight image, one group, colsum + colsq (+ resid) and nothing else, >= 64 row tiles: "
            "ask cartnet_gemm_gate_stats_ok first)");
-  CN_CHECK(!a.seg_out[0] || segment_sums_launch_ok(a),
-           "cartnet_gemm: seg_out is set but this launch does not reach the kernel with the per-target sums in its epilogue "
-           "(precision 0, N = 256, weight images, dact and nothing else, the 256-wide kernel: ask "
-           "cartnet_gemm_segment_sums_ok first)");
   cn_gemm::GemmFlags fl;
   fl.tile_m0 = 0;
   fl.split0 = 0;

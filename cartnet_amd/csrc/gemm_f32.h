@@ -17,9 +17,7 @@ constexpr int F32_B_BYTES = F32_BN * BK * 4;            // 16 KB per K-step per 
 constexpr int F32_BUF_BYTES = F32_A_BYTES + F32_B_BYTES;
 __device__ __host__ __forceinline__ int f32_swz(int row, int quad) { return row * 64 + ((quad ^ ((row >> 2) & 3)) << 4); }
 
-// SEGK: the dpre product with the per-target sums of its output rows in the epilogue (CartnetGemmArgs.seg_*, epilogue kind
-// 4 | 256) as a kernel of its own (its epilogue registers do not disturb the allocation of the other forms).
-template <bool A_ACT, bool SEGK = false>
+template <bool A_ACT>
 __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const CartnetGemmArgs p, const GemmFlags fl) {
   using S = Shape<F32_BN>;
   static_assert(S::TM == 2 && S::TN == 2, "wave tile is 64 x 64");
@@ -180,24 +178,19 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
     CN_PHASE(2);
   }
   // epilogue (shared with gemm_kernel.h)
+  const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
+                   (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);
 #define CN_EPIW(K) epilogue_wide<F32_BN, K>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem, kind)
-  if constexpr (SEGK) {
-    const int kind = 260;
-    CN_EPIW(260);
-  } else {
-    const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
-                     (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);
-    switch (kind) {
-      case 0: CN_EPIW(0); break;
-      case 1: CN_EPIW(1); break;
-      case 16: CN_EPIW(16); break;
-      case 96: CN_EPIW(96); break;
-      case 2: CN_EPIW(2); break;
-      case 4: CN_EPIW(4); break;
-      case 12: CN_EPIW(12); break;
-      case 14: CN_EPIW(14); break;
-      default: CN_EPIW(-1); break;
-    }
+  switch (kind) {
+    case 0: CN_EPIW(0); break;
+    case 1: CN_EPIW(1); break;
+    case 16: CN_EPIW(16); break;
+    case 96: CN_EPIW(96); break;
+    case 2: CN_EPIW(2); break;
+    case 4: CN_EPIW(4); break;
+    case 12: CN_EPIW(12); break;
+    case 14: CN_EPIW(14); break;
+    default: CN_EPIW(-1); break;
   }
 #undef CN_EPIW
 #ifdef CN_PHASE_STAMP

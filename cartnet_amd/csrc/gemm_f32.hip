@@ -4,8 +4,7 @@
 namespace cn_gemm {
 
 void launch_f32nn(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st) {
-  if (a.seg_out[0]) hipLaunchKernelGGL((cn_gemm_f32nn_kernel<false, true>), grid, dim3(NTHREADS), 0, st, a, fl);   // (cartnet_gemm checked: no a_act)
-  else if (a_act) hipLaunchKernelGGL((cn_gemm_f32nn_kernel<true>), grid, dim3(NTHREADS), 0, st, a, fl);
+  if (a_act) hipLaunchKernelGGL((cn_gemm_f32nn_kernel<true>), grid, dim3(NTHREADS), 0, st, a, fl);
   else hipLaunchKernelGGL((cn_gemm_f32nn_kernel<false>), grid, dim3(NTHREADS), 0, st, a, fl);
 }
 

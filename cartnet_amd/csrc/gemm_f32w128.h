@@ -15,9 +15,12 @@ constexpr int W128_BN = 128;
 constexpr int W128_B_BYTES = W128_BN * BK * 4;          // 8 KB per K-step per 128-column tile
 constexpr int W128_BUF_BYTES = F32_A_BYTES + W128_B_BYTES;
 
-// GSTK: the dE product with the gate statistics of the layer below in its epilogue (CartnetGemmArgs.gst_*, epilogue kind
-// 2 | 128) as a kernel of its own, so that the extra epilogue registers cannot disturb the allocation of the other forms.
-template <bool A_ACT, bool GSTK = false>
+// GSTK != 0: the dE product with the gate statistics of the layer below in its epilogue (CartnetGemmArgs.gst_*) as kernels
+// of their own -- 1: with the edge residual (epilogue kind 2 | 128), 2: without (kind 128; the last layer: the head does
+// not read the edge features) -- so that the extra epilogue registers cannot disturb the allocation of the other forms
+// (one kernel carrying both kinds spilled 30 registers and lost 27 us per launch; each alone: 80 VGPRs, none).
+// (A kernel of its own for the node-term gather form -- kind 1, no spills either -- measured within noise: 393-394 vs 394-399 us.)
+template <bool A_ACT, int GSTK = 0>
 __global__ __launch_bounds__(NTHREADS, 6) void cn_gemm_f32nn128_kernel(const CartnetGemmArgs p, const GemmFlags fl) {
   using S = Shape<W128_BN>;
   static_assert(S::TM == 2 && S::TN == 1 && S::WGM == 2 && S::WGN == 4, "wave tile is 64 x 32");
@@ -160,11 +163,12 @@ __global__ __launch_bounds__(NTHREADS, 6) void cn_gemm_f32nn128_kernel(const Car
     }
   }
 #define CN_EPIW(K) epilogue_wide<W128_BN, K>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem, kind)
-  if constexpr (GSTK) {
-    // with the edge residual (layers below the last) or without (the last layer: the head does not read the edge features)
-    const int kind = p.resid[g] ? 130 : 128;
-    if (p.resid[g]) CN_EPIW(130);
-    else CN_EPIW(128);
+  if constexpr (GSTK == 1) {
+    const int kind = 130;
+    CN_EPIW(130);
+  } else if constexpr (GSTK == 2) {
+    const int kind = 128;
+    CN_EPIW(128);
   } else {
     const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
                      (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);

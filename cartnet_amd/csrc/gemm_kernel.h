@@ -409,9 +409,7 @@ __device__ __forceinline__ void epilogue_wide_s(const CartnetGemmArgs& p, ACC& a
   // bit 7: gate statistics (CartnetGemmArgs.gst_*), compile-time kinds only -- the run-time form (KIND < 0) does not carry
   // the code, and cartnet_gemm refuses a launch with gst_g set that would not reach a kernel with the case
   constexpr bool GST = KIND >= 0 && (KIND & 128) != 0;
-  // bit 8: per-target sums of the output rows (CartnetGemmArgs.seg_*), compile-time kinds only, 32x32 MFMA tiles only
-  constexpr bool SEG = KIND >= 0 && (KIND & 256) != 0 && !MF16;
-  constexpr int KBASE = KIND >= 0 ? (KIND & 127) : KIND;      // the kind without the two extension bits
+  constexpr int KBASE = KIND >= 0 ? (KIND & 127) : KIND;      // the kind without the extension bit
   const int li = lane & 31, lh = lane >> 5;
   const int c4 = lane & 7, rsub = lane >> 3;
   float* C = p.C[g];
@@ -438,10 +436,11 @@ __device__ __forceinline__ void epilogue_wide_s(const CartnetGemmArgs& p, ACC& a
 #pragma unroll
     for (int b = 0; b < S::TN; ++b) {
       const int gcol = col0 + wn * S::WN + b * 32 + c4 * 4;
-      gmean[b] = ldv4(p.gst_mean_rstd + gcol);
+      // per column: ghat = g * rstd - mean * rstd;  -log2(e) * bn = ghat * (-log2(e) gamma) - log2(e) beta
       grstd[b] = ldv4(p.gst_mean_rstd + p.N + gcol);
-      ggam[b] = ldv4(p.gst_gamma + gcol);
-      gbet[b] = ldv4(p.gst_beta + gcol);
+      gmean[b] = -ldv4(p.gst_mean_rstd + gcol) * grstd[b];
+      ggam[b] = ldv4(p.gst_gamma + gcol) * -1.44269504088896f;
+      gbet[b] = ldv4(p.gst_beta + gcol) * -1.44269504088896f;
       gs1[b] = f32x4{0.f, 0.f, 0.f, 0.f};
       gs2[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -482,30 +481,6 @@ __device__ __forceinline__ void epilogue_wide_s(const CartnetGemmArgs& p, ACC& a
             }
           }
       }
-    }
-  }
-  // SEG: the rows of a tile are edges sorted by target; a wave owns S::WM consecutive rows (a "run") and walks each of its
-  // columns down the run, adding rows in order and flushing at every row that starts a new target: a target whose rows
-  // lie inside the run goes straight to seg_out, the pieces before the run's first start (head) and after its last one
-  // (tail) go to seg_bnd[run][0 / 1] and cartnet_segment_fixup adds the pieces of such targets in run order.
-  unsigned long long seg_mask = 0;
-  int seg_tv = 0, seg_nr = 0, seg_run = 0;
-  float seg_carry[S::TN];
-  bool seg_seen[S::TN];
-  if constexpr (SEG) {
-    static_assert(S::WM == 64, "a run is the 64 rows of a wave");
-    const int run_row0 = row0 + wm * S::WM;
-    seg_run = run_row0 >> 6;
-    const int gr = run_row0 + lane;
-    const int grc = min(gr, p.M - 1);
-    seg_tv = p.tgt[grc];
-    const int tprev = p.tgt[max(grc - 1, 0)];
-    seg_mask = __ballot(gr < p.M && (gr == 0 || seg_tv != tprev));
-    seg_nr = min(max(p.M - run_row0, 0), S::WM);
-#pragma unroll
-    for (int b = 0; b < S::TN; ++b) {
-      seg_carry[b] = 0.f;
-      seg_seen[b] = false;
     }
   }
 #pragma unroll
@@ -551,7 +526,7 @@ __device__ __forceinline__ void epilogue_wide_s(const CartnetGemmArgs& p, ACC& a
       // recycled row by row that was a wait for the previous row's store to be ACKNOWLEDGED on every row (1-2 us next
       // to a busy partner workgroup: profiles/r03_exp_phases.md); now it is one wait per block.  Same-box A B A B:
       // K = 80 / 128 launches -4 %, K = 256 -0.5 % (fp32) and -1...-2 % (bf16x3); the training step within noise.
-      constexpr bool SETS = (KBASE == 0 || KBASE == 16) && !GST && !SEG;
+      constexpr bool SETS = (KBASE == 0 || KBASE == 16) && !GST;
       if constexpr (SETS) {
         f32x4 vv[4];
         float* ptr[4];
@@ -618,11 +593,14 @@ __device__ __forceinline__ void epilogue_wide_s(const CartnetGemmArgs& p, ACC& a
           const float ev = p.gst_env ? p.gst_env[grow[i]] : 1.0f;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float ghat = (gv[q] - gmean[b][q]) * grstd[b][q];
-            const float z = fast_sigmoid(ghat * ggam[b][q] + gbet[b][q]);
-            const float t = v[q] * (ev * z * (1.0f - z));
-            gs1[b][q] += t;
-            gs2[b][q] += t * ghat;
+            // z (1 - z) = t / (1 + t)^2 with t = exp(-bn): one v_exp_f32, one v_rcp_f32.  (the clamp keeps t finite: beyond
+            // it z (1 - z) < 1e-37 either way, and inf * 0 would be a NaN)
+            const float ghat = gv[q] * grstd[b][q] + gmean[b][q];
+            const float t = __builtin_amdgcn_exp2f(fminf(ghat * ggam[b][q] + gbet[b][q], 126.0f));
+            const float r = __builtin_amdgcn_rcpf(1.0f + t);
+            const float tv = (v[q] * ev) * ((t * r) * r);
+            gs1[b][q] += tv;
+            gs2[b][q] += tv * ghat;
           }
         }
         if (CPRE) stv4(cpre + (size_t)grow[i] * p.ldc + gcol, v);
@@ -631,50 +609,8 @@ __device__ __forceinline__ void epilogue_wide_s(const CartnetGemmArgs& p, ACC& a
           for (int q = 0; q < 4; ++q) v[q] = fast_silu(v[q]);
         }
         stv4(C + (size_t)grow[i] * p.ldc + gcol, v);
-        if constexpr (SEG) stv4(scr + (rsub + 8 * i) * SCR_LD + c4 * 4, v);      // back into the lane's own four slots
       }
       __builtin_amdgcn_wave_barrier();
-      if constexpr (SEG) {
-        // column li of the block, rows a*32 .. in order (LDS operations of a wave execute in issue order: the values
-        // written above are what these reads return); lanes 32..63 shadow lanes 0..31 and write nothing
-        const int nr_blk = min(max(seg_nr - a * 32, 0), 32);
-        const unsigned mask32 = (unsigned)(seg_mask >> (a * 32));
-        float* __restrict__ so = p.seg_out[g] + col0 + wn * S::WN + b * 32 + li;
-        float* __restrict__ sb = p.seg_bnd + (size_t)seg_run * 2 * ((size_t)p.ngroups * p.N) + (size_t)g * p.N + col0 +
-                                 wn * S::WN + b * 32 + li;
-        float accv = seg_carry[b];
-        bool seen = seg_seen[b];
-#pragma unroll 1
-        for (int q0 = 0; q0 < nr_blk; q0 += 8) {
-          float x[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) x[j] = scr[min(q0 + j, 31) * SCR_LD + li];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int r = q0 + j;
-            if (r < nr_blk) {
-              if ((mask32 >> r) & 1u) {            // row a*32 + r opens a target: what was summed so far is complete
-                if (lane < 32) {
-                  if (seen) so[(size_t)__builtin_amdgcn_readlane(seg_tv, max(a * 32 + r - 1, 0)) * p.seg_ldo] = accv;
-                  else sb[0] = accv;               // ... or is the head of the run (rows of a target that began earlier)
-                }
-                seen = true;
-                accv = 0.f;
-              }
-              accv += x[j];
-            }
-          }
-        }
-        seg_carry[b] = accv;
-        seg_seen[b] = seen;
-        if (a == S::TM - 1 && seg_nr > 0 && lane < 32) {
-          // the piece after the last start runs on into the next run (or ends with the matrix): tail; a run without any
-          // start is ONE piece of a target that began earlier and goes on: head, empty tail
-          if (seen) sb[(size_t)p.ngroups * p.N] = accv;
-          else { sb[0] = accv; sb[(size_t)p.ngroups * p.N] = 0.f; }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
 #ifdef CN_PHASE_STAMP
       if (a == 0 && b == 0) { CN_PHASE(6); }
       if (a == 0 && b == S::TN - 1) { CN_PHASE(7); }

@@ -36,9 +36,6 @@ struct Work {
   // update's apply pass (include/cartnet_hip.h: cartnet_gate_scatter_fwd_bc).  nullptr = the statistics pass runs.
   float* bc[CARTNET_MAX_LAYERS];
   double *gpa, *gpb;
-  // by-target sums of dpre from the dpre product's epilogue (CartnetGemmArgs.seg_*): head / tail rows of every 64-row run,
-  // [2 * ceil(E / 64)][2D]; nullptr = the by-target cartnet_segment_sum pass runs
-  float* seg_bnd;
   // silu(pre) / silu(he_pre), written by the forward GEMMs that activate them (CartnetGemmArgs.a_act_out) for the weight
   // gradients of the second Linears; nullptr = recompute the SiLU in the weight-gradient kernel
   float *act[CARTNET_MAX_LAYERS], *he_act;
@@ -60,21 +57,13 @@ struct Work {
 // de_out (544 MB per layer at the benchmark batch): needs the kernel that carries the epilogue (cartnet_gemm_gate_stats_ok:
 // fp32 MFMA, D = 256 -- the two K-segments of dE fold into one product --, at least 64 row tiles), one BatchNorm group and
 // per-rank statistics.  Training-mode passes only (the callers check `training`).
-inline bool gate_sums_fused(const CartnetModel& m, int G, int tiles_e) {
+inline bool gate_sums_fused(const CartnetModel& m, int G, int tiles_e, long long E) {
 #ifdef CN_NO_GATE_FUSE      /* A/B builds only (tools/build_variant.sh): the statistics pass of rounds 1-4 */
   return false;
 #endif
-  return m.gemm_precision == 0 && m.D == 256 && G == 1 && tiles_e >= 64 && m.half_storage == 0 && m.bn_allreduce == nullptr;
-}
-
-// The by-target sums of dpre (the node halves of the first Linears' gradient, index_select backward of cartnet.py:218) come
-// out of the dpre product's epilogue instead of a segment-sum pass that re-reads dpre (363 MB per layer at the benchmark
-// batch): needs the 256-wide fp32 kernel (cartnet_gemm_segment_sums_ok: D = 256, two groups of at least 100 row tiles).
-inline bool dpre_sums_fused(const CartnetModel& m, int tiles_e) {
-#ifdef CN_NO_SEG_FUSE       /* A/B builds only (tools/build_variant.sh) */
-  return false;
-#endif
-  return m.gemm_precision == 0 && m.D == 256 && 2 * tiles_e >= 200 && m.half_storage == 0;
+  // (the DMA-fed kernels address their A operand with 32-bit byte offsets: E * 2D * 4 < 2^32)
+  return m.gemm_precision == 0 && m.D == 256 && G == 1 && tiles_e >= 64 && m.half_storage == 0 && m.bn_allreduce == nullptr &&
+         (double)E * 2 * m.D * 4.0 < 4294967296.0;
 }
 
 Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_bwd, char* base, size_t* total) {
@@ -163,7 +152,7 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
     for (int l = 0; l < L; ++l) w.act[l] = c.take<float>(En * 2 * D);
     w.he_act = c.take<float>(En * 2 * D);
   }
-  if (need_bwd && gate_sums_fused(m, w.G, w.tiles_e)) {
+  if (need_bwd && gate_sums_fused(m, w.G, w.tiles_e, E)) {
     for (int l = 0; l < L; ++l) w.bc[l] = c.take<float>(Nn * 2 * D);
     w.gpa = c.take<double>((size_t)(w.tiles_e + w.nparts_n) * D);
     w.gpb = c.take<double>((size_t)(w.tiles_e + w.nparts_n) * D);
@@ -223,7 +212,6 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
       w.dPn[i] = c.take<float>(Nn * 4 * D);
       w.dpre[i] = take_edge2d();
     }
-    if (dpre_sums_fused(m, w.tiles_e)) w.seg_bnd = c.take<float>(((En + 63) / 64) * 2 * 2 * D);
     w.dhe = c.take<float>(En * 2 * D);
     w.dx0 = c.take<float>(Nn * 2 * D);
     w.seg_tmp = c.take<float>(Nn * 2 * D);
@@ -843,12 +831,6 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       // (no column sums here: the bias gradients of the first Linears are the column sums of dpre over all edges =
       //  the column sums over atoms of its by-target segment sums, 14x fewer rows -- taken from dPn below)
       if (w.i_dpre[l]) { a.b_split[0] = w.i_dpre[l]; a.b_split[1] = w.i_dpre[l] + img_blk(m); }
-      if (w.seg_bnd) {   // by-target sums of dpre (the first half of dPn) from the epilogue; segsums() completes them
-        a.seg_out[0] = dPn; a.seg_out[1] = dPn + D; a.seg_ldo = 4 * D; a.seg_bnd = w.seg_bnd; a.tgt = w.tgt32;
-        CN_CHECK(cartnet_gemm_segment_sums_ok(&a) == 1,
-                 "cartnet_model_backward: the dpre product of layer %d does not take the kernel with the per-target sums "
-                 "(model.hip: dpre_sums_fused is out of step with gemm.hip: segment_sums_launch_ok)", l);
-      }
       return cartnet_gemm(&a, st);
     };
     auto side_w1e = [&]() -> int {   // edge-block weight gradients of the first Linears
@@ -902,8 +884,6 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     };
     // node-side halves: reduce dpre over each atom's incoming (target) and outgoing (source) edges
     auto segsums = [&](void* s_) -> int {
-      if (w.seg_bnd) RUN(cartnet_segment_fixup(w.rowptr, w.seg_bnd, N, b.E, 2 * D, dPn, 4 * D, s_));
-      else
       RUN((half ? cartnet_segment_sum_h : cartnet_segment_sum_f)(dpre, 2 * D, w.rowptr, nullptr, N, 2 * D, dPn, 4 * D, s_));
       return (half ? cartnet_segment_sum_h : cartnet_segment_sum_f)(dpre, 2 * D, w.colptr, w.perm, N, 2 * D, dPn + 2 * D,
                                                                     4 * D, s_);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CARTNET_LIB (tools only): a diagnostic / A-B build of the same ABI next to the product library (tools/build_variant.sh)
 LIB_PATH = os.environ.get("CARTNET_LIB") or os.path.join(_HERE, "libcartnet_hip.so")
 MAX_GROUPS = 4
-ABI_VERSION = 8          # cartnet_abi_version() of the library this binding mirrors (include/cartnet_hip.h)
+ABI_VERSION = 9          # cartnet_abi_version() of the library this binding mirrors (include/cartnet_hip.h)
 
 _lib: Optional[C.CDLL] = None
 
@@ -55,7 +55,6 @@ class GemmArgs(C.Structure):
         ("a_half", C.c_int32), ("b_half", C.c_int32), ("c_half", C.c_int32), ("dact_half", C.c_int32),
         ("gst_g", C.c_void_p), ("gst_env", C.c_void_p), ("gst_mean_rstd", C.c_void_p), ("gst_gamma", C.c_void_p),
         ("gst_beta", C.c_void_p), ("gst_ld", C.c_int32),
-        ("seg_out", C.c_void_p * MAX_GROUPS), ("seg_bnd", C.c_void_p), ("seg_ldo", C.c_int32),
         ("tile_policy", C.c_int32),
     ]
 
@@ -243,8 +242,6 @@ PROTOTYPES = {
     "cartnet_node_update_bwd_apply_bc": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32,
                                                    C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "cartnet_gemm_gate_stats_ok": (C.c_int, [C.POINTER(GemmArgs)]),
-    "cartnet_gemm_segment_sums_ok": (C.c_int, [C.POINTER(GemmArgs)]),
-    "cartnet_segment_fixup": (C.c_int, [c_i32p, c_f32p, C.c_int32, C.c_int64, C.c_int32, c_f32p, C.c_int32, c_stream]),
     "cartnet_gate_scatter_bwd_stats": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p,
                                                  C.c_int32, C.c_int32, c_f32p, c_f32p, c_groups, c_stream]),
     "cartnet_gate_scatter_bwd_apply": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p,

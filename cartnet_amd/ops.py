@@ -78,7 +78,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
          a_kstrided: bool = False, b_kstrided: bool = False, a_act: bool = False, b_act: bool = False,
          out_act: bool = False, segments: bool = False, bias=None, gather_i=None, gather_j=None, tgt=None, src=None,
          resid=None, dact=None, cpre=None, colsum=None, colsq=None, splitk: int = 1, precision: int = 0,
-         b_split=None, b_split_folded=None, a_act_out=None, tile_policy: int = 0, gate_stats=None, seg_sums=None) -> None:
+         b_split=None, b_split_folded=None, a_act_out=None, tile_policy: int = 0, gate_stats=None) -> None:
     """C[g] = epilogue(sum_s opA(A[s]) @ opB(B[s])) on the fp32 matrix cores (see include/cartnet_hip.h).
 
     A / B / C_out: one tensor or a list.  With ``segments=False`` the lists are independent problems (groups) of
@@ -90,8 +90,6 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
     ``gate_stats`` = (g [M, N] (a column block of a wider matrix is fine), env [M] or None, mean_rstd [2N], gamma [N],
     beta [N]): CartnetGemmArgs.gst_* -- colsum / colsq then receive the partial sums of v w and v w ghat (see the header);
     raises unless the launch reaches the kernel that carries that epilogue.
-    ``seg_sums`` = (outs: one [n_targets, N] view per group (column blocks of one matrix), bnd [2 * ceil(M/64), ngroups*N],
-    tgt [M] int32 ascending): CartnetGemmArgs.seg_* -- per-target sums of the output rows; finish with ``segment_fixup``.
     """
     lib = _l.load()
     A, B, C_out = _aslist(A, 1), _aslist(B, 1), _aslist(C_out, 1)
@@ -231,34 +229,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
         if not lib.cartnet_gemm_gate_stats_ok(C.byref(args)):
             raise ValueError("gemm gate_stats: this launch does not reach the kernel with the gate-statistics epilogue "
                              "(precision 0, N = 256, weight image, resid + colsum + colsq only, >= 64 row tiles)")
-    if seg_sums is not None:
-        souts, sbnd, stgt = seg_sums
-        souts = _aslist(souts, ngroups)
-        if len(souts) != ngroups:
-            raise ValueError(f"gemm seg_sums: expected {ngroups} outputs")
-        for g, t in enumerate(souts):
-            _f32_2d(t, f"gemm seg_sums out[{g}]")
-            if t.shape[1] != N or _ld(t) != _ld(souts[0]):
-                raise ValueError("gemm seg_sums: outputs need N columns and one row stride")
-            args.seg_out[g] = t.data_ptr()
-        _vec(stgt, M, "gemm seg_sums tgt", torch.int32)
-        _vec(sbnd, 2 * ((M + 63) // 64) * ngroups * N, "gemm seg_sums bnd")
-        args.seg_ldo, args.seg_bnd, args.tgt = _ld(souts[0]), sbnd.data_ptr(), stgt.data_ptr()
-        if not lib.cartnet_gemm_segment_sums_ok(C.byref(args)):
-            raise ValueError("gemm seg_sums: this launch does not reach the kernel with the per-target sums in its epilogue "
-                             "(precision 0, N = 256, weight images, dact only, the 256-wide kernel)")
     _l.check(lib.cartnet_gemm(C.byref(args), _l.stream_ptr()), "cartnet_gemm")
-
-
-def segment_fixup(rowptr: Tensor, bnd: Tensor, E: int, out: Tensor) -> None:
-    """cartnet_segment_fixup: completes the per-target sums of a ``gemm(..., seg_sums=...)`` launch.  ``out`` [N, W]: the
-    matrix whose column blocks were that launch's outputs (W = ngroups * N of the launch)."""
-    _f32_2d(out, "segment_fixup out")
-    N, W = out.shape
-    _vec(rowptr, N + 1, "segment_fixup rowptr", torch.int32)
-    _vec(bnd, 2 * ((int(E) + 63) // 64) * W, "segment_fixup bnd")
-    _l.check(_l.load().cartnet_segment_fixup(rowptr.data_ptr(), bnd.data_ptr(), N, int(E), W, out.data_ptr(), _ld(out),
-                                             _l.stream_ptr()), "cartnet_segment_fixup")
 
 
 def pack_b(mats: Sequence[Tensor], outs: Optional[Sequence[Tensor]] = None) -> list:

@@ -35,7 +35,7 @@ int cartnet_abi_version(void);
 /* sizeof of every struct below, in header order (CartnetGemmArgs, CartnetShard, CartnetCollated, CartnetGemmProfile,
  * CartnetGroups, CartnetLayerParams, CartnetLayerBuffers, CartnetParams, CartnetModel, CartnetBatch,
  * CartnetGateGemmArgs, CartnetIcfConv, CartnetIcfParams, CartnetIcfModel); returns the number of structs.  A binding checks its mirrors against these when it loads the
- * library, and cartnet_abi_version() against the version it was written for (8: gst_* in CartnetGemmArgs; 7: tile_policy in CartnetGemmArgs,
+ * library, and cartnet_abi_version() against the version it was written for (9: gst_* in CartnetGemmArgs (8 also carried seg_*: per-target sums in an epilogue, measured and removed); 7: tile_policy in CartnetGemmArgs,
  * aux_stream in cartnet_model_forward, CartnetGateGemmArgs in the size table; cartnet_gemm_tile_policy() is gone). */
 int cartnet_abi_struct_sizes(size_t* out, int32_t capacity);
 
@@ -126,18 +126,6 @@ typedef struct CartnetGemmArgs {
   const float* gst_gamma;
   const float* gst_beta;
   int32_t gst_ld;
-  /* Per-target sums of the output rows in the epilogue (precision 0 with a weight image, N = 256, dact given and nothing
-   * else, enough row tiles for the 256-wide kernel: the dpre product of CartNet's backward).  The M rows are edges sorted
-   * by target (tgt[m] ascending: models/cartnet.py:218 with the reference's edge order, dataset/utils.py:235).  A target
-   * whose rows lie inside one 64-row run (rows 64 r .. 64 r + 63) with another target's first row after them in the same
-   * run gets its column sums written to seg_out[g][tgt * seg_ldo + n]; every run also leaves the sums of its rows before
-   * its first target start ("head") and from its last target start on ("tail") in seg_bnd[(run*2 + 0 / 1) * ngroups*N +
-   * g*N + n] (seg_bnd: 2 * ceil(M/64) * ngroups * N floats), and cartnet_segment_fixup completes the other targets from
-   * those.  Replaces a cartnet_segment_sum pass over C (index_select backward, cartnet.py:218).  Any other launch with
-   * seg_out[0] set is refused (cartnet_gemm_segment_sums_ok). */
-  float* seg_out[CARTNET_MAX_GROUPS];
-  float* seg_bnd;
-  int32_t seg_ldo;
   int32_t tile_policy; /* column-tile width of the DMA-fed fp32 activation x weight kernels (precision 0, b_split given).
                           0: the library's choice per launch (128 x 256 tiles on two workgroups per CU; 128 x 128 on three
                           for the node-term gather epilogue, for single-group N = 256 products and for launches with few
@@ -149,14 +137,6 @@ int cartnet_gemm(const CartnetGemmArgs* args, void* stream);
 /* 1 if a launch with these arguments (gst_* set) takes the kernel that carries the gate-statistics epilogue; cartnet_gemm
  * refuses such a launch otherwise.  Host only, no launch. */
 int cartnet_gemm_gate_stats_ok(const CartnetGemmArgs* args);
-/* The same question for seg_out / seg_bnd. */
-int cartnet_gemm_segment_sums_ok(const CartnetGemmArgs* args);
-/* Completes the per-target sums a launch with seg_out left unfinished: for every target t (rows rowptr[t] .. rowptr[t+1]
- * of the M = E rows) that the epilogue did not write -- its rows cross a 64-row run boundary, or run on to the end of a
- * run or of the matrix -- out[t, 0:W] = tail of its first run + heads of the following ones (fixed order); targets without
- * rows get zeros.  W = ngroups * N of that launch (bnd as written by it), out / ldo = seg_out[0] / seg_ldo. */
-int cartnet_segment_fixup(const int32_t* rowptr, const float* bnd, int32_t N, int64_t E, int32_t W, float* out, int32_t ldo,
-                          void* stream);
 
 /* bf16x3 pre-split of a k-strided GEMM operand B [K, N] (element (k, n) = src[k*stride_k + n*stride_n]; a weight
  * W [out, in] used as B = W^T has stride_k = 1, stride_n = ld) into the image cartnet_gemm reads through

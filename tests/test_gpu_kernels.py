@@ -1052,55 +1052,3 @@ def test_gate_backward_sums_without_the_statistics_pass(ops, with_env):
         ops.gemm([dpre[:small, :D], dpre[:small, D:]], [W[:D], W[D:]], de_out[:small], segments=True, b_kstrided=True,
                  resid=resid[:small], b_split=img, b_split_folded=folded, colsum=ca[:50 * D], colsq=cb[:50 * D],
                  gate_stats=(gs[:small, :D], None, mean_rstd, gamma, beta))
-
-
-@pytest.mark.parametrize("pattern", ["random", "long", "aligned", "tail"])
-def test_per_target_sums_from_the_dpre_epilogue(ops, pattern):
-    """Round 5: the by-target segment sums of dpre (index_select backward, models/cartnet.py:218) from the epilogue of the
-    product that writes dpre (CartnetGemmArgs.seg_*) + cartnet_segment_fixup, against cartnet_segment_sum over the written
-    matrix and the fp64 sum.  Degree patterns: random (0..40), targets longer than a 64-row run (70, 130, 200 rows: whole
-    runs without a start), targets that end exactly on run / tile boundaries, and a last target that runs to the end of a
-    ragged last tile.  Integer-valued operands make every sum exact: the comparison with the segment-sum kernel is bitwise."""
-    D = 256
-    g = torch.Generator().manual_seed({"random": 1, "long": 2, "aligned": 3, "tail": 4}[pattern])
-    if pattern == "random":
-        degs = torch.randint(0, 41, (700,), generator=g).tolist()
-    elif pattern == "long":
-        degs = ([70, 3, 130, 0, 0, 200, 1, 64, 63, 65, 128, 2] * 12) + torch.randint(5, 30, (300,), generator=g).tolist()
-    elif pattern == "aligned":
-        degs = ([64] * 10 + [32, 32] * 10 + [16] * 8 + [128] * 4 + [1] * 64 + [63, 1] * 6) * 4
-    else:
-        degs = torch.randint(8, 25, (900,), generator=g).tolist() + [37]
-    ei, ptr = _graph_with_degrees(degs, seed=5)
-    N, E = len(degs), ei.shape[1]
-    assert 2 * ((E + 127) // 128) >= 200, E                      # the 256-wide kernel's range (two groups)
-    if pattern == "tail":
-        assert E % 128 != 0
-    lay = ops.GraphLayout(ei.to(dev()), N, ptr.to(dev()))
-    A = torch.randint(-3, 4, (E, 2 * D), generator=g).float().to(dev())
-    W = [torch.randint(-2, 3, (D, D), generator=g).float().to(dev()) for _ in range(2)]      # [K, N], k-strided
-    pre = torch.zeros(E, 2 * D, device=dev())                    # silu'(0) = 0.5: the epilogue halves every (even) product
-    W = [2.0 * w for w in W]
-    img = ops.pack_b(W)
-    dpre = torch.empty(E, 2 * D, device=dev())
-    dPn = torch.full((N, 4 * D), 9.0, device=dev())
-    bnd = torch.full((2 * ((E + 63) // 64) * 2 * D,), 9.0, device=dev())
-    ops.gemm([A[:, :D], A[:, D:]], W, [dpre[:, :D], dpre[:, D:]], b_kstrided=True, dact=[pre[:, :D], pre[:, D:]], b_split=img,
-             seg_sums=([dPn[:, :D], dPn[:, D:2 * D]], bnd, lay.tgt))
-    ops.segment_fixup(lay.rowptr, bnd, E, dPn[:, :2 * D])
-    plain = torch.empty(E, 2 * D, device=dev())
-    ops.gemm([A[:, :D], A[:, D:]], W, [plain[:, :D], plain[:, D:]], b_kstrided=True, dact=[pre[:, :D], pre[:, D:]], b_split=img)
-    assert torch.equal(plain, dpre)
-    ref = torch.cat([A[:, :D].double().cpu() @ W[0].double().cpu(), A[:, D:].double().cpu() @ W[1].double().cpu()], 1) * 0.5
-    assert torch.equal(dpre.double().cpu(), ref)
-    want = torch.empty(N, 2 * D, device=dev())
-    ops.segment_sum(dpre, lay.rowptr, None, want)
-    seg_ref = torch.zeros(N, 2 * D, dtype=torch.float64).index_add_(0, ei[1], ref)
-    assert torch.equal(want.double().cpu(), seg_ref)
-    assert torch.equal(dPn[:, :2 * D], want)
-    assert bool((dPn[:, 2 * D:] == 9.0).all())                   # the by-source half is not touched
-    # a launch outside the kernel's range is refused
-    with pytest.raises(ValueError, match="per-target sums"):
-        ops.gemm([A[:6400, :D], A[:6400, D:]], W, [dpre[:6400, :D], dpre[:6400, D:]], b_kstrided=True,
-                 dact=[pre[:6400, :D], pre[:6400, D:]], b_split=img,
-                 seg_sums=([dPn[:, :D], dPn[:, D:2 * D]], bnd, lay.tgt))

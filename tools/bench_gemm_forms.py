@@ -70,11 +70,6 @@ if prec == 0:
     rowptr = torch.zeros(N + 1, dtype=torch.int32, device=dev)
     rowptr[1:] = torch.cumsum(torch.bincount(tgt.long(), minlength=N), 0).to(torch.int32)
     dPn = torch.empty(N, 4*D, device=dev)
-    bnd = torch.empty(2 * ((E + 63) // 64) * 2*D, device=dev)
-    timeit("dpre: x2 * silu'(pre) + per-target sums (seg_*)", lambda: ops.gemm([gs[:, :D], gs[:, D:]], [W2g, W2a], [out2[:, :D], out2[:, D:]],
-           b_kstrided=True, b_split=img_dpre, precision=prec, dact=[pre[:, :D], pre[:, D:]],
-           seg_sums=([dPn[:, :D], dPn[:, D:2*D]], bnd, tgt)), F)
-    timeit("pass: segment_fixup", lambda: ops.segment_fixup(rowptr, bnd, E, dPn[:, :2*D]), F)
     timeit("pass: segment_sum by target [E, 2D]", lambda: ops.segment_sum(out2, rowptr, None, dPn[:, :2*D]), F)
     env = torch.rand(E, generator=g).to(dev); mr = torch.cat([rnd(D, sc=0.1), 1.0 + torch.rand(D, generator=g).to(dev)]).contiguous()
     gam, bet = rnd(D), rnd(D)
