@@ -57,10 +57,22 @@ def build_batch(n_graphs: int, first: int, atoms: int):
 
 def cpu_baseline(seconds_budget: float = 12.0, which: str = "cartnet"):
     """Time the oracle (plain-torch CPU restatement of models/cartnet.py -- or models/comformer.py for
-    ``--model icomformer`` -- with autograd backward) on 4 crystals."""
+    ``--model icomformer`` -- with autograd backward) on 4 crystals; ``which="jarvis"``: the configs[2] workload itself
+    (CartNet with the scalar head on the 64 crystals of 2-20 atoms the jarvis_bf16 pass times)."""
     n_graphs = 4
     batch = build_batch(n_graphs, 10_000, 194)
-    if which == "icomformer":
+    if which == "jarvis":
+        from cartnet_amd.data import Batch
+        from cartnet_amd.model import make_state_dict
+        from cartnet_amd.synthetic import make_crystal
+        from oracle import cartnet_ref as orc
+        gen = torch.Generator().manual_seed(7)
+        sizes = torch.randint(2, 21, (64,), generator=gen).tolist()
+        n_graphs = 64
+        batch = Batch.from_data_list([make_crystal(5000 + i, n, adp=False) for i, n in enumerate(sizes)])
+        sd = make_state_dict(256, 64, 4, seed=0, cholesky=False, temperature=False)
+        fwd = lambda p: orc.cartnet_forward(p, batch, num_layers=4, training=True, use_temperature=False, cholesky=False)
+    elif which == "icomformer":
         from cartnet_amd.comformer import make_icomformer_state_dict
         from oracle import icomformer_ref as orc
         sd = make_icomformer_state_dict(256, seed=0)
@@ -117,8 +129,9 @@ def cpu_baseline(seconds_budget: float = 12.0, which: str = "cartnet"):
         pass
     return {"value": round(n_graphs / med, 3), "unit": "graphs/s", "cores": cores, "kind": "port",
             "one_thread_value": round(n_graphs / one_thread, 3), "cpu_model": cpu_model,
-            "sample": f"oracle fwd+bwd (fp32, train-mode BN) on {n_graphs} crystals x 194 atoms "
-                      f"(E={int(batch.edge_index.shape[1])}), median of {iters} runs after warm-up, best of 8/32/64 "
+            "sample": f"oracle fwd+bwd (fp32, train-mode BN) on {n_graphs} crystals "
+                      f"({'2-20' if which == 'jarvis' else '194'} atoms each, N={int(batch.x.shape[0])}, "
+                      f"E={int(batch.edge_index.shape[1])}), median of {iters} runs after warm-up, best of 8/32/64 "
                       f"torch CPU threads = {cores} (host: {cpu_model}, {ncpu} logical CPUs); one_thread_value: same "
                       f"step on 1 thread"}
 
@@ -152,7 +165,8 @@ def timed_pass(step, fresh, warm: int, steps: int, graphs: int, sampler_factory,
     step(bs[warm])
     torch.cuda.synchronize()
     ops.profile_gemm(False)
-    gflop = sum(v["flops"] for v in ops.profile_gemm_read().values())
+    variants = ops.profile_gemm_read()
+    gflop = sum(v["flops"] for v in variants.values())
     # host time to enqueue one step on an IDLE queue (median of 3): over back-to-back steps the host of a C++-sequenced
     # model runs ahead until the device queue is full and then waits, which is not host work
     idle = []
@@ -194,6 +208,21 @@ def timed_pass(step, fresh, warm: int, steps: int, graphs: int, sampler_factory,
            "host_loop_ms_per_step": round(1e3 * t_enq / steps, 3),
            "gemm_flops_per_step": int(gflop),
            "whole_step_frac": round(gflop / (dt / steps) / 1e12 / peak_tflops, 4), "peak_tflops": peak_tflops}
+    if variants:
+        # the dominant cartnet_gemm variant of this workload, priced with HIP events on its launch stream during ONE
+        # instrumented step right after the warm-up (every GEMM launch of that step carries an event pair; the timed
+        # steps above carry none): executed 2 M N K / event time, in-step (two streams share the chip in backward)
+        key = max(variants, key=lambda k: variants[k]["ms"])
+        d = variants[key]
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+                           "frac": round(ach / peak_tflops, 4), "traffic": None,
+                           "kernel": f"cartnet_gemm variant {key}", "launches": d["launches"],
+                           "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+                           "share_of_step": round(d["ms"] / (1e3 * dt / steps), 3),
+                           "measured": "one instrumented step after the warm-up (an event pair on every GEMM launch)",
+                           "all_gemm_variants_ms_per_step": {k: round(v["ms"], 3) for k, v in sorted(variants.items())
+                                                             if v["ms"] >= 0.02}}
     if tel is not None:
         out["telemetry_during"] = tel
     return out
@@ -703,6 +732,8 @@ def main():
             r.update({"workload": f"BASELINE configs[2]: CartNet L=4 D=256 Scalar_head, no temperature, 64 crystals of 2-20 "
                                   f"atoms per step (N={int(jb.x.shape[0])}, E={int(jb.edge_index.shape[1])}), bf16 MFMA "
                                   "operands, bf16 storage of pre / gs / dpre, fp32 accumulate", "dtype": "bf16"})
+            if not args.no_cpu_baseline:
+                r["cpu_baseline"] = cpu_baseline(4.0, which="jarvis")
             sub_cfg["jarvis_bf16"] = r
         del jm, jopt, jb
         # (ii) configs[4]: iComformer (models/comformer.py:115-132) on the headline's batch, fp32 MFMA
@@ -715,6 +746,8 @@ def main():
         if r is not None:
             r.update({"workload": f"BASELINE configs[4]: iComformer D=256 (4 attention layers + edge-update layer, Cholesky "
                                   f"head) fp32 train step on the headline's batch (N={N}, E={E})", "dtype": "f32"})
+            if not args.no_cpu_baseline:
+                r["cpu_baseline"] = cpu_baseline(5.0, which="icomformer")
             sub_cfg["icomformer"] = r
         del im, iopt
         torch.cuda.empty_cache()

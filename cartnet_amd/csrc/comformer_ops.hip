@@ -261,6 +261,28 @@ __global__ __launch_bounds__(256) void cn_colsum_partial_kernel(const float* __r
   }
 }
 
+// Column partial sums of d[r, c] * bc[r, c] and d[r, c] * bc[r, C + c] (bc [R, 2C]): the targets' share of the gate's
+// BatchNorm-backward sums from the per-target sums the forward gate kernel left (cartnet_gate_scatter_fwd_bc).
+__global__ __launch_bounds__(256) void cn_coldot_bc_partial_kernel(const float* __restrict__ d, int ld,
+                                                                   const float* __restrict__ bc, int R, int C,
+                                                                   double* __restrict__ parts_a, double* __restrict__ parts_b) {
+  __shared__ double red[NODES_PER_BLOCK * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + lane * 4;
+    const bool active = c < C;
+    f64x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+    for (int r = blockIdx.x * NODES_PER_BLOCK + wid; r < R; r += gridDim.x * NODES_PER_BLOCK)
+      if (active) {
+        const f32x4 v = ld4(d + (size_t)r * ld + c);
+        cn_acc4(pa, v * ld4(bc + (size_t)r * 2 * C + c));
+        cn_acc4(pb, v * ld4(bc + (size_t)r * 2 * C + C + c));
+      }
+    cn_block_store_parts(pa, red, parts_a, C, c, active, wid, lane);
+    cn_block_store_parts(pb, red, parts_b, C, c, active, wid, lane);
+  }
+}
+
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -390,6 +412,16 @@ extern "C" int cartnet_softplus_update_bwd_apply(const float* o, const float* x,
 }
 
 extern "C" int cartnet_segment_nparts(int32_t S) { return seg_parts(S); }
+
+extern "C" int cartnet_coldot_bc_partial(const float* d, int32_t ld, const float* bc, int32_t R, int32_t C, double* parts_a,
+                                         double* parts_b, void* stream) {
+  CN_CHECK(R >= 0 && C >= 4 && C % 4 == 0 && ld % 4 == 0 && ld >= C, "cartnet_coldot_bc_partial: C/ld must be multiples of 4");
+  CN_CHECK(((d && bc) || R == 0) && parts_a && parts_b, "cartnet_coldot_bc_partial: null pointer");
+  hipLaunchKernelGGL(cn_coldot_bc_partial_kernel, dim3(seg_parts(R)), dim3(256), 0, ST(stream), d, ld, bc, R, C, parts_a,
+                     parts_b);
+  CN_LAUNCH_CHECK("cartnet_coldot_bc_partial");
+  return 0;
+}
 
 extern "C" int cartnet_colsum_partial(const float* x, int32_t ld, int32_t R, int32_t C, double* parts, void* stream) {
   CN_CHECK(R >= 0 && C >= 4 && C % 4 == 0 && ld % 4 == 0 && ld >= C, "cartnet_colsum_partial: C/ld must be multiples of 4");

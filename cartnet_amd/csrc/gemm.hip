@@ -199,18 +199,21 @@ static bool f32_image_path(const CartnetGemmArgs& a) {
 
 static int choose_bn(const CartnetGemmArgs& a);
 
-// CartnetGemmArgs.gst_*: the launch reaches cn_gemm_f32nn128_kernel<false, true>, the one kernel that carries the gate
-// statistics epilogue.  (The same predicates the dispatch below and launch_variant apply, in their order.)
+// CartnetGemmArgs.gst_*: the launch reaches a kernel that carries the gate statistics epilogue -- precision 0:
+// cn_gemm_f32nn128_kernel<false, 1 / 2>; precision 1 (bf16x3): cn_gemm_x3nn16_kernel<false, 1 / 2>.  (The same predicates the
+// dispatch below and launch_variant apply, in their order; the two DMA-fed families take the same shapes.)
 static bool gate_stats_launch_ok(const CartnetGemmArgs& a) {
   if (!(a.gst_g && a.gst_mean_rstd && a.gst_gamma && a.gst_beta && a.gst_ld >= a.N && a.gst_ld % 4 == 0)) return false;
   if (!(aligned16(a.gst_g) && aligned16(a.gst_mean_rstd) && aligned16(a.gst_gamma) && aligned16(a.gst_beta))) return false;
-  if (!(a.precision == 0 && a.ngroups == 1 && !a.a_act && !a.b_act && !a.out_act && !a.dact[0] &&
+  if (!((a.precision == 0 || a.precision == 1) && a.ngroups == 1 && !a.a_act && !a.b_act && !a.out_act && !a.dact[0] &&
         !a.gather_i[0] && !a.cpre[0] && !a.bias[0] && a.colsum[0] && a.colsq[0] && !a.a_act_out[0] && a.N == 256))
     return false;
-  if (!f32_image_path(a) || choose_bn(a) != 256) return false;
+  CartnetGemmArgs q = a;
+  q.precision = 0;                       // (the image-path conditions do not depend on the operand format)
+  if (!f32_image_path(q) || choose_bn(a) != 256 || cn_gemm::any_half(a)) return false;
   CartnetGemmArgs f = a;
   if (segments_fold(a)) { f.K *= f.nsegs; f.nsegs = 1; }
-  return f.nsegs == 1 && cn_gemm::use_f32nn128(f);
+  return f.nsegs == 1 && (a.precision == 1 || cn_gemm::use_f32nn128(f));
 }
 
 extern "C" int cartnet_gemm_gate_stats_ok(const CartnetGemmArgs* args) { return args && gate_stats_launch_ok(*args) ? 1 : 0; }
@@ -354,7 +357,7 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
   }
   CN_CHECK(!a.gst_g || gate_stats_launch_ok(a),
            "cartnet_gemm: gst_g is set but this launch does not reach the kernel with the gate-statistics epilogue "
-           "(precision 0, N = 256, weight image, one group, colsum + colsq (+ resid) and nothing else, >= 64 row tiles: "
+           "(precision 0 / 1, N = 256, weight image, one group, colsum + colsq (+ resid) and nothing else, >= 64 / 96 row tiles: "
            "ask cartnet_gemm_gate_stats_ok first)");
   cn_gemm::GemmFlags fl;
   fl.tile_m0 = 0;

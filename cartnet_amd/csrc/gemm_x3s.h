@@ -21,7 +21,9 @@
 
 namespace cn_gemm {
 
-template <bool A_ACT>
+// GSTK (as in gemm_f32w128.h): 1 / 2 = the dE product with the gate statistics of the layer below in its epilogue, with /
+// without the edge residual, as kernels of their own.
+template <bool A_ACT, int GSTK = 0>
 __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn16_kernel(const CartnetGemmArgs p, const GemmFlags fl) {
   using S = Shape<X3_BN>;
   static_assert(S::WM == 64 && S::WN == 64, "wave tile is 64 x 64");
@@ -312,7 +314,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_x3nn16_kernel(const Cartn
     CN_STAMP_END();
     CN_PHASE(2);
   }
-  x3_epilogue<0>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem);
+  if constexpr (GSTK == 1) epilogue_wide<X3_BN, 130>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem, 130);
+  else if constexpr (GSTK == 2) epilogue_wide<X3_BN, 128>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem, 128);
+  else x3_epilogue<0>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem);
 #ifdef CN_PHASE_STAMP
   CN_PHASE(3);                                             // last store issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -4,7 +4,10 @@
 namespace cn_gemm {
 
 void launch_x3nn16(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st) {
-  if (a_act) hipLaunchKernelGGL((cn_gemm_x3nn16_kernel<true>), grid, dim3(NTHREADS), 0, st, a, fl);
+  // (cartnet_gemm checked a launch with gst_g: one group, no a_act)
+  if (a.gst_g && a.resid[0]) hipLaunchKernelGGL((cn_gemm_x3nn16_kernel<false, 1>), grid, dim3(NTHREADS), 0, st, a, fl);
+  else if (a.gst_g) hipLaunchKernelGGL((cn_gemm_x3nn16_kernel<false, 2>), grid, dim3(NTHREADS), 0, st, a, fl);
+  else if (a_act) hipLaunchKernelGGL((cn_gemm_x3nn16_kernel<true>), grid, dim3(NTHREADS), 0, st, a, fl);
   else hipLaunchKernelGGL((cn_gemm_x3nn16_kernel<false>), grid, dim3(NTHREADS), 0, st, a, fl);
 }
 

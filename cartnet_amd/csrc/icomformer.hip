@@ -101,6 +101,7 @@ struct IWork {
   float *r_e, *pre_e, *e0, *r_nl, *pre_nl, *NLt, *r_na, *pre_na, *NA;
   // attention layers 0..3 and the edge layer (index 4)
   float *QKV[5], *KPi[4], *KPj[4], *pr[5], *keyb[5], *gs[5], *mr1[5], *aggr[5], *o[5], *mr2[5], *y[5];
+  float* bc[5];      // conv layers (training): per-target sums of the forward gate kernel for the backward's BatchNorm sums
   float* act[5];     // silu(pr), kept by the forward GEMM that activates it (fp32 with images): dW2 then reads a plain operand
   float *KY, *VY, *Ka, *KYb, *bias3;
   float *Fk[5], *Fm[5], *ck[5], *cm[5], *dFk[5], *dFm[5];    // folded lin_edge (x) W1e per layer: F [C, C], c [C]; gradient temps
@@ -161,6 +162,9 @@ IWork icarve(const CartnetIcfModel& m, int N, long long E, int Bg, int M, char* 
     // on a stream with slack); round 4's trace of the C++ sequence shows the register-staged dY^T silu(X) kernel at 1.36 ms
     // per launch, 6.8 ms per step, on a side stream the main stream now WAITS for at its joins
     w.act[l] = (w.use_img && m.gemm_precision == 0) ? c.take<float>(R * 2 * C) : nullptr;
+    // (the edge layer's segments are the edges themselves, three rows each: bc would be an [E, 2C] matrix, as many bytes
+    //  as a third of the statistics pass it saves -- conv layers only)
+    w.bc[l] = edge ? nullptr : c.take<float>(S * 2 * C);
     w.mr1[l] = c.take<float>(2 * C); w.aggr[l] = c.take<float>(S * C); w.o[l] = c.take<float>(S * C);
     w.mr2[l] = c.take<float>(2 * C);
     w.y[l] = (l == 3) ? nullptr : c.take<float>(S * C);     // layer 3 writes the caller's x_out
@@ -394,8 +398,12 @@ int att_forward(const CartnetIcfModel& m, const CartnetIcfConv& P, const Cartnet
   RUN(cartnet_rowmul_fwd(w.keyb[l], 2 * C, t.q, t.ldq, t.segptr, t.S, C, scale, w.gs[l], 2 * C, w.pa, w.pb, st));
   RUN(cartnet_bn_finalize(w.pa, w.pb, t.sparts, t.count, C, m.bn_eps, m.bn_momentum, training, bn_att.mean, bn_att.var,
                           bn_att.nbt, w.mr1[l], nullptr, 1, 1, st));
-  RUN(cartnet_gate_scatter_fwd(w.gs[l], nullptr, nullptr, t.segptr, w.mr1[l], P.bn_att_w, P.bn_att_b, t.S, C, nullptr,
-                               w.aggr[l], w.pc, w.pd, nullptr, st));
+  if (training && w.bc[l])
+    RUN(cartnet_gate_scatter_fwd_bc(w.gs[l], nullptr, nullptr, t.segptr, w.mr1[l], P.bn_att_w, P.bn_att_b, t.S, C, nullptr,
+                                    w.aggr[l], w.pc, w.pd, w.bc[l], st));
+  else
+    RUN(cartnet_gate_scatter_fwd(w.gs[l], nullptr, nullptr, t.segptr, w.mr1[l], P.bn_att_w, P.bn_att_b, t.S, C, nullptr,
+                                 w.aggr[l], w.pc, w.pd, nullptr, st));
   return 0;
 }
 }  // namespace
@@ -661,13 +669,19 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
                           float* dq_out) -> int {
     const ConvW& cw = w.cw[l];
     float* gs = w.gs[l];
-    RUN(cartnet_gate_scatter_bwd_stats(gs, nullptr, daggr, nullptr, t.segptr, w.mr1[l], q.bn_att_w, q.bn_att_b, t.S, C, w.pa,
-                                       w.pb, nullptr, st));
+    // sum(dbn), sum(dbn ghat): no edge residual here, so with the per-target sums of the forward pass (conv layers) both
+    // are sums over the TARGETS -- 25 MB instead of a 363 MB pass over gs
+    const bool fused_sums = training && w.bc[l] != nullptr;
+    if (fused_sums)
+      RUN(cartnet_coldot_bc_partial(daggr, C, w.bc[l], t.S, C, w.pa, w.pb, st));
+    else
+      RUN(cartnet_gate_scatter_bwd_stats(gs, nullptr, daggr, nullptr, t.segptr, w.mr1[l], q.bn_att_w, q.bn_att_b, t.S, C, w.pa,
+                                         w.pb, nullptr, st));
     {
       double* parts[2] = {w.pa, w.pb};
       float* outs[2] = {w.sums1[l], w.sums1[l] + C};
       float* gr[2] = {g.bn_att_b, g.bn_att_w};
-      RUN(cartnet_colsum_finalize2(parts, outs, gr, 2, t.gparts, C, st));
+      RUN(cartnet_colsum_finalize2(parts, outs, gr, 2, fused_sums ? cartnet_segment_nparts(t.S) : t.gparts, C, st));
     }
     RUN(cartnet_gate_scatter_bwd_apply(gs, nullptr, daggr, nullptr, t.segptr, w.mr1[l], q.bn_att_w, q.bn_att_b, w.sums1[l],
                                        t.count, training, t.S, C, w.pc, w.pd, nullptr, st));     // gs = [dalpha | dmsg]

@@ -54,15 +54,16 @@ struct Work {
 };
 
 // The gate's BatchNorm-backward sums come from the dE epilogue + per-atom sums instead of a statistics pass over gs and
-// de_out (544 MB per layer at the benchmark batch): needs the kernel that carries the epilogue (cartnet_gemm_gate_stats_ok:
-// fp32 MFMA, D = 256 -- the two K-segments of dE fold into one product --, at least 64 row tiles), one BatchNorm group and
-// per-rank statistics.  Training-mode passes only (the callers check `training`).
+// de_out (544 MB per layer at the benchmark batch): needs a kernel that carries the epilogue (cartnet_gemm_gate_stats_ok:
+// fp32 MFMA or bf16x3, D = 256 -- the two K-segments of dE fold into one product --, at least 64 / 96 row tiles), one
+// BatchNorm group and per-rank statistics.  Training-mode passes only (the callers check `training`).
 inline bool gate_sums_fused(const CartnetModel& m, int G, int tiles_e, long long E) {
 #ifdef CN_NO_GATE_FUSE      /* A/B builds only (tools/build_variant.sh): the statistics pass of rounds 1-4 */
   return false;
 #endif
   // (the DMA-fed kernels address their A operand with 32-bit byte offsets: E * 2D * 4 < 2^32)
-  return m.gemm_precision == 0 && m.D == 256 && G == 1 && tiles_e >= 64 && m.half_storage == 0 && m.bn_allreduce == nullptr &&
+  return m.gemm_precision <= 1 && m.D == 256 && G == 1 && tiles_e >= (m.gemm_precision == 0 ? 64 : 96) && m.half_storage == 0 &&
+         m.bn_allreduce == nullptr &&
          (double)E * 2 * m.D * 4.0 < 4294967296.0;
 }
 

@@ -291,6 +291,7 @@ PROTOTYPES = {
     "cartnet_softplus_update_bwd_apply": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32,
                                                     C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_stream]),
     "cartnet_colsum_partial": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_stream]),
+    "cartnet_coldot_bc_partial": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_stream]),
     "cartnet_radius_graph_count": (C.c_int, [c_f32p, c_f32p, c_i64p, c_i64p, C.c_int32, C.c_int32, C.c_float, c_i32p,
                                              c_i32p, c_stream]),
     "cartnet_radius_graph_fill": (C.c_int, [c_f32p, c_f32p, c_i64p, c_i64p, c_i32p, c_i64p, C.c_int32, C.c_int32,

@@ -112,7 +112,7 @@ typedef struct CartnetGemmArgs {
                           stay in ELEMENTS).  Honoured by the half-storage kernels (csrc/gemm_h.h): activation x weight
                           products with a pre-split weight image (b_split) and weight gradients (both operands
                           k-strided); every other launch with one of these flags set is refused. */
-  /* Gate statistics in the epilogue (precision 0 with a weight image, ngroups == 1, resid optional, nothing else: the dE
+  /* Gate statistics in the epilogue (precision 0 or 1 with a weight image, ngroups == 1, resid optional, nothing else: the dE
    * product of CartNet's backward).  v = the value written to C (de_out of the layer BELOW, models/cartnet.py:225).  With
    * g = gst_g[m*gst_ld + n] (that layer's gate pre-activation, cartnet.py:237), ghat = (g - mean[n]) * rstd[n] with
    * mean_rstd = [mean | rstd] (2N floats), w = gst_env[m] * s * (1 - s), s = sigmoid(ghat * gamma[n] + beta[n])
@@ -219,6 +219,12 @@ int cartnet_colstats_partial(const float* x, int32_t ld, int32_t R, int32_t C, d
 /* parts[p][c] = partial column sums of the [R, C] view x (p < cartnet_segment_nparts(R)); finalise with
  * cartnet_colsum_finalize (bias gradients of Linears whose output gradient is not produced by a GEMM epilogue). */
 int cartnet_colsum_partial(const float* x, int32_t ld, int32_t R, int32_t C, double* parts, void* stream);
+/* parts_a[p][c] / parts_b[p][c] = partial column sums of d[r, c] * bc[r, c] / d[r, c] * bc[r, C + c] (d: an [R, C] view, bc
+ * [R, 2C] from cartnet_gate_scatter_fwd_bc, p < cartnet_segment_nparts(R)): sum_t daggr[t] B[t] and sum_t daggr[t] C[t], the
+ * whole of the gate's two BatchNorm-backward sums when there is no edge residual (iComformer's attention gate,
+ * models/comformer_conv.py:90-99) -- no statistics pass over the edges. */
+int cartnet_coldot_bc_partial(const float* d, int32_t ld, const float* bc, int32_t R, int32_t C, double* parts_a,
+                              double* parts_b, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Periodic radius graph on the GPU (reference: dataset/utils.py:57-237 radius_graph_pbc as used by

@@ -963,16 +963,17 @@ def test_gate_gemm_eval_matches_the_two_kernel_path(ops, D, degs):
     assert torch.equal(a2, aggr) and (E == 0 or torch.equal(e2, e_out))
 
 
+@pytest.mark.parametrize("precision", [0, 1])
 @pytest.mark.parametrize("with_env", [True, False])
-def test_gate_backward_sums_without_the_statistics_pass(ops, with_env):
+def test_gate_backward_sums_without_the_statistics_pass(ops, with_env, precision):
     """Round 5: sum(dbn) and sum(dbn ghat) of the gate's BatchNorm backward (models/cartnet.py:238) from three places
     where the operands are in registers anyway -- per-target sums of the forward gate kernel (bc), the node update's
     apply pass (daggr * bc) and the epilogue of the dE product that writes de_out (CartnetGemmArgs.gst_*) -- against the
     statistics pass they replace and against the fp64 formula.  D = 256, E >= 64 row tiles: the fused kernel's range."""
     D = 256
-    ei, ptr = _random_graph_batch(26, 50, 80, 14, seed=77)
+    ei, ptr = _random_graph_batch(30, 50, 80, 14, seed=77)
     N, E = int(ptr[-1]), ei.shape[1]
-    assert (E + 127) // 128 >= 64
+    assert (E + 127) // 128 >= 96                              # the bf16x3 kernel's range (64 row tiles at fp32)
     lay = ops.GraphLayout(ei.to(dev()), N, ptr.to(dev()))
     gs, e_in = rnd(E, 2 * D, seed=1), rnd(E, D, seed=2)
     env = torch.rand(E, generator=torch.Generator().manual_seed(3)).to(dev()) if with_env else None
@@ -1019,20 +1020,29 @@ def test_gate_backward_sums_without_the_statistics_pass(ops, with_env):
     # edge share: the dE product de_out = resid + dpre @ [W1; W2] (two folded K-segments of 256) with the epilogue
     dpre, resid = rnd(E, 2 * D, seed=21, scale=0.3), rnd(E, D, seed=22)
     W = rnd(2 * D, D, seed=23, scale=0.05)                    # [K = 512, N = 256]: segments W[:256], W[256:]
-    img = ops.pack_b([W[:D], W[D:]])
+    img = (ops.pack_b if precision == 0 else ops.split_b)([W[:D], W[D:]])
     folded = torch.cat([t.view(-1) for t in img]).contiguous()
     de_out = torch.empty(E, D, device=dev())
     tiles = ops.gemm_tiles_m(E)
     ca, cb = (torch.full((tiles * D,), 3.0, device=dev(), dtype=torch.float64) for _ in range(2))
     ops.gemm([dpre[:, :D], dpre[:, D:]], [W[:D], W[D:]], de_out, segments=True, b_kstrided=True, resid=resid,
-             b_split=img, b_split_folded=folded, colsum=ca, colsq=cb,
+             b_split=img, b_split_folded=folded, colsum=ca, colsq=cb, precision=precision,
              gate_stats=(gs[:, :D], env, mean_rstd, gamma, beta))
     de_ref = c(resid) + c(dpre) @ c(W)
     assert rel_err(de_out, de_ref) < TOL
     plain = torch.empty(E, D, device=dev())
     ops.gemm([dpre[:, :D], dpre[:, D:]], [W[:D], W[D:]], plain, segments=True, b_kstrided=True, resid=resid, b_split=img,
-             b_split_folded=folded)
+             b_split_folded=folded, precision=precision)
     assert torch.equal(plain, de_out)                         # the statistics do not touch the product
+    # the last layer's form: no edge residual (the head does not read the edge features)
+    nores = torch.empty(E, D, device=dev())
+    ca2, cb2 = (torch.full((tiles * D,), 3.0, device=dev(), dtype=torch.float64) for _ in range(2))
+    ops.gemm([dpre[:, :D], dpre[:, D:]], [W[:D], W[D:]], nores, segments=True, b_kstrided=True, b_split=img,
+             b_split_folded=folded, colsum=ca2, colsq=cb2, precision=precision,
+             gate_stats=(gs[:, :D], env, mean_rstd, gamma, beta))
+    assert rel_err(nores, c(dpre) @ c(W)) < TOL
+    assert rel_err(ca2.view(tiles, D).sum(0).cpu(), (c(nores) * w).sum(0)) < 2e-6
+    assert rel_err(cb2.view(tiles, D).sum(0).cpu(), (c(nores) * w * ghat).sum(0)) < 2e-6
     edge_a, edge_b = ca.view(tiles, D).sum(0).cpu(), cb.view(tiles, D).sum(0).cpu()
     assert rel_err(edge_a, (c(de_out) * w).sum(0)) < 2e-6
     assert rel_err(edge_b, (c(de_out) * w * ghat).sum(0)) < 2e-6
@@ -1051,4 +1061,4 @@ def test_gate_backward_sums_without_the_statistics_pass(ops, with_env):
     with pytest.raises(ValueError, match="gate-statistics"):
         ops.gemm([dpre[:small, :D], dpre[:small, D:]], [W[:D], W[D:]], de_out[:small], segments=True, b_kstrided=True,
                  resid=resid[:small], b_split=img, b_split_folded=folded, colsum=ca[:50 * D], colsq=cb[:50 * D],
-                 gate_stats=(gs[:small, :D], None, mean_rstd, gamma, beta))
+                 precision=precision, gate_stats=(gs[:small, :D], None, mean_rstd, gamma, beta))
