@@ -65,7 +65,11 @@ def test_two_epochs_against_the_reference_train_epoch():
             if key.startswith(pre):
                 got, ref = st[key[len(pre):]].cpu(), torch.from_numpy(z[key])
                 if ref.is_floating_point():
-                    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-6), key
+                    # The gate BatchNorm's running mean contains MLP_gate.2.bias, the one parameter whose true gradient is
+                    # zero (a constant in front of a training-mode BatchNorm): Adam moves it by +-lr per step along the
+                    # sign of rounding noise, in the reference as here, so that mean may differ by the learning rates spent
+                    drift_ok = sum(r["lr"] for r in seen) if key.endswith(".norm.running_mean") else 0.0
+                    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-6 + drift_ok), key
                 else:
                     assert int(got) == int(ref), key
     assert len(seen) == 4                                       # 2 epochs x (micro-batches 3 and 5)
@@ -79,13 +83,12 @@ def test_two_epochs_against_the_reference_train_epoch():
         dd = np.abs(rec["param"] - p_ref)
         print(f"step {s}: lr {rec['lr']:.3e} beta1 {rec['beta1']:.4f} grad err {np.abs(rec['grad'] - g_ref).max() / gmax:.2e} "
               f"param err well-conditioned {dd[mask].max() / rec['lr']:.2e} lr, all {dd.max() / rec['lr']:.2e} lr")
-        # accumulated gradient of the window: unscaled sum over its micro-batches.  The first window starts from the
-        # fixture's weights (3e-5, the model tests' bound); later ones from parameters that already differ where Adam
-        # amplified rounding noise (see train_epoch_utils.well_conditioned), hence the wider bound
-        assert np.abs(rec["grad"] - g_ref).max() <= (3e-5 if s == 0 else 3e-4) * gmax, s
+        # accumulated gradient of the window: unscaled sum over its micro-batches, the model tests' bound (measured:
+        # 4e-6 .. 1.4e-5 over the four free-running windows)
+        assert np.abs(rec["grad"] - g_ref).max() <= 3e-5 * gmax, s
         # parameters: where the gradient is well above rounding noise the update is determined to O(relative gradient
-        # error) of the learning rate
-        drift += 2e-2 * rec["lr"]
+        # error) of the learning rate (measured: 0, 3e-5, 5e-5, 2e-4 of the step's learning rate)
+        drift += 2e-3 * rec["lr"]
         d = np.abs(rec["param"] - p_ref)
         assert d[mask].max() <= drift + 2e-7 * np.abs(p_ref).max(), (s, d[mask].max(), rec["lr"])
         # everywhere (noise-driven elements included) a step moves a parameter by about lr at most
