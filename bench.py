@@ -447,7 +447,7 @@ def main():
     torch.cuda.synchronize()
     # one in TIMED_EVERY launches of the dominant variant carries an event pair inside the timed region (4 is coprime with
     # the nine such launches of a step: the sample walks over all of them): the pairs cost the step ~0.7 % when every
-    # launch had one (same-box A/B, tools/ab_timer.sh), which is the difference between 14.0 and 14.1 ms
+    # launch had one (same-box A/B, tools/experiments/ab_timer.sh), which is the difference between 14.0 and 14.1 ms
     timed_every = TIMED_EVERY if (timer and only is not None) else 1
     sampler = new_sampler()
     # The bookkeeping above (reading ~260 event pairs, a sysfs snapshot, starting the sampler) leaves the card idle for

@@ -23,7 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", 
 if os.environ.get("CARTNET_BUILD_EXPERIMENTAL"):       # experiments kept as a record (csrc/experimental/), never shipped
     SOURCES.append("experimental/gemm_f32q.hip")
     FLAGS.append("-DCN_EXPERIMENTAL_Q")
-FLAGS += os.environ.get("CARTNET_HIPCC_EXTRA", "").split()      # e.g. -DCN_SETPRIO=0 for an A/B library (tools/ab_bench.sh)
+FLAGS += os.environ.get("CARTNET_HIPCC_EXTRA", "").split()      # e.g. -DCN_SETPRIO=0 for an A/B library (tools/experiments/ab_bench.sh)
 
 
 def _digest(paths) -> str:

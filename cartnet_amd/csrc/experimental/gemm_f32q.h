@@ -1,7 +1,7 @@
 // EXPERIMENT (round 4), NOT part of libcartnet_hip.so: measured slower than gemm_f32.h on every form, alone and inside the
 // training step (profiles/r04_exp_phases.md has the numbers and the in-kernel stamps).  Built only with
 // CARTNET_BUILD_EXPERIMENTAL=1 (cartnet_amd/build.py adds this directory's sources and -DCN_EXPERIMENTAL_Q; the switch
-// is then cartnet_gemm_experimental_q(1), tools/ab_q.sh).  Kept as the record of what "more resident workgroups" buys.
+// is then cartnet_gemm_experimental_q(1), tools/experiments/ab_q.sh).  Kept as the record of what "more resident workgroups" buys.
 //
 // fp32-MFMA kernel for activations x weights with FOUR small workgroups per CU instead of two large ones.
 //

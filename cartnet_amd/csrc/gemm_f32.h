@@ -117,7 +117,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
     asm volatile("" ::: "memory");
   };
   // steady state (u + 3 < nsteps): fragments of both k-groups first, then the MFMA chain with the staging of the next
-  // tiles in its shadow.  (Round 3, measured with in-kernel stamps -- tools/exp_phases.py, profiles/r03_exp_phases.md --
+  // tiles in its shadow.  (Round 3, measured with in-kernel stamps -- tools/experiments/exp_phases.py, profiles/r03_exp_phases.md --
   // and NOT adopted: the barrier in the middle of the chain with the next step's first fragments read behind it, and
   // the two waves of a SIMD staging at different places of the chain.  Neither moves a launch.)
   auto step_full = [&](auto cur_c, int u, f32x4& r) {

@@ -131,7 +131,7 @@ struct Stager {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// Diagnostic build only (-DCN_CLOCK_STAMP, tools/exp_clock_x3.py): one (shader clock ticks, 100 MHz ticks) pair per
+// Diagnostic build only (-DCN_CLOCK_STAMP, tools/experiments/exp_clock_x3.py): one (shader clock ticks, 100 MHz ticks) pair per
 // workgroup around the main loop, into a buffer nothing else reads; the product build has no stamp.
 #ifdef CN_CLOCK_STAMP
 static __device__ unsigned long long cn_clock_dbg[2 * 4096];
@@ -145,7 +145,7 @@ static __device__ unsigned long long cn_clock_dbg[2 * 4096];
 #define CN_STAMP_BEGIN()
 #define CN_STAMP_END()
 #endif
-// Second diagnostic (-DCN_PHASE_STAMP, tools/exp_phases.py): per workgroup of the fp32 activation x weight kernel the
+// Second diagnostic (-DCN_PHASE_STAMP, tools/experiments/exp_phases.py): per workgroup of the fp32 activation x weight kernel the
 // 100 MHz time at entry, main-loop start, main-loop end, last store issued and all stores acknowledged, with the
 // hardware id of the CU it ran on -- the life of every workgroup on every CU of one launch.
 #ifdef CN_PHASE_STAMP

@@ -1,7 +1,7 @@
 // The bf16x3 activation x weight kernel of gemm_x3.h on the 16x16x32 MFMA shape.
 //
 // Why: the bf16x3 main loop runs at 0.94 of the matrix pipe's cycles, but the chip holds only 1.53-1.70 GHz under it
-// (2.37 GHz on zeros: tools/exp_clock_x3.py, tools/micro/x3_shape.hip) -- the loop is bound by the power the matrix
+// (2.37 GHz on zeros: tools/experiments/exp_clock_x3.py, tools/experiments/micro/x3_shape.hip) -- the loop is bound by the power the matrix
 // work draws, and MI355X holds a higher clock on v_mfma_f32_16x16x32_bf16 than on v_mfma_f32_32x32x16_bf16 at equal
 // cycles per FLOP (MI355X_MICROARCH.md, 'DVFS give-back' item 7).  Measured on this kernel's loop body in isolation,
 // operands from LDS, random data: +7.8 % FLOP/s with the 20 fragment reads per K-step used here, +13.9 % at the 12

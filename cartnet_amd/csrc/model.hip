@@ -924,7 +924,7 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     if (pairs && S.dual) {
       // host order: the main stream's dpre and dE are in its queue before the ten launches of the side stream are made
       // (configs[2]: they are ~60 us of host time, and the main stream sat idle for them between dpre and dE)
-      // Side-stream order by batch size (same-box A/B, tools/ab_pairs_order.sh).  Full-size batch: the second Linears'
+      // Side-stream order by batch size (same-box A/B, tools/experiments/ab_pairs_order.sh).  Full-size batch: the second Linears'
       // weight gradients first, under dpre -- they need only gs, and the stream would idle until dpre is done (bf16x3 10.37
       // vs 10.52 ms).  Small batch (configs[2]): every kernel is one tile's latency and dX waits for the segment sums, which
       // came ~15 us after dE was done when queued behind those weight gradients (1.20 vs 1.17 ms): segment sums first.

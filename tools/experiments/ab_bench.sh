@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B comparison of two builds of libcartnet_hip.so on ONE GPU box (boxes of the pool differ by +-2 %, more than most
 # kernel changes are worth): build variant A, copy cartnet_amd/libcartnet_hip.so to cartnet_amd/libcartnet_hip_A.so,
-# build variant B likewise (*.so files travel with the gpurun snapshot), then on the box:  bash tools/ab_bench.sh
+# build variant B likewise (*.so files travel with the gpurun snapshot), then on the box:  bash tools/experiments/ab_bench.sh
 # Prints ms/step and graphs/s of the fp32 and bf16x3 passes for A B A B.
 for v in A B A B; do
   cp cartnet_amd/libcartnet_hip_$v.so cartnet_amd/libcartnet_hip.so

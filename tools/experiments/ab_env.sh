@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-binary A/B on ONE GPU box: the training step with and without an environment switch (boxes of the pool differ by
-# +-2 %, more than most kernel changes are worth).  usage: bash tools/ab_env.sh VAR [VALUE]   ->  A = VAR unset, B = VAR=VALUE (default 1)
+# +-2 %, more than most kernel changes are worth).  usage: bash tools/experiments/ab_env.sh VAR [VALUE]   ->  A = VAR unset, B = VAR=VALUE (default 1)
 # (The C library reads no environment variable since round 4: this serves Python-side switches such as CARTNET_FUSED_LOSS;
 #  library variants are compared with tools/build_variant.sh + tools/ab_lib.sh.)
 VAR=${1:-CARTNET_FUSED_LOSS}

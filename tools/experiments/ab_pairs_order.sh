@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of library variants on the bf16x3 and bf16 + bf16-storage steps at full size: tools/ab_pairs_order.sh A.so B.so ...
+# Same-box A/B of library variants on the bf16x3 and bf16 + bf16-storage steps at full size: tools/experiments/ab_pairs_order.sh A.so B.so ...
 for v in "$@" "$@"; do
   echo "== $v"
   for args in "--precision 1" "--precision 2 --half-storage"; do

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Per-kernel rocprofv3 stats of the fp32 training step for two builds of the library (see tools/ab_bench.sh for A / B).
+# Per-kernel rocprofv3 stats of the fp32 training step for two builds of the library (see tools/experiments/ab_bench.sh for A / B).
 # -> gpurun_out/abprof_{A,B}/.../*kernel_stats.csv
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 for v in A B; do
   cp $ROOT/cartnet_amd/libcartnet_hip_$v.so $ROOT/cartnet_amd/libcartnet_hip.so

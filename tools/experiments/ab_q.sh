@@ -14,7 +14,7 @@ for v in 0 1 0 1; do
 done > gpurun_out/q_forms.log 2>&1
 cat gpurun_out/q_forms.log
 if [ -f cartnet_amd/libcartnet_hip_stamp.so ]; then
-  CARTNET_LIB=$PWD/cartnet_amd/libcartnet_hip_stamp.so CARTNET_Q=1 python tools/exp_phases.py 256 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ph_q.txt
+  CARTNET_LIB=$PWD/cartnet_amd/libcartnet_hip_stamp.so CARTNET_Q=1 python tools/experiments/exp_phases.py 256 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ph_q.txt
 fi
 if [ "${STEP:-0}" == "1" ]; then
 for v in 0 1 2 0 1 2; do

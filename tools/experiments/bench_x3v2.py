@@ -1,6 +1,6 @@
 """Correctness (vs fp64) and speed of the second-generation bf16x3 kernels at the CartNet layer shapes."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import torch
 from cartnet_amd import ops
 

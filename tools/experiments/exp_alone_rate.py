@@ -2,7 +2,7 @@
 DMA-fed kernel, from the slope of launch time over K -- is a lone workgroup (2 waves per SIMD) able to keep the matrix
 pipe busy?  Ideal: 32 MFMAs x 64 cycles per wave per K-step; 2 (4) waves per SIMD -> 4096 (8192) cycles per K-step."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import torch
 from cartnet_amd import ops
 dev = torch.device("cuda:0")

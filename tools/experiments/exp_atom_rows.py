@@ -1,7 +1,7 @@
 """Experiment (GPU box): atom-sized activation x weight products (M = 12,416) with and without their weight image --
 with the image the launch takes the 128-wide DMA-fed kernel, without it the register-staged narrow-tile kernels."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import torch
 from cartnet_amd import ops
 

@@ -7,7 +7,7 @@ clock is their ratio x 100 MHz (MI355X_MICROARCH.md, 'DVFS give-back' item 6).  
 Also prints the launch time and, from K = 1024 / 4096, the main loop's rate in MFMA cycles per K-step.
 """
 import ctypes, os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np
 import torch
 from cartnet_amd import ops, lib as _lib

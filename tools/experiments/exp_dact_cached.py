@@ -2,7 +2,7 @@
 traffic or latency / VALU work?  Same launch with the `dact` operand's row stride set to 0, so that every row reads the
 same 2 KB (L2 hits, no HBM traffic) but the epilogue executes the same loads and the same arithmetic."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import torch
 from cartnet_amd import ops
 

@@ -3,7 +3,7 @@ activation x weight kernel, from the clock stamps (-DCN_CLOCK_STAMP), for diagno
 compiled out (-DCN_EXP_NO_DMA / NO_ASTORE / NO_ALOAD / NO_BARRIER / NO_FRAGS: wrong results, timing only).  The matrix
 pipe needs 4,096 cycles per K-step for the workgroup's two waves per SIMD."""
 import ctypes, os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np
 import torch
 from cartnet_amd import ops, lib as _lib

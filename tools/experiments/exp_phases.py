@@ -6,7 +6,7 @@ entry, main-loop start, main-loop end, last store issued, all stores acknowledge
 (median over workgroups), and per CU the timeline of the workgroups it ran -- how much of the launch each CU had 0, 1
 or 2 workgroups inside their main loops, and the gap between a workgroup leaving and its successor's first stamp."""
 import ctypes, os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np
 import torch
 from cartnet_amd import ops, lib as _lib

@@ -4,7 +4,7 @@ gemm_f32q.o built with -DCN_CLOCK_STAMP (tools/build_variant.sh clock "-DCN_CLOC
 Every workgroup stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around its loop; after 2.5 s of
 back-to-back launches the median ratio is the in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6)."""
 import ctypes, os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np
 import torch
 from cartnet_amd import ops, lib as _lib, telemetry as tele

@@ -1,5 +1,5 @@
 """Round 4: where the time of a configs[2]-sized precision-2 product goes.  Launch durations are read from a rocprofv3
-kernel trace of THIS script (python calls cost more than these kernels run): tools/exp_small_gemm.sh.  Every case is
+kernel trace of THIS script (python calls cost more than these kernels run): tools/experiments/exp_small_gemm.sh.  Every case is
 RUNS launches of one kernel; the post-processing (this file with the CSV as argument) takes the median of each run.
 Cases: duration against K (slope = one K-step, intercept = launch + pipeline head + epilogue) for atom-sized (M = 736)
 and edge-sized (M = 9,970) activation x weight products, bare, with the gather epilogue, with gather + column sums."""
@@ -17,7 +17,7 @@ if len(sys.argv) > 1:
     raise SystemExit
 import torch
 import os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from cartnet_amd import ops
 dev = "cuda"
 g = torch.Generator().manual_seed(0)

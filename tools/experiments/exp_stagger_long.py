@@ -2,7 +2,7 @@
 launch (10x the benchmark's rows, ~54 rounds of tiles: start-up and tail are negligible) of the plain two-group product,
 with the library as built (env CARTNET lib A/B chosen by the caller)."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import torch
 from cartnet_amd import ops
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Experiment (GPU box): the 128-wide DMA-fed fp32 kernel (three workgroups per CU) against the 256-wide one on the
 layer GEMM variants, sustained.  Run with TILE_POLICY=256 and =128 (unset / 0: the library's own choice per variant; CartnetGemmArgs.tile_policy)."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import torch
 from cartnet_amd import ops
 

@@ -2,7 +2,7 @@
 taken over 20 back-to-back steps and includes the time the host waits for room in the device queue when it runs ahead):
 native C++ sequence (csrc/icomformer.hip) against the Python sequence.  GPU box."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import torch
 from cartnet_amd.comformer import iComformer
 from cartnet_amd.optim import FlatAdam

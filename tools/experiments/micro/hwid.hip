@@ -1,5 +1,5 @@
 // Which hardware wave slots do the waves of co-resident 512-thread workgroups get?  (round 3, for the asymmetric-priority experiment)
-// hipcc --offload-arch=gfx950 -O3 -o tools/micro/hwid tools/micro/hwid.hip
+// hipcc --offload-arch=gfx950 -O3 -o tools/experiments/micro/hwid tools/experiments/micro/hwid.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>

@@ -1,6 +1,6 @@
 // Micro-benchmark (round 3): HBM write rate of the GEMM epilogue's store pattern (a wave instruction = 8 rows x 128 B,
 // rows 2 KB apart) against full-row stores (a wave instruction = 1 KB contiguous), same bytes, same grid.
-// hipcc --offload-arch=gfx950 -O3 -o /tmp/store_pattern tools/micro/store_pattern.hip && /tmp/store_pattern
+// hipcc --offload-arch=gfx950 -O3 -o /tmp/store_pattern tools/experiments/micro/store_pattern.hip && /tmp/store_pattern
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));

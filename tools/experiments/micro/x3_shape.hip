@@ -6,7 +6,7 @@
 //           ([h|m] x [h|h] = hh + mh, [h|m] x [m|m] = hm + mm, [h|l] x [l|h] = hl + lh): 20 ds_read_b128 + 48 MFMAs
 //   mode 2: mode 1's MFMAs with only 12 reads (B fragments reused: wrong arithmetic, isolates the shape from the LDS bytes)
 // Prints wall time per K-step pair of a CU, the in-kernel clock (s_memtime / s_memrealtime) and the matrix-pipe occupancy.
-// hipcc --offload-arch=gfx950 -O3 -o tools/micro/x3_shape tools/micro/x3_shape.hip
+// hipcc --offload-arch=gfx950 -O3 -o tools/experiments/micro/x3_shape tools/experiments/micro/x3_shape.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

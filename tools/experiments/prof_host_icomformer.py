@@ -1,6 +1,6 @@
 """Where the host time of an iComformer training step goes (cProfile over 5 steps, GPU box)."""
 import cProfile, os, pstats, sys
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import torch
 from cartnet_amd.config import cfg
 from cartnet_amd.comformer import iComformer

@@ -1,7 +1,7 @@
 """cProfile INSIDE iComformer's backward (it runs on autograd's device thread, which a profile of the main thread never
 sees): where the host time of `_IComformerFunction.backward` goes.  GPU box."""
 import cProfile, os, pstats, sys, io
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import torch
 from cartnet_amd.config import cfg
 from cartnet_amd import comformer
