@@ -564,6 +564,10 @@ class CartNet(nn.Module):
             raise RuntimeError("cartnet_amd.CartNet runs only on an AMD GPU (HIP kernels); move the model and the "
                                "batch to 'cuda' -- there is no CPU fallback")
         self._grad_mode = torch.is_grad_enabled()       # read by _CartNetFunction.forward (grad mode is off in there)
+        owner = self.__dict__.get("_flat_owner")
+        if self._flat_grad is not None and owner is not None and owner() is None:
+            self._flat_grad = None                      # the FlatAdam that owned the buffer is gone: gradients go to .grad again
+            self.__dict__.pop("_flat_owner", None)
         if self._flat_grad is not None and self._flat_grad.device == params[0].device and torch.is_grad_enabled():
             # every gradient goes to the optimiser's flat buffer (FlatAdam): one differentiable input is enough to have
             # backward called, and 60 fewer arguments through autograd are 0.05 ms of host time per step.  FlatAdam was
