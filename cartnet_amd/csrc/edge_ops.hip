@@ -291,6 +291,56 @@ __global__ __launch_bounds__(256) void cn_segment_sum_kernel(const float* __rest
   }
 }
 
+// Both sums of a layer's backward in ONE launch: out_t[n] = sum of the rows of target n (contiguous, CSR), out_s[n] = sum
+// of the rows of source n (through the CSC permutation).  The two walk the same rows -- an edge row is read once as its
+// target's and once as its source's, and both atoms belong to the same crystal -- so the items are dealt out interleaved
+// (node n by target, node n by source, node n + 1 by target, ...): the second reader of a row runs microseconds after the
+// first and finds it in the L2 / the memory-side cache instead of HBM (two separate launches stream the 363 MB of a layer's
+// dpre twice; the descending sweep of the second only saved what the 256 MB cache still held).
+template <bool RH>
+__global__ __launch_bounds__(256) void cn_segment_sum_pair_kernel(const float* __restrict__ rows, int ld,
+                                                                  const int* __restrict__ rowptr,
+                                                                  const int* __restrict__ colptr,
+                                                                  const int* __restrict__ perm, int N, int W,
+                                                                  float* __restrict__ out_t, float* __restrict__ out_s,
+                                                                  int ldo) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int chunks = (W + 255) / 256;
+  const long long items = 2LL * N * chunks;
+  for (long long it = (long long)blockIdx.x * NODES_PER_BLOCK + wid; it < items; it += (long long)gridDim.x * NODES_PER_BLOCK) {
+    const int per_node = 2 * chunks;
+    const int t = (int)(it / per_node);
+    const int sub = (int)(it % per_node);
+    const bool by_src = sub >= chunks;
+    const int c = (by_src ? sub - chunks : sub) * 256 + lane * 4;
+    if (c >= W) continue;
+    const int* __restrict__ ptr = by_src ? colptr : rowptr;
+    const int k0 = ptr[t], k1 = ptr[t + 1];
+    f32x4 acc = {0, 0, 0, 0};
+    int k = k0;
+    for (; k + SEG_BATCH <= k1; k += SEG_BATCH) {
+      f32x4 v[SEG_BATCH];
+#pragma unroll
+      for (int u = 0; u < SEG_BATCH; ++u) v[u] = ldrow<RH>(rows, (size_t)(by_src ? perm[k + u] : k + u) * ld + c);
+#pragma unroll
+      for (int u = 0; u < SEG_BATCH; ++u) acc += v[u];
+    }
+    if (k < k1) {
+      f32x4 v[SEG_BATCH];
+#pragma unroll
+      for (int u = 0; u < SEG_BATCH - 1; ++u) {
+        const int kk = min(k + u, k1 - 1);
+        v[u] = ldrow<RH>(rows, (size_t)(by_src ? perm[kk] : kk) * ld + c);
+      }
+#pragma unroll
+      for (int u = 0; u < SEG_BATCH - 1; ++u)
+        if (k + u < k1) acc += v[u];
+    }
+    st4((by_src ? out_s : out_t) + (size_t)t * ldo + c, acc);
+  }
+}
+
 // Long-segment variant (few, very uneven segments, e.g. atoms grouped by element): pass 1 cuts the sorted positions
 // into chunks of LONG_CHUNK rows, one wave per (chunk, 256-column slab), and writes one partial row per run of equal
 // segment id at tmp[first position of the run]; pass 2 adds each segment's partial rows in position order.
@@ -561,6 +611,38 @@ static int segment_sum_impl(bool half, const float* rows, int32_t ld, const int3
                        rows, ld, ptr, perm, N, W, out, ldo, /*reverse=*/perm ? 1 : 0);
   CN_LAUNCH_CHECK("cartnet_segment_sum");
   return 0;
+}
+
+static int segment_sum_pair_impl(bool half, const float* rows, int32_t ld, const int32_t* rowptr, const int32_t* colptr,
+                                 const int32_t* perm, int32_t N, int32_t W, float* out_t, float* out_s, int32_t ldo,
+                                 void* stream) {
+  CN_CHECK(N >= 0 && W >= 4 && W % 4 == 0 && ld % 4 == 0 && ldo % 4 == 0 && ld >= W && ldo >= W,
+           "cartnet_segment_sum_pair: W=%d ld=%d ldo=%d must be multiples of 4", W, ld, ldo);
+  if (N == 0) return 0;
+  CN_CHECK(rows && rowptr && colptr && perm && out_t && out_s, "cartnet_segment_sum_pair: null pointer");
+  long long items = 2LL * N * ((W + 255) / 256);
+  long long blocks = (items + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;
+  if (blocks > 65536) blocks = 65536;
+  if (half)
+    hipLaunchKernelGGL(cn_segment_sum_pair_kernel<true>, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       rows, ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo);
+  else
+    hipLaunchKernelGGL(cn_segment_sum_pair_kernel<false>, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       rows, ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo);
+  CN_LAUNCH_CHECK("cartnet_segment_sum_pair");
+  return 0;
+}
+
+extern "C" int cartnet_segment_sum_pair(const float* rows, int32_t ld, const int32_t* rowptr, const int32_t* colptr,
+                                        const int32_t* perm, int32_t N, int32_t W, float* out_t, float* out_s, int32_t ldo,
+                                        void* stream) {
+  return segment_sum_pair_impl(false, rows, ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo, stream);
+}
+extern "C" int cartnet_segment_sum_pair_h(const void* rows_bf16, int32_t ld, const int32_t* rowptr, const int32_t* colptr,
+                                          const int32_t* perm, int32_t N, int32_t W, float* out_t, float* out_s,
+                                          int32_t ldo, void* stream) {
+  return segment_sum_pair_impl(true, static_cast<const float*>(rows_bf16), ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo,
+                               stream);
 }
 
 extern "C" int cartnet_segment_sum(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t N,

@@ -571,6 +571,10 @@ def test_segment_sum_every_batch_remainder_is_exact(ops, W):
     ref_t = torch.zeros(N, W).index_add_(0, ei[1], rows.cpu())
     ref_s = torch.zeros(N, W).index_add_(0, ei[0], rows.cpu())
     assert torch.equal(out_t.cpu(), ref_t) and torch.equal(out_s.cpu(), ref_s)
+    # both sums in one launch (round 5: the model's backward), into the two halves of one matrix
+    both = torch.full((N, 2 * W), 7.0, device=dev())
+    ops.segment_sum_pair(rows, lay, both[:, :W], both[:, W:])
+    assert torch.equal(both[:, :W].cpu(), ref_t) and torch.equal(both[:, W:].cpu(), ref_s)
 
 
 def test_gate_scatter_fwd_every_batch_remainder(ops):

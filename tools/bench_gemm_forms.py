@@ -71,6 +71,16 @@ if prec == 0:
     rowptr[1:] = torch.cumsum(torch.bincount(tgt.long(), minlength=N), 0).to(torch.int32)
     dPn = torch.empty(N, 4*D, device=dev)
     timeit("pass: segment_sum by target [E, 2D]", lambda: ops.segment_sum(out2, rowptr, None, dPn[:, :2*D]), F)
+    # by source through a CSC permutation of a random graph with the same degrees + both in one launch
+    order = torch.argsort(src.long(), stable=True).to(torch.int32)
+    colptr = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+    colptr[1:] = torch.cumsum(torch.bincount(src.long(), minlength=N), 0).to(torch.int32)
+    def two():
+        ops.segment_sum(out2, rowptr, None, dPn[:, :2*D]); ops.segment_sum(out2, colptr, order, dPn[:, 2*D:])
+    timeit("pass: segment_sum by target, then by source (2 launches)", two, F)
+    class LP: pass
+    lp = LP(); lp.E, lp.N, lp.rowptr, lp.colptr, lp.perm = E, N, rowptr, colptr, order
+    timeit("pass: segment_sum_pair (1 launch)", lambda: ops.segment_sum_pair(out2, lp, dPn[:, :2*D], dPn[:, 2*D:]), F)
     env = torch.rand(E, generator=g).to(dev); mr = torch.cat([rnd(D, sc=0.1), 1.0 + torch.rand(D, generator=g).to(dev)]).contiguous()
     gam, bet = rnd(D), rnd(D)
     ca = torch.empty(tiles*D, dtype=torch.float64, device=dev); cb = torch.empty_like(ca)

@@ -57,7 +57,7 @@ def analyse(fpath, wpath, verbose=True):
         else:
             m3 = re.match(r"cn_gemm::cn_gemm_f32(nn|tn)_kernel<(\w+)>", name)
             m2 = re.match(r"cn_gemm::cn_gemm_x3(nn|tn)_kernel<(\w+), (\w+)>", name)
-            m5 = re.match(r"cn_gemm::cn_gemm_x3nn16_kernel<(\w+)>", name)      # gemm_x3s.h: 16x16x32 MFMA shape
+            m5 = re.match(r"cn_gemm::cn_gemm_x3nn16_kernel<(\w+)(?:, \d+)?>", name)      # gemm_x3s.h: 16x16x32 MFMA shape (round 5: <A_ACT, GSTK>)
             if m5:
                 key = "nn256" + ("+silu(A)" if m5.group(1) == "true" else "")
                 v = variants["x3"].setdefault(key, {"launches_profiled": 0, "fetch": 0.0, "write": 0.0})
@@ -65,7 +65,7 @@ def analyse(fpath, wpath, verbose=True):
                 v["fetch"] += fetch * n
                 v["write"] += write * n
                 continue
-            m4 = re.match(r"cn_gemm::cn_gemm_f32nn128_kernel<(\w+)>", name)
+            m4 = re.match(r"cn_gemm::cn_gemm_f32nn128_kernel<(\w+)(?:, \d+)?>", name)
             if m4 or name == "cn_gemm::cn_gemm_f32nn_actout_kernel":
                 key = ("nn128" + ("+silu(A)" if m4.group(1) == "true" else "")) if m4 else "nn256+silu(A)+out"
                 v = variants["fp32"].setdefault(key, {"launches_profiled": 0, "fetch": 0.0, "write": 0.0})
@@ -101,9 +101,11 @@ def analyse(fpath, wpath, verbose=True):
         name = short(k)
         for pat, mode, key in ((r"cn_gemm::cn_gemm_f32nn_kernel<false>", "fp32", "nn256"),
                                (r"cn_gemm::cn_gemm_f32nn128_kernel<false>", "fp32", "nn128"),
+                               (r"cn_gemm::cn_gemm_f32nn128_kernel<false, 0>", "fp32", "nn128"),
                                (r"cn_gemm::cn_gemm_f32tn_kernel<false>", "fp32", "tn256"),
                                (r"cn_gemm::cn_gemm_x3nn_kernel<false, false>", "x3", "nn256"),
-                               (r"cn_gemm::cn_gemm_x3nn16_kernel<false>", "x3", "nn256")):
+                               (r"cn_gemm::cn_gemm_x3nn16_kernel<false>", "x3", "nn256"),
+                               (r"cn_gemm::cn_gemm_x3nn16_kernel<false, 0>", "x3", "nn256")):
             if name == pat and key in variants[mode]:
                 n = fbc[k]
                 variants[mode][key]["hbm_bytes_per_launch_edge_rows"] = int(
