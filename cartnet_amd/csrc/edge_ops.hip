@@ -407,6 +407,79 @@ __global__ __launch_bounds__(256) void cn_segment_long_pass1_kernel(const float*
   }
 }
 
+// The COMPACT pass 1 for rows that are FOLD pieces of W / FOLD columns side by side (iComformer's edge layer: [E, 3, 2C]
+// seen as [E, 6C]), with the pieces' sum per row as a by-product: fold_out[p, c] = sum_i rows[p, i * W/FOLD + c].  A wave owns
+// a 32-row chunk and one 256-column slab of the FOLDED width and reads its FOLD pieces of every row together, so each row
+// is read once for both results (the per-crystal sums over all edges and the per-edge sum over the lattice vectors were
+// two passes over 1.09 GB at the benchmark batch).
+template <int FOLD>
+__global__ __launch_bounds__(256) void cn_segment_long_fold_pass1_kernel(const float* __restrict__ rows, int ld,
+                                                                         const int* __restrict__ ptr, int nseg, int total,
+                                                                         int W, float* __restrict__ tmp,
+                                                                         float* __restrict__ fold_out) {
+  constexpr int FB = 8;                        // rows whose FOLD x 1 KiB loads are in flight together
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int Wf = W / FOLD;
+  const int slabs = (Wf + 255) / 256;
+  const int nchunks = (total + LONG_CHUNK - 1) / LONG_CHUNK;
+  for (long long it = (long long)blockIdx.x * NODES_PER_BLOCK + wid; it < (long long)nchunks * slabs;
+       it += (long long)gridDim.x * NODES_PER_BLOCK) {
+    const int chunk = (int)(it / slabs);
+    const int c = (int)(it % slabs) * 256 + lane * 4;
+    const bool on = c < Wf;
+    const int p0 = chunk * LONG_CHUNK, p1 = min(total, p0 + LONG_CHUNK);
+    int below = 0;
+    for (int s0 = 0; s0 < nseg; s0 += 64) below += (s0 + lane < nseg && ptr[s0 + lane] <= p0) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+    int seg = below > 0 ? below - 1 : 0;
+    int next = ptr[seg + 1];
+    int run_start = p0;
+    auto slot = [&](int start, int seg_of_run) -> size_t {
+      return (size_t)(start % LONG_CHUNK == 0 ? start / LONG_CHUNK : nchunks + seg_of_run);
+    };
+    f32x4 acc[FOLD];
+#pragma unroll
+    for (int i = 0; i < FOLD; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    auto flush = [&](int start, int seg_of_run) {
+      if (!on) return;
+#pragma unroll
+      for (int i = 0; i < FOLD; ++i) st4(tmp + slot(start, seg_of_run) * W + i * Wf + c, acc[i]);
+    };
+    for (int pb = p0; pb < p1; pb += FB) {
+      f32x4 v[FB][FOLD];
+#pragma unroll
+      for (int u = 0; u < FB; ++u)
+#pragma unroll
+        for (int i = 0; i < FOLD; ++i) {
+          v[u][i] = f32x4{0, 0, 0, 0};
+          if (pb + u < p1 && on) v[u][i] = ld4(rows + (size_t)(pb + u) * ld + i * Wf + c);
+        }
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        const int p = pb + u;
+        if (p < p1) {
+          while (seg + 1 <= nseg && p >= next) {
+            if (p > run_start) flush(run_start, seg);
+#pragma unroll
+            for (int i = 0; i < FOLD; ++i) acc[i] = f32x4{0, 0, 0, 0};
+            run_start = p;
+            ++seg;
+            next = seg + 1 <= nseg ? ptr[seg + 1] : 0x7fffffff;
+          }
+          f32x4 s = v[u][0];
+#pragma unroll
+          for (int i = 1; i < FOLD; ++i) s += v[u][i];          // ((piece 0 + piece 1) + piece 2): the order of cn_icf_sum3
+#pragma unroll
+          for (int i = 0; i < FOLD; ++i) acc[i] += v[u][i];
+          if (on) st4(fold_out + (size_t)p * Wf + c, s);
+        }
+      }
+    }
+    if (p1 > run_start) flush(run_start, seg);
+  }
+}
+
 template <bool COMPACT>
 __global__ __launch_bounds__(256) void cn_segment_long_pass2_kernel(const float* __restrict__ tmp,
                                                                     const int* __restrict__ ptr, int nseg, int W,
@@ -687,6 +760,31 @@ extern "C" int cartnet_segment_sum_long(const float* rows, int32_t ld, const int
 
 extern "C" int32_t cartnet_segment_chunked_rows(int32_t nseg, int32_t total) {
   return (total + LONG_CHUNK - 1) / LONG_CHUNK + (nseg > 0 ? nseg : 0);
+}
+
+extern "C" int cartnet_segment_sum_chunked_fold3(const float* rows, int32_t ld, const int32_t* ptr, int32_t nseg, int32_t total,
+                                                 int32_t W, float* tmp, float* out, int32_t ldo, float* fold_out,
+                                                 void* stream) {
+  CN_CHECK(nseg >= 1 && total >= 0 && W >= 12 && W % 12 == 0 && ld % 4 == 0 && ldo % 4 == 0 && ld >= W && ldo >= W,
+           "cartnet_segment_sum_chunked_fold3: W=%d must be a multiple of 12 (three pieces of 16-byte columns), ld=%d ldo=%d of 4",
+           W, ld, ldo);
+  CN_CHECK((rows || total == 0) && ptr && tmp && out && (fold_out || total == 0), "cartnet_segment_sum_chunked_fold3: null pointer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int slabs_f = (W / 3 + 255) / 256, slabs = (W + 255) / 256;
+  const int nchunks = (total + LONG_CHUNK - 1) / LONG_CHUNK;
+  if (total > 0) {
+    long long blocks = ((long long)nchunks * slabs_f + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cn_segment_long_fold_pass1_kernel<3>, dim3((int)blocks), dim3(256), 0, st, rows, ld, ptr, nseg, total, W,
+                       tmp, fold_out);
+    CN_LAUNCH_CHECK("cartnet_segment_sum_chunked_fold3");
+  }
+  long long blocks2 = ((long long)nseg * slabs + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;
+  if (blocks2 > 4096) blocks2 = 4096;
+  hipLaunchKernelGGL(cn_segment_long_pass2_kernel<true>, dim3((int)blocks2), dim3(256), 0, st, tmp, ptr, nseg, W, out, ldo,
+                     nchunks);
+  CN_LAUNCH_CHECK("cartnet_segment_sum_chunked_fold3");
+  return 0;
 }
 
 extern "C" int cartnet_segment_sum_chunked(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm,

@@ -26,23 +26,6 @@ using namespace cn_model;
 
 thread_local EventPool g_icf_events;
 
-// out[e, :] = rows[3e, :] + rows[3e + 1, :] + rows[3e + 2, :]   (rows [3E, 4 * cols4] contiguous): the edge layer's per-edge
-// term sums each edge's three lattice-vector rows.  Two edges' worth of columns per 256 threads when cols4 = 128; the
-// thread -> (edge, column) split is done once, outside the loop.
-__global__ __launch_bounds__(256) void cn_icf_sum3_kernel(const float* __restrict__ rows, long long E, int cols4,
-                                                          float* __restrict__ out) {
-  const long long gtid = (long long)blockIdx.x * 256 + threadIdx.x, gsize = (long long)gridDim.x * 256;
-  const long long per = gsize / cols4;                 // edges advanced per round (host: gsize is a multiple of cols4)
-  const int c = (int)(gtid % cols4) * 4;
-  for (long long e = gtid / cols4; e < E; e += per) {
-    const float* r = rows + (size_t)e * 3 * cols4 * 4 + c;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(r);
-    const f32x4 b2 = *reinterpret_cast<const f32x4*>(r + (size_t)cols4 * 4);
-    const f32x4 c2 = *reinterpret_cast<const f32x4*>(r + (size_t)cols4 * 8);
-    *reinterpret_cast<f32x4*>(out + (size_t)e * cols4 * 4 + c) = (a + b2) + c2;
-  }
-}
-
 // ---- small index kernel: rows r = 3 e + i of the edge layer -------------------------------------------------------------
 // idx_edge[r] = e, idx_gl[r] = 3 * crystal(source of e) + i, ptr3[e] = 3 e, gedge_ptr[g] = rowptr[graph_ptr[g]]
 __global__ void cn_icf_index_kernel(const int* __restrict__ src32, const int64_t* __restrict__ batch, long long E,
@@ -836,15 +819,9 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     // (dpr is [3E, 2C] = [E, 3, 2C]: the per-edge term is the sum of each edge's three rows, the per-(crystal, lattice
     //  vector) term the sum over the crystal's edges of the [E, 6C] view.  Through cartnet_segment_sum -- one wave per
     //  segment -- the second was 64 x 2 waves on the whole chip, three times: 3 ms of the step; the first ran at 1.5 TB/s.)
-    if (b.E > 0) {
-      const int cols4 = 2 * C / 4;                      // threads of the grid: a multiple of cols4 (C % 8 == 0 => 256 * cols4)
-      const long long items = (long long)b.E * cols4;
-      long long blocks = std::min<long long>((items + 255) / 256, 16384);
-      blocks = (blocks + cols4 - 1) / cols4 * cols4;
-      hipLaunchKernelGGL(cn_icf_sum3_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)st, dpr, (long long)b.E, cols4, w.dKa);
-      CN_LAUNCH_CHECK("cartnet_icomformer_backward (three-row sums)");
-    }
-    RUN(cartnet_segment_sum_chunked(dpr, 6 * C, w.gedge_ptr, nullptr, Bg, E, 6 * C, w.seg_tmp_e, w.dKYb, 6 * C, st));
+    // (round 5: ONE pass over dpr for both -- cartnet_segment_sum_chunked_fold3 -- instead of a three-row-sum kernel + the
+    //  chunked sums, 1.09 GB each at the benchmark batch: 28.68 / 28.82 vs 28.86 / 29.06 ms per step, same box)
+    RUN(cartnet_segment_sum_chunked_fold3(dpr, 6 * C, w.gedge_ptr, Bg, E, 6 * C, w.seg_tmp_e, w.dKYb, 6 * C, w.dKa, st));
     RUN(wg({w.dKa, w.dKa + C}, 2 * C, {w.QKV[l] + C, w.QKV[l] + 2 * C}, 3 * C, {g.key0_w, g.msg0_w}, 3 * C, b.E, C, C));
     RUN(wg({w.dKYb, w.dKYb + C}, 2 * C, {w.KY, w.VY}, C, {g.key0_w + C, g.msg0_w + C}, 3 * C, (long long)Bg * 3, C, C));
     RUN(dgemm(w.dKa, 2 * C, q.key0_w, 3 * C, w.use_img ? cw.B[B_K1I] : nullptr, w.dQKV[l] + C, 3 * C, b.E, C, C, nullptr, 0, st));

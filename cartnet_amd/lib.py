@@ -224,6 +224,8 @@ PROTOTYPES = {
     "cartnet_segment_chunked_rows": (C.c_int32, [C.c_int32, C.c_int32]),
     "cartnet_segment_sum_chunked": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
                                               c_f32p, C.c_int32, c_stream]),
+    "cartnet_segment_sum_chunked_fold3": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
+                                                    c_f32p, C.c_int32, c_f32p, c_stream]),
     "cartnet_bn_finalize": (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float,
                                       C.c_int32, c_f32p, c_f32p, c_i64p, c_f32p, c_groups, C.c_int32, C.c_int32,
                                       c_stream]),

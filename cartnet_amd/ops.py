@@ -505,6 +505,24 @@ def segment_sum_chunked(rows: Tensor, ptr_: Tensor, perm: Optional[Tensor], tota
                                              tmp.data_ptr(), out.data_ptr(), _ld(out), _l.stream_ptr()),
              "cartnet_segment_sum_chunked")
 
+def segment_sum_chunked_fold3(rows: Tensor, ptr_: Tensor, total: int, out: Tensor, fold_out: Tensor) -> None:
+    """cartnet_segment_sum_chunked_fold3: the chunked per-segment sums of rows [total, W] (no permutation) and, from the same
+    read, fold_out[p] = (rows[p, :W/3] + rows[p, W/3:2W/3]) + rows[p, 2W/3:]  ([total, W/3] contiguous)."""
+    _f32_2d(rows, "segment_sum_chunked_fold3 rows")
+    _f32_2d(out, "segment_sum_chunked_fold3 out")
+    _f32_2d(fold_out, "segment_sum_chunked_fold3 fold_out")
+    nseg, W = out.shape
+    if rows.shape[1] != W or rows.shape[0] < total or W % 12 or tuple(fold_out.shape) != (int(total), W // 3) or \
+            not fold_out.is_contiguous():
+        raise ValueError("segment_sum_chunked_fold3: rows [total, W], W % 12 == 0, fold_out contiguous [total, W / 3]")
+    _vec(ptr_, nseg + 1, "segment_sum_chunked_fold3 ptr", torch.int32)
+    lib = _l.load()
+    tmp = torch.empty((int(lib.cartnet_segment_chunked_rows(nseg, int(total))), W), dtype=torch.float32, device=rows.device)
+    _l.check(lib.cartnet_segment_sum_chunked_fold3(rows.data_ptr(), _ld(rows), ptr_.data_ptr(), nseg, int(total), W,
+                                                   tmp.data_ptr(), out.data_ptr(), _ld(out), fold_out.data_ptr(),
+                                                   _l.stream_ptr()), "cartnet_segment_sum_chunked_fold3")
+
+
 def bn_finalize(parts_sum, parts_sq, nparts: int, count: int, Cc: int, eps: float, momentum: float, training: bool,
                 running_mean, running_var, nbt, mean_rstd: Tensor) -> None:
     _vec(mean_rstd, 2 * Cc, "bn_finalize mean_rstd")

@@ -589,6 +589,12 @@ int cartnet_segment_sum_long(const float* rows, int32_t ld, const int32_t* ptr, 
 int32_t cartnet_segment_chunked_rows(int32_t nseg, int32_t total);
 int cartnet_segment_sum_chunked(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t nseg,
                                 int32_t total, int32_t W, float* tmp, float* out, int32_t ldo, void* stream);
+/* The same for rows that are THREE pieces of W / 3 columns side by side (iComformer's edge layer: every edge's three
+ * lattice-vector rows [E, 3, 2C] seen as [E, 6C]; perm = NULL), with the pieces' sum per row as a by-product:
+ * fold_out[p, c] = (rows[p, c] + rows[p, W/3 + c]) + rows[p, 2 W/3 + c]  ([total, W/3] contiguous) -- each row is read once for
+ * the per-crystal sums over all edges AND the per-edge sum over the lattice vectors (comformer_conv.py:160-193 backward). */
+int cartnet_segment_sum_chunked_fold3(const float* rows, int32_t ld, const int32_t* ptr, int32_t nseg, int32_t total, int32_t W,
+                                      float* tmp, float* out, int32_t ldo, float* fold_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Node update (models/cartnet.py:269 norm2, :223 SiLU + residual):  x_out = silu(bn(aggr)) + x_in.

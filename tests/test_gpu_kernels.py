@@ -704,6 +704,24 @@ def test_segment_sum_chunked_equals_the_long_form_and_torch(ops, total, nseg, W,
     assert int(lib.cartnet_segment_chunked_rows(nseg, total)) == (total + 31) // 32 + nseg
 
 
+@pytest.mark.parametrize("total,nseg,W", [(1, 1, 12), (31, 3, 768), (32, 1, 1536), (1000, 7, 516), (50000, 64, 1536), (97, 40, 24)])
+def test_segment_sum_chunked_fold3_is_both_passes_in_one(ops, total, nseg, W):
+    """Round 5 (iComformer's edge layer backward): the per-segment sums of cartnet_segment_sum_chunked AND every row's sum
+    over its three pieces from ONE read -- bitwise the chunked sums, bitwise (a + b) + c for the fold."""
+    g = torch.Generator().manual_seed(3 * total + nseg)
+    rows = rnd(total, W, seed=total + 1)
+    cuts = torch.sort(torch.randint(0, total + 1, (nseg - 1,), generator=g)).values if nseg > 1 else torch.zeros(0, dtype=torch.int64)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), cuts, torch.tensor([total])]).int().to(dev())
+    a = torch.full((nseg, W), float("nan"), device=dev())
+    b = torch.full((nseg, W), float("nan"), device=dev())
+    fold = torch.full((total, W // 3), float("nan"), device=dev())
+    ops.segment_sum_chunked_fold3(rows, ptr, total, a, fold)
+    ops.segment_sum_chunked(rows, ptr, None, total, b)
+    assert torch.equal(a, b)
+    q = W // 3
+    assert torch.equal(fold, (rows[:, :q] + rows[:, q:2 * q]) + rows[:, 2 * q:])
+
+
 @pytest.mark.parametrize("H", [8, 32, 128])
 def test_cholesky_head_fwd_bwd(ops, H):
     from oracle import cartnet_ref as orc
