@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void cn_segment_sum_pair_kernel(const float* _
                                                                   const int* __restrict__ colptr,
                                                                   const int* __restrict__ perm, int N, int W,
                                                                   float* __restrict__ out_t, float* __restrict__ out_s,
-                                                                  int ldo) {
+                                                                  int ldo, int ochunk) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int chunks = (W + 255) / 256;
@@ -313,7 +313,8 @@ __global__ __launch_bounds__(256) void cn_segment_sum_pair_kernel(const float* _
     const int t = (int)(it / per_node);
     const int sub = (int)(it % per_node);
     const bool by_src = sub >= chunks;
-    const int c = (by_src ? sub - chunks : sub) * 256 + lane * 4;
+    const int chunk = by_src ? sub - chunks : sub;
+    const int c = chunk * 256 + lane * 4;
     if (c >= W) continue;
     const int* __restrict__ ptr = by_src ? colptr : rowptr;
     const int k0 = ptr[t], k1 = ptr[t + 1];
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void cn_segment_sum_pair_kernel(const float* _
       for (int u = 0; u < SEG_BATCH - 1; ++u)
         if (k + u < k1) acc += v[u];
     }
-    st4((by_src ? out_s : out_t) + (size_t)t * ldo + c, acc);
+    st4((by_src ? out_s : out_t) + (size_t)t * ldo + (size_t)chunk * ochunk + lane * 4, acc);
   }
 }
 
@@ -688,9 +689,11 @@ static int segment_sum_impl(bool half, const float* rows, int32_t ld, const int3
 
 static int segment_sum_pair_impl(bool half, const float* rows, int32_t ld, const int32_t* rowptr, const int32_t* colptr,
                                  const int32_t* perm, int32_t N, int32_t W, float* out_t, float* out_s, int32_t ldo,
-                                 void* stream) {
-  CN_CHECK(N >= 0 && W >= 4 && W % 4 == 0 && ld % 4 == 0 && ldo % 4 == 0 && ld >= W && ldo >= W,
-           "cartnet_segment_sum_pair: W=%d ld=%d ldo=%d must be multiples of 4", W, ld, ldo);
+                                 int32_t ochunk, void* stream) {
+  CN_CHECK(N >= 0 && W >= 4 && W % 4 == 0 && ld % 4 == 0 && ldo % 4 == 0 && ld >= W && ochunk >= 256 && ochunk % 4 == 0 &&
+               ldo >= ((W + 255) / 256 - 1) * ochunk + (W - (W - 1) / 256 * 256),
+           "cartnet_segment_sum_pair: W=%d ld=%d ldo=%d ochunk=%d (multiples of 4; the last chunk must end inside a row)", W, ld,
+           ldo, ochunk);
   if (N == 0) return 0;
   CN_CHECK(rows && rowptr && colptr && perm && out_t && out_s, "cartnet_segment_sum_pair: null pointer");
   long long items = 2LL * N * ((W + 255) / 256);
@@ -698,24 +701,24 @@ static int segment_sum_pair_impl(bool half, const float* rows, int32_t ld, const
   if (blocks > 65536) blocks = 65536;
   if (half)
     hipLaunchKernelGGL(cn_segment_sum_pair_kernel<true>, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       rows, ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo);
+                       rows, ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo, ochunk);
   else
     hipLaunchKernelGGL(cn_segment_sum_pair_kernel<false>, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       rows, ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo);
+                       rows, ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo, ochunk);
   CN_LAUNCH_CHECK("cartnet_segment_sum_pair");
   return 0;
 }
 
 extern "C" int cartnet_segment_sum_pair(const float* rows, int32_t ld, const int32_t* rowptr, const int32_t* colptr,
                                         const int32_t* perm, int32_t N, int32_t W, float* out_t, float* out_s, int32_t ldo,
-                                        void* stream) {
-  return segment_sum_pair_impl(false, rows, ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo, stream);
+                                        int32_t ochunk, void* stream) {
+  return segment_sum_pair_impl(false, rows, ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo, ochunk, stream);
 }
 extern "C" int cartnet_segment_sum_pair_h(const void* rows_bf16, int32_t ld, const int32_t* rowptr, const int32_t* colptr,
                                           const int32_t* perm, int32_t N, int32_t W, float* out_t, float* out_s,
-                                          int32_t ldo, void* stream) {
+                                          int32_t ldo, int32_t ochunk, void* stream) {
   return segment_sum_pair_impl(true, static_cast<const float*>(rows_bf16), ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo,
-                               stream);
+                               ochunk, stream);
 }
 
 extern "C" int cartnet_segment_sum(const float* rows, int32_t ld, const int32_t* ptr, const int32_t* perm, int32_t N,

@@ -780,10 +780,17 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     // adjacent column blocks, and the sum over them is ONE product over K = 2C on the DMA-fed kernel (b_split_folded) --
     // as two-segment products without images they ran on the general kernel, 0.2 ms each on the main stream
     float* dKP = w.dKP[l];
-    RUN(cartnet_segment_sum(dpr, 2 * C, w.rowptr, nullptr, N, C, dKP, 4 * C, st));
-    RUN(cartnet_segment_sum(dpr + C, 2 * C, w.rowptr, nullptr, N, C, dKP + 2 * C, 4 * C, st));
-    RUN(cartnet_segment_sum(dpr, 2 * C, w.colptr, w.perm, N, C, dKP + C, 4 * C, st));
-    RUN(cartnet_segment_sum(dpr + C, 2 * C, w.colptr, w.perm, N, C, dKP + 3 * C, 4 * C, st));
+    if (C == 256) {
+      // round 5: all four sums in ONE launch (cartnet_segment_sum_pair: a node's by-target and by-source sums adjacent, the
+      // second read of a crystal's rows from cache; chunk j of 256 columns = key / msg lands at column j * 2C): 28.91 / 29.01 vs
+      // 29.04 / 29.05 ms per step, same box)
+      RUN(cartnet_segment_sum_pair(dpr, 2 * C, w.rowptr, w.colptr, w.perm, N, 2 * C, dKP, dKP + C, 4 * C, 2 * C, st));
+    } else {
+      RUN(cartnet_segment_sum(dpr, 2 * C, w.rowptr, nullptr, N, C, dKP, 4 * C, st));
+      RUN(cartnet_segment_sum(dpr + C, 2 * C, w.rowptr, nullptr, N, C, dKP + 2 * C, 4 * C, st));
+      RUN(cartnet_segment_sum(dpr, 2 * C, w.colptr, w.perm, N, C, dKP + C, 4 * C, st));
+      RUN(cartnet_segment_sum(dpr + C, 2 * C, w.colptr, w.perm, N, C, dKP + 3 * C, 4 * C, st));
+    }
     const float* k = w.QKV[l] + C; const float* v = w.QKV[l] + 2 * C;
     RUN(wg({dKP, dKP + 2 * C, dKP + C, dKP + 3 * C}, 4 * C, {k, v, k, v}, 3 * C,
            {g.key0_w, g.msg0_w, g.key0_w + C, g.msg0_w + C}, 3 * C, N, C, C));

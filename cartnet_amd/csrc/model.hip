@@ -886,8 +886,8 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     // node-side halves: reduce dpre over each atom's incoming (target) and outgoing (source) edges
     auto segsums = [&](void* s_) -> int {
 #ifndef CN_NO_SEG_PAIR      /* (A/B builds: the two launches of rounds 1-4) */
-      if (!half) return cartnet_segment_sum_pair(dpre, 2 * D, w.rowptr, w.colptr, w.perm, N, 2 * D, dPn, dPn + 2 * D, 4 * D, s_);
-      return cartnet_segment_sum_pair_h(dpre, 2 * D, w.rowptr, w.colptr, w.perm, N, 2 * D, dPn, dPn + 2 * D, 4 * D, s_);
+      if (!half) return cartnet_segment_sum_pair(dpre, 2 * D, w.rowptr, w.colptr, w.perm, N, 2 * D, dPn, dPn + 2 * D, 4 * D, 256, s_);
+      return cartnet_segment_sum_pair_h(dpre, 2 * D, w.rowptr, w.colptr, w.perm, N, 2 * D, dPn, dPn + 2 * D, 4 * D, 256, s_);
 #endif
       RUN((half ? cartnet_segment_sum_h : cartnet_segment_sum_f)(dpre, 2 * D, w.rowptr, nullptr, N, 2 * D, dPn, 4 * D, s_));
       return (half ? cartnet_segment_sum_h : cartnet_segment_sum_f)(dpre, 2 * D, w.colptr, w.perm, N, 2 * D, dPn + 2 * D,

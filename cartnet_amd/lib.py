@@ -254,9 +254,9 @@ PROTOTYPES = {
     "cartnet_segment_sum_h": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int32,
                                         c_stream]),
     "cartnet_segment_sum_pair": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p,
-                                           C.c_int32, c_stream]),
+                                           C.c_int32, C.c_int32, c_stream]),
     "cartnet_segment_sum_pair_h": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, c_i32p, C.c_int32, C.c_int32, c_f32p,
-                                             c_f32p, C.c_int32, c_stream]),
+                                             c_f32p, C.c_int32, C.c_int32, c_stream]),
     "cartnet_gate_scatter_fwd_h": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, C.c_int32,
                                              C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_groups, c_stream]),
     "cartnet_gate_scatter_bwd_stats_h": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p,

@@ -673,19 +673,23 @@ def segment_sum(rows: Tensor, ptr_: Tensor, perm: Optional[Tensor], out: Tensor)
                                            out.data_ptr(), _ld(out), _l.stream_ptr()), "cartnet_segment_sum")
 
 
-def segment_sum_pair(rows: Tensor, layout: "GraphLayout", out_t: Tensor, out_s: Tensor) -> None:
+def segment_sum_pair(rows: Tensor, layout: "GraphLayout", out_t: Tensor, out_s: Tensor, ochunk: int = 256) -> None:
     """cartnet_segment_sum_pair: by-target and by-source sums of the same rows in one launch (out_t / out_s: [N, W] views
-    with one row stride, e.g. the two halves of a wider matrix)."""
+    with one row stride, e.g. the two halves of a wider matrix).  ``ochunk`` != 256: the 256-column chunk j of a sum is
+    written at column j * ochunk of its output row (out_t / out_s are then views that START at the first chunk's place and
+    are at least W wide; the caller owns the rest of the row)."""
     half = rows.dtype == torch.bfloat16
     _f32_2d(rows, "segment_sum_pair rows", half_ok=True)
     _f32_2d(out_t, "segment_sum_pair out_t")
     _f32_2d(out_s, "segment_sum_pair out_s")
     N, W = out_t.shape
-    if tuple(out_s.shape) != (N, W) or _ld(out_s) != _ld(out_t) or rows.shape != (layout.E, W) or N != layout.N:
+    W = int(rows.shape[1])
+    if out_s.shape[0] != N or _ld(out_s) != _ld(out_t) or rows.shape[0] != layout.E or N != layout.N or \
+            (ochunk == 256 and (out_t.shape[1] != W or out_s.shape[1] != W)):
         raise ValueError("segment_sum_pair: rows [E, W], out_t / out_s [N, W] with one row stride")
     fn = _l.load().cartnet_segment_sum_pair_h if half else _l.load().cartnet_segment_sum_pair
     _l.check(fn(rows.data_ptr(), _ld(rows), layout.rowptr.data_ptr(), layout.colptr.data_ptr(), layout.perm.data_ptr(), N, W,
-                out_t.data_ptr(), out_s.data_ptr(), _ld(out_t), _l.stream_ptr()), "cartnet_segment_sum_pair")
+                out_t.data_ptr(), out_s.data_ptr(), _ld(out_t), int(ochunk), _l.stream_ptr()), "cartnet_segment_sum_pair")
 
 
 def node_update_fwd(aggr, x_in, mean_rstd, gamma, beta, x_out) -> None:

@@ -570,12 +570,14 @@ int cartnet_segment_sum_h(const void* rows_bf16, int32_t ld, const int32_t* ptr,
 /* Both index_select backwards of a layer in one launch: out_t[t, :] = the by-target sum (rowptr, rows in place), out_s[t, :]
  * = the by-source sum (colptr + perm), same values and summation orders as two cartnet_segment_sum calls.  The work items
  * of a node's two sums are adjacent, so the rows of a crystal are read twice within microseconds and the second read
- * comes from cache instead of HBM. */
+ * comes from cache instead of HBM.  `ochunk`: where the 256-column chunk j of a sum lands in its output row --
+ * out[t * ldo + j * ochunk + 0..255]; 256 = the columns keep their places (CartNet: dPn = [by target | by source]); iComformer
+ * with C = 256 passes 2C and out_s = out_t + C to interleave them as [i key | j key | i msg | j msg]. */
 int cartnet_segment_sum_pair(const float* rows, int32_t ld, const int32_t* rowptr, const int32_t* colptr, const int32_t* perm,
-                             int32_t N, int32_t W, float* out_t, float* out_s, int32_t ldo, void* stream);
+                             int32_t N, int32_t W, float* out_t, float* out_s, int32_t ldo, int32_t ochunk, void* stream);
 int cartnet_segment_sum_pair_h(const void* rows_bf16, int32_t ld, const int32_t* rowptr, const int32_t* colptr,
                                const int32_t* perm, int32_t N, int32_t W, float* out_t, float* out_s, int32_t ldo,
-                               void* stream);
+                               int32_t ochunk, void* stream);
 /* Same sums for FEW, very uneven segments (atoms grouped by element): sorted positions [0,total) are cut into
  * 128-row chunks summed by independent wavefronts into tmp [total, W] (one partial row per run), then each segment
  * adds its partial rows in position order -- evenly loaded and still bitwise reproducible. */

@@ -575,6 +575,11 @@ def test_segment_sum_every_batch_remainder_is_exact(ops, W):
     both = torch.full((N, 2 * W), 7.0, device=dev())
     ops.segment_sum_pair(rows, lay, both[:, :W], both[:, W:])
     assert torch.equal(both[:, :W].cpu(), ref_t) and torch.equal(both[:, W:].cpu(), ref_s)
+    if W == 512:     # iComformer's layout: chunk j of 256 columns at column j * 512 -> [t0 | s0 | t1 | s1]
+        inter = torch.full((N, 4 * 256), 7.0, device=dev())
+        ops.segment_sum_pair(rows, lay, inter[:, :768], inter[:, 256:], ochunk=512)
+        want = torch.cat([ref_t[:, :256], ref_s[:, :256], ref_t[:, 256:], ref_s[:, 256:]], 1)
+        assert torch.equal(inter.cpu(), want)
 
 
 def test_gate_scatter_fwd_every_batch_remainder(ops):
