@@ -999,6 +999,21 @@ def softplus_update_bwd_apply(o, x, dy, mean_rstd, gamma, beta, sums, training: 
              "cartnet_softplus_update_bwd_apply")
 
 
+def coldot_bc(d: Tensor, bc: Tensor, out_a: Tensor, out_b: Tensor) -> None:
+    """out_a[c] = sum_r d[r, c] * bc[r, c], out_b[c] = sum_r d[r, c] * bc[r, C + c]  (cartnet_coldot_bc_partial + finaliser):
+    the targets' share of the gate's BatchNorm-backward sums from the per-target sums of gate_scatter_fwd(..., bc=...)."""
+    _f32_2d(d, "coldot_bc d")
+    R, Cc = d.shape
+    _edge_rows(bc, R, 2 * Cc, "coldot_bc bc")
+    _vec(out_a, Cc, "coldot_bc out_a")
+    _vec(out_b, Cc, "coldot_bc out_b")
+    npart = segment_nparts(R)
+    pa, pb = (torch.empty(npart * Cc, dtype=torch.float64, device=d.device) for _ in range(2))
+    _l.check(_l.load().cartnet_coldot_bc_partial(d.data_ptr(), _ld(d), bc.data_ptr(), R, Cc, pa.data_ptr(), pb.data_ptr(),
+                                                 _l.stream_ptr()), "cartnet_coldot_bc_partial")
+    colsum_finalize([pa, pb], npart, [out_a, out_b])
+
+
 def colsum(x: Tensor, out: Tensor) -> None:
     """out[c] = sum_r x[r, c] (fp64 partials, fixed order) for a 2-D fp32 view."""
     _f32_2d(x, "colsum x")

@@ -727,6 +727,16 @@ def test_segment_sum_chunked_fold3_is_both_passes_in_one(ops, total, nseg, W):
     assert torch.equal(fold, (rows[:, :q] + rows[:, q:2 * q]) + rows[:, 2 * q:])
 
 
+@pytest.mark.parametrize("R,Cc", [(1, 4), (777, 256), (12416, 256), (300, 320)])
+def test_coldot_bc(ops, R, Cc):
+    """cartnet_coldot_bc_partial (iComformer's conv layers: sum_t daggr[t] B[t], sum_t daggr[t] C[t]) against fp64."""
+    d, bc = rnd(R, Cc, seed=R), rnd(R, 2 * Cc, seed=R + 1)
+    a, b = torch.full((Cc,), 9.0, device=dev()), torch.full((Cc,), 9.0, device=dev())
+    ops.coldot_bc(d, bc, a, b)
+    d64, bc64 = d.double().cpu(), bc.double().cpu()
+    assert rel_err(a, (d64 * bc64[:, :Cc]).sum(0)) < 1e-6 and rel_err(b, (d64 * bc64[:, Cc:]).sum(0)) < 1e-6
+
+
 @pytest.mark.parametrize("H", [8, 32, 128])
 def test_cholesky_head_fwd_bwd(ops, H):
     from oracle import cartnet_ref as orc
