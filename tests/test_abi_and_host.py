@@ -63,6 +63,40 @@ def test_host_side_argument_validation_without_gpu():
     assert l.cartnet_node_nparts(1) == 1
 
 
+def test_gate_statistics_epilogue_is_only_accepted_where_a_kernel_carries_it():
+    """CartnetGemmArgs.gst_* (round 5): the host-side predicate cartnet_gemm_gate_stats_ok decides from shapes and
+    pointers alone (no launch), and cartnet_gemm refuses what it rejects instead of computing without the sums."""
+    from cartnet_amd import lib
+    l = lib.load()
+    a = lib.GemmArgs()
+    assert l.cartnet_gemm_gate_stats_ok(ctypes.byref(a)) == 0                    # nothing set
+    D, E = 256, 64 * 128
+    a.M, a.N, a.K = E, D, D
+    a.lda, a.ldb, a.ldc, a.ldr = 2 * D, 3 * D, D, D
+    a.ngroups, a.nsegs, a.splitk, a.b_kstrided = 1, 2, 1, 1
+    fake = 1 << 20                                                                # 16-byte aligned, never dereferenced
+    a.A[0], a.A[1], a.B[0], a.B[1], a.C[0], a.resid[0] = fake, fake + 4 * D, fake, fake, fake, fake
+    a.b_split_folded = fake
+    a.colsum[0], a.colsq[0] = fake, fake
+    a.gst_g, a.gst_ld, a.gst_mean_rstd, a.gst_gamma, a.gst_beta = fake, 2 * D, fake, fake, fake
+    assert l.cartnet_gemm_gate_stats_ok(ctypes.byref(a)) == 1                    # the dE product of a D = 256 layer, 64 row tiles
+    a.precision = 1
+    assert l.cartnet_gemm_gate_stats_ok(ctypes.byref(a)) == 0                    # bf16x3 takes the narrow tiles below 96 row tiles
+    a.M = 96 * 128
+    assert l.cartnet_gemm_gate_stats_ok(ctypes.byref(a)) == 1
+    a.precision = 2
+    assert l.cartnet_gemm_gate_stats_ok(ctypes.byref(a)) == 0                    # plain bf16: no such kernel
+    a.precision, a.M = 0, 63 * 128
+    assert l.cartnet_gemm_gate_stats_ok(ctypes.byref(a)) == 0                    # too few row tiles: the narrow general kernel
+    a.M = E
+    a.colsq[0] = None
+    assert l.cartnet_gemm_gate_stats_ok(ctypes.byref(a)) == 0                    # both sums or none
+    assert l.cartnet_gemm(ctypes.byref(a), None) != 0 and b"gst_g" in l.cartnet_last_error()
+    a.colsq[0] = fake
+    a.N = a.ldc = a.ldr = 512
+    assert l.cartnet_gemm_gate_stats_ok(ctypes.byref(a)) == 0                    # D = 512: the K-segments do not fold
+
+
 def test_weight_image_sizes_and_gemm_precision_validation_without_gpu():
     """Pure host functions of the GEMM ABI: image sizes (6 B per element for the three bf16 planes, 4 B for the swizzled
     fp32 rows; 0 for shapes without an image) and the precision range check."""

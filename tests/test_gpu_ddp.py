@@ -46,6 +46,11 @@ def test_bench_contract_with_two_ranks(tmp_path):
     assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1 and "cpu_baseline" not in d
     assert d["config"]["parallelism"] == "graph-sharded dp2"
+    # round 5: what a multi-rank line says about itself
+    assert d["ranks_seen"] == 2 and d["backend"] == "gloo"
+    assert 0 < d["rank_ms_per_step"]["min"] <= d["rank_ms_per_step"]["max"] <= d["ms_per_step"] * 1.001
+    assert d["cold"]["steps"] == 3 and d["cold"]["warmup"] == 2 and d["cold"]["ms_per_step"] > 0
+    assert d["untimed_steps_total"] == max(d["preroll_steps"], 5) + d["warmup"] + d["spinup"]
 
 
 def test_divergence_is_detected():
