@@ -222,7 +222,9 @@ def timed_pass(step, fresh, warm: int, steps: int, graphs: int, sampler_factory,
                            "share_of_step": round(d["ms"] / (1e3 * dt / steps), 3),
                            "measured": "one instrumented step after the warm-up (an event pair on every GEMM launch)",
                            "all_gemm_variants_ms_per_step": {k: round(v["ms"], 3) for k, v in sorted(variants.items())
-                                                             if v["ms"] >= 0.02}}
+                                                             if v["ms"] >= 0.02},
+                           "all_gemm_variants_frac": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak_tflops, 3)
+                                                      for k, v in sorted(variants.items()) if v["ms"] >= 0.02}}
     if tel is not None:
         out["telemetry_during"] = tel
     return out

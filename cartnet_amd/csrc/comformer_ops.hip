@@ -150,12 +150,20 @@ __global__ __launch_bounds__(256) void cn_rowmul_fwd_kernel(const float* __restr
 }
 
 // dalpha (in place) <- dkey = dalpha * q[s] * scale;  dq[s] = sum_r dalpha[r] * key[r] * scale   (fixed row order)
+// SUMS (C <= 256, one column chunk): also the fp64 column partials of dkey and of dq, one row per workgroup -- the bias
+// gradients of key_update.2 and lin_query, which were a pass over dkey (181 MB at the benchmark batch, 544 MB in the edge
+// layer) and one over dq each.
+template <bool SUMS>
 __global__ __launch_bounds__(256) void cn_rowmul_bwd_kernel(float* dalpha, int lda, const float* __restrict__ key,
                                                             int ldk, const float* __restrict__ q, int ldq,
                                                             const int* __restrict__ ptr, int S, int C, float scale,
-                                                            float* __restrict__ dq, int lddq) {
+                                                            float* __restrict__ dq, int lddq,
+                                                            double* __restrict__ parts_dkey,
+                                                            double* __restrict__ parts_dq) {
+  __shared__ double red[SUMS ? NODES_PER_BLOCK * 256 : 1];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int chunks = (C + 255) / 256;
+  f64x4 pk = {0, 0, 0, 0}, pq = {0, 0, 0, 0};
   for (long long it = (long long)blockIdx.x * NODES_PER_BLOCK + wid; it < (long long)S * chunks;
        it += (long long)gridDim.x * NODES_PER_BLOCK) {
     const int s = (int)(it / chunks);
@@ -166,9 +174,18 @@ __global__ __launch_bounds__(256) void cn_rowmul_bwd_kernel(float* dalpha, int l
     for (int r = ptr[s]; r < ptr[s + 1]; ++r) {
       const f32x4 da = ld4(dalpha + (size_t)r * lda + c);
       acc += da * ld4(key + (size_t)r * ldk + c);
-      st4(dalpha + (size_t)r * lda + c, da * qv);
+      const f32x4 dk = da * qv;
+      st4(dalpha + (size_t)r * lda + c, dk);
+      if (SUMS) cn_acc4(pk, dk);
     }
-    st4(dq + (size_t)s * lddq + c, acc * scale);
+    acc = acc * scale;
+    st4(dq + (size_t)s * lddq + c, acc);
+    if (SUMS) cn_acc4(pq, acc);
+  }
+  if (SUMS) {      // chunks == 1: a lane's columns are the same in every iteration
+    const int c = lane * 4;
+    cn_block_store_parts(pk, red, parts_dkey, C, c, c < C, wid, lane);
+    cn_block_store_parts(pq, red, parts_dq, C, c, c < C, wid, lane);
   }
 }
 
@@ -191,7 +208,7 @@ __global__ void cn_softplus_update_fwd_kernel(const float* __restrict__ o, const
 }
 
 // MODE 0: du = dy * sigmoid(u), u = x + bn(o); partial sums of du and du * ohat.
-// MODE 1: do = gamma * rstd * (du - sum_a/N - ohat * sum_b/N); dx = du (+ dx_add).
+// MODE 1: do = gamma * rstd * (du - sum_a/N - ohat * sum_b/N); dx = du (+ dx_add); with parts_a: column partials of do.
 template <int MODE>
 __global__ __launch_bounds__(256) void cn_softplus_update_bwd_kernel(
     const float* __restrict__ o, const float* __restrict__ x, const float* __restrict__ dy,
@@ -235,6 +252,7 @@ __global__ __launch_bounds__(256) void cn_softplus_update_bwd_kernel(
       }
       if (MODE == 1) {
         st4(d_o + (size_t)n * D + c, vo);
+        if (parts_a) cn_acc4(pa, vo);
         if (dx_add) vx += ld4(dx_add + (size_t)n * D + c);
         st4(dx + (size_t)n * D + c, vx);
       }
@@ -242,6 +260,8 @@ __global__ __launch_bounds__(256) void cn_softplus_update_bwd_kernel(
     if (MODE == 0) {
       cn_block_store_parts(pa, red, parts_a, D, c, active, wid, lane);
       cn_block_store_parts(pb, red, parts_b, D, c, active, wid, lane);
+    } else if (parts_a) {     // MODE 1: the column partials of d_o (the bias gradient of the Linear that produced o)
+      cn_block_store_parts(pa, red, parts_a, D, c, active, wid, lane);
     }
   }
 }
@@ -257,6 +277,31 @@ __global__ __launch_bounds__(256) void cn_colsum_partial_kernel(const float* __r
     f64x4 ps = {0, 0, 0, 0};
     for (int r = blockIdx.x * NODES_PER_BLOCK + wid; r < R; r += gridDim.x * NODES_PER_BLOCK)
       if (active) cn_acc4(ps, ld4(x + (size_t)r * ld + c));
+    cn_block_store_parts(ps, red, parts, C, c, active, wid, lane);
+  }
+}
+
+// out = a * sigmoid(b) (softplus backward, cartnet_eltwise op 1) with the fp64 column partials of out in the same pass:
+// the bias gradient of the Linear in front of the softplus, which was a second pass over `out`.
+__global__ __launch_bounds__(256) void cn_softplus_bwd_sums_kernel(const float* __restrict__ a, int lda,
+                                                                   const float* __restrict__ b, int ldb,
+                                                                   float* __restrict__ out, int ldo, int R, int C,
+                                                                   double* __restrict__ parts) {
+  __shared__ double red[NODES_PER_BLOCK * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + lane * 4;
+    const bool active = c < C;
+    f64x4 ps = {0, 0, 0, 0};
+    for (int r = blockIdx.x * NODES_PER_BLOCK + wid; r < R; r += gridDim.x * NODES_PER_BLOCK)
+      if (active) {
+        const f32x4 x = ld4(a + (size_t)r * lda + c), p = ld4(b + (size_t)r * ldb + c);
+        f32x4 y;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[q] = x[q] * (p[q] > 20.f ? 1.f : cn_sigmoid(p[q]));
+        st4(out + (size_t)r * ldo + c, y);
+        cn_acc4(ps, y);
+      }
     cn_block_store_parts(ps, red, parts, C, c, active, wid, lane);
   }
 }
@@ -363,9 +408,23 @@ extern "C" int cartnet_rowmul_bwd(float* dalpha, int32_t lda, const float* key, 
   CN_CHECK(dalpha && key && q && ptr && dq, "cartnet_rowmul_bwd: null pointer");
   long long blocks = ((long long)S * ((C + 255) / 256) + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(cn_rowmul_bwd_kernel, dim3((int)blocks), dim3(256), 0, ST(stream), dalpha, lda, key, ldk, q, ldq,
-                     ptr, S, C, scale, dq, lddq);
+  hipLaunchKernelGGL(cn_rowmul_bwd_kernel<false>, dim3((int)blocks), dim3(256), 0, ST(stream), dalpha, lda, key, ldk, q,
+                     ldq, ptr, S, C, scale, dq, lddq, (double*)nullptr, (double*)nullptr);
   CN_LAUNCH_CHECK("cartnet_rowmul_bwd");
+  return 0;
+}
+
+// The same pass, leaving the fp64 column partials of dkey and dq as well: cartnet_segment_nparts(S) rows of C each
+// (-> cartnet_colsum_finalize).  C <= 256.
+extern "C" int cartnet_rowmul_bwd_sums(float* dalpha, int32_t lda, const float* key, int32_t ldk, const float* q,
+                                       int32_t ldq, const int32_t* ptr, int32_t S, int32_t C, float scale, float* dq,
+                                       int32_t lddq, double* parts_dkey, double* parts_dq, void* stream) {
+  CN_CHECK(S >= 0 && C >= 4 && C % 4 == 0 && C <= 256 && ldk % 4 == 0 && ldq % 4 == 0 && lda % 4 == 0 && lddq % 4 == 0,
+           "cartnet_rowmul_bwd_sums: C <= 256, C and leading dimensions multiples of 4");
+  CN_CHECK(parts_dkey && parts_dq && (S == 0 || (dalpha && key && q && ptr && dq)), "cartnet_rowmul_bwd_sums: null pointer");
+  hipLaunchKernelGGL(cn_rowmul_bwd_kernel<true>, dim3(seg_parts(S)), dim3(256), 0, ST(stream), dalpha, lda, key, ldk, q,
+                     ldq, ptr, S, C, scale, dq, lddq, parts_dkey, parts_dq);
+  CN_LAUNCH_CHECK("cartnet_rowmul_bwd_sums");
   return 0;
 }
 
@@ -396,18 +455,48 @@ extern "C" int cartnet_softplus_update_bwd_stats(const float* o, const float* x,
   return 0;
 }
 
+static int softplus_update_bwd_apply(const char* who, const float* o, const float* x, const float* dy,
+                                     const float* mean_rstd, const float* gamma, const float* beta, const float* sums,
+                                     int32_t training, int32_t N, int32_t D, float* d_o, const float* dx_add, float* dx,
+                                     double* parts_do, void* stream) {
+  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "%s: D=%d must be a multiple of 4", who, D);
+  if (N == 0 && !parts_do) return 0;
+  CN_CHECK(mean_rstd && gamma && beta && sums && (N == 0 || (o && x && dy && d_o && dx)), "%s: null pointer", who);
+  const float inv = (training && N > 0) ? (float)(1.0 / (double)N) : 0.f;
+  hipLaunchKernelGGL(cn_softplus_update_bwd_kernel<1>, dim3(seg_parts(N)), dim3(256), 0, ST(stream), o, x, dy,
+                     mean_rstd, gamma, beta, sums, inv, N, D, parts_do, (double*)nullptr, d_o, dx_add, dx);
+  CN_LAUNCH_CHECK(who);
+  return 0;
+}
+
 extern "C" int cartnet_softplus_update_bwd_apply(const float* o, const float* x, const float* dy,
                                                  const float* mean_rstd, const float* gamma, const float* beta,
                                                  const float* sums, int32_t training, int32_t N, int32_t D, float* d_o,
                                                  const float* dx_add, float* dx, void* stream) {
-  CN_CHECK(N >= 0 && D >= 4 && D % 4 == 0, "cartnet_softplus_update_bwd_apply: D=%d must be a multiple of 4", D);
-  if (N == 0) return 0;
-  CN_CHECK(o && x && dy && mean_rstd && gamma && beta && sums && d_o && dx,
-           "cartnet_softplus_update_bwd_apply: null pointer");
-  const float inv = (training && N > 0) ? (float)(1.0 / (double)N) : 0.f;
-  hipLaunchKernelGGL(cn_softplus_update_bwd_kernel<1>, dim3(seg_parts(N)), dim3(256), 0, ST(stream), o, x, dy,
-                     mean_rstd, gamma, beta, sums, inv, N, D, (double*)nullptr, (double*)nullptr, d_o, dx_add, dx);
-  CN_LAUNCH_CHECK("cartnet_softplus_update_bwd_apply");
+  return softplus_update_bwd_apply("cartnet_softplus_update_bwd_apply", o, x, dy, mean_rstd, gamma, beta, sums, training, N, D,
+                                   d_o, dx_add, dx, nullptr, stream);
+}
+
+// ... leaving the fp64 column partials of d_o too (cartnet_segment_nparts(N) rows of D -> cartnet_colsum_finalize)
+extern "C" int cartnet_softplus_update_bwd_apply_sums(const float* o, const float* x, const float* dy,
+                                                      const float* mean_rstd, const float* gamma, const float* beta,
+                                                      const float* sums, int32_t training, int32_t N, int32_t D,
+                                                      float* d_o, const float* dx_add, float* dx, double* parts_do,
+                                                      void* stream) {
+  CN_CHECK(parts_do, "cartnet_softplus_update_bwd_apply_sums: null pointer");
+  return softplus_update_bwd_apply("cartnet_softplus_update_bwd_apply_sums", o, x, dy, mean_rstd, gamma, beta, sums, training,
+                                   N, D, d_o, dx_add, dx, parts_do, stream);
+}
+
+// out = a * sigmoid(b) over [R, C] views + the fp64 column partials of out (cartnet_segment_nparts(R) rows of C)
+extern "C" int cartnet_softplus_bwd_sums(const float* a, int32_t lda, const float* b, int32_t ldb, float* out, int32_t ldo,
+                                         int32_t R, int32_t C, double* parts, void* stream) {
+  CN_CHECK(R >= 0 && C >= 4 && C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldo % 4 == 0 && lda >= C && ldb >= C && ldo >= C,
+           "cartnet_softplus_bwd_sums: C and leading dimensions must be multiples of 4");
+  CN_CHECK(parts && (R == 0 || (a && b && out)), "cartnet_softplus_bwd_sums: null pointer");
+  hipLaunchKernelGGL(cn_softplus_bwd_sums_kernel, dim3(seg_parts(R)), dim3(256), 0, ST(stream), a, lda, b, ldb, out, ldo, R, C,
+                     parts);
+  CN_LAUNCH_CHECK("cartnet_softplus_bwd_sums");
   return 0;
 }
 

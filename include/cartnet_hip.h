@@ -176,6 +176,12 @@ int cartnet_rowmul_fwd(const float* key, int32_t ldk, const float* q, int32_t ld
 /* Backward, in place: dalpha <- dkey = dalpha * q[s] * scale;  dq[s] = scale * sum_r dalpha[r] * key[r]. */
 int cartnet_rowmul_bwd(float* dalpha, int32_t lda, const float* key, int32_t ldk, const float* q, int32_t ldq,
                        const int32_t* ptr, int32_t S, int32_t C, float scale, float* dq, int32_t lddq, void* stream);
+/* The same pass, also leaving the fp64 column partials of dkey and of dq ([cartnet_segment_nparts(S)][C] each, C <= 256 ->
+ * cartnet_colsum_finalize): the bias gradients of key_update.2 and lin_query (comformer_conv.py:45-47,72), which autograd
+ * takes as column sums of those two tensors -- here without a pass of their own. */
+int cartnet_rowmul_bwd_sums(float* dalpha, int32_t lda, const float* key, int32_t ldk, const float* q, int32_t ldq,
+                            const int32_t* ptr, int32_t S, int32_t C, float scale, float* dq, int32_t lddq,
+                            double* parts_dkey, double* parts_dq, void* stream);
 /* y = softplus(x + bn(o)) (comformer_conv.py:88,193) and its backward in the two-pass BatchNorm form:
  * stats: du = dy * sigmoid(x + bn(o)); partial sums of du and du*ohat -> parts [cartnet_segment_nparts(N)][D];
  * apply: d_o = gamma*rstd*(du - sum_a/N - ohat*sum_b/N) (mean terms dropped when training == 0), dx = du (+ dx_add). */
@@ -187,6 +193,17 @@ int cartnet_softplus_update_bwd_stats(const float* o, const float* x, const floa
 int cartnet_softplus_update_bwd_apply(const float* o, const float* x, const float* dy, const float* mean_rstd,
                                       const float* gamma, const float* beta, const float* sums, int32_t training,
                                       int32_t N, int32_t D, float* d_o, const float* dx_add, float* dx, void* stream);
+/* apply + the fp64 column partials of d_o ([cartnet_segment_nparts(N)][D]): the bias gradient of lin_concate
+ * (comformer_conv.py:87,190), whose output gradient d_o is. */
+int cartnet_softplus_update_bwd_apply_sums(const float* o, const float* x, const float* dy, const float* mean_rstd,
+                                           const float* gamma, const float* beta, const float* sums, int32_t training,
+                                           int32_t N, int32_t D, float* d_o, const float* dx_add, float* dx,
+                                           double* parts_do, void* stream);
+/* out = a * sigmoid(b) over [R, C] views (cartnet_eltwise op 1: the softplus of the RBF branches backward,
+ * comformer.py:93-105) + the fp64 column partials of out ([cartnet_segment_nparts(R)][C]): the bias gradient of the
+ * Linear in front of the softplus. */
+int cartnet_softplus_bwd_sums(const float* a, int32_t lda, const float* b, int32_t ldb, float* out, int32_t ldo,
+                              int32_t R, int32_t C, double* parts, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * eComformer's equivariant update (models/comformer_conv.py:197-280: ComformerConvEqui = two TensorProductConvLayer
