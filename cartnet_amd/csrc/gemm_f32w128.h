@@ -179,6 +179,7 @@ __global__ __launch_bounds__(NTHREADS, 6) void cn_gemm_f32nn128_kernel(const Car
       case 96: CN_EPIW(96); break;
       case 2: CN_EPIW(2); break;
       case 4: CN_EPIW(4); break;
+      case 8: CN_EPIW(8); break;      // column sums only (iComformer: bias gradients of lin_key / lin_value)
       case 12: CN_EPIW(12); break;
       case 14: CN_EPIW(14); break;
       default: CN_EPIW(-1); break;

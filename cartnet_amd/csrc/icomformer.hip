@@ -614,9 +614,10 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
   };
   // dX (+ resid) = dY W with W [K = out, N = in] (leading dimension ldw) and its backward image if there is one
   auto dgemm = [&](const float* dY, int ldy, const float* W_, int ldw, const char* img, float* dX, int ldx, long long rows,
-                   int Kout, int Nin, const float* resid, int ldr, void* s_) -> int {
+                   int Kout, int Nin, const float* resid, int ldr, void* s_, double* colparts = nullptr) -> int {
     CartnetGemmArgs a = gargs(prec, (int)rows, Nin, Kout, ldy, ldw, ldx);
     a.b_kstrided = 1; a.A[0] = dY; a.B[0] = W_; a.C[0] = dX; a.resid[0] = resid; a.ldr = ldr;
+    a.colsum[0] = colparts;                                   // [tiles_m(rows)][Nin] partial column sums of dX
     if (img && rows >= 2048) a.b_split[0] = img;
     return cartnet_gemm(&a, s_);
   };
@@ -635,15 +636,31 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
   RUN(dgemm(w.dhid, H, P.head0_w, C, (w.use_img && H % 16 == 0) ? w.head0B : nullptr, w.dx_head, C, N, H, C, nullptr, 0, st));
 
   // backward of y = softplus(x_in + bn(o)): d_o[l], dres[l]; the BatchNorm affine gradients are the two column sums
+  // (round 5: the bias gradients that are column sums of a tensor an element-wise pass of this file writes come out of
+  //  that pass -- d_o here, dkey / dq in cartnet_rowmul_bwd_sums, the RBF branches' dpre -- and those of a tensor a GEMM
+  //  writes out of its epilogue; they were 34 cartnet_colsum_partial passes per step, 1.5 ms of the main stream's work)
+#ifdef CN_ICF_NO_BIAS_FUSE
+  const bool bias_fuse = false;
+#else
+  const bool bias_fuse = C <= 256;
+#endif
   auto softplus_bwd = [&](int l, const CartnetIcfConv& q, const CartnetIcfConv& g, const float* dy, int rows,
-                          const float* x_in) -> int {
+                          const float* x_in, float* concate_b) -> int {
     RUN(cartnet_softplus_update_bwd_stats(w.o[l], x_in, dy, w.mr2[l], q.bn_w, q.bn_b, rows, C, w.pa, w.pb, st));
     double* parts[2] = {w.pa, w.pb};
     float* outs[2] = {w.sums2[l], w.sums2[l] + C};
     float* gr[2] = {g.bn_b, g.bn_w};
     RUN(cartnet_colsum_finalize2(parts, outs, gr, 2, cartnet_segment_nparts(rows), C, st));
-    return cartnet_softplus_update_bwd_apply(w.o[l], x_in, dy, w.mr2[l], q.bn_w, q.bn_b, w.sums2[l], training, rows, C,
-                                             w.d_o[l], nullptr, w.dres[l], st);
+    if (!bias_fuse) {
+      RUN(cartnet_softplus_update_bwd_apply(w.o[l], x_in, dy, w.mr2[l], q.bn_w, q.bn_b, w.sums2[l], training, rows, C,
+                                            w.d_o[l], nullptr, w.dres[l], st));
+      return colsum(w.d_o[l], C, rows, C, w.pa, concate_b, st);
+    }
+    RUN(cartnet_softplus_update_bwd_apply_sums(w.o[l], x_in, dy, w.mr2[l], q.bn_w, q.bn_b, w.sums2[l], training, rows, C,
+                                               w.d_o[l], nullptr, w.dres[l], w.pa, st));
+    double* bp[1] = {w.pa};
+    float* bo[1] = {concate_b};
+    return cartnet_colsum_finalize(bp, bo, 1, cartnet_segment_nparts(rows), C, st);
   };
 
   // backward of the attention block: consumes gs[l]; leaves dpr[l] (gradient at the first Linears' pre-activation,
@@ -674,8 +691,16 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
       RUN(cartnet_colsum_finalize(parts, outs, 1, t.gparts, C, st));
     }
     const float scale = 1.0f / sqrtf((float)C);
-    RUN(cartnet_rowmul_bwd(gs, 2 * C, w.keyb[l], 2 * C, t.q, t.ldq, t.segptr, t.S, C, scale, dq_out, 3 * C, st));  // gs = [dkey | dmsg]
-    RUN(colsum(gs, 2 * C, t.R, C, w.pa, g.key2_b, st));
+    if (bias_fuse) {    // gs = [dkey | dmsg]; key_update.2's and lin_query's bias gradients from the same pass
+      RUN(cartnet_rowmul_bwd_sums(gs, 2 * C, w.keyb[l], 2 * C, t.q, t.ldq, t.segptr, t.S, C, scale, dq_out, 3 * C, w.pa, w.pb, st));
+      double* parts[2] = {w.pa, w.pb};
+      float* outs[2] = {g.key2_b, g.query_b};
+      RUN(cartnet_colsum_finalize(parts, outs, 2, cartnet_segment_nparts(t.S), C, st));
+    } else {
+      RUN(cartnet_rowmul_bwd(gs, 2 * C, w.keyb[l], 2 * C, t.q, t.ldq, t.segptr, t.S, C, scale, dq_out, 3 * C, st));
+      RUN(colsum(gs, 2 * C, t.R, C, w.pa, g.key2_b, st));
+      RUN(colsum(dq_out, 3 * C, t.S, C, w.pa, g.query_b, st));
+    }
     if (w.act[l]) RUN(wg({gs, gs + C}, 2 * C, {w.act[l], w.act[l] + C}, 2 * C, {g.key2_w, g.msg2_w}, C, t.R, C, C, false));
     else RUN(wg({gs, gs + C}, 2 * C, {w.pr[l], w.pr[l] + C}, 2 * C, {g.key2_w, g.msg2_w}, C, t.R, C, C, true));
     {  // dpr = (gs W2) * silu'(pr), column sums = bias gradients of the first Linears
@@ -745,10 +770,9 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
   };
 
   // d(inp) + resid of the query / key / value Linears that share the input `inp`
+  // (lin_query's bias gradient: att_backward; lin_key's / lin_value's: the callers, from the products that write dk / dv)
   auto linear3_bwd = [&](int l, const CartnetIcfConv& q, const CartnetIcfConv& g, const float* inp, int rows, float* d_in) -> int {
     float* dQ = w.dQKV[l];
-    float* gb[3] = {g.query_b, g.key_b, g.value_b};
-    for (int j = 0; j < 3; ++j) RUN(colsum(dQ + j * C, 3 * C, rows, C, w.pa, gb[j], st));
     RUN(wg({dQ, dQ + C, dQ + 2 * C}, 3 * C, {inp, inp, inp}, C, {g.query_w, g.key_w, g.value_w}, C, rows, C, C));
     CartnetGemmArgs a = gargs(prec, rows, C, C, 3 * C, C, C);
     a.nsegs = 3; a.b_kstrided = 1;
@@ -765,8 +789,7 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     const ConvW& cw = w.cw[l];
     const float* x_in = l == 0 ? w.x0 : w.y[l - 1];
     const float* e_in = l == 0 ? w.e0 : w.y[4];
-    RUN(softplus_bwd(l, q, g, dy, N, x_in));
-    RUN(colsum(w.d_o[l], C, N, C, w.pa, g.concate_b, st));
+    RUN(softplus_bwd(l, q, g, dy, N, x_in, g.concate_b));
     RUN(wg({w.d_o[l]}, C, {w.aggr[l]}, C, {g.concate_w}, C, N, C, C));
     RUN(dgemm(w.d_o[l], C, q.concate_w, C, w.use_img ? cw.B[B_CAT] : nullptr, w.daggr[l], C, N, C, C, nullptr, 0, st));
     Att t{E, N, w.rowptr, w.tgt32, w.src32, w.KPi[l], w.KPj[l], w.QKV[l], 3 * C, (long long)b.E, w.gp_n, w.sp_n};
@@ -801,7 +824,16 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
       a.A[0] = dKP + km * 2 * C; a.A[1] = a.A[0] + C; a.B[0] = W1; a.B[1] = W1 + C;
       a.C[0] = w.dQKV[l] + (1 + km) * C;
       if (w.use_img && N >= 2048) a.b_split_folded = cw.B[km ? B_M1I : B_K1I];
+      if (bias_fuse) a.colsum[0] = km ? w.cq : w.cs;          // lin_key's / lin_value's bias gradients
       RUN(cartnet_gemm(&a, st));
+    }
+    if (bias_fuse) {
+      double* parts[2] = {w.cs, w.cq};
+      float* outs[2] = {g.key_b, g.value_b};
+      RUN(cartnet_colsum_finalize(parts, outs, 2, w.tiles_n, C, st));
+    } else {
+      RUN(colsum(w.dQKV[l] + C, 3 * C, N, C, w.pa, g.key_b, st));
+      RUN(colsum(w.dQKV[l] + 2 * C, 3 * C, N, C, w.pa, g.value_b, st));
     }
     return linear3_bwd(l, q, g, x_in, N, w.dx[l]);
   };
@@ -812,8 +844,7 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     const CartnetIcfConv& q = P.edge;
     const CartnetIcfConv& g = G.edge;
     const ConvW& cw = w.cw[l];
-    RUN(softplus_bwd(l, q, g, dy, E, w.e0));
-    RUN(colsum(w.d_o[l], C, b.E, C, w.pa, w.tmpb, st));
+    RUN(softplus_bwd(l, q, g, dy, E, w.e0, w.tmpb));
     RUN(cartnet_eltwise(3, w.tmpb, nullptr, g.concate_b, 1, C, C, 0, C, 3.0f, st));     // the bias entered three times
     RUN(wg({w.d_o[l]}, C, {w.aggr[l]}, C, {g.concate_w}, C, b.E, C, C));
     RUN(dgemm(w.d_o[l], C, q.concate_w, C, w.use_img ? cw.B[B_CAT] : nullptr, w.daggr[l], C, b.E, C, C, nullptr, 0, st));
@@ -831,8 +862,18 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     RUN(cartnet_segment_sum_chunked_fold3(dpr, 6 * C, w.gedge_ptr, Bg, E, 6 * C, w.seg_tmp_e, w.dKYb, 6 * C, w.dKa, st));
     RUN(wg({w.dKa, w.dKa + C}, 2 * C, {w.QKV[l] + C, w.QKV[l] + 2 * C}, 3 * C, {g.key0_w, g.msg0_w}, 3 * C, b.E, C, C));
     RUN(wg({w.dKYb, w.dKYb + C}, 2 * C, {w.KY, w.VY}, C, {g.key0_w + C, g.msg0_w + C}, 3 * C, (long long)Bg * 3, C, C));
-    RUN(dgemm(w.dKa, 2 * C, q.key0_w, 3 * C, w.use_img ? cw.B[B_K1I] : nullptr, w.dQKV[l] + C, 3 * C, b.E, C, C, nullptr, 0, st));
-    RUN(dgemm(w.dKa + C, 2 * C, q.msg0_w, 3 * C, w.use_img ? cw.B[B_M1I] : nullptr, w.dQKV[l] + 2 * C, 3 * C, b.E, C, C, nullptr, 0, st));
+    RUN(dgemm(w.dKa, 2 * C, q.key0_w, 3 * C, w.use_img ? cw.B[B_K1I] : nullptr, w.dQKV[l] + C, 3 * C, b.E, C, C, nullptr, 0, st,
+              bias_fuse ? w.cs : nullptr));
+    RUN(dgemm(w.dKa + C, 2 * C, q.msg0_w, 3 * C, w.use_img ? cw.B[B_M1I] : nullptr, w.dQKV[l] + 2 * C, 3 * C, b.E, C, C, nullptr, 0, st,
+              bias_fuse ? w.cq : nullptr));
+    if (bias_fuse) {
+      double* parts[2] = {w.cs, w.cq};
+      float* outs[2] = {g.key_b, g.value_b};
+      RUN(cartnet_colsum_finalize(parts, outs, 2, w.tiles_e, C, st));
+    } else {
+      RUN(colsum(w.dQKV[l] + C, 3 * C, E, C, w.pa, g.key_b, st));
+      RUN(colsum(w.dQKV[l] + 2 * C, 3 * C, E, C, w.pa, g.value_b, st));
+    }
     RUN(dgemm(w.dKYb, 2 * C, q.key0_w + C, 3 * C, nullptr, w.dKY, C, (long long)Bg * 3, C, C, nullptr, 0, st));
     RUN(dgemm(w.dKYb + C, 2 * C, q.msg0_w + C, 3 * C, nullptr, w.dVY, C, (long long)Bg * 3, C, C, nullptr, 0, st));
     // lin_key_e{i} / lin_value_e{i} on the lattice-length features ([Bg, 3C] views)
@@ -870,9 +911,16 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
   // ---- RBF branches: out = softplus(pre), pre = rbf W^T + b; rbf.1 is shared by the distance and the lattice-length
   //      features, so its gradients add up
   auto rbf_bwd = [&](const float* r, const float* pre, const float* dout, long long n, float* dpre, float* gw, float* gb) -> int {
-    RUN(cartnet_eltwise(1, dout, pre, dpre, n, C, C, C, C, 1.0f, st));
+    if (!bias_fuse) {
+      RUN(cartnet_eltwise(1, dout, pre, dpre, n, C, C, C, C, 1.0f, st));
+      RUN(wg({dpre}, C, {r}, C, {gw}, C, n, C, C));
+      return colsum(dpre, C, n, C, w.pa, gb, st);
+    }
+    RUN(cartnet_softplus_bwd_sums(dout, C, pre, C, dpre, C, (int)n, C, w.pa, st));
     RUN(wg({dpre}, C, {r}, C, {gw}, C, n, C, C));
-    return colsum(dpre, C, n, C, w.pa, gb, st);
+    double* parts[1] = {w.pa};
+    float* outs[1] = {gb};
+    return cartnet_colsum_finalize(parts, outs, 1, cartnet_segment_nparts((int)n), C, st);
   };
   RUN(rbf_bwd(w.r_e, w.pre_e, w.de[0], b.E, w.dpre_e, w.gw1, w.gb1));
   RUN(rbf_bwd(w.r_nl, w.pre_nl, w.dNL3, (long long)Bg * 3, w.dpre_nl, w.gw2, w.gb2));

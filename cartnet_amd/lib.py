@@ -290,12 +290,19 @@ PROTOTYPES = {
                                      c_f32p, C.c_int32, c_f32p, c_f32p, c_stream]),
     "cartnet_rowmul_bwd": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_i32p, C.c_int32,
                                      C.c_int32, C.c_float, c_f32p, C.c_int32, c_stream]),
+    "cartnet_rowmul_bwd_sums": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_i32p, C.c_int32,
+                                          C.c_int32, C.c_float, c_f32p, C.c_int32, c_f32p, c_f32p, c_stream]),
     "cartnet_softplus_update_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p,
                                               c_stream]),
     "cartnet_softplus_update_bwd_stats": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32,
                                                     C.c_int32, c_f32p, c_f32p, c_stream]),
     "cartnet_softplus_update_bwd_apply": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32,
                                                     C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_stream]),
+    "cartnet_softplus_update_bwd_apply_sums": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                                         C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
+                                                         c_stream]),
+    "cartnet_softplus_bwd_sums": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32,
+                                            c_f32p, c_stream]),
     "cartnet_colsum_partial": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_stream]),
     "cartnet_coldot_bc_partial": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_stream]),
     "cartnet_radius_graph_count": (C.c_int, [c_f32p, c_f32p, c_i64p, c_i64p, C.c_int32, C.c_int32, C.c_float, c_i32p,

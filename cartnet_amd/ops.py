@@ -936,7 +936,10 @@ def rowmul_fwd(key: Tensor, q: Tensor, ptr_: Tensor, scale: float, alpha: Tensor
                                           parts_sq.data_ptr(), _l.stream_ptr()), "cartnet_rowmul_fwd")
 
 
-def rowmul_bwd(dalpha: Tensor, key: Tensor, q: Tensor, ptr_: Tensor, scale: float, dq: Tensor) -> None:
+def rowmul_bwd(dalpha: Tensor, key: Tensor, q: Tensor, ptr_: Tensor, scale: float, dq: Tensor,
+               sum_dkey: Optional[Tensor] = None, sum_dq: Optional[Tensor] = None) -> None:
+    """dalpha <- dkey = dalpha * q[s] * scale in place, dq[s] = scale * sum_r dalpha[r] * key[r]; with ``sum_dkey`` /
+    ``sum_dq`` ([C] each, C <= 256) also the column sums of dkey and dq from the same pass (cartnet_rowmul_bwd_sums)."""
     _f32_2d(dalpha, "rowmul_bwd dalpha")
     _f32_2d(key, "rowmul_bwd key")
     _f32_2d(q, "rowmul_bwd q")
@@ -946,6 +949,19 @@ def rowmul_bwd(dalpha: Tensor, key: Tensor, q: Tensor, ptr_: Tensor, scale: floa
     if tuple(dalpha.shape) != (R, Cc) or tuple(dq.shape) != (S, Cc) or q.shape[1] != Cc:
         raise ValueError("rowmul_bwd: shape mismatch")
     _vec(ptr_, S + 1, "rowmul_bwd ptr", torch.int32)
+    if (sum_dkey is None) != (sum_dq is None):
+        raise ValueError("rowmul_bwd: sum_dkey and sum_dq come together")
+    if sum_dkey is not None:
+        _vec(sum_dkey, Cc, "rowmul_bwd sum_dkey")
+        _vec(sum_dq, Cc, "rowmul_bwd sum_dq")
+        npart = segment_nparts(S)
+        pk, pq = (torch.empty(npart * Cc, dtype=torch.float64, device=key.device) for _ in range(2))
+        _l.check(_l.load().cartnet_rowmul_bwd_sums(dalpha.data_ptr(), _ld(dalpha), key.data_ptr(), _ld(key), q.data_ptr(),
+                                                   _ld(q), ptr_.data_ptr(), S, Cc, float(scale), dq.data_ptr(), _ld(dq),
+                                                   pk.data_ptr(), pq.data_ptr(), _l.stream_ptr()),
+                 "cartnet_rowmul_bwd_sums")
+        colsum_finalize([pk, pq], npart, [sum_dkey, sum_dq])
+        return
     _l.check(_l.load().cartnet_rowmul_bwd(dalpha.data_ptr(), _ld(dalpha), key.data_ptr(), _ld(key), q.data_ptr(), _ld(q),
                                           ptr_.data_ptr(), S, Cc, float(scale), dq.data_ptr(), _ld(dq),
                                           _l.stream_ptr()), "cartnet_rowmul_bwd")
@@ -981,7 +997,9 @@ def softplus_update_bwd_stats(o, x, dy, mean_rstd, gamma, beta, parts_a, parts_b
              "cartnet_softplus_update_bwd_stats")
 
 
-def softplus_update_bwd_apply(o, x, dy, mean_rstd, gamma, beta, sums, training: bool, d_o, dx_add, dx) -> None:
+def softplus_update_bwd_apply(o, x, dy, mean_rstd, gamma, beta, sums, training: bool, d_o, dx_add, dx,
+                              sum_do: Optional[Tensor] = None) -> None:
+    """``sum_do`` [D]: also the column sums of d_o from the same pass (cartnet_softplus_update_bwd_apply_sums)."""
     _f32_2d(o, "softplus_update_bwd_apply o")
     N, D = o.shape
     for name, t in (("o", o), ("x", x), ("dy", dy), ("d_o", d_o), ("dx", dx)):
@@ -992,11 +1010,40 @@ def softplus_update_bwd_apply(o, x, dy, mean_rstd, gamma, beta, sums, training: 
     _vec(gamma, D, "gamma")
     _vec(beta, D, "beta")
     _vec(sums, 2 * D, "sums")
+    if sum_do is not None:
+        _vec(sum_do, D, "softplus_update_bwd_apply sum_do")
+        npart = segment_nparts(N)
+        pd = torch.empty(npart * D, dtype=torch.float64, device=o.device)
+        _l.check(_l.load().cartnet_softplus_update_bwd_apply_sums(o.data_ptr(), x.data_ptr(), dy.data_ptr(),
+                                                                  mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                                  sums.data_ptr(), int(training), N, D, d_o.data_ptr(),
+                                                                  _l.ptr(dx_add), dx.data_ptr(), pd.data_ptr(),
+                                                                  _l.stream_ptr()),
+                 "cartnet_softplus_update_bwd_apply_sums")
+        colsum_finalize([pd], npart, [sum_do])
+        return
     _l.check(_l.load().cartnet_softplus_update_bwd_apply(o.data_ptr(), x.data_ptr(), dy.data_ptr(), mean_rstd.data_ptr(),
                                                          gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(),
                                                          int(training), N, D, d_o.data_ptr(), _l.ptr(dx_add),
                                                          dx.data_ptr(), _l.stream_ptr()),
              "cartnet_softplus_update_bwd_apply")
+
+
+def softplus_bwd_sums(a: Tensor, b: Tensor, out: Tensor, sum_out: Tensor) -> None:
+    """out = a * sigmoid(b) (the backward of out = softplus(b)) and sum_out[c] = sum_r out[r, c] from the same pass
+    (cartnet_softplus_bwd_sums + finaliser): the RBF branches of iComformer, comformer.py:93-105."""
+    _f32_2d(a, "softplus_bwd_sums a")
+    R, Cc = a.shape
+    _f32_2d(b, "softplus_bwd_sums b")
+    _f32_2d(out, "softplus_bwd_sums out")
+    if tuple(b.shape) != (R, Cc) or tuple(out.shape) != (R, Cc):
+        raise ValueError("softplus_bwd_sums: shape mismatch")
+    _vec(sum_out, Cc, "softplus_bwd_sums sum_out")
+    npart = segment_nparts(R)
+    ps = torch.empty(npart * Cc, dtype=torch.float64, device=a.device)
+    _l.check(_l.load().cartnet_softplus_bwd_sums(a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), out.data_ptr(), _ld(out), R, Cc,
+                                                 ps.data_ptr(), _l.stream_ptr()), "cartnet_softplus_bwd_sums")
+    colsum_finalize([ps], npart, [sum_out])
 
 
 def coldot_bc(d: Tensor, bc: Tensor, out_a: Tensor, out_b: Tensor) -> None:

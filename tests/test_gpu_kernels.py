@@ -737,6 +737,60 @@ def test_coldot_bc(ops, R, Cc):
     assert rel_err(a, (d64 * bc64[:, :Cc]).sum(0)) < 1e-6 and rel_err(b, (d64 * bc64[:, Cc:]).sum(0)) < 1e-6
 
 
+@pytest.mark.parametrize("S,Cc,maxdeg", [(1, 4, 3), (500, 256, 30), (3000, 256, 1), (12416, 128, 40)])
+def test_rowmul_bwd_sums_is_the_plain_pass_plus_both_column_sums(ops, S, Cc, maxdeg):
+    """cartnet_rowmul_bwd_sums (iComformer: the bias gradients of key_update.2 and lin_query out of the pass that writes
+    dkey and dq): dkey / dq bitwise those of cartnet_rowmul_bwd, the sums against fp64."""
+    g = torch.Generator().manual_seed(S + Cc)
+    deg = torch.randint(0, maxdeg + 1, (S,), generator=g)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), deg.cumsum(0)]).int().to(dev())
+    R = int(deg.sum())
+    buf = rnd(max(R, 1), 2 * Cc, seed=1)[:R]
+    key, q = rnd(max(R, 1), 2 * Cc, seed=2)[:R, :Cc], rnd(S, 3 * Cc, seed=3)[:, :Cc]
+    a, b = buf.clone(), buf.clone()
+    dqa, dqb = (torch.full((S, 3 * Cc), float("nan"), device=dev())[:, :Cc] for _ in range(2))
+    sk, sq = torch.full((Cc,), 9.0, device=dev()), torch.full((Cc,), 9.0, device=dev())
+    ops.rowmul_bwd(a[:, :Cc], key, q, ptr, 0.0625, dqa)
+    ops.rowmul_bwd(b[:, :Cc], key, q, ptr, 0.0625, dqb, sum_dkey=sk, sum_dq=sq)
+    assert torch.equal(a, b) and torch.equal(dqa, dqb)
+    if R == 0:
+        assert float(sk.abs().max()) == 0.0 and float(sq.abs().max()) == 0.0 and float(dqb.abs().max()) == 0.0
+    else:
+        assert rel_err(sk, a[:, :Cc].double().cpu().sum(0)) < 1e-6
+        assert rel_err(sq, dqa.double().cpu().sum(0)) < 1e-6
+
+
+@pytest.mark.parametrize("R,Cc", [(1, 4), (777, 256), (20000, 256), (300, 320)])
+def test_softplus_bwd_sums(ops, R, Cc):
+    """cartnet_softplus_bwd_sums: out bitwise cartnet_eltwise op 1, its column sums against fp64."""
+    a, b = rnd(R, Cc, seed=R), rnd(R, Cc, seed=R + 1, scale=8.0)
+    o1, o2 = torch.empty_like(a), torch.empty_like(a)
+    s = torch.full((Cc,), 9.0, device=dev())
+    ops.eltwise(1, a, b, o1)
+    ops.softplus_bwd_sums(a, b, o2, s)
+    assert torch.equal(o1, o2)
+    assert rel_err(o1, a.double().cpu() * torch.sigmoid(b.double().cpu())) < 1e-6
+    assert rel_err(s, o1.double().cpu().sum(0)) < 1e-6
+
+
+@pytest.mark.parametrize("N,D,training", [(1, 8, True), (999, 256, True), (999, 256, False), (12416, 128, True)])
+def test_softplus_update_bwd_apply_sums(ops, N, D, training):
+    """cartnet_softplus_update_bwd_apply_sums: d_o / dx bitwise the plain apply pass; sum_do against fp64 of d_o (in
+    training mode that sum is rounding noise around zero -- BatchNorm's output does not move with a constant added to its
+    input -- so the comparison is absolute, against the scale of |d_o| summed)."""
+    o, x, dy = rnd(N, D, seed=1), rnd(N, D, seed=2), rnd(N, D, seed=3)
+    mr = torch.cat([rnd(D, seed=4, scale=0.1), rnd(D, seed=5).abs() + 0.5])
+    gam, bet, sums = rnd(D, seed=6), rnd(D, seed=7), rnd(2 * D, seed=8)
+    d1, d2, x1, x2 = (torch.empty(N, D, device=dev()) for _ in range(4))
+    sd = torch.full((D,), 9.0, device=dev())
+    ops.softplus_update_bwd_apply(o, x, dy, mr, gam, bet, sums, training, d1, None, x1)
+    ops.softplus_update_bwd_apply(o, x, dy, mr, gam, bet, sums, training, d2, None, x2, sum_do=sd)
+    assert torch.equal(d1, d2) and torch.equal(x1, x2)
+    ref = d1.double().cpu().sum(0)
+    scale = d1.double().cpu().abs().sum(0).max()
+    assert float((sd.double().cpu() - ref).abs().max()) <= 1e-6 * float(scale)
+
+
 @pytest.mark.parametrize("H", [8, 32, 128])
 def test_cholesky_head_fwd_bwd(ops, H):
     from oracle import cartnet_ref as orc
