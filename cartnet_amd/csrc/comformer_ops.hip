@@ -189,6 +189,79 @@ __global__ __launch_bounds__(256) void cn_rowmul_bwd_kernel(float* dalpha, int l
   }
 }
 
+// The attention gate's backward and the query x key product's backward in ONE pass over the rows (round 5).
+//   forward (comformer_conv.py:90-99): alpha = key * q[s] * scale, z = sigmoid(bn_att(alpha)), aggr[s] = sum_r z * msg
+//   here, per row r of segment s, with gs = [alpha | msg] in place -> [dkey | dmsg]:
+//     dbn = daggr[s] * msg * z (1 - z);  dalpha = gamma rstd (dbn - sum_a / n - ahat sum_b / n);  dmsg = daggr[s] * z
+//     dkey = dalpha * q[s] * scale;       dq[s] = scale * sum_r dalpha * key
+//   + fp64 column partials of dkey, dmsg and dq (the bias gradients of key_update.2, lin_msg_update.2 and lin_query).
+// As cartnet_gate_scatter_bwd_apply followed by cartnet_rowmul_bwd_sums it wrote dalpha, read it back and wrote dkey over
+// it: one write and one read of [R, C] per attention block (181 MB each at the benchmark batch, 544 MB in the edge layer).
+// Descending sweep: the statistics pass in front (or the products that wrote daggr) ran ascending.
+__global__ __launch_bounds__(256) void cn_att_gate_bwd_kernel(
+    float* gs, const float* __restrict__ key, int ldk, const float* __restrict__ q, int ldq,
+    const float* __restrict__ daggr, const int* __restrict__ ptr, const float* __restrict__ mean_rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums, float inv_count,
+    float scale, int S, int D, float* __restrict__ dq, int lddq, double* __restrict__ parts_dkey,
+    double* __restrict__ parts_dmsg, double* __restrict__ parts_dq) {
+  __shared__ double red[NODES_PER_BLOCK * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int ld = 2 * D;
+  const int stride = gridDim.x * NODES_PER_BLOCK, nsweeps = (S + stride - 1) / stride;
+  for (int c0 = 0; c0 < D; c0 += 256) {
+    const int c = c0 + lane * 4;
+    const bool active = c < D;
+    f32x4 mean = {0, 0, 0, 0}, rstd = {0, 0, 0, 0}, gam = {0, 0, 0, 0}, shift = {0, 0, 0, 0};
+    f32x4 m_a = {0, 0, 0, 0}, m_b = {0, 0, 0, 0};
+    if (active) {
+      mean = ld4(mean_rstd + c);
+      rstd = ld4(mean_rstd + D + c);
+      gam = ld4(gamma + c);
+      shift = ld4(beta + c);
+      m_a = ld4(sums + c) * inv_count;
+      m_b = ld4(sums + D + c) * inv_count;
+    }
+    f64x4 tk = {0, 0, 0, 0}, tm = {0, 0, 0, 0}, tq = {0, 0, 0, 0};
+    for (int j = nsweeps - 1; j >= 0; --j) {
+      const int t = blockIdx.x * NODES_PER_BLOCK + wid + j * stride;
+      if (t >= S || !active) continue;
+      const int k0 = ptr[t], k1 = ptr[t + 1];
+      const f32x4 dm = ld4(daggr + (size_t)t * D + c);
+      const f32x4 qv = ld4(q + (size_t)t * ldq + c) * scale;
+      f32x4 pk = {0, 0, 0, 0}, pm = {0, 0, 0, 0}, accq = {0, 0, 0, 0};   // fp32 over one segment's rows, fp64 across segments
+#pragma unroll 2
+      for (int k = k0; k < k1; ++k) {
+        const f32x4 a = ld4(gs + (size_t)k * ld + c);
+        const f32x4 m = ld4(gs + (size_t)k * ld + D + c);
+        const f32x4 kv = ld4(key + (size_t)k * ldk + c);
+        f32x4 dkv, dmv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float ahat = (a[i] - mean[i]) * rstd[i];
+          const float z = cn_sigmoid(ahat * gam[i] + shift[i]);
+          const float dbn = dm[i] * m[i] * z * (1.0f - z);
+          const float da = gam[i] * rstd[i] * (dbn - m_a[i] - ahat * m_b[i]);
+          dkv[i] = da * qv[i];
+          dmv[i] = dm[i] * z;
+          accq[i] += da * kv[i];
+        }
+        st4(gs + (size_t)k * ld + c, dkv);
+        st4(gs + (size_t)k * ld + D + c, dmv);
+        pk += dkv;
+        pm += dmv;
+      }
+      accq = accq * scale;
+      st4(dq + (size_t)t * lddq + c, accq);
+      cn_acc4(tk, pk);
+      cn_acc4(tm, pm);
+      cn_acc4(tq, accq);
+    }
+    cn_block_store_parts(tk, red, parts_dkey, D, c, active, wid, lane);
+    cn_block_store_parts(tm, red, parts_dmsg, D, c, active, wid, lane);
+    cn_block_store_parts(tq, red, parts_dq, D, c, active, wid, lane);
+  }
+}
+
 // y = softplus(x + bn(o))   (ComformerConv.forward, comformer_conv.py:88)
 __global__ void cn_softplus_update_fwd_kernel(const float* __restrict__ o, const float* __restrict__ x,
                                               const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
@@ -425,6 +498,23 @@ extern "C" int cartnet_rowmul_bwd_sums(float* dalpha, int32_t lda, const float* 
   hipLaunchKernelGGL(cn_rowmul_bwd_kernel<true>, dim3(seg_parts(S)), dim3(256), 0, ST(stream), dalpha, lda, key, ldk, q,
                      ldq, ptr, S, C, scale, dq, lddq, parts_dkey, parts_dq);
   CN_LAUNCH_CHECK("cartnet_rowmul_bwd_sums");
+  return 0;
+}
+
+extern "C" int cartnet_att_gate_bwd_apply(float* gs, const float* key, int32_t ldk, const float* q, int32_t ldq,
+                                          const float* daggr, const int32_t* ptr, const float* mean_rstd,
+                                          const float* gamma, const float* beta, const float* sums, int64_t count,
+                                          int32_t training, float scale, int32_t S, int32_t D, float* dq, int32_t lddq,
+                                          double* parts_dkey, double* parts_dmsg, double* parts_dq, void* stream) {
+  CN_CHECK(S >= 0 && D >= 4 && D % 4 == 0 && ldk % 4 == 0 && ldq % 4 == 0 && lddq % 4 == 0 && ldk >= D && ldq >= D && lddq >= D,
+           "cartnet_att_gate_bwd_apply: D and leading dimensions must be multiples of 4");
+  CN_CHECK(mean_rstd && gamma && beta && sums && parts_dkey && parts_dmsg && parts_dq &&
+               (S == 0 || (gs && key && q && daggr && ptr && dq)),
+           "cartnet_att_gate_bwd_apply: null pointer");
+  const float inv = (training && count > 0) ? (float)(1.0 / (double)count) : 0.f;
+  hipLaunchKernelGGL(cn_att_gate_bwd_kernel, dim3(seg_parts(S)), dim3(256), 0, ST(stream), gs, key, ldk, q, ldq, daggr, ptr,
+                     mean_rstd, gamma, beta, sums, inv, scale, S, D, dq, lddq, parts_dkey, parts_dmsg, parts_dq);
+  CN_LAUNCH_CHECK("cartnet_att_gate_bwd_apply");
   return 0;
 }
 

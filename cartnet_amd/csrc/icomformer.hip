@@ -683,23 +683,37 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
       float* gr[2] = {g.bn_att_b, g.bn_att_w};
       RUN(cartnet_colsum_finalize2(parts, outs, gr, 2, fused_sums ? cartnet_segment_nparts(t.S) : t.gparts, C, st));
     }
-    RUN(cartnet_gate_scatter_bwd_apply(gs, nullptr, daggr, nullptr, t.segptr, w.mr1[l], q.bn_att_w, q.bn_att_b, w.sums1[l],
-                                       t.count, training, t.S, C, w.pc, w.pd, nullptr, st));     // gs = [dalpha | dmsg]
-    {
-      double* parts[1] = {w.pd};
-      float* outs[1] = {g.msg2_b};
-      RUN(cartnet_colsum_finalize(parts, outs, 1, t.gparts, C, st));
-    }
     const float scale = 1.0f / sqrtf((float)C);
-    if (bias_fuse) {    // gs = [dkey | dmsg]; key_update.2's and lin_query's bias gradients from the same pass
-      RUN(cartnet_rowmul_bwd_sums(gs, 2 * C, w.keyb[l], 2 * C, t.q, t.ldq, t.segptr, t.S, C, scale, dq_out, 3 * C, w.pa, w.pb, st));
-      double* parts[2] = {w.pa, w.pb};
-      float* outs[2] = {g.key2_b, g.query_b};
-      RUN(cartnet_colsum_finalize(parts, outs, 2, cartnet_segment_nparts(t.S), C, st));
+#ifdef CN_ICF_NO_GATE_ROWMUL
+    const bool gate_rowmul = false;
+#else
+    const bool gate_rowmul = bias_fuse;
+#endif
+    if (gate_rowmul) {
+      // gate backward + query x key backward + the three bias gradients in one pass: gs = [dkey | dmsg], dq
+      RUN(cartnet_att_gate_bwd_apply(gs, w.keyb[l], 2 * C, t.q, t.ldq, daggr, t.segptr, w.mr1[l], q.bn_att_w, q.bn_att_b,
+                                     w.sums1[l], t.count, training, scale, t.S, C, dq_out, 3 * C, w.pa, w.pd, w.pb, st));
+      double* parts[3] = {w.pa, w.pd, w.pb};
+      float* outs[3] = {g.key2_b, g.msg2_b, g.query_b};
+      RUN(cartnet_colsum_finalize(parts, outs, 3, cartnet_segment_nparts(t.S), C, st));
     } else {
-      RUN(cartnet_rowmul_bwd(gs, 2 * C, w.keyb[l], 2 * C, t.q, t.ldq, t.segptr, t.S, C, scale, dq_out, 3 * C, st));
-      RUN(colsum(gs, 2 * C, t.R, C, w.pa, g.key2_b, st));
-      RUN(colsum(dq_out, 3 * C, t.S, C, w.pa, g.query_b, st));
+      RUN(cartnet_gate_scatter_bwd_apply(gs, nullptr, daggr, nullptr, t.segptr, w.mr1[l], q.bn_att_w, q.bn_att_b, w.sums1[l],
+                                         t.count, training, t.S, C, w.pc, w.pd, nullptr, st));     // gs = [dalpha | dmsg]
+      {
+        double* parts[1] = {w.pd};
+        float* outs[1] = {g.msg2_b};
+        RUN(cartnet_colsum_finalize(parts, outs, 1, t.gparts, C, st));
+      }
+      if (bias_fuse) {    // gs = [dkey | dmsg]; key_update.2's and lin_query's bias gradients from the same pass
+        RUN(cartnet_rowmul_bwd_sums(gs, 2 * C, w.keyb[l], 2 * C, t.q, t.ldq, t.segptr, t.S, C, scale, dq_out, 3 * C, w.pa, w.pb, st));
+        double* parts[2] = {w.pa, w.pb};
+        float* outs[2] = {g.key2_b, g.query_b};
+        RUN(cartnet_colsum_finalize(parts, outs, 2, cartnet_segment_nparts(t.S), C, st));
+      } else {
+        RUN(cartnet_rowmul_bwd(gs, 2 * C, w.keyb[l], 2 * C, t.q, t.ldq, t.segptr, t.S, C, scale, dq_out, 3 * C, st));
+        RUN(colsum(gs, 2 * C, t.R, C, w.pa, g.key2_b, st));
+        RUN(colsum(dq_out, 3 * C, t.S, C, w.pa, g.query_b, st));
+      }
     }
     if (w.act[l]) RUN(wg({gs, gs + C}, 2 * C, {w.act[l], w.act[l] + C}, 2 * C, {g.key2_w, g.msg2_w}, C, t.R, C, C, false));
     else RUN(wg({gs, gs + C}, 2 * C, {w.pr[l], w.pr[l] + C}, 2 * C, {g.key2_w, g.msg2_w}, C, t.R, C, C, true));

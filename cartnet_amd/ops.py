@@ -967,6 +967,37 @@ def rowmul_bwd(dalpha: Tensor, key: Tensor, q: Tensor, ptr_: Tensor, scale: floa
                                           _l.stream_ptr()), "cartnet_rowmul_bwd")
 
 
+def att_gate_bwd_apply(gs: Tensor, key: Tensor, q: Tensor, daggr: Tensor, ptr_: Tensor, mean_rstd: Tensor, gamma: Tensor,
+                       beta: Tensor, sums: Tensor, count: int, training: bool, scale: float, dq: Tensor,
+                       sum_dkey: Tensor, sum_dmsg: Tensor, sum_dq: Tensor) -> None:
+    """cartnet_att_gate_bwd_apply + finaliser: gs = [alpha | msg] -> [dkey | dmsg] in place, dq, and the column sums of
+    dkey / dmsg / dq (iComformer's attention block backward in one pass; comformer_conv.py:90-99)."""
+    _f32_2d(gs, "att_gate_bwd_apply gs")
+    _f32_2d(key, "att_gate_bwd_apply key")
+    _f32_2d(q, "att_gate_bwd_apply q")
+    _f32_2d(dq, "att_gate_bwd_apply dq")
+    R, D = key.shape
+    S = int(q.shape[0])
+    if tuple(gs.shape) != (R, 2 * D) or q.shape[1] != D or tuple(dq.shape) != (S, D):
+        raise ValueError("att_gate_bwd_apply: shape mismatch")
+    _edge_rows(daggr, S, D, "att_gate_bwd_apply daggr")
+    _vec(ptr_, S + 1, "att_gate_bwd_apply ptr", torch.int32)
+    _vec(mean_rstd, 2 * D, "mean_rstd")
+    _vec(gamma, D, "gamma")
+    _vec(beta, D, "beta")
+    _vec(sums, 2 * D, "sums")
+    for t in (sum_dkey, sum_dmsg, sum_dq):
+        _vec(t, D, "att_gate_bwd_apply sums out")
+    npart = segment_nparts(S)
+    pk, pm, pq = (torch.empty(npart * D, dtype=torch.float64, device=gs.device) for _ in range(3))
+    _l.check(_l.load().cartnet_att_gate_bwd_apply(
+        gs.data_ptr(), key.data_ptr(), _ld(key), q.data_ptr(), _ld(q), daggr.data_ptr(), ptr_.data_ptr(),
+        mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), int(count), int(training), float(scale),
+        S, D, dq.data_ptr(), _ld(dq), pk.data_ptr(), pm.data_ptr(), pq.data_ptr(), _l.stream_ptr()),
+        "cartnet_att_gate_bwd_apply")
+    colsum_finalize([pk, pm, pq], npart, [sum_dkey, sum_dmsg, sum_dq])
+
+
 def softplus_update_fwd(o, x, mean_rstd, gamma, beta, y) -> None:
     _f32_2d(o, "softplus_update_fwd o")
     N, D = o.shape

@@ -182,6 +182,15 @@ int cartnet_rowmul_bwd(float* dalpha, int32_t lda, const float* key, int32_t ldk
 int cartnet_rowmul_bwd_sums(float* dalpha, int32_t lda, const float* key, int32_t ldk, const float* q, int32_t ldq,
                             const int32_t* ptr, int32_t S, int32_t C, float scale, float* dq, int32_t lddq,
                             double* parts_dkey, double* parts_dq, void* stream);
+/* The attention gate's backward (cartnet_gate_scatter_bwd_apply with e_out = env = NULL) and cartnet_rowmul_bwd_sums in ONE
+ * pass (comformer_conv.py:90-99 backward): gs = [alpha | msg] [R, 2D] in place -> [dkey | dmsg], dq [S, D] (leading
+ * dimension lddq); sums = [sum dbn | sum dbn ahat] (the finalised BatchNorm-backward sums of bn_att), count = the rows they
+ * were taken over; fp64 column partials of dkey, dmsg and dq ([cartnet_segment_nparts(S)][D] each). */
+int cartnet_att_gate_bwd_apply(float* gs, const float* key, int32_t ldk, const float* q, int32_t ldq, const float* daggr,
+                               const int32_t* ptr, const float* mean_rstd, const float* gamma, const float* beta,
+                               const float* sums, int64_t count, int32_t training, float scale, int32_t S, int32_t D,
+                               float* dq, int32_t lddq, double* parts_dkey, double* parts_dmsg, double* parts_dq,
+                               void* stream);
 /* y = softplus(x + bn(o)) (comformer_conv.py:88,193) and its backward in the two-pass BatchNorm form:
  * stats: du = dy * sigmoid(x + bn(o)); partial sums of du and du*ohat -> parts [cartnet_segment_nparts(N)][D];
  * apply: d_o = gamma*rstd*(du - sum_a/N - ohat*sum_b/N) (mean terms dropped when training == 0), dx = du (+ dx_add). */

@@ -760,6 +760,39 @@ def test_rowmul_bwd_sums_is_the_plain_pass_plus_both_column_sums(ops, S, Cc, max
         assert rel_err(sq, dqa.double().cpu().sum(0)) < 1e-6
 
 
+@pytest.mark.parametrize("S,D,maxdeg,training", [(3, 8, 4, True), (700, 256, 30, True), (700, 256, 30, False), (5000, 320, 3, True)])
+def test_att_gate_bwd_apply_is_gate_apply_then_rowmul(ops, S, D, maxdeg, training):
+    """cartnet_att_gate_bwd_apply (iComformer, round 5) against the two passes it replaces -- cartnet_gate_scatter_bwd_apply
+    (no edge residual, no envelope) then cartnet_rowmul_bwd -- and its three column sums against fp64."""
+    from cartnet_amd.ops import GraphLayout
+    g = torch.Generator().manual_seed(S + D)
+    deg = torch.randint(0 if S > 3 else 1, maxdeg + 1, (S,), generator=g)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), deg.cumsum(0)]).int().to(dev())
+    R = int(deg.sum())
+    gs0, key, q, daggr = rnd(R, 2 * D, seed=1), rnd(R, 2 * D, seed=2)[:, :D], rnd(S, 3 * D, seed=3)[:, :D], rnd(S, D, seed=4)
+    mr = torch.cat([rnd(D, seed=5, scale=0.1), rnd(D, seed=6).abs() + 0.5])
+    gam, bet, sums = rnd(D, seed=7), rnd(D, seed=8), rnd(2 * D, seed=9)
+    scale = 1.0 / D ** 0.5
+    # reference: the two passes
+    lay = GraphLayout.__new__(GraphLayout)
+    lay.E, lay.N, lay.rowptr = R, S, ptr
+    a = gs0.clone()
+    npart = ops.gate_nparts(S)
+    pg, ps = (torch.empty(npart * D, dtype=torch.float64, device=dev()) for _ in range(2))
+    ops.gate_scatter_bwd_apply(a, None, daggr, None, lay, mr, gam, bet, sums, training, pg, ps)
+    dqa = torch.empty(S, D, device=dev())
+    ops.rowmul_bwd(a[:, :D], key, q, ptr, scale, dqa)
+    # fused
+    b = gs0.clone()
+    dqb = torch.full((S, 3 * D), float("nan"), device=dev())[:, :D]
+    sk, sm, sq = (torch.full((D,), 9.0, device=dev()) for _ in range(3))
+    ops.att_gate_bwd_apply(b, key, q, daggr, ptr, mr, gam, bet, sums, R, training, scale, dqb, sk, sm, sq)
+    assert rel_err(b, a) < 2e-6 and rel_err(dqb, dqa) < 2e-6
+    assert rel_err(sk, a[:, :D].double().cpu().sum(0)) < 1e-5
+    assert rel_err(sm, a[:, D:].double().cpu().sum(0)) < 1e-5
+    assert rel_err(sq, dqa.double().cpu().sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("R,Cc", [(1, 4), (777, 256), (20000, 256), (300, 320)])
 def test_softplus_bwd_sums(ops, R, Cc):
     """cartnet_softplus_bwd_sums: out bitwise cartnet_eltwise op 1, its column sums against fp64."""
