@@ -367,6 +367,8 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
   fl.wide = epilogue_rows_aligned(a) ? 1 : 0;
   CN_CHECK(a.precision >= 0 && a.precision <= 2, "cartnet_gemm: precision=%d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = bf16)",
            a.precision);
+  CN_CHECK(a.dact_kind == 0 || (a.dact_kind == 1 && !cn_gemm::any_half(a)),
+           "cartnet_gemm: dact_kind=%d (0 = silu', 1 = sigmoid / softplus'; 1 not with bf16 storage)", a.dact_kind);
   CN_CHECK(a.tile_policy == 0 || a.tile_policy == 1 || a.tile_policy == 128 || a.tile_policy == 256,
            "cartnet_gemm: tile_policy=%d (0 = automatic, 1 = narrow tiles for grouped N = 256 products too, 128 / 256 = force)",
            a.tile_policy);

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_kernel(const Cartne
   }
   // epilogue (shared with gemm_kernel.h)
   const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
-                   (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);
+                   (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0) |
+                   (p.dact_kind ? 256 : 0);
 #define CN_EPIW(K) epilogue_wide<F32_BN, K>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem, kind)
   switch (kind) {
     case 0: CN_EPIW(0); break;
@@ -365,7 +366,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
     return;
   }
   const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
-                   (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);
+                   (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0) |
+                   (p.dact_kind ? 256 : 0);
   epilogue_wide<F32_BN, -1>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem, kind);
 }
 

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(NTHREADS, 6) void cn_gemm_f32nn128_kernel(const Car
     CN_EPIW(128);
   } else {
     const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
-                     (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);
+                     (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0) |
+                   (p.dact_kind ? 256 : 0);
     switch (kind) {
       case 0: CN_EPIW(0); break;
       case 1: CN_EPIW(1); break;
@@ -182,6 +183,8 @@ __global__ __launch_bounds__(NTHREADS, 6) void cn_gemm_f32nn128_kernel(const Car
       case 8: CN_EPIW(8); break;      // column sums only (iComformer: bias gradients of lin_key / lin_value)
       case 12: CN_EPIW(12); break;
       case 14: CN_EPIW(14); break;
+      case 268: CN_EPIW(268); break;  // * softplus'(pre), bias gradient (+ resid: 270): iComformer's RBF branches
+      case 270: CN_EPIW(270); break;
       default: CN_EPIW(-1); break;
     }
   }

@@ -273,7 +273,7 @@ struct Shape {
 };
 
 // Epilogue flags: bit 0 gather, 1 resid, 2 dact, 3 column sums (fp32 per lane), 4 column sums + squares (fp64),
-// 5 cpre, 6 out_act.  KIND >= 0: compile-time flags (branch-free per-element code); KIND < 0: read at run time.
+// 5 cpre, 6 out_act, (7 gate statistics: wide form only,) 8 the dact factor is sigmoid (softplus') instead of silu'.  KIND >= 0: compile-time flags (branch-free per-element code); KIND < 0: read at run time.
 template <int BN, int KIND>
 __device__ __forceinline__ void epilogue(const CartnetGemmArgs& p, f32x16 (&acc)[Shape<BN>::TM][Shape<BN>::TN], int g,
                                          int row0, int col0, int tile_m, int wm, int wn, int li, int lh, int tid,
@@ -319,7 +319,10 @@ __device__ __forceinline__ void epilogue(const CartnetGemmArgs& p, f32x16 (&acc)
         float v = acc[a][b][r] + biasv[b];
         if (GATHER) v += gi[(size_t)ti * p.ldg + gcol] + gj[(size_t)sj * p.ldg + gcol];
         if (RESID) v += resid[(size_t)grow * p.ldr + gcol];
-        if (DACT) v *= fast_dsilu(dact[(size_t)grow * p.ldd + gcol]);
+        if (DACT) {
+          const float d = dact[(size_t)grow * p.ldd + gcol];
+          v *= (kind & 256) ? fast_sigmoid(d) : fast_dsilu(d);      // bit 8: dact_kind 1, softplus'
+        }
         if (SUM1) csf[b] += v;
         if (SUM2) {
           cs[b] += (double)v;
@@ -409,7 +412,9 @@ __device__ __forceinline__ void epilogue_wide_s(const CartnetGemmArgs& p, ACC& a
   // bit 7: gate statistics (CartnetGemmArgs.gst_*), compile-time kinds only -- the run-time form (KIND < 0) does not carry
   // the code, and cartnet_gemm refuses a launch with gst_g set that would not reach a kernel with the case
   constexpr bool GST = KIND >= 0 && (KIND & 128) != 0;
-  constexpr int KBASE = KIND >= 0 ? (KIND & 127) : KIND;      // the kind without the extension bit
+  constexpr int KBASE = KIND >= 0 ? (KIND & 127) : KIND;      // the kind without the extension bits
+  // bit 8: CartnetGemmArgs.dact_kind = 1, v *= sigmoid(dact) (softplus') instead of silu'(dact)
+  const bool DSP = (kind & 256) != 0;
   const int li = lane & 31, lh = lane >> 5;
   const int c4 = lane & 7, rsub = lane >> 3;
   float* C = p.C[g];
@@ -583,7 +588,7 @@ __device__ __forceinline__ void epilogue_wide_s(const CartnetGemmArgs& p, ACC& a
         if (DACT) {
           const f32x4 d = BATCH ? op[i] : ldv4(dact + (size_t)grow[i] * p.ldd + gcol);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] *= fast_dsilu(d[q]);
+          for (int q = 0; q < 4; ++q) v[q] *= DSP ? fast_sigmoid(d[q]) : fast_dsilu(d[q]);
         }
         if (SUM1) sum4[b] += v;
         if constexpr (GST) {
@@ -930,7 +935,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_kernel(const CartnetGemmA
   constexpr bool WIDE_OK = FAST && (2 * BUF >= (NTHREADS / 64) * SCR_FLOATS);
   double* red = reinterpret_cast<double*>(smem);
   const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
-                   (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);
+                   (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0) |
+                   (p.dact_kind ? 256 : 0);
   if (WIDE_OK && fl.wide) {
 #define CN_EPIW(K) epilogue_wide<BN, K>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem, kind)
     switch (kind) {

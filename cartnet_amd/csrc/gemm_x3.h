@@ -33,7 +33,8 @@ template <int KIND_RT, class ACC>
 __device__ __forceinline__ void x3_epilogue(const CartnetGemmArgs& p, ACC& acc, int g, int row0, int col0,
                                             int tile_m, int wm, int wn, int lane, int tid, float* smem) {
   const int kind = (p.gather_i[g] ? 1 : 0) | (p.resid[g] ? 2 : 0) | (p.dact[g] ? 4 : 0) |
-                   (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0);
+                   (p.colsum[g] ? (p.colsq[g] ? 16 : 8) : 0) | (p.cpre[g] ? 32 : 0) | (p.out_act ? 64 : 0) |
+                   (p.dact_kind ? 256 : 0);
 #define CN_EPIW(K) epilogue_wide<X3_BN, K>(p, acc, g, row0, col0, tile_m, wm, wn, lane, tid, smem, kind)
   switch (kind) {
     case 0: CN_EPIW(0); break;

@@ -644,6 +644,11 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
 #else
   const bool bias_fuse = C <= 256;
 #endif
+#ifdef CN_ICF_NO_RBF_FUSE
+  const bool rbf_fuse = false;
+#else
+  const bool rbf_fuse = bias_fuse;
+#endif
   auto softplus_bwd = [&](int l, const CartnetIcfConv& q, const CartnetIcfConv& g, const float* dy, int rows,
                           const float* x_in, float* concate_b) -> int {
     RUN(cartnet_softplus_update_bwd_stats(w.o[l], x_in, dy, w.mr2[l], q.bn_w, q.bn_b, rows, C, w.pa, w.pb, st));
@@ -737,8 +742,12 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
   // rows_ready[l]: d(rows) of layer l is complete on the side stream -- what the main stream waits for where it reads it
   // (a full join there also waited for the C x C gradient products queued behind it: 1.0 + 1.5 ms of the step)
   hipEvent_t rows_ready[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // sp_pre (round 5): the rows are the output of an RBF branch, rows = softplus(sp_pre), and nothing but that branch's
+  // backward reads d(rows): the product writes d(sp_pre) = d(rows) * sigmoid(sp_pre) (CartnetGemmArgs.dact_kind = 1) and the
+  // column partials of it -- the branch's bias gradient sp_bias -- so the element-wise pass and the column-sum pass over
+  // [R, C] (3E rows for the angle branch) are gone from the main stream.
   auto fold_backward = [&](int l, const CartnetIcfConv& q, const CartnetIcfConv& g, const float* rows_in, long long R,
-                           float* d_rows, const float* resid) -> int {
+                           float* d_rows, const float* resid, const float* sp_pre = nullptr, float* sp_bias = nullptr) -> int {
     const ConvW& cw = w.cw[l];
     float* dpr = w.dpr[l];
     FORK();
@@ -747,8 +756,14 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
       a.nsegs = 2; a.b_kstrided = 1;
       a.A[0] = dpr; a.A[1] = dpr + C; a.B[0] = w.Fk[l]; a.B[1] = w.Fm[l]; a.C[0] = d_rows; a.resid[0] = resid; a.ldr = C;
       if (w.use_img) a.b_split_folded = cw.B[B_E1];
+      if (sp_pre) { a.dact[0] = sp_pre; a.ldd = C; a.dact_kind = 1; a.colsum[0] = w.cs_side; }
       RUN(cartnet_gemm(&a, sw));
       rows_ready[l] = S.mark_side();
+      if (sp_pre) {
+        double* parts[1] = {w.cs_side};
+        float* outs[1] = {sp_bias};
+        RUN(cartnet_colsum_finalize(parts, outs, 1, tiles_m(R), C, sw));
+      }
     }
     {
       const float* dY[2] = {dpr, dpr + C};
@@ -811,7 +826,8 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     float* dpr = w.dpr[l];
     // lin_edge (folded into the row block): nothing on the chain of atom gradients reads de before the edge layer's
     // backward (or the end), so d(e) and the C x C gradients run on the side stream
-    RUN(fold_backward(l, q, g, e_in, b.E, w.de[l], de_acc));
+    if (l == 0 && rbf_fuse) RUN(fold_backward(l, q, g, e_in, b.E, w.dpre_e, de_acc, w.pre_e, w.gb1));   // e0 = softplus(pre_e)
+    else RUN(fold_backward(l, q, g, e_in, b.E, w.de[l], de_acc));
     // node terms: reduce dpr over incoming (target) / outgoing (source) edges
     // ... into dKP = [i key | j key | i msg | j msg] (leading dimension 4C): the two K-segments of dk (and of dv) are then
     // adjacent column blocks, and the sum over them is ONE product over K = 2C on the DMA-fed kernel (b_split_folded) --
@@ -866,7 +882,8 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     RUN(att_backward(l, q, g, t, w.daggr[l], w.dQKV[l]));
     float* dpr = w.dpr[l];
     // angle branch (lin_edge folded, no bias): only the RBF backward at the very end reads dNA
-    RUN(fold_backward(l, q, g, w.NA, 3LL * b.E, w.dNA, nullptr));
+    if (rbf_fuse) RUN(fold_backward(l, q, g, w.NA, 3LL * b.E, w.dpre_na, nullptr, w.pre_na, G.rbf_angle_b));
+    else RUN(fold_backward(l, q, g, w.NA, 3LL * b.E, w.dNA, nullptr));
     // per-edge term (sum over the three lattice vectors) and per-(crystal, lattice vector) term
     // (dpr is [3E, 2C] = [E, 3, 2C]: the per-edge term is the sum of each edge's three rows, the per-(crystal, lattice
     //  vector) term the sum over the crystal's edges of the [E, 6C] view.  Through cartnet_segment_sum -- one wave per
@@ -918,8 +935,10 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
   RUN(conv_edge_bwd(de_new));
   RUN(conv_bwd(0, dx, w.de_old));
   dx = w.dx[0];
-  WAIT_ROWS(0);                                      // de[0]
-  WAIT_ROWS(4);                                      // dNA
+  if (!rbf_fuse) {
+    WAIT_ROWS(0);                                    // de[0]
+    WAIT_ROWS(4);                                    // dNA
+  }
 #undef WAIT_ROWS
 
   // ---- RBF branches: out = softplus(pre), pre = rbf W^T + b; rbf.1 is shared by the distance and the lattice-length
@@ -936,9 +955,15 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     float* outs[1] = {gb};
     return cartnet_colsum_finalize(parts, outs, 1, cartnet_segment_nparts((int)n), C, st);
   };
-  RUN(rbf_bwd(w.r_e, w.pre_e, w.de[0], b.E, w.dpre_e, w.gw1, w.gb1));
-  RUN(rbf_bwd(w.r_nl, w.pre_nl, w.dNL3, (long long)Bg * 3, w.dpre_nl, w.gw2, w.gb2));
-  RUN(rbf_bwd(w.r_na, w.pre_na, w.dNA, 3LL * b.E, w.dpre_na, G.rbf_angle_w, G.rbf_angle_b));
+  if (rbf_fuse) {     // dpre_e / dpre_na and the two bias gradients came out of the products above (side stream)
+    RUN(wg({w.dpre_e}, C, {w.r_e}, C, {w.gw1}, C, b.E, C, C));
+    RUN(rbf_bwd(w.r_nl, w.pre_nl, w.dNL3, (long long)Bg * 3, w.dpre_nl, w.gw2, w.gb2));
+    RUN(wg({w.dpre_na}, C, {w.r_na}, C, {G.rbf_angle_w}, C, 3LL * b.E, C, C));
+  } else {
+    RUN(rbf_bwd(w.r_e, w.pre_e, w.de[0], b.E, w.dpre_e, w.gw1, w.gb1));
+    RUN(rbf_bwd(w.r_nl, w.pre_nl, w.dNL3, (long long)Bg * 3, w.dpre_nl, w.gw2, w.gb2));
+    RUN(rbf_bwd(w.r_na, w.pre_na, w.dNA, 3LL * b.E, w.dpre_na, G.rbf_angle_w, G.rbf_angle_b));
+  }
   JOIN();                                            // gw1 / gw2 come from the side stream
   RUN(cartnet_eltwise(2, w.gw1, w.gw2, G.rbf_w, C, C, C, C, C, 1.0f, st));
   RUN(cartnet_eltwise(2, w.gb1, w.gb2, G.rbf_b, 1, C, C, C, C, 1.0f, st));

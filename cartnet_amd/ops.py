@@ -78,7 +78,8 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
          a_kstrided: bool = False, b_kstrided: bool = False, a_act: bool = False, b_act: bool = False,
          out_act: bool = False, segments: bool = False, bias=None, gather_i=None, gather_j=None, tgt=None, src=None,
          resid=None, dact=None, cpre=None, colsum=None, colsq=None, splitk: int = 1, precision: int = 0,
-         b_split=None, b_split_folded=None, a_act_out=None, tile_policy: int = 0, gate_stats=None) -> None:
+         b_split=None, b_split_folded=None, a_act_out=None, tile_policy: int = 0, gate_stats=None,
+         dact_kind: int = 0) -> None:
     """C[g] = epilogue(sum_s opA(A[s]) @ opB(B[s])) on the fp32 matrix cores (see include/cartnet_hip.h).
 
     A / B / C_out: one tensor or a list.  With ``segments=False`` the lists are independent problems (groups) of
@@ -90,6 +91,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
     ``gate_stats`` = (g [M, N] (a column block of a wider matrix is fine), env [M] or None, mean_rstd [2N], gamma [N],
     beta [N]): CartnetGemmArgs.gst_* -- colsum / colsq then receive the partial sums of v w and v w ghat (see the header);
     raises unless the launch reaches the kernel that carries that epilogue.
+    ``dact_kind``: 0 = the ``dact`` factor is silu'(dact), 1 = sigmoid(dact) (softplus backward).
     """
     lib = _l.load()
     A, B, C_out = _aslist(A, 1), _aslist(B, 1), _aslist(C_out, 1)
@@ -134,6 +136,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
     args.a_act, args.b_act, args.out_act = int(a_act), int(b_act), int(out_act)
     args.precision = int(precision)
     args.tile_policy = int(tile_policy)
+    args.dact_kind = int(dact_kind)
     args.a_half, args.b_half, args.c_half = int(is_half(A, "A")), int(is_half(B, "B")), int(is_half(C_out, "C"))
     for i in range(nptr):
         args.A[i] = A[i].data_ptr()

@@ -35,7 +35,7 @@ int cartnet_abi_version(void);
 /* sizeof of every struct below, in header order (CartnetGemmArgs, CartnetShard, CartnetCollated, CartnetGemmProfile,
  * CartnetGroups, CartnetLayerParams, CartnetLayerBuffers, CartnetParams, CartnetModel, CartnetBatch,
  * CartnetGateGemmArgs, CartnetIcfConv, CartnetIcfParams, CartnetIcfModel); returns the number of structs.  A binding checks its mirrors against these when it loads the
- * library, and cartnet_abi_version() against the version it was written for (9: gst_* in CartnetGemmArgs (8 also carried seg_*: per-target sums in an epilogue, measured and removed); 7: tile_policy in CartnetGemmArgs,
+ * library, and cartnet_abi_version() against the version it was written for (10: dact_kind closes CartnetGemmArgs, the *_sums / cartnet_att_gate_bwd_apply entry points; 9: gst_* in CartnetGemmArgs (8 also carried seg_*: per-target sums in an epilogue, measured and removed); 7: tile_policy in CartnetGemmArgs,
  * aux_stream in cartnet_model_forward, CartnetGateGemmArgs in the size table; cartnet_gemm_tile_policy() is gone). */
 int cartnet_abi_struct_sizes(size_t* out, int32_t capacity);
 
@@ -56,7 +56,7 @@ int cartnet_abi_struct_sizes(size_t* out, int32_t capacity);
  *
  * Epilogue, applied in this order to v = accumulator:
  *   v += bias[g][n]; v += gather_i[g][tgt[m]*ldg + n] + gather_j[g][src[m]*ldg + n]; v += resid[g][m*ldr+n];
- *   v *= silu'(dact[g][m*ldd + n]);
+ *   v *= silu'(dact[g][m*ldd + n]);            (dact_kind = 1: v *= sigmoid(dact[g][m*ldd + n]), softplus')
  *   if colsum[g]: per-column partial sums of v (and v*v into colsq[g]) over this block's rows are written to
  *                 colsum[g][tile_m * N + n]  (tile_m in [0, ceil(M/128)); reduce with cartnet_colsum_finalize
  *                 or cartnet_bn_finalize -- deterministic, no atomics);
@@ -131,6 +131,10 @@ typedef struct CartnetGemmArgs {
                           for the node-term gather epilogue, for single-group N = 256 products and for launches with few
                           tiles).  1: grouped N = 256 products take the narrow tile too (the iComformer path: -1.8 % per
                           step; CartNet's two-group layer products lose).  128 / 256: force one kernel (A/B runs). */
+  int32_t dact_kind;   /* 0: v *= silu'(dact) (the SiLU between two Linears, models/cartnet.py:127,136).  1: v *= sigmoid(dact),
+                          the derivative of softplus (iComformer's RBF branches, models/comformer.py:93-105: the product that
+                          yields d(softplus output) writes d(pre-activation) and, with colsum, the bias gradient -- no
+                          element-wise pass, no column-sum pass).  Not with the bf16-storage flags. */
 } CartnetGemmArgs;
 
 int cartnet_gemm(const CartnetGemmArgs* args, void* stream);

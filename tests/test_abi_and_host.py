@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(cdll, name), f"{name} is declared in include/cartnet_hip.h but not exported"
     # the ctypes prototypes cover exactly the declared set
     assert sorted(lib.PROTOTYPES) == declared
-    assert lib.load().cartnet_abi_version() == 9 == lib.ABI_VERSION
+    assert lib.load().cartnet_abi_version() == 10 == lib.ABI_VERSION
 
 
 def test_ctypes_mirrors_have_the_c_struct_layouts():
@@ -44,7 +44,9 @@ def test_ctypes_mirrors_have_the_c_struct_layouts():
     # round 5: the gst_* block sits between dact_half and tile_policy (five pointers + gst_ld; tile_policy closes the struct)
     assert lib.GemmArgs.gst_g.offset == lib.GemmArgs.dact_half.offset + 4
     assert lib.GemmArgs.gst_ld.offset == lib.GemmArgs.gst_g.offset + 40
-    assert lib.GemmArgs.tile_policy.offset + 4 == ctypes.sizeof(lib.GemmArgs)                       # last field
+    # ... and dact_kind (ABI 10) closes it: gst_ld, tile_policy, dact_kind + 4 bytes of tail padding
+    assert lib.GemmArgs.dact_kind.offset == lib.GemmArgs.tile_policy.offset + 4
+    assert lib.GemmArgs.dact_kind.offset + 8 == ctypes.sizeof(lib.GemmArgs)
     assert lib.Model.grad_ready_user.offset + 8 == ctypes.sizeof(lib.Model)                          # last field
 
 

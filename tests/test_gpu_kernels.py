@@ -352,6 +352,33 @@ def test_gemm_edge_sized_rows_through_every_model_epilogue(ops, case):
         assert rel_err(Cs[g], ref[g]) < TOL, g
 
 
+@pytest.mark.parametrize("precision,M,with_resid,image", [(0, 40000, True, True), (0, 40000, False, True), (1, 40000, True, True),
+                                                          (0, 333, True, False), (0, 12416, False, True)])
+def test_gemm_softplus_backward_epilogue(ops, precision, M, with_resid, image):
+    """CartnetGemmArgs.dact_kind = 1 (ABI 10; iComformer's RBF branches): v = (sum_s X_s W_s (+ resid)) * sigmoid(pre) with the
+    bias-gradient column sums, two folded K-segments -- the form cartnet_icomformer_backward gives the 128-wide fp32 kernel
+    (compiled kinds 268 / 270), the bf16x3 kernel and the general kernel (flag read at run time)."""
+    K, N = 256, 256
+    X = rnd(M, 2 * K, seed=3)
+    Ws = [rnd(K, N, seed=20 + i, scale=0.1) for i in range(2)]
+    resid = rnd(M, N, seed=5) if with_resid else None
+    pre = rnd(M, N, seed=6, scale=6.0)
+    tiles = ops.gemm_tiles_m(M)
+    cs = torch.full((tiles * N,), float("nan"), dtype=torch.float64, device=dev())
+    C_ = torch.full((M, N), float("nan"), device=dev())
+    img = torch.cat((ops.pack_b if precision == 0 else ops.split_b)(Ws)) if image else None
+    ops.gemm([X[:, :K], X[:, K:]], Ws, C_, b_kstrided=True, segments=True, resid=resid, dact=pre, colsum=cs,
+             b_split_folded=img, precision=precision, dact_kind=1)
+    ref = X[:, :K].double() @ Ws[0].double() + X[:, K:].double() @ Ws[1].double()
+    if with_resid:
+        ref = ref + resid.double()
+    ref = ref * torch.sigmoid(pre.double())
+    assert rel_err(C_, ref) < TOL
+    assert rel_err(cs.view(tiles, N).sum(0), C_.double().sum(0)) < 1e-6
+    with pytest.raises(RuntimeError, match="dact_kind"):
+        ops.gemm([X[:, :K], X[:, K:]], Ws, C_, b_kstrided=True, segments=True, dact=pre, dact_kind=2)
+
+
 @pytest.mark.parametrize("precision", [0, 1, 2])
 def test_gemm_folded_segments_with_images(ops, precision):
     """sum_s X[:, sK:(s+1)K] W_s: K-segments that are adjacent column blocks run as one product (b_split_folded); the
