@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void cn_rowmul_fwd_kernel(const float* __restr
       const f32x4 qv = ld4(q + (size_t)s * ldq + c) * scale;
       for (int r = ptr[s]; r < ptr[s + 1]; ++r) {
         const f32x4 a = ld4(key + (size_t)r * ldk + c) * qv;
-        st4(alpha + (size_t)r * lda + c, a);
+        if (alpha) st4(alpha + (size_t)r * lda + c, a);      // NULL: statistics only (alpha is never materialised)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           ps[k] += (double)a[k];
@@ -189,6 +189,66 @@ __global__ __launch_bounds__(256) void cn_rowmul_bwd_kernel(float* dalpha, int l
   }
 }
 
+// The attention gate forward with the query x key product recomputed in place of a stored alpha (round 5):
+//   gs = [key | msg] [R, 2D];  alpha = key * q[s] * scale;  z = sigmoid(bn_att(alpha));  aggr[s] = sum_r z * msg
+//   BC: also B[s] = sum_r msg w, C[s] = sum_r msg w ahat with w = z (1 - z) (bc [S, 2D]: the backward pass's BatchNorm sums
+//   are then sums over the segments, cartnet_coldot_bc_partial).
+// cartnet_rowmul_fwd wrote alpha (R x D) and cartnet_gate_scatter_fwd read it back; here the statistics pass
+// (cartnet_rowmul_fwd with alpha = NULL) only reads, and this kernel reads the key rows where that one read alpha.
+constexpr int ATT_BATCH = 8;
+template <bool BC>
+__global__ __launch_bounds__(256) void cn_att_gate_fwd_kernel(const float* __restrict__ gs, const float* __restrict__ q, int ldq,
+                                                              const int* __restrict__ ptr,
+                                                              const float* __restrict__ mean_rstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float qscale, int S, int D,
+                                                              float* __restrict__ aggr, float* __restrict__ bc) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int ld = 2 * D;
+  const int chunks = (D + 255) / 256;
+  const long long items = (long long)S * chunks;
+  for (long long it0 = (long long)blockIdx.x * NODES_PER_BLOCK + wid; it0 < items;
+       it0 += (long long)gridDim.x * NODES_PER_BLOCK) {
+    const long long it = items - 1 - it0;      // descending: the statistics pass in front ran ascending
+    const int t = (int)(it / chunks);
+    const int c = (int)(it % chunks) * 256 + lane * 4;
+    if (c >= D) continue;
+    const f32x4 mean = ld4(mean_rstd + c), rstd = ld4(mean_rstd + D + c), gam = ld4(gamma + c), shift = ld4(beta + c);
+    const f32x4 qv = ld4(q + (size_t)t * ldq + c) * qscale;
+    const int k0 = ptr[t], k1 = ptr[t + 1];
+    f32x4 acc = {0, 0, 0, 0}, accb = {0, 0, 0, 0}, accc = {0, 0, 0, 0};
+    for (int k = k0; k < k1; k += ATT_BATCH) {
+      f32x4 kv[ATT_BATCH], mv[ATT_BATCH];
+#pragma unroll
+      for (int u = 0; u < ATT_BATCH; ++u) {
+        const int kk = min(k + u, k1 - 1);
+        kv[u] = ld4(gs + (size_t)kk * ld + c);
+        mv[u] = ld4(gs + (size_t)kk * ld + D + c);
+      }
+#pragma unroll
+      for (int u = 0; u < ATT_BATCH; ++u) {
+        if (k + u >= k1) break;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float ahat = (kv[u][i] * qv[i] - mean[i]) * rstd[i];
+          const float z = cn_sigmoid(ahat * gam[i] + shift[i]);
+          acc[i] += z * mv[u][i];
+          if (BC) {
+            const float sw = mv[u][i] * z * (1.0f - z);
+            accb[i] += sw;
+            accc[i] += sw * ahat;
+          }
+        }
+      }
+    }
+    st4(aggr + (size_t)t * D + c, acc);
+    if (BC) {
+      st4(bc + (size_t)t * ld + c, accb);
+      st4(bc + (size_t)t * ld + D + c, accc);
+    }
+  }
+}
+
 // The attention gate's backward and the query x key product's backward in ONE pass over the rows (round 5).
 //   forward (comformer_conv.py:90-99): alpha = key * q[s] * scale, z = sigmoid(bn_att(alpha)), aggr[s] = sum_r z * msg
 //   here, per row r of segment s, with gs = [alpha | msg] in place -> [dkey | dmsg]:
@@ -198,6 +258,9 @@ __global__ __launch_bounds__(256) void cn_rowmul_bwd_kernel(float* dalpha, int l
 // As cartnet_gate_scatter_bwd_apply followed by cartnet_rowmul_bwd_sums it wrote dalpha, read it back and wrote dkey over
 // it: one write and one read of [R, C] per attention block (181 MB each at the benchmark batch, 544 MB in the edge layer).
 // Descending sweep: the statistics pass in front (or the products that wrote daggr) ran ascending.
+// KEY_IN_GS: gs[:, :D] holds the key rows themselves (alpha = key * q[s] * scale is recomputed here as the forward gate
+// kernel cn_att_gate_fwd_kernel recomputed it: alpha is never written), `key` is unused.
+template <bool KEY_IN_GS>
 __global__ __launch_bounds__(256) void cn_att_gate_bwd_kernel(
     float* gs, const float* __restrict__ key, int ldk, const float* __restrict__ q, int ldq,
     const float* __restrict__ daggr, const int* __restrict__ ptr, const float* __restrict__ mean_rstd,
@@ -231,9 +294,15 @@ __global__ __launch_bounds__(256) void cn_att_gate_bwd_kernel(
       f32x4 pk = {0, 0, 0, 0}, pm = {0, 0, 0, 0}, accq = {0, 0, 0, 0};   // fp32 over one segment's rows, fp64 across segments
 #pragma unroll 2
       for (int k = k0; k < k1; ++k) {
-        const f32x4 a = ld4(gs + (size_t)k * ld + c);
+        f32x4 a = ld4(gs + (size_t)k * ld + c);
         const f32x4 m = ld4(gs + (size_t)k * ld + D + c);
-        const f32x4 kv = ld4(key + (size_t)k * ldk + c);
+        f32x4 kv;
+        if (KEY_IN_GS) {
+          kv = a;
+          a = kv * qv;
+        } else {
+          kv = ld4(key + (size_t)k * ldk + c);
+        }
         f32x4 dkv, dmv;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -465,7 +534,7 @@ extern "C" int cartnet_rowmul_fwd(const float* key, int32_t ldk, const float* q,
                                   double* parts_sq, void* stream) {
   CN_CHECK(S >= 0 && C >= 4 && C % 4 == 0 && ldk % 4 == 0 && ldq % 4 == 0 && lda % 4 == 0,
            "cartnet_rowmul_fwd: C and leading dimensions must be multiples of 4");
-  CN_CHECK(key && q && ptr && alpha && parts_sum && parts_sq, "cartnet_rowmul_fwd: null pointer");
+  CN_CHECK(key && q && ptr && parts_sum && parts_sq, "cartnet_rowmul_fwd: null pointer");
   hipLaunchKernelGGL(cn_rowmul_fwd_kernel, dim3(seg_parts(S)), dim3(256), 0, ST(stream), key, ldk, q, ldq, ptr, S, C,
                      scale, alpha, lda, parts_sum, parts_sq);
   CN_LAUNCH_CHECK("cartnet_rowmul_fwd");
@@ -501,6 +570,25 @@ extern "C" int cartnet_rowmul_bwd_sums(float* dalpha, int32_t lda, const float* 
   return 0;
 }
 
+extern "C" int cartnet_att_gate_fwd(const float* gs, const float* q, int32_t ldq, const int32_t* ptr, const float* mean_rstd,
+                                    const float* gamma, const float* beta, float scale, int32_t S, int32_t D, float* aggr,
+                                    float* bc, void* stream) {
+  CN_CHECK(S >= 0 && D >= 4 && D % 4 == 0 && ldq % 4 == 0 && ldq >= D, "cartnet_att_gate_fwd: D / ldq must be multiples of 4");
+  if (S == 0) return 0;
+  CN_CHECK(gs && q && ptr && mean_rstd && gamma && beta && aggr, "cartnet_att_gate_fwd: null pointer");
+  CN_CHECK(!bc || (reinterpret_cast<uintptr_t>(bc) & 15u) == 0, "cartnet_att_gate_fwd: bc must be 16-byte aligned");
+  long long blocks = ((long long)S * ((D + 255) / 256) + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;
+  if (blocks > 4096) blocks = 4096;
+  if (bc)
+    hipLaunchKernelGGL(cn_att_gate_fwd_kernel<true>, dim3((int)blocks), dim3(256), 0, ST(stream), gs, q, ldq, ptr, mean_rstd,
+                       gamma, beta, scale, S, D, aggr, bc);
+  else
+    hipLaunchKernelGGL(cn_att_gate_fwd_kernel<false>, dim3((int)blocks), dim3(256), 0, ST(stream), gs, q, ldq, ptr, mean_rstd,
+                       gamma, beta, scale, S, D, aggr, bc);
+  CN_LAUNCH_CHECK("cartnet_att_gate_fwd");
+  return 0;
+}
+
 extern "C" int cartnet_att_gate_bwd_apply(float* gs, const float* key, int32_t ldk, const float* q, int32_t ldq,
                                           const float* daggr, const int32_t* ptr, const float* mean_rstd,
                                           const float* gamma, const float* beta, const float* sums, int64_t count,
@@ -509,11 +597,15 @@ extern "C" int cartnet_att_gate_bwd_apply(float* gs, const float* key, int32_t l
   CN_CHECK(S >= 0 && D >= 4 && D % 4 == 0 && ldk % 4 == 0 && ldq % 4 == 0 && lddq % 4 == 0 && ldk >= D && ldq >= D && lddq >= D,
            "cartnet_att_gate_bwd_apply: D and leading dimensions must be multiples of 4");
   CN_CHECK(mean_rstd && gamma && beta && sums && parts_dkey && parts_dmsg && parts_dq &&
-               (S == 0 || (gs && key && q && daggr && ptr && dq)),
+               (S == 0 || (gs && q && daggr && ptr && dq)),
            "cartnet_att_gate_bwd_apply: null pointer");
   const float inv = (training && count > 0) ? (float)(1.0 / (double)count) : 0.f;
-  hipLaunchKernelGGL(cn_att_gate_bwd_kernel, dim3(seg_parts(S)), dim3(256), 0, ST(stream), gs, key, ldk, q, ldq, daggr, ptr,
-                     mean_rstd, gamma, beta, sums, inv, scale, S, D, dq, lddq, parts_dkey, parts_dmsg, parts_dq);
+  if (key)
+    hipLaunchKernelGGL(cn_att_gate_bwd_kernel<false>, dim3(seg_parts(S)), dim3(256), 0, ST(stream), gs, key, ldk, q, ldq, daggr,
+                       ptr, mean_rstd, gamma, beta, sums, inv, scale, S, D, dq, lddq, parts_dkey, parts_dmsg, parts_dq);
+  else
+    hipLaunchKernelGGL(cn_att_gate_bwd_kernel<true>, dim3(seg_parts(S)), dim3(256), 0, ST(stream), gs, key, ldk, q, ldq, daggr,
+                       ptr, mean_rstd, gamma, beta, sums, inv, scale, S, D, dq, lddq, parts_dkey, parts_dmsg, parts_dq);
   CN_LAUNCH_CHECK("cartnet_att_gate_bwd_apply");
   return 0;
 }

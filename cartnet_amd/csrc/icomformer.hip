@@ -76,6 +76,18 @@ struct Jobs {                // batched image / transpose requests of a step
 };
 thread_local Jobs g_jobs;
 
+// Round 5: alpha = q_i * key / sqrt(C) is never written -- the second Linear leaves the key rows in gs[:, :C], the
+// statistics pass only reads them, and the gate kernels of both directions recompute the product (cartnet_att_gate_fwd,
+// cartnet_att_gate_bwd_apply with key = NULL).  Needs the one-chunk kernels (C <= 256).
+inline bool icf_alpha_free(int C) {
+#ifdef CN_ICF_KEEP_ALPHA
+  (void)C;
+  return false;
+#else
+  return C <= 256;
+#endif
+}
+
 struct IWork {
   // graph
   int *src32, *tgt32, *rowptr, *colptr, *perm, *idx, *idx_edge, *idx_gl, *ptr3, *gedge_ptr, *zperm, *zptr, *zstatus;
@@ -140,14 +152,16 @@ IWork icarve(const CartnetIcfModel& m, int N, long long E, int Bg, int M, char* 
     w.ck[l] = c.take<float>(C); w.cm[l] = c.take<float>(C);
     w.dFk[l] = c.take<float>((size_t)C * C); w.dFm[l] = c.take<float>((size_t)C * C);
     if (!edge) { w.KPi[l] = c.take<float>(Nn * 2 * C); w.KPj[l] = c.take<float>(Nn * 2 * C); }
-    w.pr[l] = c.take<float>(R * 2 * C); w.keyb[l] = c.take<float>(R * 2 * C); w.gs[l] = c.take<float>(R * 2 * C);
+    w.pr[l] = c.take<float>(R * 2 * C); w.keyb[l] = icf_alpha_free(C) ? nullptr : c.take<float>(R * 2 * C); w.gs[l] = c.take<float>(R * 2 * C);
     // Kept activation.  Rounds 2-3 measured no gain from it on the Python-sequenced path (the cheaper weight gradient sat
     // on a stream with slack); round 4's trace of the C++ sequence shows the register-staged dY^T silu(X) kernel at 1.36 ms
     // per launch, 6.8 ms per step, on a side stream the main stream now WAITS for at its joins
     w.act[l] = (w.use_img && m.gemm_precision == 0) ? c.take<float>(R * 2 * C) : nullptr;
     // (the edge layer's segments are the edges themselves, three rows each: bc would be an [E, 2C] matrix, as many bytes
     //  as a third of the statistics pass it saves -- conv layers only)
-    w.bc[l] = edge ? nullptr : c.take<float>(S * 2 * C);
+    // per-segment sums for the backward BatchNorm sums (conv layers; with the alpha-free forward the edge layer too: its
+    // statistics pass would need alpha, and 363 MB written + 544 MB read there replace a 1.09 GB pass)
+    w.bc[l] = (edge && !icf_alpha_free(C)) ? nullptr : c.take<float>(S * 2 * C);
     w.mr1[l] = c.take<float>(2 * C); w.aggr[l] = c.take<float>(S * C); w.o[l] = c.take<float>(S * C);
     w.mr2[l] = c.take<float>(2 * C);
     w.y[l] = (l == 3) ? nullptr : c.take<float>(S * C);     // layer 3 writes the caller's x_out
@@ -357,6 +371,7 @@ struct Att {
 int att_forward(const CartnetIcfModel& m, const CartnetIcfConv& P, const CartnetIcfBn& bn_att, const ConvW& cw, const Att& t,
                 int l, const float* rows_in, IWork& w, int training, void* st) {
   const int C = m.C, prec = m.gemm_precision;
+  const bool afree = icf_alpha_free(C);
   {  // pr = rows_in F^T + c + term_i[idx_i] + term_j[idx_j]      (key | msg; F = W1[:, 2C:] We: lin_edge folded in)
     CartnetGemmArgs a = gargs(prec, t.R, C, C, C, C, 2 * C);
     a.ngroups = 2; fwd_form(a, cw, F_K1E, C, w.use_img);
@@ -373,15 +388,19 @@ int att_forward(const CartnetIcfModel& m, const CartnetIcfConv& P, const Cartnet
     a.ngroups = 2; a.a_act = 1; fwd_form(a, cw, F_K2, C, w.use_img);
     a.A[0] = w.pr[l]; a.A[1] = w.pr[l] + C;
     fwd_operand(a, 0, cw, F_K2, w.use_img); fwd_operand(a, 1, cw, F_M2, w.use_img);
-    a.C[0] = w.keyb[l]; a.C[1] = w.gs[l] + C; a.bias[0] = P.key2_b; a.bias[1] = P.msg2_b;
+    a.C[0] = afree ? w.gs[l] : w.keyb[l]; a.C[1] = w.gs[l] + C; a.bias[0] = P.key2_b; a.bias[1] = P.msg2_b;
     if (w.act[l]) { a.a_act_out[0] = w.act[l]; a.a_act_out[1] = w.act[l] + C; }
     RUN(cartnet_gemm(&a, st));
   }
   const float scale = 1.0f / sqrtf((float)C);
-  RUN(cartnet_rowmul_fwd(w.keyb[l], 2 * C, t.q, t.ldq, t.segptr, t.S, C, scale, w.gs[l], 2 * C, w.pa, w.pb, st));
+  RUN(cartnet_rowmul_fwd(afree ? w.gs[l] : w.keyb[l], 2 * C, t.q, t.ldq, t.segptr, t.S, C, scale, afree ? nullptr : w.gs[l],
+                         2 * C, w.pa, w.pb, st));
   RUN(cartnet_bn_finalize(w.pa, w.pb, t.sparts, t.count, C, m.bn_eps, m.bn_momentum, training, bn_att.mean, bn_att.var,
                           bn_att.nbt, w.mr1[l], nullptr, 1, 1, st));
-  if (training && w.bc[l])
+  if (afree)
+    RUN(cartnet_att_gate_fwd(w.gs[l], t.q, t.ldq, t.segptr, w.mr1[l], P.bn_att_w, P.bn_att_b, scale, t.S, C, w.aggr[l],
+                             w.bc[l], st));     // (in eval mode too: the sums identity does not depend on the mode)
+  else if (training && w.bc[l])
     RUN(cartnet_gate_scatter_fwd_bc(w.gs[l], nullptr, nullptr, t.segptr, w.mr1[l], P.bn_att_w, P.bn_att_b, t.S, C, nullptr,
                                     w.aggr[l], w.pc, w.pd, w.bc[l], st));
   else
@@ -676,7 +695,7 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     float* gs = w.gs[l];
     // sum(dbn), sum(dbn ghat): no edge residual here, so with the per-target sums of the forward pass (conv layers) both
     // are sums over the TARGETS -- 25 MB instead of a 363 MB pass over gs
-    const bool fused_sums = training && w.bc[l] != nullptr;
+    const bool fused_sums = w.bc[l] != nullptr && (training || icf_alpha_free(C));
     if (fused_sums)
       RUN(cartnet_coldot_bc_partial(daggr, C, w.bc[l], t.S, C, w.pa, w.pb, st));
     else
@@ -694,9 +713,10 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
 #else
     const bool gate_rowmul = bias_fuse;
 #endif
+    CN_CHECK(gate_rowmul || !icf_alpha_free(C), "cartnet_icomformer_backward: the alpha-free forward needs the fused gate backward");
     if (gate_rowmul) {
       // gate backward + query x key backward + the three bias gradients in one pass: gs = [dkey | dmsg], dq
-      RUN(cartnet_att_gate_bwd_apply(gs, w.keyb[l], 2 * C, t.q, t.ldq, daggr, t.segptr, w.mr1[l], q.bn_att_w, q.bn_att_b,
+      RUN(cartnet_att_gate_bwd_apply(gs, icf_alpha_free(C) ? nullptr : w.keyb[l], 2 * C, t.q, t.ldq, daggr, t.segptr, w.mr1[l], q.bn_att_w, q.bn_att_b,
                                      w.sums1[l], t.count, training, scale, t.S, C, dq_out, 3 * C, w.pa, w.pd, w.pb, st));
       double* parts[3] = {w.pa, w.pd, w.pb};
       float* outs[3] = {g.key2_b, g.msg2_b, g.query_b};

@@ -293,6 +293,8 @@ PROTOTYPES = {
                                      C.c_int32, C.c_float, c_f32p, C.c_int32, c_stream]),
     "cartnet_rowmul_bwd_sums": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_i32p, C.c_int32,
                                           C.c_int32, C.c_float, c_f32p, C.c_int32, c_f32p, c_f32p, c_stream]),
+    "cartnet_att_gate_fwd": (C.c_int, [c_f32p, c_f32p, C.c_int32, c_i32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_int32,
+                                       C.c_int32, c_f32p, c_f32p, c_stream]),
     "cartnet_att_gate_bwd_apply": (C.c_int, [c_f32p, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, c_i32p, c_f32p, c_f32p,
                                              c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_int32, c_f32p,
                                              C.c_int32, c_f32p, c_f32p, c_f32p, c_stream]),

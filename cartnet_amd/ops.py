@@ -921,22 +921,24 @@ def segment_nparts(S: int) -> int:
     return int(_l.load().cartnet_segment_nparts(int(S)))
 
 
-def rowmul_fwd(key: Tensor, q: Tensor, ptr_: Tensor, scale: float, alpha: Tensor, parts_sum: Tensor,
+def rowmul_fwd(key: Tensor, q: Tensor, ptr_: Tensor, scale: float, alpha: Optional[Tensor], parts_sum: Tensor,
                parts_sq: Tensor) -> None:
+    """``alpha`` None: the bn_att statistics only (alpha itself is recomputed by att_gate_fwd / att_gate_bwd_apply)."""
     _f32_2d(key, "rowmul_fwd key")
     _f32_2d(q, "rowmul_fwd q")
-    _f32_2d(alpha, "rowmul_fwd alpha")
     R, Cc = key.shape
     S = int(q.shape[0])
-    if tuple(alpha.shape) != (R, Cc) or q.shape[1] != Cc:
+    if alpha is not None:
+        _f32_2d(alpha, "rowmul_fwd alpha")
+    if (alpha is not None and tuple(alpha.shape) != (R, Cc)) or q.shape[1] != Cc:
         raise ValueError("rowmul_fwd: shape mismatch")
     _vec(ptr_, S + 1, "rowmul_fwd ptr", torch.int32)
     npart = segment_nparts(S)
     _vec(parts_sum, npart * Cc, "rowmul_fwd parts_sum", torch.float64)
     _vec(parts_sq, npart * Cc, "rowmul_fwd parts_sq", torch.float64)
     _l.check(_l.load().cartnet_rowmul_fwd(key.data_ptr(), _ld(key), q.data_ptr(), _ld(q), ptr_.data_ptr(), S, Cc,
-                                          float(scale), alpha.data_ptr(), _ld(alpha), parts_sum.data_ptr(),
-                                          parts_sq.data_ptr(), _l.stream_ptr()), "cartnet_rowmul_fwd")
+                                          float(scale), _l.ptr(alpha), _ld(alpha) if alpha is not None else Cc,
+                                          parts_sum.data_ptr(), parts_sq.data_ptr(), _l.stream_ptr()), "cartnet_rowmul_fwd")
 
 
 def rowmul_bwd(dalpha: Tensor, key: Tensor, q: Tensor, ptr_: Tensor, scale: float, dq: Tensor,
@@ -970,17 +972,43 @@ def rowmul_bwd(dalpha: Tensor, key: Tensor, q: Tensor, ptr_: Tensor, scale: floa
                                           _l.stream_ptr()), "cartnet_rowmul_bwd")
 
 
-def att_gate_bwd_apply(gs: Tensor, key: Tensor, q: Tensor, daggr: Tensor, ptr_: Tensor, mean_rstd: Tensor, gamma: Tensor,
+def att_gate_fwd(gs: Tensor, q: Tensor, ptr_: Tensor, mean_rstd: Tensor, gamma: Tensor, beta: Tensor, scale: float,
+                 aggr: Tensor, bc: Optional[Tensor] = None) -> None:
+    """cartnet_att_gate_fwd: gs = [key | msg] [R, 2D]; aggr[s] = sum_r sigmoid(bn(key q[s] scale)) msg (+ bc [S, 2D])."""
+    _f32_2d(gs, "att_gate_fwd gs")
+    _f32_2d(q, "att_gate_fwd q")
+    S, D = aggr.shape
+    if gs.shape[1] != 2 * D or tuple(q.shape) != (S, D):
+        raise ValueError("att_gate_fwd: shape mismatch")
+    _edge_rows(aggr, S, D, "att_gate_fwd aggr")
+    _vec(ptr_, S + 1, "att_gate_fwd ptr", torch.int32)
+    _vec(mean_rstd, 2 * D, "mean_rstd")
+    _vec(gamma, D, "gamma")
+    _vec(beta, D, "beta")
+    if bc is not None:
+        _edge_rows(bc, S, 2 * D, "att_gate_fwd bc")
+    if _ld(gs) != 2 * D:
+        raise ValueError("att_gate_fwd: gs must be a contiguous [R, 2D] matrix")
+    _l.check(_l.load().cartnet_att_gate_fwd(gs.data_ptr(), q.data_ptr(), _ld(q), ptr_.data_ptr(), mean_rstd.data_ptr(),
+                                            gamma.data_ptr(), beta.data_ptr(), float(scale), S, D, aggr.data_ptr(),
+                                            _l.ptr(bc), _l.stream_ptr()), "cartnet_att_gate_fwd")
+
+
+def att_gate_bwd_apply(gs: Tensor, key: Optional[Tensor], q: Tensor, daggr: Tensor, ptr_: Tensor, mean_rstd: Tensor, gamma: Tensor,
                        beta: Tensor, sums: Tensor, count: int, training: bool, scale: float, dq: Tensor,
                        sum_dkey: Tensor, sum_dmsg: Tensor, sum_dq: Tensor) -> None:
     """cartnet_att_gate_bwd_apply + finaliser: gs = [alpha | msg] -> [dkey | dmsg] in place, dq, and the column sums of
-    dkey / dmsg / dq (iComformer's attention block backward in one pass; comformer_conv.py:90-99)."""
+    dkey / dmsg / dq (iComformer's attention block backward in one pass; comformer_conv.py:90-99).  ``key`` None: gs holds
+    [key | msg] (the forward pass went through att_gate_fwd; alpha is recomputed)."""
     _f32_2d(gs, "att_gate_bwd_apply gs")
-    _f32_2d(key, "att_gate_bwd_apply key")
+    if key is not None:
+        _f32_2d(key, "att_gate_bwd_apply key")
     _f32_2d(q, "att_gate_bwd_apply q")
     _f32_2d(dq, "att_gate_bwd_apply dq")
-    R, D = key.shape
+    R, D = int(gs.shape[0]), int(gs.shape[1]) // 2
     S = int(q.shape[0])
+    if (key is not None and tuple(key.shape) != (R, D)) or _ld(gs) != 2 * D:
+        raise ValueError("att_gate_bwd_apply: key / gs shape mismatch")
     if tuple(gs.shape) != (R, 2 * D) or q.shape[1] != D or tuple(dq.shape) != (S, D):
         raise ValueError("att_gate_bwd_apply: shape mismatch")
     _edge_rows(daggr, S, D, "att_gate_bwd_apply daggr")
@@ -994,7 +1022,7 @@ def att_gate_bwd_apply(gs: Tensor, key: Tensor, q: Tensor, daggr: Tensor, ptr_: 
     npart = segment_nparts(S)
     pk, pm, pq = (torch.empty(npart * D, dtype=torch.float64, device=gs.device) for _ in range(3))
     _l.check(_l.load().cartnet_att_gate_bwd_apply(
-        gs.data_ptr(), key.data_ptr(), _ld(key), q.data_ptr(), _ld(q), daggr.data_ptr(), ptr_.data_ptr(),
+        gs.data_ptr(), _l.ptr(key), _ld(key) if key is not None else D, q.data_ptr(), _ld(q), daggr.data_ptr(), ptr_.data_ptr(),
         mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), int(count), int(training), float(scale),
         S, D, dq.data_ptr(), _ld(dq), pk.data_ptr(), pm.data_ptr(), pq.data_ptr(), _l.stream_ptr()),
         "cartnet_att_gate_bwd_apply")

@@ -172,7 +172,8 @@ int cartnet_lattice_features(const float* cell, const int64_t* batch, const int3
 int cartnet_eltwise(int32_t op, const float* a, const float* b, float* out, int64_t rows, int32_t cols, int32_t lda,
                     int32_t ldb, int32_t ldo, float scale, void* stream);
 /* alpha[r] = key[r] * q[s] * scale for rows r in [ptr[s], ptr[s+1])  (query_i * key / sqrt(C), comformer_conv.py:95)
- * + fp64 column partial sums of alpha / alpha^2 [cartnet_segment_nparts(S)][C] for bn_att. */
+ * + fp64 column partial sums of alpha / alpha^2 [cartnet_segment_nparts(S)][C] for bn_att.  alpha == NULL: the statistics
+ * only (alpha is then recomputed by cartnet_att_gate_fwd and cartnet_att_gate_bwd_apply and never written). */
 int cartnet_segment_nparts(int32_t S);
 int cartnet_rowmul_fwd(const float* key, int32_t ldk, const float* q, int32_t ldq, const int32_t* ptr, int32_t S,
                        int32_t C, float scale, float* alpha, int32_t lda, double* parts_sum, double* parts_sq,
@@ -186,10 +187,17 @@ int cartnet_rowmul_bwd(float* dalpha, int32_t lda, const float* key, int32_t ldk
 int cartnet_rowmul_bwd_sums(float* dalpha, int32_t lda, const float* key, int32_t ldk, const float* q, int32_t ldq,
                             const int32_t* ptr, int32_t S, int32_t C, float scale, float* dq, int32_t lddq,
                             double* parts_dkey, double* parts_dq, void* stream);
+/* The attention gate forward from the KEY rows (comformer_conv.py:90-99): gs = [key | msg] [R, 2D], alpha = key * q[s] * scale
+ * recomputed per row, aggr[s] = sum_r sigmoid(bn_att(alpha)) * msg with mean_rstd from cartnet_rowmul_fwd's statistics;
+ * bc != NULL: the per-segment sums B | C [S, 2D] of cartnet_gate_scatter_fwd_bc. */
+int cartnet_att_gate_fwd(const float* gs, const float* q, int32_t ldq, const int32_t* ptr, const float* mean_rstd,
+                         const float* gamma, const float* beta, float scale, int32_t S, int32_t D, float* aggr, float* bc,
+                         void* stream);
 /* The attention gate's backward (cartnet_gate_scatter_bwd_apply with e_out = env = NULL) and cartnet_rowmul_bwd_sums in ONE
  * pass (comformer_conv.py:90-99 backward): gs = [alpha | msg] [R, 2D] in place -> [dkey | dmsg], dq [S, D] (leading
  * dimension lddq); sums = [sum dbn | sum dbn ahat] (the finalised BatchNorm-backward sums of bn_att), count = the rows they
- * were taken over; fp64 column partials of dkey, dmsg and dq ([cartnet_segment_nparts(S)][D] each). */
+ * were taken over; fp64 column partials of dkey, dmsg and dq ([cartnet_segment_nparts(S)][D] each).
+ * key == NULL: gs = [key | msg] (the forward pass of cartnet_att_gate_fwd: alpha is recomputed from the key rows). */
 int cartnet_att_gate_bwd_apply(float* gs, const float* key, int32_t ldk, const float* q, int32_t ldq, const float* daggr,
                                const int32_t* ptr, const float* mean_rstd, const float* gamma, const float* beta,
                                const float* sums, int64_t count, int32_t training, float scale, int32_t S, int32_t D,

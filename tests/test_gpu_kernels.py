@@ -818,6 +818,52 @@ def test_att_gate_bwd_apply_is_gate_apply_then_rowmul(ops, S, D, maxdeg, trainin
     assert rel_err(sk, a[:, :D].double().cpu().sum(0)) < 1e-5
     assert rel_err(sm, a[:, D:].double().cpu().sum(0)) < 1e-5
     assert rel_err(sq, dqa.double().cpu().sum(0)) < 1e-5
+    # key = None: gs carries [key | msg] and alpha = key q[s] scale is recomputed (the alpha-free forward)
+    rep = torch.repeat_interleave(torch.arange(S, device=dev()), (ptr[1:] - ptr[:-1]).long())
+    c = torch.cat([key, gs0[:, D:]], dim=1).contiguous()
+    g2 = c.clone()
+    g2[:, :D] = key * (q[rep] * scale)          # what the stored-alpha form would have been given
+    dq2, dq3 = torch.empty(S, D, device=dev()), torch.empty(S, D, device=dev())
+    ops.att_gate_bwd_apply(g2, key, q, daggr, ptr, mr, gam, bet, sums, R, training, scale, dq2, sk, sm, sq)
+    ops.att_gate_bwd_apply(c, None, q, daggr, ptr, mr, gam, bet, sums, R, training, scale, dq3, sk, sm, sq)
+    assert rel_err(c, g2) < 2e-6 and rel_err(dq3, dq2) < 2e-6
+
+
+@pytest.mark.parametrize("S,D,maxdeg,with_bc", [(3, 8, 4, True), (700, 256, 30, True), (700, 256, 30, False), (5000, 320, 3, True)])
+def test_att_gate_fwd_is_rowmul_then_gate(ops, S, D, maxdeg, with_bc):
+    """cartnet_att_gate_fwd (alpha recomputed from the key rows) against cartnet_rowmul_fwd + cartnet_gate_scatter_fwd(_bc);
+    the statistics of cartnet_rowmul_fwd with alpha = None are those of the storing pass, bitwise."""
+    from cartnet_amd.ops import GraphLayout
+    g = torch.Generator().manual_seed(S + D + 1)
+    deg = torch.randint(0 if S > 3 else 1, maxdeg + 1, (S,), generator=g)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), deg.cumsum(0)]).int().to(dev())
+    R = int(deg.sum())
+    gs = rnd(R, 2 * D, seed=1)                     # [key | msg]
+    q = rnd(S, 3 * D, seed=3)[:, :D]
+    gam, bet = rnd(D, seed=7), rnd(D, seed=8)
+    scale = 1.0 / D ** 0.5
+    npart = ops.segment_nparts(S)
+    ps, pq, ps2, pq2 = (torch.empty(npart * D, dtype=torch.float64, device=dev()) for _ in range(4))
+    ref = gs.clone()
+    ops.rowmul_fwd(gs[:, :D], q, ptr, scale, ref[:, :D], ps, pq)
+    ops.rowmul_fwd(gs[:, :D], q, ptr, scale, None, ps2, pq2)
+    assert torch.equal(ps, ps2) and torch.equal(pq, pq2)
+    cnt = max(R, 1)
+    mean = ps.view(npart, D).sum(0) / cnt
+    var = (pq.view(npart, D).sum(0) / cnt - mean * mean).clamp_min(0)
+    mr = torch.cat([mean, 1.0 / torch.sqrt(var + 1e-5)]).float()
+    lay = GraphLayout.__new__(GraphLayout)
+    lay.E, lay.N, lay.rowptr = R, S, ptr
+    gp = ops.gate_nparts(S)
+    d1, d2 = (torch.empty(gp * D, dtype=torch.float64, device=dev()) for _ in range(2))
+    a1, a2 = torch.empty(S, D, device=dev()), torch.full((S, D), float("nan"), device=dev())
+    b1 = torch.empty(S, 2 * D, device=dev()) if with_bc else None
+    b2 = torch.full((S, 2 * D), float("nan"), device=dev()) if with_bc else None
+    ops.gate_scatter_fwd(ref, None, None, lay, mr, gam, bet, None, a1, d1, d2, bc=b1)
+    ops.att_gate_fwd(gs, q, ptr, mr, gam, bet, scale, a2, bc=b2)
+    assert rel_err(a2, a1) < 2e-6
+    if with_bc:
+        assert rel_err(b2, b1) < 1e-5
 
 
 @pytest.mark.parametrize("R,Cc", [(1, 4), (777, 256), (20000, 256), (300, 320)])
