@@ -185,6 +185,7 @@ __global__ __launch_bounds__(NTHREADS, 6) void cn_gemm_f32nn128_kernel(const Car
       case 14: CN_EPIW(14); break;
       case 268: CN_EPIW(268); break;  // * softplus'(pre), bias gradient (+ resid: 270): iComformer's RBF branches
       case 270: CN_EPIW(270); break;
+      case 352: CN_EPIW(352); break;  // keep the pre-activation, softplus: the RBF branches forward
       default: CN_EPIW(-1); break;
     }
   }

@@ -42,6 +42,14 @@ __device__ __forceinline__ float fast_dsilu(float x) {
   const float s = fast_sigmoid(x);
   return s * (1.0f + x * (1.0f - s));
 }
+// softplus(x) = max(x, 0) + log1p(exp(-|x|)) on the hardware exp / log (comformer_ops.hip's softplus_f: the same expression,
+// so a value is the same whether an epilogue or the element-wise kernel produced it); threshold 20 as torch's.
+__device__ __forceinline__ float fast_softplus(float x) {
+  if (x > 20.f) return x;
+  const float t = __expf(-fabsf(x));
+  const float l = t < 4.8828125e-4f ? t - 0.5f * t * t : __logf(1.0f + t);
+  return fmaxf(x, 0.f) + l;
+}
 
 // One operand tile (ROWS x BK) per K-step: global -> registers -> LDS.
 template <int ROWS, bool KS, bool ACT>
@@ -329,7 +337,7 @@ __device__ __forceinline__ void epilogue(const CartnetGemmArgs& p, f32x16 (&acc)
           cq[b] += (double)v * (double)v;
         }
         if (CPRE) cpre[(size_t)grow * p.ldc + gcol] = v;
-        if (OUTACT) v = fast_silu(v);
+        if (OUTACT) v = (kind & 256) ? fast_softplus(v) : fast_silu(v);
         C[(size_t)grow * p.ldc + gcol] = v;
       }
     }
@@ -413,7 +421,8 @@ __device__ __forceinline__ void epilogue_wide_s(const CartnetGemmArgs& p, ACC& a
   // the code, and cartnet_gemm refuses a launch with gst_g set that would not reach a kernel with the case
   constexpr bool GST = KIND >= 0 && (KIND & 128) != 0;
   constexpr int KBASE = KIND >= 0 ? (KIND & 127) : KIND;      // the kind without the extension bits
-  // bit 8: CartnetGemmArgs.dact_kind = 1, v *= sigmoid(dact) (softplus') instead of silu'(dact)
+  // bit 8: CartnetGemmArgs.dact_kind = 1, the activation of this launch is softplus: v *= sigmoid(dact) (softplus') instead
+  // of silu'(dact), out_act = softplus instead of SiLU
   const bool DSP = (kind & 256) != 0;
   const int li = lane & 31, lh = lane >> 5;
   const int c4 = lane & 7, rsub = lane >> 3;
@@ -611,7 +620,7 @@ __device__ __forceinline__ void epilogue_wide_s(const CartnetGemmArgs& p, ACC& a
         if (CPRE) stv4(cpre + (size_t)grow[i] * p.ldc + gcol, v);
         if (OUTACT) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = fast_silu(v[q]);
+          for (int q = 0; q < 4; ++q) v[q] = DSP ? fast_softplus(v[q]) : fast_silu(v[q]);
         }
         stv4(C + (size_t)grow[i] * p.ldc + gcol, v);
       }

@@ -486,8 +486,15 @@ extern "C" int cartnet_icomformer_forward(const CartnetIcfModel* model, const Ca
     const bool img = w.use_img && n >= 2048;      // a handful of rows (lattice lengths): the plain NT form
     a.A[0] = r; a.C[0] = pre; a.bias[0] = bias;
     if (img) { a.b_kstrided = 1; a.B[0] = T_; a.b_split[0] = F_; } else { a.B[0] = W_; }
+#ifndef CN_ICF_NO_RBF_FUSE
+    // pre and softplus(pre) from the product's epilogue (CartnetGemmArgs.dact_kind = 1 with cpre + out_act): the element-wise
+    // pass read pre and wrote out, 0.25 ms per step over the E + 3E rows
+    a.C[0] = out; a.cpre[0] = pre; a.out_act = 1; a.dact_kind = 1;
+    return cartnet_gemm(&a, st);
+#else
     RUN(cartnet_gemm(&a, st));
     return cartnet_eltwise(0, pre, nullptr, out, n, C, C, 0, C, 1.0f, st);
+#endif
   };
   RUN(rbf_branch(w.edge_feat, b.E, m.rbf_centers, m.gamma_rbf, P.rbf_w, w.rbfT, w.rbfF, P.rbf_b, w.r_e, w.pre_e, w.e0));
   RUN(rbf_branch(w.nl, (long long)Bg * 3, m.rbf_centers, m.gamma_rbf, P.rbf_w, w.rbfT, w.rbfF, P.rbf_b, w.r_nl, w.pre_nl, w.NLt));

@@ -61,7 +61,7 @@ int cartnet_abi_struct_sizes(size_t* out, int32_t capacity);
  *                 colsum[g][tile_m * N + n]  (tile_m in [0, ceil(M/128)); reduce with cartnet_colsum_finalize
  *                 or cartnet_bn_finalize -- deterministic, no atomics);
  *   if cpre[g]:   cpre[g][m*ldc + n] = v;      (pre-activation kept for backward)
- *   if out_act:   v = silu(v);
+ *   if out_act:   v = silu(v);                 (dact_kind = 1: v = softplus(v))
  *   C[g][m*ldc + n] = v.
  * splitk > 1 (only with a_kstrided = b_kstrided = 1, no epilogue): the K range is cut into `splitk` chunks and
  *   chunk s writes its raw partial tile to C[g] + s*M*ldc; reduce with cartnet_splitk_reduce.
@@ -131,10 +131,12 @@ typedef struct CartnetGemmArgs {
                           for the node-term gather epilogue, for single-group N = 256 products and for launches with few
                           tiles).  1: grouped N = 256 products take the narrow tile too (the iComformer path: -1.8 % per
                           step; CartNet's two-group layer products lose).  128 / 256: force one kernel (A/B runs). */
-  int32_t dact_kind;   /* 0: v *= silu'(dact) (the SiLU between two Linears, models/cartnet.py:127,136).  1: v *= sigmoid(dact),
+  int32_t dact_kind;   /* The activation family of the launch's epilogue (dact and out_act).
+                          0: v *= silu'(dact) (the SiLU between two Linears, models/cartnet.py:127,136).  1: v *= sigmoid(dact),
                           the derivative of softplus (iComformer's RBF branches, models/comformer.py:93-105: the product that
                           yields d(softplus output) writes d(pre-activation) and, with colsum, the bias gradient -- no
-                          element-wise pass, no column-sum pass).  Not with the bf16-storage flags. */
+                          element-wise pass, no column-sum pass); out_act then applies softplus (threshold 20) instead of
+                          SiLU: with cpre the forward of such a branch in one launch.  Not with the bf16-storage flags. */
 } CartnetGemmArgs;
 
 int cartnet_gemm(const CartnetGemmArgs* args, void* stream);

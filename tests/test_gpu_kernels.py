@@ -379,6 +379,25 @@ def test_gemm_softplus_backward_epilogue(ops, precision, M, with_resid, image):
         ops.gemm([X[:, :K], X[:, K:]], Ws, C_, b_kstrided=True, segments=True, dact=pre, dact_kind=2)
 
 
+@pytest.mark.parametrize("precision,M,image", [(0, 40000, True), (1, 40000, True), (0, 192, False), (0, 12416, True)])
+def test_gemm_softplus_forward_epilogue(ops, precision, M, image):
+    """dact_kind = 1 with cpre + out_act: pre = X W + b kept, out = softplus(pre) (threshold 20) -- an RBF branch of iComformer
+    forward in one launch; the values are those of cartnet_eltwise op 0 on the kept pre-activation, bitwise."""
+    K, N = 256, 256
+    X, W, b = rnd(M, K, seed=3, scale=3.0), rnd(K, N, seed=4, scale=0.4), rnd(N, seed=5)
+    pre = torch.full((M, N), float("nan"), device=dev())
+    out = torch.full((M, N), float("nan"), device=dev())
+    img = (ops.pack_b if precision == 0 else ops.split_b)([W])[0] if image else None
+    ops.gemm(X, W, out, b_kstrided=True, bias=b, cpre=pre, out_act=True, b_split=img, precision=precision, dact_kind=1)
+    ref = X.double() @ W.double() + b.double()
+    assert rel_err(pre, ref) < TOL
+    assert float(pre.max()) > 20.0 and float(pre.min()) < -10.0          # both tails of the softplus are exercised
+    assert rel_err(out, torch.nn.functional.softplus(ref)) < TOL
+    chk = torch.empty_like(out)
+    ops.eltwise(0, pre, None, chk)
+    assert torch.equal(out, chk)
+
+
 @pytest.mark.parametrize("precision", [0, 1, 2])
 def test_gemm_folded_segments_with_images(ops, precision):
     """sum_s X[:, sK:(s+1)K] W_s: K-segments that are adjacent column blocks run as one product (b_split_folded); the
