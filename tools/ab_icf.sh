@@ -1,4 +1,4 @@
 for v in "$@" "$@"; do
   echo "== $v"
-  CARTNET_LIB=$PWD/$v timeout -k 10 200 python bench.py --model icomformer --no-telemetry --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timer --no-x3-pass --no-recipe-pass --no-calibration --sustain-seconds 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])"
+  CARTNET_LIB=$PWD/$v timeout -k 10 200 python bench.py --model icomformer --no-telemetry --steps 60 --warmup 10 --no-cpu-baseline --no-kernel-timer --no-x3-pass --no-recipe-pass --no-calibration --sustain-seconds 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])"
 done
