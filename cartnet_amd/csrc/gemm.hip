@@ -222,7 +222,10 @@ extern "C" int cartnet_gemm_gate_stats_ok(const CartnetGemmArgs* args) { return 
 // with few tiles.  Shared with the launch timer so that its variant names the kernel family that really runs.
 static int choose_bn(const CartnetGemmArgs& a) {
   int bn = a.N > 128 ? 256 : (a.N > 64 ? 128 : 64);
-  if (bn == 256 && a.precision <= 1 && !a.a_kstrided && a.splitk == 1 && a.N % 64 == 0) {
+  // (transposed-A launches: only the K-segment form -- iComformer's 256 x 256 x 512 chain-rule product dWe ran as TWO
+  //  workgroups of the 256-wide general kernel, 110-150 us on the weight-gradient stream, five times per step; weight
+  //  gradients proper carry split-K or take the DMA-fed kernel and are left alone)
+  if (bn == 256 && a.precision <= 1 && (!a.a_kstrided || a.nsegs > 1) && a.splitk == 1 && a.N % 64 == 0) {
     const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 255) / 256) * a.ngroups;
     // bf16x3 tiles are ~2x shorter: switch later (96: the benchmark batch's 97-row-tile dX product, K = 1024, stays on
     // the DMA-fed bf16x3 kernel -- +0.4 % on the step in a same-box A/B)
