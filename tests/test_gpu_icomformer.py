@@ -141,22 +141,28 @@ def test_properties_at_the_adp_shape(precision):
     assert sum(float(g.abs().sum()) for g in outs[0][1].values()) > 0
 
 
-def test_native_sequence_equals_the_python_sequence():
+@pytest.mark.parametrize("train_mode", [True, False])
+def test_native_sequence_equals_the_python_sequence(train_mode):
     """cartnet_icomformer_forward / _backward (csrc/icomformer.hip: one C-ABI call per direction) against the same kernels
     sequenced launch by launch from Python (`native_sequence = False`, the path eComformer still takes): predictions,
-    every gradient and the BatchNorm buffers, at a golden width (no weight images) and at C = 256 (DMA-fed kernels)."""
+    every gradient and the BatchNorm buffers, at a golden width (no weight images) and at C = 256 (DMA-fed kernels).
+    The two sequences differ in more than order since round 5: the C++ one never writes alpha, takes the gate's
+    BatchNorm-backward sums from per-segment sums (in eval mode too) and the bias gradients from their producers.
+    train_mode False: gradients through running-statistics BatchNorm (fine-tuning with frozen statistics)."""
     from cartnet_amd.comformer import iComformer, make_icomformer_state_dict
     from cartnet_amd.data import Batch
     from cartnet_amd.synthetic import make_crystal
     b = Batch.from_data_list([make_crystal(960 + i, 10 + 7 * i) for i in range(3)])
-    for width in (32, 256):
+    # (320 > 256 columns: the C++ sequence takes its stored-alpha form there -- the one-chunk kernels of the alpha-free form
+    #  need C <= 256)
+    for width in (32, 256) + ((320,) if train_mode else ()):
         sd = make_icomformer_state_dict(width, seed=11)
         res = []
         for native in (True, False):
             m = iComformer(width)
             m.load_state_dict(sd)
             m.native_sequence = native
-            m = m.to("cuda:0").train()
+            m = m.to("cuda:0").train(train_mode)
             pred, true = m(_clone(b).to("cuda:0"))
             (pred - true).abs().mean().backward()
             res.append((pred.detach(), {k: p.grad for k, p in m.named_parameters()}, m.state_dict()))
