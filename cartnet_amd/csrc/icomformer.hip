@@ -47,11 +47,53 @@ __global__ void cn_icf_index_kernel(const int* __restrict__ src32, const int64_t
   for (long long g = i0; g <= Bg; g += stride) gedge_ptr[g] = rowptr[(int)graph_ptr[g]];
 }
 
-// out[i, t] += u[i] * v[t]  (C x C block with row stride ldo): the bias part of dW1e = dF We^T + db be^T
-__global__ void cn_icf_rank1_kernel(float* __restrict__ out, int ldo, const float* __restrict__ u, const float* __restrict__ v,
-                                    int C) {
+// out[i, t] += u[i] * v[t]  (C x C block with row stride ldo): the bias part of dW1e = dF We^T + db be^T; blockIdx.y picks
+// the (out, u) pair: key / msg in one launch
+__global__ void cn_icf_rank1_kernel(float* __restrict__ out0, float* __restrict__ out1, int ldo, const float* __restrict__ u0,
+                                    const float* __restrict__ u1, const float* __restrict__ v, int C) {
+  float* __restrict__ out = blockIdx.y ? out1 : out0;
+  const float* __restrict__ u = blockIdx.y ? u1 : u0;
   const int i = blockIdx.x;
   for (int t = threadIdx.x; t < C; t += blockDim.x) out[(size_t)i * ldo + t] += u[i] * v[t];
+}
+
+// out[n] = sum_k a0[k] B0[k * ldb + n] + sum_k a1[k] B1[k * ldb + n]  (a row times two C x C blocks: dbe = W1k[:, 2C:]^T db_k +
+// W1m[:, 2C:]^T db_m).  As a one-row cartnet_gemm launch it was a 128-row tile of the general kernel, 30-70 us on the
+// weight-gradient stream next to the big products; 16 columns x 16 k-slices per 256-thread block, eight loads in flight per
+// thread, slices added in a fixed order.  (First forms: one load per iteration = a chain of 128 round trips, 156 us; the
+// same with 1,024-thread blocks: 365 us -- sixteen waves of one block wait for a CU that the resident GEMM workgroups
+// have left room on, four fit in the gaps.)
+__global__ __launch_bounds__(256) void cn_icf_rowvec2_kernel(float* __restrict__ out, const float* __restrict__ a0,
+                                                              const float* __restrict__ B0, const float* __restrict__ a1,
+                                                              const float* __restrict__ B1, int ldb, int C) {
+  __shared__ float red[16][16];
+  const int cl = threadIdx.x & 15, col = blockIdx.x * 16 + cl, sl = threadIdx.x >> 4;
+  float acc = 0.f;
+  if (col < C) {
+    for (int m = 0; m < 2; ++m) {
+      const float* __restrict__ a = m ? a1 : a0;
+      const float* __restrict__ B = m ? B1 : B0;
+      for (int k0 = sl; k0 < C; k0 += 16 * 8) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + 16 * u;
+          av[u] = k < C ? a[k] : 0.f;
+          bv[u] = k < C ? B[(size_t)k * ldb + col] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += av[u] * bv[u];
+      }
+    }
+  }
+  red[sl][cl] = acc;
+  __syncthreads();
+  if (sl == 0 && col < C) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int s = 1; s < 16; ++s) t += red[s][cl];
+    out[col] = t;
+  }
 }
 
 // ---- weight forms of one step -----------------------------------------------------------------------------------------
@@ -806,8 +848,8 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
       RUN(cartnet_gemm(&a, sw));
     }
     if (q.edge_b) {   // ... + db be^T  (db = the bias gradients of the first Linears, already summed on the main stream)
-      hipLaunchKernelGGL(cn_icf_rank1_kernel, dim3(C), dim3(256), 0, (hipStream_t)sw, g.key0_w + 2 * C, 3 * C, g.key0_b, q.edge_b, C);
-      hipLaunchKernelGGL(cn_icf_rank1_kernel, dim3(C), dim3(256), 0, (hipStream_t)sw, g.msg0_w + 2 * C, 3 * C, g.msg0_b, q.edge_b, C);
+      hipLaunchKernelGGL(cn_icf_rank1_kernel, dim3(C, 2), dim3(256), 0, (hipStream_t)sw, g.key0_w + 2 * C, g.msg0_w + 2 * C, 3 * C,
+                         g.key0_b, g.msg0_b, q.edge_b, C);
       CN_LAUNCH_CHECK("cartnet_icomformer_backward (rank-1 update)");
     }
     {  // dWe = W1k[:, 2C:]^T dFk + W1m[:, 2C:]^T dFm
@@ -817,10 +859,9 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
       RUN(cartnet_gemm(&a, sw));
     }
     if (q.edge_b) {   // dbe = W1k[:, 2C:]^T db_k + W1m[:, 2C:]^T db_m   (a row times W)
-      CartnetGemmArgs a = gargs(0, 1, C, C, C, 3 * C, C);
-      a.nsegs = 2; a.b_kstrided = 1; a.tile_policy = 0;
-      a.A[0] = g.key0_b; a.A[1] = g.msg0_b; a.B[0] = q.key0_w + 2 * C; a.B[1] = q.msg0_w + 2 * C; a.C[0] = g.edge_b;
-      RUN(cartnet_gemm(&a, sw));
+      hipLaunchKernelGGL(cn_icf_rowvec2_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)sw, g.edge_b, g.key0_b,
+                         q.key0_w + 2 * C, g.msg0_b, q.msg0_w + 2 * C, 3 * C, C);
+      CN_LAUNCH_CHECK("cartnet_icomformer_backward (dbe)");
     }
     return 0;
   };
