@@ -222,8 +222,13 @@ __global__ __launch_bounds__(256) void cn_att_gate_fwd_kernel(const float* __res
 #pragma unroll
       for (int u = 0; u < ATT_BATCH; ++u) {
         const int kk = min(k + u, k1 - 1);
+#ifndef CN_NO_GATE_LOAD_NT      /* last use of the key / msg rows before backward (as in cn_gate_scatter_fwd_kernel) */
+        kv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gs + (size_t)kk * ld + c));
+        mv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gs + (size_t)kk * ld + D + c));
+#else
         kv[u] = ld4(gs + (size_t)kk * ld + c);
         mv[u] = ld4(gs + (size_t)kk * ld + D + c);
+#endif
       }
 #pragma unroll
       for (int u = 0; u < ATT_BATCH; ++u) {

@@ -11,6 +11,16 @@
 #pragma once
 #include "gemm_f32.h"
 
+// Cache policy of the silu(A) store.  Its next reader is the weight gradient of this Linear, milliseconds later: written
+// through and not kept (sc0 sc1 nt), the 363 MB per launch stop evicting the output `gs` that the gate kernel reads next
+// -- same-box A B A B A B, 60 steps each: 14.01-14.06 vs 14.19-14.20 ms per step (nt alone / sc1 alone: half of that;
+// the same bits on the weight-gradient kernel's operand loads, non-temporal A loads here: nothing / +0.1 ms).
+#ifdef CN_NO_STREAM_STORES
+#define CN_AO_STORE_POLICY ""
+#else
+#define CN_AO_STORE_POLICY "sc0 sc1 nt"
+#endif
+
 namespace cn_gemm {
 
 __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_actout_kernel(const CartnetGemmArgs p, const GemmFlags fl) {
@@ -62,7 +72,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32nn_actout_kernel(const
     const float* base = h0 + step_v * BK;
     // s_nop: a store of more than 8 bytes reads its data registers up to two cycles after issue; the hazard
     // recogniser does not look inside inline asm, and the next VALU instruction may overwrite them
-    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(a_voff), "v"(v), "s"(base) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 " CN_AO_STORE_POLICY "\n\ts_nop 1" :: "v"(a_voff), "v"(v), "s"(base) : "memory");
   };
   auto a_store = [&](f32x4 v, int buf, int step_v) {
 #pragma unroll

@@ -384,6 +384,17 @@ constexpr int SCR_FLOATS = 32 * SCR_LD;
 
 __device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void stv4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// A store whose next reader is milliseconds away (what forward keeps for backward): written through, not kept in the
+// caches (round 5: the same policy on the kept silu(pre) of the layers' second products was worth 0.17 ms per step --
+// gemm_f32ao.h).  (s_nop: a store of more than 8 bytes reads its data registers up to two cycles after issue and the
+// hazard recogniser does not look inside inline asm.)
+__device__ __forceinline__ void stv4_stream(float* p, f32x4 v) {
+#ifdef CN_NO_STREAM_STORES
+  stv4(p, v);
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#endif
+}
 
 // Accumulator layouts the wide epilogue takes: 32x32 MFMA tiles (f32x16 per tile: column = lane & 31, rows
 // (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) or 16x16 tiles (f32x4 per tile: column = lane & 15, rows 4 (lane >> 4) + r;
@@ -617,7 +628,7 @@ __device__ __forceinline__ void epilogue_wide_s(const CartnetGemmArgs& p, ACC& a
             gs2[b][q] += tv * ghat;
           }
         }
-        if (CPRE) stv4(cpre + (size_t)grow[i] * p.ldc + gcol, v);
+        if (CPRE) stv4_stream(cpre + (size_t)grow[i] * p.ldc + gcol, v);
         if (OUTACT) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = DSP ? fast_softplus(v[q]) : fast_silu(v[q]);
