@@ -372,8 +372,9 @@ static int cartnet_gemm_impl(const CartnetGemmArgs* args, void* stream) {
            a.precision);
   CN_CHECK(a.dact_kind == 0 || (a.dact_kind == 1 && !cn_gemm::any_half(a)),
            "cartnet_gemm: dact_kind=%d (0 = silu', 1 = sigmoid / softplus'; 1 not with bf16 storage)", a.dact_kind);
-  CN_CHECK(a.tile_policy == 0 || a.tile_policy == 1 || a.tile_policy == 128 || a.tile_policy == 256,
-           "cartnet_gemm: tile_policy=%d (0 = automatic, 1 = narrow tiles for grouped N = 256 products too, 128 / 256 = force)",
+  CN_CHECK(a.tile_policy == 0 || a.tile_policy == 1 || a.tile_policy == 3 || a.tile_policy == 128 || a.tile_policy == 256,
+           "cartnet_gemm: tile_policy=%d (0 = automatic, 1 = narrow tiles for grouped N = 256 products too, 3 = the persistent "
+           "kernel wherever it has the form, 128 / 256 = force)",
            a.tile_policy);
   // Few row tiles (atom-sized M, small batches): 128 x 256 tiles would leave most of the 256 CUs idle and the launch
   // would last one tile's latency (16+ K-steps of a full tile); narrower column tiles (the general kernel's 128- and

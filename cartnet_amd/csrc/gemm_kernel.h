@@ -1002,6 +1002,9 @@ bool use_f32nn128(const CartnetGemmArgs& a);
 void launch_f32nnq(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
 bool use_f32nnq(const CartnetGemmArgs& a);
 #endif
+// gemm_f32p.hip: the persistent kernel (one workgroup per CU, two accumulator sets; K = 256 / 512)
+bool use_f32p(const CartnetGemmArgs& a);
+void launch_f32p(const CartnetGemmArgs& a, hipStream_t st);
 // gemm_f32ao.hip: the a_act form of the 256-wide kernel that also writes silu(A) (CartnetGemmArgs.a_act_out)
 void launch_f32nn_actout(const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st);
 // gemm_x3s.hip: the bf16x3 activation x weight kernel on the 16x16x32 MFMA shape (precision 1; the 32x32x16 kernel of
@@ -1088,7 +1091,8 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
         const int nptr = a.ngroups > 1 ? a.ngroups : a.nsegs;
         for (int i = 0; i < nptr; ++i) prepacked = prepacked && a.b_split[i] != nullptr;
         if (prepacked) {
-          if (A_ACT && a.a_act_out[0]) launch_f32nn_actout(a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
+          if (use_f32p(a)) launch_f32p(a, st);
+          else if (A_ACT && a.a_act_out[0]) launch_f32nn_actout(a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);
 #ifdef CN_EXPERIMENTAL_Q
           else if (use_f32nnq(a)) launch_f32nnq(A_ACT, a, fl, dim3(nm * tiles_n * 2, ns, a.ngroups), st);
 #endif

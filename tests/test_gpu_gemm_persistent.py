@@ -1,0 +1,175 @@
+"""The persistent fp32 activation x weight kernel (csrc/gemm_f32p.h; CartnetGemmArgs.tile_policy = 3 forces it, 256 excludes
+it) through the C ABI: every compiled epilogue form against an fp64 torch evaluation of the same arithmetic
+(max|delta| <= 1e-5 * max|ref|, north_star's fp32 bar) AND against the shipped second-generation kernels, which the forms
+without a transcendental in the epilogue must equal bit for bit (same MFMA chain, same order of every sum).
+
+Shapes exercise what the kernel's structure can get wrong: workgroups without a tile / with one / with an odd and an even
+number of tiles (the two accumulator sets, the drain behind either loop exit), a ragged last row tile (rows dropped by the
+buffer descriptors' range check, statistics masked), two and four groups and two column tiles (the workgroup -> (group,
+column tile) map), column-block views (row strides wider than N)."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+D = 256
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from cartnet_amd import ops as _ops
+    from cartnet_amd import lib
+    lib.load()
+    return _ops
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev())
+
+
+def silu64(x):
+    return x * torch.sigmoid(x)
+
+
+def dsilu64(x):
+    s = torch.sigmoid(x)
+    return s * (1 + x * (1 - s))
+
+
+# M: 1 row; one full tile; 2 tiles + ragged; 257 row tiles (every workgroup of a group pair gets one, some two);
+# 700 tiles + ragged (2-3 per workgroup: both loop exits)
+SHAPES = [1, 128, 300, 128 * 257, 89500]
+
+
+def _run(ops, pol, M, groups, N, form, seed=0):
+    """One launch of `form` with tile_policy `pol`; returns the outputs and the fp64 references."""
+    G = groups
+    A = rnd(M, G * D, seed=seed + 1)                                   # groups read column blocks of one matrix
+    W = [rnd(D, N, seed=seed + 10 + g, scale=0.06) for g in range(G)]  # [K, N]: b_kstrided
+    img = ops.pack_b(W)
+    out = torch.full((M, G * N), float("nan"), device=dev())
+    Av = [A[:, g * D:(g + 1) * D] for g in range(G)]
+    Cv = [out[:, g * N:(g + 1) * N] for g in range(G)]
+    bias = [rnd(N, seed=seed + 20 + g) for g in range(G)]
+    tiles = ops.gemm_tiles_m(M)
+    kw = dict(b_kstrided=True, b_split=img, tile_policy=pol)
+    res = {"out": out}
+    ref = {}
+    A64 = [a.double() for a in Av]
+    W64 = [w.double() for w in W]
+    if form == "plain":
+        ops.gemm(Av, W, Cv, **kw)
+        ref["out"] = torch.cat([A64[g] @ W64[g] for g in range(G)], 1)
+    elif form == "bias":
+        ops.gemm(Av, W, Cv, bias=bias, **kw)
+        ref["out"] = torch.cat([A64[g] @ W64[g] + bias[g].double() for g in range(G)], 1)
+    elif form in ("act", "stats", "stats_actout"):
+        cs = [torch.full((tiles * N,), float("nan"), dtype=torch.float64, device=dev()) for _ in range(G)]
+        cq = [torch.full((tiles * N,), float("nan"), dtype=torch.float64, device=dev()) for _ in range(G)]
+        act = torch.full((M, G * D), float("nan"), device=dev())
+        extra = {}
+        if form != "act":
+            # (the model takes the statistics of the first group only: a missing statistic must simply be dropped)
+            extra.update(colsum=[cs[0]] + [None] * (G - 1), colsq=[cq[0]] + [None] * (G - 1))
+            res.update(cs=cs[0], cq=cq[0])
+        if form == "stats_actout":
+            extra.update(a_act_out=[act[:, g * D:(g + 1) * D] for g in range(G)])
+            res["act"] = act
+        ops.gemm(Av, W, Cv, a_act=True, bias=bias, **extra, **kw)
+        v = [silu64(A64[g]) @ W64[g] + bias[g].double() for g in range(G)]
+        ref["out"] = torch.cat(v, 1)
+        if form != "act":
+            pad = tiles * 128 - M
+            v0 = torch.cat([v[0], torch.zeros(pad, N, dtype=torch.float64, device=dev())]).view(tiles, 128, N)
+            ref["cs"] = v0.sum(1).reshape(-1)
+            ref["cq"] = (v0 * v0).sum(1).reshape(-1)
+        if form == "stats_actout":
+            ref["act"] = silu64(A.double())
+    elif form in ("dpre", "dpre_colsum"):
+        pre = rnd(M, G * N, seed=seed + 30)
+        Pv = [pre[:, g * N:(g + 1) * N] for g in range(G)]
+        extra = {}
+        if form == "dpre_colsum":
+            cs = [torch.full((tiles * N,), float("nan"), dtype=torch.float64, device=dev()) for _ in range(G)]
+            extra["colsum"] = cs
+        ops.gemm(Av, W, Cv, dact=Pv, **extra, **kw)
+        if form == "dpre_colsum":
+            res["cs_all"] = torch.stack(cs)
+        v = [(A64[g] @ W64[g]) * dsilu64(Pv[g].double()) for g in range(G)]
+        ref["out"] = torch.cat(v, 1)
+        if form == "dpre_colsum":
+            pad = tiles * 128 - M
+            ref["cs_all"] = torch.stack([torch.cat([x, torch.zeros(pad, N, dtype=torch.float64, device=dev())])
+                                         .view(tiles, 128, N).sum(1).reshape(-1) for x in v])
+    else:
+        raise AssertionError(form)
+    torch.cuda.synchronize()
+    return res, ref
+
+
+@pytest.mark.parametrize("form", ["plain", "bias", "act", "stats", "stats_actout", "dpre", "dpre_colsum"])
+@pytest.mark.parametrize("M", SHAPES)
+def test_every_form_against_fp64_and_the_shipped_kernels(ops, form, M):
+    new, ref = _run(ops, 3, M, 2, D, form)
+    old, _ = _run(ops, 256, M, 2, D, form)
+    for k in ref:
+        assert not torch.isnan(new[k]).any(), f"{form} M={M}: {k} has elements the kernel never wrote"
+        # column statistics are sums of up to 128 values: the bar is relative to the largest sum
+        assert rel_err(new[k], ref[k]) < (TOL if k in ("out", "act") else 2e-5), (form, M, k)
+    bitwise = form in ("plain", "bias", "act", "stats", "stats_actout")
+    for k in ref:
+        if bitwise:
+            assert torch.equal(new[k], old[k]), f"{form} M={M}: {k} differs from the shipped kernel"
+        else:          # hardware exp / rcp in the epilogue, fused differently: one rounding
+            assert rel_err(new[k], old[k]) < 2e-6, (form, M, k)
+
+
+@pytest.mark.parametrize("groups,N", [(1, 512), (4, 256), (1, 1024), (2, 512), (1, 256)])
+def test_groups_and_column_tiles(ops, groups, N):
+    M = 128 * 70 + 33
+    for form in ("bias", "stats"):
+        new, ref = _run(ops, 3, M, groups, N, form, seed=3)
+        old, _ = _run(ops, 256, M, groups, N, form, seed=3)
+        for k in ref:
+            assert not torch.isnan(new[k]).any()
+            assert rel_err(new[k], ref[k]) < (TOL if k == "out" else 2e-5), (groups, N, form, k)
+            assert torch.equal(new[k], old[k]), (groups, N, form, k)
+
+
+def test_is_bitwise_repeatable_and_leaves_the_rest_of_the_buffers_alone(ops):
+    """Column-block views: the bytes between a group's N columns and the row stride must not be touched (every store is a
+    dword inside the view), and two launches give the same bits."""
+    M, N, G = 128 * 300 + 77, D, 2
+    A = rnd(M, G * D + 64, seed=5)
+    W = [rnd(D, N, seed=6 + g, scale=0.06) for g in range(G)]
+    img = ops.pack_b(W)
+    outs = []
+    for rep in range(2):
+        out = torch.full((M, G * N + 32), 7.25, device=dev())
+        ops.gemm([A[:, g * D:(g + 1) * D] for g in range(G)], W, [out[:, g * N:(g + 1) * N] for g in range(G)],
+                 b_kstrided=True, b_split=img, tile_policy=3)
+        torch.cuda.synchronize()
+        assert torch.all(out[:, G * N:] == 7.25)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.cat([A[:, g * D:(g + 1) * D].double() @ W[g].double() for g in range(G)], 1)
+    assert rel_err(outs[0][:, :G * N], ref) < TOL
+
+
+def test_the_library_picks_it_for_the_model_sized_launches_only(ops):
+    """tile_policy 0: the edge-sized two-group layer products take the persistent kernel (same bits as policy 3), small
+    launches keep the 2,768-workgroup kernels (same bits as policy 256) -- and either way the results agree."""
+    for M in (300, 177140):
+        a, _ = _run(ops, 0, M, 2, D, "stats", seed=9)
+        b, _ = _run(ops, 3, M, 2, D, "stats", seed=9)
+        c, _ = _run(ops, 256, M, 2, D, "stats", seed=9)
+        for k in ("out", "cs", "cq"):
+            assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k])
