@@ -310,6 +310,7 @@ def main():
         raise SystemExit(self_launch(args))
 
     from cartnet_amd import distributed as cdist
+    os.environ.setdefault("CARTNET_DIST_TIMEOUT", "300")     # a benchmark rank that never arrives must not hold the box
     rank, world, local = cdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, the two must agree")
@@ -587,6 +588,32 @@ def main():
         torch.cuda.synchronize()
         dt3 = cdist.max_over_ranks(time.perf_counter() - t1, dev)
         tel3 = sampler3.stop() if sampler3 is not None else None
+        # its own roofline: ONE more step, outside the timed region above, with an event pair on every
+        # cartnet_gemm launch; six bf16 MFMA products per fp32 product -> the ceiling is the dense bf16 peak / 6
+        x3_roof = None
+        if rank == 0 and not args.no_kernel_timer:
+            bx = fresh()
+            torch.cuda.synchronize()
+            ops.profile_gemm(True)
+            step(bx)
+            torch.cuda.synchronize()
+            ops.profile_gemm(False)
+            v3 = ops.profile_gemm_read()
+            if v3:
+                peak3 = 2500.0 / 6.0
+                k3 = max(v3, key=lambda k: v3[k]["ms"])
+                d3 = v3[k3]
+                ach3 = d3["flops"] / (d3["ms"] * 1e-3) / 1e12
+                g3 = sum(v["flops"] for v in v3.values())
+                x3_roof = {"bound": "mfma", "achieved": round(ach3, 2), "peak": round(peak3, 1), "unit": "TFLOP/s",
+                           "frac": round(ach3 / peak3, 4), "traffic": None,
+                           "kernel": f"cartnet_gemm variant {k3} (bf16x3: fp32-equivalent FLOPs against the dense bf16 peak / 6)",
+                           "launches": d3["launches"], "avg_launch_us": round(1e3 * d3["ms"] / d3["launches"], 2),
+                           "measured": "one instrumented step after the timed ones (an event pair on every GEMM launch), in-step",
+                           "whole_step_frac": round(g3 / (dt3 / args.steps) / 1e12 / peak3, 4),
+                           "all_gemm_variants_ms_per_step": {k: round(v["ms"], 3) for k, v in sorted(v3.items()) if v["ms"] >= 0.05},
+                           "all_gemm_variants_frac": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak3, 3)
+                                                      for k, v in sorted(v3.items()) if v["ms"] >= 0.05}}
         model.gemm_precision = 0
         if torch.isfinite(loss3):
             x3 = {"value": round(args.graphs * world * args.steps / dt3, 2), "unit": "graphs/s",
@@ -596,6 +623,8 @@ def main():
                   "telemetry_during": tel3,
                   "note": "same step with gemm_precision=1: every fp32 product rebuilt from six bf16 MFMA products "
                           "(operands split exactly into three bf16 pieces), fp32 accumulate; same 1e-5 parity tests"}
+            if x3_roof is not None:
+                x3["roofline"] = x3_roof
 
     # bf16 mode with bf16 storage (BASELINE configs[2]'s arithmetic at this batch: DESIGN.md 4c), same bracketing
     bf16s = None
@@ -871,6 +900,8 @@ def main():
                 kernel_name = f"cn_gemm_{fam}nn_actout_kernel"      # gemm_f32ao.h / gemm_x3ao.h
             elif key.startswith("nn128") and args.precision == 0:
                 kernel_name = "cn_gemm_f32nn128_kernel"             # gemm_f32w128.h
+            if key.split("+")[0].split("[")[0].endswith("p"):
+                kernel_name = "cn_gemm_f32p_kernel"                 # gemm_f32p.h: the persistent kernel
             # traffic.json aggregates every launch of the kernel template (all shapes): a per-launch average
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
                                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
@@ -922,6 +953,10 @@ def main():
                     if v["ms"] / 3 >= 0.05}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(which=args.model)
+        elif world > 1:
+            # (a SCALE record explains itself)
+            out["cpu_baseline"] = None
+            out["cpu_baseline_note"] = "the CPU oracle is timed on rank 0 of the N = 1 line only"
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -213,6 +213,9 @@ static bool gate_stats_launch_ok(const CartnetGemmArgs& a) {
   if (!f32_image_path(q) || choose_bn(a) != 256 || cn_gemm::any_half(a)) return false;
   CartnetGemmArgs f = a;
   if (segments_fold(a)) { f.K *= f.nsegs; f.nsegs = 1; }
+#ifdef CN_EXPERIMENTAL_Q
+  if (a.precision == 0 && cn_gemm::use_f32nnq(f)) return false;     // (launch_variant asks the quad kernel first: no GST code there)
+#endif
   return f.nsegs == 1 && (a.precision == 1 || cn_gemm::use_f32nn128(f));
 }
 
@@ -305,13 +308,19 @@ extern "C" int cartnet_gemm(const CartnetGemmArgs* args, void* stream) {
   // the variant names the kernel that runs: the 128-wide DMA-fed kernel reports tile width 128, the kernels that also
   // write silu(A) set bit 9
   const bool actout = args->a_act_out[0] != nullptr;
-  if (bn == 4 && !actout && f32_image_path(*args) && cn_gemm::use_f32nn128(*args)) bn = 2;
+  if (bn == 4 && !actout && f32_image_path(*args) && cn_gemm::use_f32nn128(*args) &&
+      !(args->nsegs == 1 && cn_gemm::use_f32p(*args)))
+    bn = 2;
   // bit 8: the streamed dimension (rows of an activation x weight product, reduction length of a weight gradient) is
   // edge-sized; bits 10..: the other inner dimension / 16 (K of an NN product, M of a weight gradient), capped
   const long long streamed = args->a_kstrided ? args->K : args->M;
   const int inner = args->a_kstrided ? args->M : args->K;
+  // bit 18: the persistent kernel takes the launch (gemm_f32p.hip; the same predicates launch_variant applies)
+  const bool persistent = bn == 4 && args->nsegs == 1 && args->splitk == 1 && epilogue_rows_aligned(*args) &&
+                          f32_image_path(*args) && cn_gemm::use_f32p(*args);
   r.variant = (args->a_kstrided ? 1 : 0) | (args->b_kstrided ? 2 : 0) | (args->a_act ? 4 : 0) | (args->b_act ? 8 : 0) |
-              (bn << 4) | (streamed >= 32768 ? 256 : 0) | (actout ? 512 : 0) | ((inner > 4080 ? 255 : inner / 16) << 10);
+              (bn << 4) | (streamed >= 32768 ? 256 : 0) | (actout ? 512 : 0) | ((inner > 4080 ? 255 : inner / 16) << 10) |
+              (persistent ? (1 << 18) : 0);
   if (g_prof_only >= 0 && r.variant != g_prof_only) return cartnet_gemm_impl(args, stream);
   if (g_prof_every > 1 && (g_prof_seen++ % g_prof_every) != 0) return cartnet_gemm_impl(args, stream);
   const int nptr = args->ngroups > 1 ? args->ngroups : args->nsegs;

@@ -4,16 +4,38 @@
 
 namespace cn_gemm {
 
-namespace {
-int p_kind(const CartnetGemmArgs& a) {
-  return (a.resid[0] ? 2 : 0) | (a.dact[0] ? 4 : 0) | (a.colsum[0] ? (a.colsq[0] ? 16 : 8) : 0) | (a.cpre[0] ? 32 : 0) |
-         (a.out_act ? 64 : 0) | (a.dact_kind ? 256 : 0);
-}
-
+// One explicit instantiation per compiled form, split over two translation units (each form is ~25 s of hipcc)
 template <bool A_ACT, bool ACT_OUT, int KIND, int NS>
 void p_launch(const CartnetGemmArgs& a, int grid, hipStream_t st) {
   hipLaunchKernelGGL((cn_gemm_f32p_kernel<A_ACT, ACT_OUT, KIND, NS>), dim3(grid), dim3(NTHREADS), 0, st, a,
                      (a.M + BM - 1) / BM);
+}
+#define CN_P_FORMS_A(X)                                                                             \
+  X(false, false, 0, 16)   /* plain (+ bias) */                                                     \
+  X(true, false, 0, 16)    /* silu(A), bias */                                                      \
+  X(true, false, 16, 16)   /* layer GEMM 2: silu(A), bias, BatchNorm statistics */                  \
+  X(true, true, 16, 16)    /* ... + silu(A) written */                                              \
+  X(false, false, 4, 16)   /* dpre: * silu'(pre) */                                                 \
+  X(false, false, 12, 16)  /* ... + bias gradient (column sums): the encoder's dhe, iComformer's dpr */
+#define CN_P_FORMS_B(X)                                                                             \
+  X(true, true, 0, 16)     /* iComformer's second Linears: silu(A), bias, silu(A) written */        \
+  X(false, false, 352, 16) /* iComformer's RBF branches: pre kept, softplus(pre) out */             \
+  X(true, true, 96, 32)    /* the edge encoder's second Linear: K = 512, pre kept, silu out */      \
+  X(false, false, 2, 32)   /* K = 512 (two folded segments) + residual */
+#define CN_P_EXTERN(AA, AO, KD, NSV) extern template void p_launch<AA, AO, KD, NSV>(const CartnetGemmArgs&, int, hipStream_t);
+#define CN_P_DEFINE(AA, AO, KD, NSV) template void p_launch<AA, AO, KD, NSV>(const CartnetGemmArgs&, int, hipStream_t);
+#ifdef CN_P_UNIT_B
+CN_P_FORMS_B(CN_P_DEFINE)
+#else
+CN_P_FORMS_B(CN_P_EXTERN)
+CN_P_FORMS_A(CN_P_DEFINE)
+#endif
+
+#ifndef CN_P_UNIT_B
+namespace {
+int p_kind(const CartnetGemmArgs& a) {
+  return (a.resid[0] ? 2 : 0) | (a.dact[0] ? 4 : 0) | (a.colsum[0] ? (a.colsq[0] ? 16 : 8) : 0) | (a.cpre[0] ? 32 : 0) |
+         (a.out_act ? 64 : 0) | (a.dact_kind ? 256 : 0);
 }
 
 // the compiled forms: (a_act, a_act_out, kind, K / 16)
@@ -21,12 +43,8 @@ typedef void (*PLaunch)(const CartnetGemmArgs&, int, hipStream_t);
 PLaunch p_find(bool a_act, bool act_out, int kind, int ns) {
 #define CN_P(AA, AO, KD, NSV) \
   if (a_act == AA && act_out == AO && kind == KD && ns == NSV) return &p_launch<AA, AO, KD, NSV>;
-  CN_P(false, false, 0, 16)      // plain (+ bias)
-  CN_P(true, false, 0, 16)       // silu(A), bias
-  CN_P(true, false, 16, 16)      // layer GEMM 2: silu(A), bias, BatchNorm statistics
-  CN_P(true, true, 16, 16)       // ... + silu(A) written
-  CN_P(false, false, 4, 16)      // dpre: * silu'(pre)
-  CN_P(false, false, 12, 16)     // ... + bias gradient (column sums): the encoder's dhe
+  CN_P_FORMS_A(CN_P)
+  CN_P_FORMS_B(CN_P)
 #undef CN_P
   return nullptr;
 }
@@ -72,9 +90,11 @@ void launch_f32p(const CartnetGemmArgs& a, hipStream_t st) {
   f(a, 256, st);
 }
 
+#endif  // CN_P_UNIT_B
+
 }  // namespace cn_gemm
 
-#ifdef CN_P_STAMP
+#if defined(CN_P_STAMP) && !defined(CN_P_UNIT_B)
 // diagnostic build: the per-workgroup, per-tile stamps of the last launch (256 x 16 x 4 64-bit words)
 extern "C" int cartnet_debug_p_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cn_gemm::cn_p_dbg), sizeof(unsigned long long) * 256 * 16 * 4);

@@ -61,10 +61,22 @@ inline bool gate_sums_fused(const CartnetModel& m, int G, int tiles_e, long long
 #ifdef CN_NO_GATE_FUSE      /* A/B builds only (tools/build_variant.sh): the statistics pass of rounds 1-4 */
   return false;
 #endif
-  // (the DMA-fed kernels address their A operand with 32-bit byte offsets: E * 2D * 4 < 2^32)
-  return m.gemm_precision <= 1 && m.D == 256 && G == 1 && tiles_e >= (m.gemm_precision == 0 ? 64 : 96) && m.half_storage == 0 &&
-         m.bn_allreduce == nullptr &&
-         (double)E * 2 * m.D * 4.0 < 4294967296.0;
+  if (!(m.gemm_precision <= 1 && G == 1 && m.half_storage == 0 && m.bn_allreduce == nullptr && E > 0)) return false;
+  // ONE predicate for "the dE product takes the kernel with the epilogue" (ADVICE r5): the launch cartnet_model_backward
+  // will build (same shapes, strides and flags; placeholder pointers with the alignment the workspace guarantees) is put
+  // to gemm.hip's own cartnet_gemm_gate_stats_ok -- forward commits to the per-target sums here, backward checks again.
+  (void)tiles_e;
+  const int D = m.D;
+  float* const ph = reinterpret_cast<float*>(uintptr_t(1) << 20);
+  CartnetGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = (int)E; a.N = D; a.K = D; a.lda = 2 * D; a.ldb = 3 * D; a.ldc = D; a.ldr = D;
+  a.ngroups = 1; a.nsegs = 2; a.splitk = 1; a.b_kstrided = 1; a.precision = m.gemm_precision;
+  a.A[0] = ph; a.A[1] = ph + D; a.B[0] = ph; a.B[1] = ph; a.C[0] = ph; a.resid[0] = ph;
+  a.b_split_folded = ph;
+  a.gst_g = ph; a.gst_ld = 2 * D; a.gst_env = ph; a.gst_mean_rstd = ph; a.gst_gamma = ph; a.gst_beta = ph;
+  a.colsum[0] = reinterpret_cast<double*>(ph); a.colsq[0] = reinterpret_cast<double*>(ph);
+  return E < (1ll << 31) && cartnet_gemm_gate_stats_ok(&a) == 1;
 }
 
 Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_bwd, char* base, size_t* total) {
@@ -885,13 +897,14 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
     };
     // node-side halves: reduce dpre over each atom's incoming (target) and outgoing (source) edges
     auto segsums = [&](void* s_) -> int {
-#ifndef CN_NO_SEG_PAIR      /* (A/B builds: the two launches of rounds 1-4) */
+#ifndef CN_NO_SEG_PAIR
       if (!half) return cartnet_segment_sum_pair(dpre, 2 * D, w.rowptr, w.colptr, w.perm, N, 2 * D, dPn, dPn + 2 * D, 4 * D, 256, s_);
       return cartnet_segment_sum_pair_h(dpre, 2 * D, w.rowptr, w.colptr, w.perm, N, 2 * D, dPn, dPn + 2 * D, 4 * D, 256, s_);
-#endif
+#else                       /* (A/B builds: the two launches of rounds 1-4) */
       RUN((half ? cartnet_segment_sum_h : cartnet_segment_sum_f)(dpre, 2 * D, w.rowptr, nullptr, N, 2 * D, dPn, 4 * D, s_));
       return (half ? cartnet_segment_sum_h : cartnet_segment_sum_f)(dpre, 2 * D, w.colptr, w.perm, N, 2 * D, dPn + 2 * D,
                                                                     4 * D, s_);
+#endif
     };
     auto side_wn = [&]() -> int {   // bias gradients of the first Linears = column sums of the by-target half of dPn; node blocks
       double* parts[2] = {w.pc[par], w.pd[par]};      // the second Linears' bias sums were finalised above (same stream)

@@ -42,9 +42,11 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
             backend = os.environ.get("CARTNET_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        # A rank that never arrives must not hang the others for torch's default 10 / 30 minutes: the rendezvous and every
-        # collective give up after CARTNET_DIST_TIMEOUT seconds (default 300) and the process exits non-zero.
-        timeout = datetime.timedelta(seconds=float(os.environ.get("CARTNET_DIST_TIMEOUT", "300")))
+        # The rendezvous and every collective give up after CARTNET_DIST_TIMEOUT seconds and the process exits non-zero.
+        # Default 1800 s = torch's own for RCCL: a training job has legitimate rank skew of minutes (rank 0 writing a
+        # checkpoint or evaluating while the others wait in the next epoch's first all-reduce, uneven shard preprocessing, a
+        # first-use build of the library); bench.py, where a rank that never arrives must not hold the box, sets 300.
+        timeout = datetime.timedelta(seconds=float(os.environ.get("CARTNET_DIST_TIMEOUT", "1800")))
         if backend == "nccl":
             # the device BEFORE any collective, and named to the process group: RCCL then builds its communicator for this
             # device at once (a bad rank -> device map fails here, not at the first all-reduce) and never has to guess

@@ -34,9 +34,10 @@ def profile_gemm_read() -> dict:
     out = {}
     for i in range(n):
         v = buf[i].variant
-        name = ("tn" if v & 1 else ("nn" if v & 2 else "nt")) + str(64 * ((v >> 4) & 15)) + \
+        # bit 18: the persistent kernel (csrc/gemm_f32p.h) took the launch
+        name = ("tn" if v & 1 else ("nn" if v & 2 else "nt")) + str(64 * ((v >> 4) & 15)) + ("p" if v & (1 << 18) else "") + \
             ("+silu(A)" if v & 4 else "") + ("+out" if v & 512 else "") + ("+silu(B)" if v & 8 else "") + \
-            (f"[{'E' if v & 256 else 'N'}-rows,{'M' if v & 1 else 'K'}={16 * (v >> 10)}]")
+            (f"[{'E' if v & 256 else 'N'}-rows,{'M' if v & 1 else 'K'}={16 * ((v >> 10) & 255)}]")
         out[name] = {"launches": int(buf[i].launches), "flops": float(buf[i].flops), "ms": float(buf[i].ms),
                      "variant": int(v)}
     return out
@@ -220,6 +221,9 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
             getattr(args, field)[g] = t.data_ptr()
     if gate_stats is not None:
         gg, genv, gmr, ggam, gbet = gate_stats
+        for nm, t in (("g", gg), ("mean_rstd", gmr), ("gamma", ggam), ("beta", gbet)):      # only env may be None
+            if t is None:
+                raise ValueError(f"gemm gate_stats {nm}: required (only env may be None)")
         _f32_2d(gg, "gemm gate_stats g")
         if tuple(gg.shape) != (M, N):
             raise ValueError(f"gemm gate_stats g: expected shape {(M, N)}, got {tuple(gg.shape)}")
@@ -231,7 +235,8 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
         args.gst_mean_rstd, args.gst_gamma, args.gst_beta = gmr.data_ptr(), ggam.data_ptr(), gbet.data_ptr()
         if not lib.cartnet_gemm_gate_stats_ok(C.byref(args)):
             raise ValueError("gemm gate_stats: this launch does not reach the kernel with the gate-statistics epilogue "
-                             "(precision 0, N = 256, weight image, resid + colsum + colsq only, >= 64 row tiles)")
+                             "(precision 0 / 1, N = 256, weight image, resid + colsum + colsq only, >= 64 row tiles; g, "
+                             "mean_rstd, gamma, beta 16-byte aligned and g's row stride a multiple of 4 elements)")
     _l.check(lib.cartnet_gemm(C.byref(args), _l.stream_ptr()), "cartnet_gemm")
 
 

@@ -232,14 +232,15 @@ def _train_epoch(loader, model, optimizer, batch_accumulation, scheduler, device
                     for lo, hi in model.grad_bucket_order():
                         sync.bucket(lo, hi)
                 seen, sync.buckets_seen = sync.buckets_seen, 0
-                if seen == n_buckets:
-                    scale = sync.finish()
-                elif seen == 0:                     # backward did not report (a path that bypasses the bucketed call):
-                    sync.finish()                   # nothing is in flight; one flat all-reduce, as before round 4
-                    scale = cdist.all_reduce_gradients(optimizer.flat_grad)
-                else:
-                    raise RuntimeError(f"gradient buckets: backward reported {seen} of {n_buckets} -- the all-reduce of "
-                                       "this step would be partial and the ranks would diverge")
+                # The collective sequence of a step is a STATIC property of the run: with `sync` every rank issues exactly the
+                # n_buckets bucket all-reduces (a rank without crystals issued them above).  A rank that chose a different
+                # sequence on its own -- one flat all-reduce because its backward reported nothing -- would pair collectives
+                # of different sizes with its peers' (ADVICE r5): any other count is an error on this rank, at once.
+                if seen != n_buckets:
+                    raise RuntimeError(f"gradient buckets: backward reported {seen} of {n_buckets} -- the all-reduces of "
+                                       "this step would not match the other ranks' (a backward that bypasses "
+                                       "cartnet_model_backward's bucket callbacks cannot be combined with GradSync)")
+                scale = sync.finish()
             else:
                 scale = cdist.all_reduce_gradients(optimizer.flat_grad) if hasattr(optimizer, "flat_grad") else 1.0
             optimizer.step(scale) if hasattr(optimizer, "flat_grad") else optimizer.step()

@@ -173,3 +173,48 @@ def test_the_library_picks_it_for_the_model_sized_launches_only(ops):
         c, _ = _run(ops, 256, M, 2, D, "stats", seed=9)
         for k in ("out", "cs", "cq"):
             assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k])
+
+
+@pytest.mark.parametrize("M", [300, 128 * 257, 89500])
+def test_forms_of_the_second_unit(ops, M):
+    """csrc/gemm_f32p2.hip: silu(A) written without statistics, the softplus family with the pre-activation kept (iComformer's
+    RBF branches), and the two K = 512 forms (32 K-steps per tile, slices on the first 16): all bit for bit the shipped
+    kernels' results, and 1e-5 of an fp64 evaluation."""
+    import torch.nn.functional as F
+    A = rnd(M, 2 * D, seed=41)
+    W = [rnd(D, D, seed=42 + g, scale=0.06) for g in range(2)]
+    bias = [rnd(D, seed=44 + g) for g in range(2)]
+    img = ops.pack_b(W)
+    Av = [A[:, :D], A[:, D:]]
+    W512 = rnd(2 * D, D, seed=46, scale=0.05)
+    img512 = ops.pack_b([W512])
+    Wseg = [rnd(D, D, seed=47 + g, scale=0.06) for g in range(2)]
+    img_fold = torch.cat(ops.pack_b(Wseg))
+    resid = rnd(M, D, seed=49)
+    res = {}
+    for pol in (3, 256):
+        o = {k: torch.full((M, 2 * D), float("nan"), device=dev()) for k in ("c1", "h1", "c2", "p2", "c3", "h3", "c4")}
+        ops.gemm(Av, W, [o["c1"][:, :D], o["c1"][:, D:]], b_kstrided=True, b_split=img, a_act=True, bias=bias,
+                 a_act_out=[o["h1"][:, :D], o["h1"][:, D:]], tile_policy=pol)
+        ops.gemm(Av, W, [o["c2"][:, :D], o["c2"][:, D:]], b_kstrided=True, b_split=img, bias=bias,
+                 cpre=[o["p2"][:, :D], o["p2"][:, D:]], out_act=True, dact_kind=1, tile_policy=pol)
+        ops.gemm(A, W512, o["c3"][:, :D], b_kstrided=True, b_split=img512, a_act=True, out_act=True, bias=bias[0],
+                 cpre=o["c3"][:, D:], a_act_out=o["h3"], tile_policy=pol)
+        ops.gemm(Av, Wseg, o["c4"][:, :D], b_kstrided=True, segments=True, resid=resid, b_split_folded=img_fold,
+                 tile_policy=pol)
+        torch.cuda.synchronize()
+        res[pol] = o
+    for k in res[3]:
+        a, b = res[3][k], res[256][k]
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), k
+        assert torch.equal(a.nan_to_num(nan=0.5), b.nan_to_num(nan=0.5)), f"M={M}: {k} differs from the shipped kernel"
+    A64 = A.double()
+    v1 = torch.cat([silu64(A64[:, g * D:(g + 1) * D]) @ W[g].double() + bias[g].double() for g in range(2)], 1)
+    assert rel_err(res[3]["c1"], v1) < TOL and rel_err(res[3]["h1"], silu64(A64)) < TOL
+    v2 = torch.cat([A64[:, g * D:(g + 1) * D] @ W[g].double() + bias[g].double() for g in range(2)], 1)
+    assert rel_err(res[3]["p2"], v2) < TOL and rel_err(res[3]["c2"], F.softplus(v2)) < TOL
+    v3 = silu64(A64) @ W512.double() + bias[0].double()
+    assert rel_err(res[3]["c3"][:, D:], v3) < TOL and rel_err(res[3]["c3"][:, :D], silu64(v3)) < TOL
+    assert rel_err(res[3]["h3"], silu64(A64)) < TOL
+    v4 = A64[:, :D] @ Wseg[0].double() + A64[:, D:] @ Wseg[1].double() + resid.double()
+    assert rel_err(res[3]["c4"][:, :D], v4) < TOL

@@ -121,8 +121,9 @@ def test_train_step_at_the_benchmark_batch_against_the_fp64_oracle(bench_batch_o
     # flip moves every gradient by ~1e-5 of the largest entry -- a property of the loss, not of the kernels (the fp32-MFMA and
     # bf16x3 passes flip different elements).  The backward pass is therefore driven with the ORACLE's subgradient: the same
     # MAE gradient wherever the two agree on the sign, and the comparison below measures arithmetic only.
-    sgn = torch.sign(ref["pred"] - batch.y.double()).float().to(pred.device) / pred.numel()
-    flips = int((torch.sign(pred.detach() - true) != sgn * pred.numel()).sum())
+    sg1 = torch.sign(ref["pred"] - batch.y.double()).float().to(pred.device)
+    sgn = sg1 / pred.numel()
+    flips = int((torch.sign(pred.detach() - true) != sg1).sum())
     (pred * sgn).sum().backward()
     assert flips <= 8, flips
     assert int(b.edge_index.shape[1]) > 170_000
@@ -146,8 +147,71 @@ def test_train_step_at_the_benchmark_batch_against_the_fp64_oracle(bench_batch_o
     print(f"precision {precision}: pred err {rel_err(pred, ref['pred']):.2e}, {flips} L1 sign flips; largest gradient errors / max|g|: " +
           ", ".join(f"{k} {e:.1e}" for e, k in reversed(worst)))
     _check_grads(got, ref["grads"], f"benchmark batch, precision {precision}")
+    # (measured 2.5e-6 here -- at this batch the bound is north_star's 1e-5, not the model tests' 3e-5)
+    assert worst[-1][0] <= 1e-5, worst[-1]
     gmax = max(v.abs().max().item() for v in ref["grads"].values())
     for k, r in ref["grads"].items():
         g = got[k].detach().double().cpu()
         assert abs(g.norm().item() - r.norm().item()) <= 1e-4 * max(r.norm().item(), 1e-2 * gmax), k
-        assert (g.flatten()[:64] - r.flatten()[:64]).abs().max().item() <= 3e-5 * gmax, k
+        assert (g.flatten()[:64] - r.flatten()[:64]).abs().max().item() <= 1e-5 * gmax, k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same for iComformer (BASELINE configs[4]): C = 256 on ADP-shaped crystals against the fp64 oracle
+# with a checkpoint around each layer (tests/oracle_large.py).  The edge-update layer's interior is a dozen [E, 3, C] fp64
+# tensors: at the benchmark batch (64 crystals, E ~ 177k) the oracle pass needs ~60 GB of host memory and runs where that
+# much is free; otherwise 16 crystals (E ~ 44k, 3E ~ 133k attention rows, ~15 GB) -- still 20x the largest oracle
+# comparison of tests/test_gpu_icomformer.py.
+@pytest.fixture(scope="module")
+def icomformer_large_oracle():
+    import psutil
+    from cartnet_amd.comformer import make_icomformer_state_dict
+    from cartnet_amd.data import Batch
+    from cartnet_amd.synthetic import make_crystal
+    import oracle_large
+    free = psutil.virtual_memory().available
+    if free < 30 * 2 ** 30:
+        pytest.skip("the fp64 iComformer oracle pass needs ~15 GB of host memory; less than 30 GB are free")
+    n = 64 if free > 120 * 2 ** 30 else 16
+    batch = Batch.from_data_list([make_crystal(7000 + g, 194) for g in range(n)])
+    sd = make_icomformer_state_dict(256, seed=23)
+    ref = oracle_large.icomformer_train_step_fp64(sd, batch)
+    print(f"fp64 iComformer oracle at {n} crystals, N={batch.x.shape[0]} E={batch.edge_index.shape[1]}: {ref['seconds']:.1f} s "
+          f"on {torch.get_num_threads()} threads")
+    return sd, batch, ref
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_icomformer_train_step_at_adp_size_against_the_fp64_oracle(icomformer_large_oracle, precision):
+    from cartnet_amd.comformer import iComformer
+    from test_gpu_model import _check_grads
+    sd, batch, ref = icomformer_large_oracle
+    m = iComformer(256)
+    m.load_state_dict(sd)
+    m.gemm_precision = precision
+    m = m.to("cuda:0").train()
+    b = batch.clone()
+    b.num_graphs = batch.num_graphs
+    pred, true = m(b.to("cuda:0"))
+    # the oracle's L1 subgradient drives the backward pass (see the CartNet test above): arithmetic only
+    sg1 = torch.sign(ref["pred"] - batch.y.double()).float().to(pred.device)
+    sgn = sg1 / pred.numel()
+    flips = int((torch.sign(pred.detach() - true) != sg1).sum())
+    (pred * sgn).sum().backward()
+    assert flips <= 8, flips
+    assert rel_err(pred, ref["pred"]) < 1e-5
+    st = m.state_dict()
+    for k, v in ref["new_stats"].items():
+        got = st[k].cpu()
+        if v.is_floating_point():
+            assert torch.allclose(got.double(), v.double(), rtol=2e-5, atol=1e-7), k
+        else:
+            assert int(got) == int(v), k
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    refg = {k: v for k, v in ref["grads"].items() if k in got}
+    assert len(refg) >= 100
+    gmax = max(v.abs().max().item() for v in refg.values())
+    worst = sorted(((got[k].detach().double().cpu() - r).abs().max().item() / gmax, k) for k, r in refg.items())[-6:]
+    print(f"iComformer precision {precision}: pred err {rel_err(pred, ref['pred']):.2e}, {flips} L1 sign flips; largest gradient "
+          f"errors / max|g|: " + ", ".join(f"{k} {e:.1e}" for e, k in reversed(worst)))
+    _check_grads(got, refg, f"iComformer at ADP size, precision {precision}")

@@ -30,6 +30,8 @@ T = lambda w: w.t().contiguous()
 W2gT, W2aT = T(W2g), T(W2a)
 img_gs = ops.pack_b([W2gT, W2aT]); img_dpre = ops.pack_b([W2g, W2a])
 Wd = rnd(D, 2 * D, sc=0.05); img_dhe = ops.pack_b([Wd])
+We2T = rnd(2 * D, D, sc=0.05); img_e2 = ops.pack_b([We2T])
+img_fold = torch.cat(ops.pack_b([W2g, W2a]))
 tiles = ops.gemm_tiles_m(E)
 F = 2.0 * E * D * D * 2
 
@@ -59,10 +61,22 @@ def form(name, o, pol):
                  tile_policy=pol)
     elif name == "dhe":       # the encoder's dhe form: * silu'(pre) + bias gradient (fp32 column sums), one group of N = 512
         ops.gemm(gs[:, :D], Wd, o["out"], b_kstrided=True, b_split=img_dhe, dact=pre, colsum=o["cs2"], tile_policy=pol)
+    elif name == "act_actout":      # iComformer's second Linears: silu(A), bias, silu(A) written, no statistics
+        ops.gemm([pre[:, :D], pre[:, D:]], [W2gT, W2aT], out, b_kstrided=True, b_split=img_gs, a_act=True, bias=[b2g, b2a],
+                 a_act_out=[o["act"][:, :D], o["act"][:, D:]], tile_policy=pol)
+    elif name == "rbf352":          # iComformer's RBF branch: pre kept, softplus(pre) out (dact_kind = 1), two groups here
+        ops.gemm([gs[:, :D], gs[:, D:]], [W2gT, W2aT], out, b_kstrided=True, b_split=img_gs, bias=[b2g, b2a],
+                 cpre=[o["act"][:, :D], o["act"][:, D:]], out_act=True, dact_kind=1, tile_policy=pol)
+    elif name == "enc2":            # the edge encoder's second Linear: K = 512, N = 256, silu(A), pre kept, silu out, silu(A) written
+        ops.gemm(pre, We2T, o["out"][:, :D], b_kstrided=True, b_split=img_e2, a_act=True, out_act=True, bias=b2g,
+                 cpre=o["out"][:, D:], a_act_out=o["act"], tile_policy=pol)
+    elif name == "k512resid":       # two folded K-segments + residual (iComformer's d(rows) products; CartNet's dE without statistics)
+        ops.gemm([pre[:, :D], pre[:, D:]], [W2g, W2a], o["out"][:, :D], b_kstrided=True, segments=True, resid=gs[:, :D],
+                 b_split_folded=img_fold, tile_policy=pol)
     else:
         raise SystemExit(f"unknown form {name}")
 
-forms = ["plain", "bias", "act", "stats", "stats_actout", "dpre", "dhe"]
+forms = ["plain", "bias", "act", "stats", "stats_actout", "dpre", "dhe", "act_actout", "rbf352", "enc2", "k512resid"]
 for name in forms:
     if only and name not in only:
         continue
@@ -77,8 +91,8 @@ for name in forms:
             if not torch.isnan(b).all():
                 msg.append(f"{k}: WRITTEN by the new kernel only")
             continue
-        same = torch.equal(a, b)
-        nan_new = int(torch.isnan(b).sum())
+        same = torch.equal(a.nan_to_num(nan=12345.0), b.nan_to_num(nan=12345.0))      # (unwritten parts stay NaN in both)
+        nan_new = int(torch.isnan(b).sum()) - int(torch.isnan(a).sum())
         err = float((a - b).abs().nan_to_num(nan=float("inf")).max())
         msg.append(f"{k}: {'bitwise equal' if same else f'DIFFERENT max|d|={err:.3e} nan_new={nan_new}'}")
     print(f"== {name}: " + "; ".join(msg), flush=True)

@@ -65,6 +65,15 @@ def analyse(fpath, wpath, verbose=True):
                 v["fetch"] += fetch * n
                 v["write"] += write * n
                 continue
+            # gemm_f32p.h (round 6): the persistent kernel <A_ACT, ACT_OUT, KIND, NS> -> bench.py's "nn256p..." keys
+            m6 = re.match(r"cn_gemm::cn_gemm_f32p_kernel<(\w+), (\w+), (\d+), (\d+)>", name)
+            if m6:
+                key = "nn256p" + ("+silu(A)" if m6.group(1) == "true" else "") + ("+out" if m6.group(2) == "true" else "")
+                v = variants["fp32"].setdefault(key, {"launches_profiled": 0, "fetch": 0.0, "write": 0.0})
+                v["launches_profiled"] += n
+                v["fetch"] += fetch * n
+                v["write"] += write * n
+                continue
             m4 = re.match(r"cn_gemm::cn_gemm_f32nn128_kernel<(\w+)(?:, \d+)?>", name)
             if m4 or name == "cn_gemm::cn_gemm_f32nn_actout_kernel":
                 key = ("nn128" + ("+silu(A)" if m4.group(1) == "true" else "")) if m4 else "nn256+silu(A)+out"
