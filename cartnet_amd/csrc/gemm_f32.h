@@ -214,6 +214,10 @@ namespace cn_gemm {
 //     s_barrier            everybody's have, and everybody is done reading stage (u+2) % 3 (used by step u-1)
 //     issue the DMA of step u+2 into that stage; read the fragments of step u; 32 MFMAs.
 // SiLU on the B operand is applied to the fragments (v_exp / v_rcp in the shadow of the 64-cycle MFMAs).
+// an LDS dword through a 32-bit address in ONE register + a constant the compiler folds into the instruction's offset field
+__device__ __forceinline__ float cn_lds_ld1(unsigned addr) {
+  return *reinterpret_cast<__attribute__((address_space(3))) float*>((unsigned long)addr);
+}
 constexpr int F32T_A_BYTES = BK * BM * 4;          // 8 KB
 constexpr int F32T_B_BYTES = BK * F32_BN * 4;      // 16 KB
 constexpr int F32T_STAGE = F32T_A_BYTES + F32T_B_BYTES;
@@ -223,6 +227,13 @@ constexpr int F32T_STAGE = F32T_A_BYTES + F32T_B_BYTES;
 #define CN_TN_STAGES 4
 #endif
 constexpr int F32T_NSTAGE = CN_TN_STAGES;
+
+#ifdef CN_TN_STAMP
+// Diagnostic build (tools/exp_tn_stamps.py): per workgroup [main-loop shader cycles, 100 MHz ticks, K-steps, 0] and per wave
+// [cycles in the counted wait, cycles in the barrier]; nothing else reads the buffers.
+static __device__ unsigned long long cn_tn_dbg[1024 * 4];
+static __device__ unsigned long long cn_tn_dbg_wave[1024 * 8 * 2];
+#endif
 
 template <bool B_ACT>
 __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const CartnetGemmArgs p, const GemmFlags fl) {
@@ -326,12 +337,104 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
     frags(0, 1);
     __builtin_amdgcn_sched_barrier(0);
     mma16(0);
-    for (int u = 0; u + 1 < nsteps; ++u) {
+#ifdef CN_TN_STAMP
+    unsigned long long st_w = 0, st_b = 0;
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // Steady state unrolled by four (round 6): with the stage index a compile-time constant every fragment read is ONE
+    // ds_read2st64_b32 off one of eight base registers (offsets in units of 256 B: k and k + 2 of one 32-row block) and every
+    // DMA destination an immediate -- the rolled loop below recomputed 24 LDS addresses in vector instructions per K-step (on
+    // an fp32 MFMA loop they are not free: 4,695 cycles per K-step measured, tools/exp_tn_stamps.py) and took five scalar
+    // branches.  It keeps the head, the tail and K ranges too short for this one.
+    unsigned fbA[2][2], fbB[2][2];       // [block][stages 2-3]
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int hi = 0; hi < 2; ++hi) {
+        fbA[x][hi] = lds0 + hi * 2 * F32T_STAGE + lh * (BM * 4) + (wm * S::WM + x * 32 + li) * 4;
+        fbB[x][hi] = lds0 + hi * 2 * F32T_STAGE + F32T_A_BYTES + lh * (F32_BN * 4) + (wn * S::WN + x * 32 + li) * 4;
+        asm volatile("" : "+v"(fbA[x][hi]), "+v"(fbB[x][hi]));
+      }
+    auto frags_c = [&](auto st_c, auto kg_c) {
+      constexpr int ST = decltype(st_c)::value, KG = decltype(kg_c)::value;
+      static_assert(F32T_NSTAGE == 4, "four stages: two base registers per block");
+      constexpr int OST = (ST & 1) * F32T_STAGE;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)               // k = KG*8 + 2j + lh (lh is in the base register)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          af[KG][x][j] = cn_lds_ld1(fbA[x][ST >> 1] + (OST + (KG * 8 + 2 * j) * (BM * 4)));
+          bf[KG][x][j] = cn_lds_ld1(fbB[x][ST >> 1] + (OST + (KG * 8 + 2 * j) * (F32_BN * 4)));
+        }
+    };
+    // DMA of tile v into stage ST: the three pieces of issue() with immediate LDS destinations
+    auto issue_c = [&](int v, auto st_c) {
+      constexpr int ST = decltype(st_c)::value;
+      const float* sa = a_base + v * a_step;
+      const float* sb = b_base + v * b_step;
+      const float* sb2 = sb + b_half;
+      const unsigned lw = lds0 + wid * 1024, va = a_voff, vb = b_voff;    // (asm operands alone do not capture in a generic lambda)
+      asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   :: "s"(lw), "v"(va), "s"(sa), "n"(ST * F32T_STAGE) : "memory", "m0", "scc");
+      asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   :: "s"(lw), "v"(vb), "s"(sb), "n"(ST * F32T_STAGE + F32T_A_BYTES) : "memory", "m0", "scc");
+      asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   :: "s"(lw), "v"(vb), "s"(sb2), "n"(ST * F32T_STAGE + F32T_A_BYTES + 8192) : "memory", "m0", "scc");
+    };
+    // one steady-state iteration (tile u -> u + 1; there are tiles u + 2 and u + 3): the rolled loop's body with constants
+    auto iter_c = [&](int u, auto c_c) {
+      constexpr int Cc = decltype(c_c)::value;           // u % 4 (u = 4 i + Cc)
       __builtin_amdgcn_sched_barrier(0);
-      if (u + 2 < nsteps) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef CN_TN_STAMP
+      const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#endif
+      asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+#ifdef CN_TN_STAMP
+      const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();
+#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifdef CN_TN_STAMP
+      const unsigned long long st_t2 = __builtin_amdgcn_s_memtime();
+      st_w += st_t1 - st_t0;
+      st_b += st_t2 - st_t1;
+#endif
+      frags_c(std::integral_constant<int, (Cc + 1) & 3>{}, std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      issue_c(u + 3, std::integral_constant<int, (Cc + 3) & 3>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma16(1);
+      __builtin_amdgcn_sched_barrier(0);
+      frags_c(std::integral_constant<int, (Cc + 1) & 3>{}, std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma16(0);
+    };
+    int u = 0;
+#ifndef CN_TN_ROLLED
+    for (; u + 7 <= nsteps; u += 4) {           // every (u + c) + 3 < nsteps
+      iter_c(u, std::integral_constant<int, 0>{});
+      iter_c(u + 1, std::integral_constant<int, 1>{});
+      iter_c(u + 2, std::integral_constant<int, 2>{});
+      iter_c(u + 3, std::integral_constant<int, 3>{});
+    }
+#endif
+    for (; u + 1 < nsteps; ++u) {
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef CN_TN_STAMP
+      const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#endif
+      if (u + 2 < nsteps) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef CN_TN_STAMP
+      const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();
+#endif
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#ifdef CN_TN_STAMP
+      const unsigned long long st_t2 = __builtin_amdgcn_s_memtime();
+      st_w += st_t1 - st_t0;
+      st_b += st_t2 - st_t1;
+#endif
       frags(u + 1, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (u + 3 < nsteps) issue(u + 3);
@@ -347,6 +450,20 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // the epilogue reuses the LDS
     asm volatile("" ::: "memory");
+#ifdef CN_TN_STAMP
+    {
+      const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      if (lin < 1024 && lane == 0) {
+        cn_tn_dbg_wave[(lin * 8 + wid) * 2] = st_w;
+        cn_tn_dbg_wave[(lin * 8 + wid) * 2 + 1] = st_b;
+        if (wid == 0) {
+          cn_tn_dbg[lin * 4] = __builtin_amdgcn_s_memtime() - st_c0;
+          cn_tn_dbg[lin * 4 + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+          cn_tn_dbg[lin * 4 + 2] = (unsigned long long)nsteps;
+        }
+      }
+    }
+#endif
   }
 
   if (p.splitk > 1) {   // raw partial slab

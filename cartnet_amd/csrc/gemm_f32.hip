@@ -98,3 +98,11 @@ extern "C" int cartnet_debug_phase_f32(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cn_gemm::cn_phase_dbg), sizeof(unsigned long long) * 8 * 8192);
 }
 #endif
+
+#ifdef CN_TN_STAMP
+// diagnostic build: the weight-gradient kernel's stamps of the last launch
+extern "C" int cartnet_debug_tn_stamps(unsigned long long* wg, unsigned long long* waves) {
+  if (hipMemcpyFromSymbol(wg, HIP_SYMBOL(cn_gemm::cn_tn_dbg), sizeof(unsigned long long) * 1024 * 4) != hipSuccess) return 1;
+  return (int)hipMemcpyFromSymbol(waves, HIP_SYMBOL(cn_gemm::cn_tn_dbg_wave), sizeof(unsigned long long) * 1024 * 8 * 2);
+}
+#endif

@@ -88,7 +88,8 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
     Shapes: A [M,K] (or [K,M] if a_kstrided), B [N,K] (or [K,N] if b_kstrided), C [M,N]
     (for splitk > 1: C is [splitk*M, N] contiguous slabs).
     ``a_act_out`` (with ``a_act`` and ``b_split`` at precision 0): tensors shaped and strided like A that receive silu(A).
-    ``tile_policy``: CartnetGemmArgs.tile_policy (0 automatic; 1 narrow tiles for grouped N = 256 products too; 128 / 256 force).
+    ``tile_policy``: CartnetGemmArgs.tile_policy (0 automatic; 1 narrow tiles for grouped N = 256 products too; 3 the persistent
+    kernel wherever it has the form; 128 / 256 force a tile kernel).
     ``gate_stats`` = (g [M, N] (a column block of a wider matrix is fine), env [M] or None, mean_rstd [2N], gamma [N],
     beta [N]): CartnetGemmArgs.gst_* -- colsum / colsq then receive the partial sums of v w and v w ghat (see the header);
     raises unless the launch reaches the kernel that carries that epilogue.

@@ -35,7 +35,7 @@ int cartnet_abi_version(void);
 /* sizeof of every struct below, in header order (CartnetGemmArgs, CartnetShard, CartnetCollated, CartnetGemmProfile,
  * CartnetGroups, CartnetLayerParams, CartnetLayerBuffers, CartnetParams, CartnetModel, CartnetBatch,
  * CartnetGateGemmArgs, CartnetIcfConv, CartnetIcfParams, CartnetIcfModel); returns the number of structs.  A binding checks its mirrors against these when it loads the
- * library, and cartnet_abi_version() against the version it was written for (10: dact_kind closes CartnetGemmArgs, the *_sums / cartnet_att_gate_bwd_apply entry points; 9: gst_* in CartnetGemmArgs (8 also carried seg_*: per-target sums in an epilogue, measured and removed); 7: tile_policy in CartnetGemmArgs,
+ * library, and cartnet_abi_version() against the version it was written for (11: CartnetGemmArgs.tile_policy = 3, the persistent activation x weight kernel; no layout change; 10: dact_kind closes CartnetGemmArgs, the *_sums / cartnet_att_gate_bwd_apply entry points; 9: gst_* in CartnetGemmArgs (8 also carried seg_*: per-target sums in an epilogue, measured and removed); 7: tile_policy in CartnetGemmArgs,
  * aux_stream in cartnet_model_forward, CartnetGateGemmArgs in the size table; cartnet_gemm_tile_policy() is gone). */
 int cartnet_abi_struct_sizes(size_t* out, int32_t capacity);
 
@@ -126,11 +126,15 @@ typedef struct CartnetGemmArgs {
   const float* gst_gamma;
   const float* gst_beta;
   int32_t gst_ld;
-  int32_t tile_policy; /* column-tile width of the DMA-fed fp32 activation x weight kernels (precision 0, b_split given).
-                          0: the library's choice per launch (128 x 256 tiles on two workgroups per CU; 128 x 128 on three
-                          for the node-term gather epilogue, for single-group N = 256 products and for launches with few
-                          tiles).  1: grouped N = 256 products take the narrow tile too (the iComformer path: -1.8 % per
-                          step; CartNet's two-group layer products lose).  128 / 256: force one kernel (A/B runs). */
+  int32_t tile_policy; /* which DMA-fed fp32 activation x weight kernel takes the launch (precision 0, b_split given).
+                          0: the library's choice per launch -- the PERSISTENT kernel (one workgroup per CU walks its tiles,
+                          the epilogue of a tile inside the next tile's MFMA chain: csrc/gemm_f32p.h) for K = 256 / 512
+                          launches of at least 4 tiles per CU whose epilogue it has a form for; otherwise 128 x 256 tiles
+                          on two workgroups per CU, or 128 x 128 on three for the node-term gather epilogue, for
+                          single-group N = 256 products and for launches with few tiles.  1: grouped N = 256 products
+                          take the narrow tile too where the persistent kernel has no form (the iComformer path).
+                          3: the persistent kernel for every launch it has the form for, whatever its size (tests, A/B
+                          runs).  128 / 256: force one of the tile kernels, never the persistent one (A/B runs). */
   int32_t dact_kind;   /* The activation family of the launch's epilogue (dact and out_act).
                           0: v *= silu'(dact) (the SiLU between two Linears, models/cartnet.py:127,136).  1: v *= sigmoid(dact),
                           the derivative of softplus (iComformer's RBF branches, models/comformer.py:93-105: the product that

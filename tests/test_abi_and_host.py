@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(cdll, name), f"{name} is declared in include/cartnet_hip.h but not exported"
     # the ctypes prototypes cover exactly the declared set
     assert sorted(lib.PROTOTYPES) == declared
-    assert lib.load().cartnet_abi_version() == 10 == lib.ABI_VERSION
+    assert lib.load().cartnet_abi_version() == 11 == lib.ABI_VERSION
 
 
 def test_ctypes_mirrors_have_the_c_struct_layouts():
