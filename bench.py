@@ -591,14 +591,17 @@ def main():
         # its own roofline: ONE more step, outside the timed region above, with an event pair on every
         # cartnet_gemm launch; six bf16 MFMA products per fp32 product -> the ceiling is the dense bf16 peak / 6
         x3_roof = None
-        if rank == 0 and not args.no_kernel_timer:
-            bx = fresh()
+        if not args.no_kernel_timer:
+            bx = fresh()                        # (every rank runs the step: it carries the gradient all-reduce)
             torch.cuda.synchronize()
-            ops.profile_gemm(True)
+            if rank == 0:
+                ops.profile_gemm(True)
             step(bx)
             torch.cuda.synchronize()
-            ops.profile_gemm(False)
-            v3 = ops.profile_gemm_read()
+            v3 = None
+            if rank == 0:
+                ops.profile_gemm(False)
+                v3 = ops.profile_gemm_read()
             if v3:
                 peak3 = 2500.0 / 6.0
                 k3 = max(v3, key=lambda k: v3[k]["ms"])

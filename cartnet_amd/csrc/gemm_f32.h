@@ -325,11 +325,12 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
   // land).  (3) 16 MFMAs of k-group 1 of tile u cover the latency of (2).  (4) k-group 1 of tile u + 1, covered by
   // (5) the 16 MFMAs of k-group 0 of tile u + 1.
   if (nsteps > 0) {
-    issue(0);
-    if (nsteps > 1) issue(1);
-    if (nsteps > 2) issue(2);
-    if (nsteps > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    constexpr int PF = F32T_NSTAGE - 1;          // tiles in flight ahead of the one being multiplied
+    static_assert(F32T_NSTAGE >= 4 && F32T_NSTAGE <= 6, "four to six stages");
+#pragma unroll
+    for (int v = 0; v < PF; ++v)
+      if (v < nsteps) issue(v);
+    if (nsteps >= PF) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (PF - 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -346,18 +347,18 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
     // DMA destination an immediate -- the rolled loop below recomputed 24 LDS addresses in vector instructions per K-step (on
     // an fp32 MFMA loop they are not free: 4,695 cycles per K-step measured, tools/exp_tn_stamps.py) and took five scalar
     // branches.  It keeps the head, the tail and K ranges too short for this one.
-    unsigned fbA[2][2], fbB[2][2];       // [block][stages 2-3]
+    constexpr int NHI = (F32T_NSTAGE + 1) / 2;
+    unsigned fbA[2][NHI], fbB[2][NHI];   // [block][pair of stages]
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-      for (int hi = 0; hi < 2; ++hi) {
+      for (int hi = 0; hi < NHI; ++hi) {
         fbA[x][hi] = lds0 + hi * 2 * F32T_STAGE + lh * (BM * 4) + (wm * S::WM + x * 32 + li) * 4;
         fbB[x][hi] = lds0 + hi * 2 * F32T_STAGE + F32T_A_BYTES + lh * (F32_BN * 4) + (wn * S::WN + x * 32 + li) * 4;
         asm volatile("" : "+v"(fbA[x][hi]), "+v"(fbB[x][hi]));
       }
     auto frags_c = [&](auto st_c, auto kg_c) {
       constexpr int ST = decltype(st_c)::value, KG = decltype(kg_c)::value;
-      static_assert(F32T_NSTAGE == 4, "four stages: two base registers per block");
       constexpr int OST = (ST & 1) * F32T_STAGE;
 #pragma unroll
       for (int j = 0; j < 4; ++j)               // k = KG*8 + 2j + lh (lh is in the base register)
@@ -383,12 +384,12 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
     };
     // one steady-state iteration (tile u -> u + 1; there are tiles u + 2 and u + 3): the rolled loop's body with constants
     auto iter_c = [&](int u, auto c_c) {
-      constexpr int Cc = decltype(c_c)::value;           // u % 4 (u = 4 i + Cc)
+      constexpr int Cc = decltype(c_c)::value;           // u % NSTAGE
       __builtin_amdgcn_sched_barrier(0);
 #ifdef CN_TN_STAMP
       const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
 #endif
-      asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(3 * (PF - 2)) : "memory");    // tile u + 1 landed; u + 2 .. stay in flight
 #ifdef CN_TN_STAMP
       const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -399,23 +400,25 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
       st_w += st_t1 - st_t0;
       st_b += st_t2 - st_t1;
 #endif
-      frags_c(std::integral_constant<int, (Cc + 1) & 3>{}, std::integral_constant<int, 0>{});
+      frags_c(std::integral_constant<int, (Cc + 1) % F32T_NSTAGE>{}, std::integral_constant<int, 0>{});
       __builtin_amdgcn_sched_barrier(0);
-      issue_c(u + 3, std::integral_constant<int, (Cc + 3) & 3>{});
+      issue_c(u + PF, std::integral_constant<int, (Cc + PF) % F32T_NSTAGE>{});
       __builtin_amdgcn_sched_barrier(0);
       mma16(1);
       __builtin_amdgcn_sched_barrier(0);
-      frags_c(std::integral_constant<int, (Cc + 1) & 3>{}, std::integral_constant<int, 1>{});
+      frags_c(std::integral_constant<int, (Cc + 1) % F32T_NSTAGE>{}, std::integral_constant<int, 1>{});
       __builtin_amdgcn_sched_barrier(0);
       mma16(0);
     };
     int u = 0;
 #ifndef CN_TN_ROLLED
-    for (; u + 7 <= nsteps; u += 4) {           // every (u + c) + 3 < nsteps
+    for (; u + 2 * F32T_NSTAGE - 1 <= nsteps; u += F32T_NSTAGE) {          // every (u + c) + PF < nsteps
       iter_c(u, std::integral_constant<int, 0>{});
       iter_c(u + 1, std::integral_constant<int, 1>{});
       iter_c(u + 2, std::integral_constant<int, 2>{});
       iter_c(u + 3, std::integral_constant<int, 3>{});
+      if constexpr (F32T_NSTAGE > 4) iter_c(u + 4, std::integral_constant<int, 4>{});
+      if constexpr (F32T_NSTAGE > 5) iter_c(u + 5, std::integral_constant<int, 5>{});
     }
 #endif
     for (; u + 1 < nsteps; ++u) {
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
 #ifdef CN_TN_STAMP
       const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
 #endif
-      if (u + 2 < nsteps) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      if (u + PF <= nsteps) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(3 * (PF - 2)) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifdef CN_TN_STAMP
       const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
 #endif
       frags(u + 1, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (u + 3 < nsteps) issue(u + 3);
+      if (u + PF < nsteps) issue(u + PF);
       __builtin_amdgcn_sched_barrier(0);
       mma16(1);
       __builtin_amdgcn_sched_barrier(0);

@@ -31,7 +31,7 @@ def test_two_ranks_train_in_lockstep(tmp_path):
 
 def test_bench_contract_with_two_ranks(tmp_path):
     """bench.py under the driver's N > 1 launch line (here 2 ranks sharing the card over gloo): rank 0 prints ONE JSON
-    line with the whole-job rate, n_gpus = 2, weak scaling, the roofline object, and no cpu_baseline (N = 1 only)."""
+    line with the whole-job rate, n_gpus = 2, weak scaling, the roofline object, and cpu_baseline: null with a note (N = 1 only)."""
     env = dict(os.environ, CARTNET_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
@@ -44,7 +44,9 @@ def test_bench_contract_with_two_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert d["unit"] == "graphs/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3
-    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1 and "cpu_baseline" not in d
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    # round 6: the N > 1 line says that it has no CPU baseline, and why
+    assert d["cpu_baseline"] is None and "N = 1" in d["cpu_baseline_note"]
     assert d["config"]["parallelism"] == "graph-sharded dp2"
     # round 5: what a multi-rank line says about itself
     assert d["ranks_seen"] == 2 and d["backend"] == "gloo"

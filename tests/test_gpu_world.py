@@ -30,7 +30,7 @@ def test_bench_line_with_four_ranks_on_one_card(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == WORLD and d["config"]["parallelism"] == f"graph-sharded dp{WORLD}" and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - WORLD * 4 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3
-    assert "cpu_baseline" not in d and d["sustained"]["steps"] >= 100 and d["sustained"]["value"] > 0
+    assert d["cpu_baseline"] is None and d["sustained"]["steps"] >= 100 and d["sustained"]["value"] > 0
     assert "telemetry" in d and "calibration" in d and 0 < d["calibration"]["frac"] < 1
 
 
