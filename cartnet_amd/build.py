@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcartnet_hip.so")
-SOURCES = ["abi.hip", "gemm.hip", "gemm_bn256.hip", "gemm_bn128.hip", "gemm_bn64.hip", "gemm_x3.hip", "gemm_x3s.hip", "gemm_f32.hip", "gemm_f32w128.hip", "gemm_f32ao.hip", "gemm_f32p.hip", "gemm_f32p2.hip", "gemm_f32gate.hip", "gemm_x3ao.hip", "gemm_h.hip", "graph_ops.hip", "edge_ops.hip", "node_ops.hip", "optim.hip", "model.hip", "icomformer.hip", "comformer_ops.hip", "equi_ops.hip", "radius_graph.hip", "metrics.hip", "collate.hip"]
+SOURCES = ["abi.hip", "gemm.hip", "gemm_bn256.hip", "gemm_bn128.hip", "gemm_bn64.hip", "gemm_x3.hip", "gemm_x3s.hip", "gemm_f32.hip", "gemm_f32w128.hip", "gemm_f32ao.hip", "gemm_f32p.hip", "gemm_f32p2.hip", "gemm_f32gate.hip", "gemm_x3ao.hip", "gemm_h.hip", "graph_ops.hip", "edge_ops.hip", "node_ops.hip", "optim.hip", "model.hip", "icomformer.hip", "comformer_ops.hip", "equi_ops.hip", "radius_graph.hip", "metrics.hip", "collate.hip", "coop_layer.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # per-source additions (the reason is at the top of the source file)
 # gemm_f32.hip: cn_gemm_f32tn_kernel declares 4 waves per SIMD to cap its registers at 128 (so that a main-stream GEMM

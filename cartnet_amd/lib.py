@@ -267,6 +267,10 @@ PROTOTYPES = {
                                                    c_groups, c_stream]),
     "cartnet_node_update_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p,
                                           c_groups, c_stream]),
+    # prototype (csrc/coop_layer.hip): one cooperative launch for one layer's forward at configs[2] sizes
+    "cartnet_coop_layer_workspace_floats": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "cartnet_coop_layer_fwd": (C.c_int, [C.c_void_p] * 15 + [C.c_int32, C.c_int32, C.c_float] + [C.c_void_p] * 8 +
+                               [C.c_uint32, C.c_void_p, c_stream]),
     "cartnet_node_update_bwd_stats": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p,
                                                 c_f32p, c_groups, c_stream]),
     "cartnet_node_update_bwd_apply": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32,

@@ -891,6 +891,24 @@ int cartnet_icomformer_backward(const CartnetIcfModel* model, const CartnetBatch
 int cartnet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                       float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * PROTOTYPE (not on the model's path): the forward of ONE CartNet layer
+ * (/root/reference/models/cartnet.py:204-274: propagate -> message -> aggregate -> update, training-mode BatchNorm,
+ * envelope on) as ONE cooperative launch for the small batches of BASELINE configs[2] -- 256 workgroups, five phases,
+ * four grid barriers (csrc/coop_layer.hip).  Precision 2 arithmetic (bf16 operands, fp32 accumulate and storage), D = 256,
+ * E <= 16,384, every atom with at least one incoming edge; running statistics are not updated.
+ * wn / w1e / w2: bf16 [4D][D] (gate_i | aggr_i | gate_j | aggr_j rows of MLP_*.0.weight), [2D][D] (its edge columns),
+ * [2D][D] (MLP_gate.2 | MLP_aggr.2); b1 / b2 [2D]; Pn [N,4D], pre / gs [E,2D], e_out [E,D], aggr / x_out [N,D];
+ * work: cartnet_coop_layer_workspace_floats(N, E) floats; bar: 3 x 8 x 32 zeroed words, epoch = launches on it so far;
+ * status: one word, set to 1 if a barrier gave up (results are then invalid).
+ * ---------------------------------------------------------------------------------------------------- */
+size_t cartnet_coop_layer_workspace_floats(int32_t N, int32_t E);
+int cartnet_coop_layer_fwd(const float* x, const float* e, const int32_t* tgt, const int32_t* src, const int32_t* rowptr,
+                           const float* env, const void* wn_bf16, const void* w1e_bf16, const void* w2_bf16, const float* b1,
+                           const float* b2, const float* bn1_w, const float* bn1_b, const float* bn2_w, const float* bn2_b,
+                           int32_t N, int32_t E, float eps, float* Pn, float* pre, float* gs, float* e_out, float* aggr,
+                           float* x_out, float* work, uint32_t* bar, uint32_t epoch, uint32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

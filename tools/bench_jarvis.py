@@ -29,7 +29,11 @@ def step(b):
     loss = compute_loss(pred, true)[0]
     ctrain.backward(loss)
     opt.step(1.0); opt.zero_grad()
-for prec, half in ((0, False), (1, False), (2, False), (2, True)):
+cases = ((0, False), (1, False), (2, False), (2, True))
+if os.environ.get("JARVIS_ONLY"):          # e.g. JARVIS_ONLY=2,0: precision 2, fp32 storage only (tools/exp_small_batch_layer.sh)
+    pr, hf = os.environ["JARVIS_ONLY"].split(",")
+    cases = ((int(pr), hf == "1"),)
+for prec, half in cases:
     model.gemm_precision = prec
     model.half_storage = half
     bs = [fresh() for _ in range(25)]
