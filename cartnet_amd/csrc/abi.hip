@@ -12,7 +12,7 @@ void cartnet_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cartnet_last_error(void) { return g_err; }
-extern "C" int cartnet_abi_version(void) { return 11; }
+extern "C" int cartnet_abi_version(void) { return 12; }
 
 // sizeof of the structs that cross the ABI, in the order of the header: a binding in another language (ctypes here)
 // compares them with its own mirrors at load time instead of finding a layout mismatch as a GPU fault.

@@ -33,6 +33,10 @@
 //   MFMA (1,0)   slice u of the PREVIOUS tile: arithmetic, * 2 stores
 //   MFMA (1,1)   * 2 stores      MFMA (1,2)  [column statistics to LDS]     MFMA (1,3)
 //   s_waitcnt vmcnt(N(u)) lgkmcnt(0); s_barrier
+// The gather form (KIND & 1: the layer's first product, v += node terms of the edge's two atoms) has two operands per value:
+// 8 row-gathering DMAs per slice, issued TWO steps ahead and BEFORE the step's tile DMAs, into a three-slot ring (48 KB; a
+// fourth slot would not fit), whose slot index therefore rotates at run time; the tile's atom indices arrive by two DMAs at
+// its step 0 in a wave-private, double-buffered 1 KB of LDS.
 // Measured (profiles/r06_exp_f32p_*.txt): 4,380-4,395 cycles per K-step against 4,096 of matrix work (0.935) -- DMA issue
 // ~35, slices ~80, fragment reads ~22, one barrier per step ~150 -- at a clock the chip lowers as the pipe fills (2.28-2.39
 // GHz; 2.19 with the barriers compiled out): the plain two-group layer product 335-352 us against 359-380 (same boxes).
@@ -72,20 +76,29 @@ __device__ __forceinline__ void p_static_for(F&& f) {
   }
 }
 
-// Vector-memory operations of step u of a tile, in issue order: [B DMA x2][A DMA][statistics store (step 0)][EL operand
-// DMAs of slice (u+3) mod NS][silu(A) store][ES stores of slice u].  Slices ride on the first 16 steps of a tile.
-template <int EL, int ES, bool AO, bool STATS, int NS>
+// Vector-memory operations of step u of a tile, in issue order: [B DMA x2][A DMA][statistics store / IX index DMAs (step 0)]
+// [EL operand DMAs of slice (u+LA) mod NS][silu(A) store][ES stores of slice u]; with ELF the operand DMAs come FIRST (the
+// gather form: LA = 2, so they must be among "everything up to the three DMAs" of their step).  Slices ride on the first 16
+// steps of a tile.
+template <int EL, int ES, bool AO, bool STATS, int NS, int LA = 3, bool ELF = false, int IX = 0>
 struct PCount {
-  static constexpr int el_at(int u) { return (((u + 3) % NS) < P_STEPS) ? EL : 0; }
+  static constexpr int el_at(int u) { return (((u + LA) % NS) < P_STEPS) ? EL : 0; }
   static constexpr int es(int u) { return ((u % NS) < P_STEPS) ? ES : 0; }
-  static constexpr int st(int u) { return (STATS && (u % NS) == 0) ? 1 : 0; }
+  static constexpr int st(int u) { return ((u % NS) == 0) ? (STATS ? 1 : 0) + IX : 0; }
   static constexpr int tot(int u) { return 3 + st(u) + el_at(u) + (AO ? 1 : 0) + es(u); }
   // s_waitcnt at the end of step u: everything up to the three DMAs of step u-1 has completed
-  static constexpr int wait_count(int u) { return tot((u + NS - 1) % NS) - 3 + tot(u % NS); }
-  // drain (slices only, [EL operand DMAs of slice u+3][ES stores of slice u] per step): the operands of slice u, issued in
-  // step u-3
-  static constexpr int del(int w) { return (w + 3 < P_STEPS) ? EL : 0; }
-  static constexpr int drain_count(int u) { return u < 3 ? 0 : ES + del(u - 2) + ES + del(u - 1) + ES + del(u); }
+  static constexpr int wait_count(int u) {
+    return tot((u + NS - 1) % NS) - 3 - (ELF ? el_at((u + NS - 1) % NS) : 0) + tot(u % NS);
+  }
+  // drain (slices only, [EL operand DMAs of slice u+LA][ES stores of slice u] per step): the operands of slice u, issued in
+  // step u-LA
+  static constexpr int del(int w) { return (w + LA < P_STEPS) ? EL : 0; }
+  static constexpr int drain_count(int u) {
+    if (u < LA) return 0;
+    int n = LA * ES;
+    for (int w = u - LA + 1; w <= u; ++w) n += del(w);
+    return n;
+  }
 };
 
 #ifdef CN_P_STAMP
@@ -96,15 +109,22 @@ static __device__ unsigned long long cn_p_dbg_wave[256 * 8 * 2];
 #endif
 
 // KIND: epilogue bits as in gemm_kernel.h (2 resid, 4 dact, 8 column sums, 16 column sums + squares (fp64), 32 cpre,
-// 64 out_act, 256 softplus family); at most one of resid / dact.  NS: K-steps per tile (16: K = 256; 32: K = 512 -- the
+// 64 out_act, 256 softplus family) + 1: node-term gather (v += gather_i[tgt[m]] + gather_j[src[m]]); at most one of
+// resid / dact / gather.  NS: K-steps per tile (16: K = 256; 32: K = 512 -- the
 // second 16 steps carry no slice).
 template <bool A_ACT, bool ACT_OUT, int KIND, int NS>
 __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const CartnetGemmArgs p, const int tiles_m) {
   using S = Shape<F32_BN>;
   constexpr bool RESID = (KIND & 2) != 0, DACT = (KIND & 4) != 0, SUM1 = (KIND & 8) != 0, SUM2 = (KIND & 16) != 0,
                  CPRE = (KIND & 32) != 0, OUTACT = (KIND & 64) != 0;
+  constexpr bool GATHER = (KIND & 1) != 0;
   constexpr bool STATS = SUM1 || SUM2;
-  constexpr int EL = (RESID || DACT) ? 4 : 0;                   // operand DMAs per slice
+  // operand DMAs per slice: one per operand -- a slice is 8 consecutive rows x 128 B of the tile in every block of the
+  // accumulator layout, i.e. ONE 16-byte-per-lane DMA (lane l: row l / 8, 16-byte piece l % 8) per operand
+  constexpr int EL = GATHER ? 2 : ((RESID || DACT) ? 1 : 0);
+  constexpr int LA = GATHER ? 2 : 3;                            // ... issued this many steps before the slice
+  constexpr int NSLOT = LA + 1;                                 // slots of the wave's operand ring (EL x 1 KB each)
+  constexpr int SLOT_BYTES = EL * 1024;
   constexpr int ES = 4 + (CPRE ? 4 : 0);                        // stores per slice
   constexpr int NA = A_ACT ? 8 : 4;                             // stages of the activation ring
   constexpr int AD = A_ACT ? 4 : 3;                             // ... and how far ahead its DMA runs (the SiLU pass needs a step)
@@ -112,12 +132,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
   static_assert(!(RESID && DACT), "one epilogue operand");
   static_assert(!(A_ACT && EL > 0), "the eight activation stages and the operand ring do not fit together");
   static_assert(!ACT_OUT || A_ACT, "silu(A) is written where it is computed");
-  using Cnt = PCount<EL, ES, ACT_OUT, STATS, NS>;
+  static_assert(!GATHER || (!RESID && !DACT && !STATS && !CPRE && NS == 16), "the gather form: bias + node terms (+ out_act)");
+  using Cnt = PCount<EL, ES, ACT_OUT, STATS, NS, LA, GATHER, GATHER ? 2 : 0>;
   static_assert(Cnt::wait_count(0) <= 63 && Cnt::wait_count(1) <= 63, "vmcnt is a 6-bit counter");
   constexpr int LDS_BIAS = P_LDS_A + NA * P_A_BYTES;            // bias[g][n] of every group, staged once
   constexpr int LDS_RED = LDS_BIAS + P_BIAS_FLOATS * 4;         // double red[2][2][256]: column statistics of one tile
-  constexpr int LDS_OPR = LDS_RED + 2 * 2 * 256 * 8;            // per wave 4 slots x 4 x 256 B: epilogue operands in flight
-  constexpr int LDS_BYTES = LDS_OPR + (EL > 0 ? 8 * 4096 : 0);
+  constexpr int LDS_OPR = LDS_RED + (STATS ? 2 * 2 * 256 * 8 : 0);   // per wave NSLOT slots x EL x 1 KB: epilogue operands in flight
+  constexpr int LDS_IDX = LDS_OPR + 8 * NSLOT * SLOT_BYTES;    // gather: per wave [tile parity][tgt | src][64 rows]
+  constexpr int LDS_BYTES = LDS_IDX + (GATHER ? 8 * 1024 : 0);
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
@@ -154,6 +176,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
   const int ldo = RESID ? p.ldr : p.ldd;                        // the epilogue operand (resid or dact)
   i32x4 o_srd = p_make_srd(RESID ? p.resid[g] : (DACT ? p.dact[g] : nullptr), ((unsigned)(p.M - 1) * (unsigned)ldo + (unsigned)p.N) * 4u);
   i32x4 h_srd = p_make_srd(ACT_OUT ? p.a_act_out[g] : nullptr, ((unsigned)(p.M - 1) * (unsigned)p.lda + (unsigned)p.K) * 4u);
+  // gather: the two node-term tables (gather_rows bounds both: use_f32p) and the edge -> atom index arrays; an index of a row
+  // past M reads 0 and the index slots start as zeros, so every gathered row is one the caller vouches for (or row 0)
+  const unsigned gbytes = GATHER ? ((unsigned)(p.gather_rows - 1) * (unsigned)p.ldg + (unsigned)p.N) * 4u : 0u;
+  i32x4 gi_srd = p_make_srd(GATHER ? p.gather_i[g] : nullptr, gbytes);
+  i32x4 gj_srd = p_make_srd(GATHER ? p.gather_j[g] : nullptr, gbytes);
+  i32x4 t_srd = p_make_srd(GATHER ? p.tgt : nullptr, (unsigned)p.M * 4u);
+  i32x4 s_srd = p_make_srd(GATHER ? p.src : nullptr, (unsigned)p.M * 4u);
   // waves 0-3 write the column sums, waves 4-7 the squares (a missing statistic: null descriptor, the store is dropped)
   i32x4 st_srd = p_make_srd(STATS ? ((wid >> 2) ? (SUM2 ? p.colsq[g] : nullptr) : p.colsum[g]) : nullptr,
                             (unsigned)tiles_m * (unsigned)p.N * 8u);
@@ -184,26 +213,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
 
   // ---- per-lane constants
   const unsigned lv_c = (unsigned)((wm * S::WM + 4 * lh) * p.ldc + col0 + wn * S::WN + li) * 4u;     // this lane's element of a block
-  const unsigned lv_o = (unsigned)((wm * S::WM + 4 * lh) * ldo + col0 + wn * S::WN + li) * 4u;
+  const unsigned lv_o = (unsigned)((wm * S::WM + (lane >> 3)) * ldo + col0 + wn * S::WN + (lane & 7) * 4) * 4u;   // operand DMAs: row l / 8, piece l % 8
   const int lane_row = wm * S::WM + 4 * lh;
   const unsigned ldc4 = (unsigned)p.ldc * 4u, ldo4 = (unsigned)ldo * 4u;
+  const unsigned lv_g = (unsigned)(col0 + wn * S::WN + (lane & 7) * 4) * 4u, ldg4 = (unsigned)p.ldg * 4u;   // gather: this lane's piece of a row
+  const unsigned lv_ix = (unsigned)(wm * S::WM + lane) * 4u;    // ... and its row of the wave's 64 in the index arrays
   const unsigned b_voff = lane * 16, b_voff2 = lane * 16 + 8192;
   unsigned lds_bw = lds0 + P_LDS_B + wid * 1024;
   unsigned lds_aw = lds0 + P_LDS_A + wid * 1024;
-  unsigned lds_ow = lds0 + LDS_OPR + wid * 4096;
+  unsigned lds_ow = lds0 + LDS_OPR + wid * (NSLOT * SLOT_BYTES);
+  unsigned lds_iw = lds0 + LDS_IDX + wid * 1024;
   const char* b_base_w = b_base + wid * 1024;
   // one base register per (region, k-group): the swizzle's XOR makes the two k-groups of a fragment differ by more than a constant
   unsigned fa0 = lds0 + P_LDS_A + f32_swz(wm * S::WM + li, 0 + lh), fa1 = lds0 + P_LDS_A + f32_swz(wm * S::WM + li, 2 + lh);
   unsigned fb0 = lds0 + P_LDS_B + f32_swz(wn * S::WN + li, 0 + lh), fb1 = lds0 + P_LDS_B + f32_swz(wn * S::WN + li, 2 + lh);
   unsigned own_base = lds0 + P_LDS_A + tid * 16;                 // this thread's own 16 bytes of an activation stage
-  unsigned opr_base = lds0 + LDS_OPR + wid * 4096 + lane * 4;    // this lane's dword of an operand slot
-  asm volatile("" : "+v"(fa0), "+v"(fa1), "+v"(fb0), "+v"(fb1), "+v"(own_base), "+v"(opr_base));
+  unsigned opr_base = lds0 + LDS_OPR + wid * (NSLOT * SLOT_BYTES) + lh * 512 + li * 4;   // operand slot [8 rows][32 columns]: rows 4lh.., column li
+  unsigned idx_base = lds0 + LDS_IDX + wid * 1024 + (lane >> 3) * 4;     // the row this lane gathers, within an 8-row group of the index arrays
+  asm volatile("" : "+v"(fa0), "+v"(fa1), "+v"(fb0), "+v"(fb1), "+v"(own_base), "+v"(opr_base), "+v"(idx_base));
+  // gather: the operand ring has three slots and a tile sixteen slices -- the slot being filled rotates at run time (scalar)
+  unsigned slot_w = 0;
   float* sbias = reinterpret_cast<float*>(lds + LDS_BIAS);
   double* red = reinterpret_cast<double*>(lds + LDS_RED);
 
   for (int i = tid; i < p.ngroups * p.N; i += NTHREADS) {
     const int gg = i / p.N, n = i - gg * p.N;
     sbias[i] = p.bias[gg] ? p.bias[gg][n] : 0.f;
+  }
+  if constexpr (GATHER) {
+    for (int i = tid; i < 8 * 256; i += NTHREADS) reinterpret_cast<int*>(lds + LDS_IDX)[i] = 0;
+    __syncthreads();
   }
 
   f32x16 acc[2][2][2];            // [set][block row][block column]; a tile's first MFMAs start from 0: never initialised
@@ -247,15 +286,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
     asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:%3 sc0 sc1 nt\n\ts_nop 1"
                  :: "v"(v), "v"(c.a_voff), "s"(srd), "n"(OFF) : "memory");
   };
-  // one dword per lane of an epilogue operand into this wave's ring: 256 B at slot*1024 + j*256 (the 128-byte column offset
-  // of block column 1 travels in the scalar offset: global address only)
+  // 16 bytes per lane of an epilogue operand into this wave's ring: the 8 rows x 128 B of a slice at slot * 1024 (the
+  // 128-byte column offset of block column 1 travels in the scalar offset: global address only)
   auto o_dma = [&](unsigned voff, auto dst_c, auto b_c) {
     constexpr int DST = decltype(dst_c)::value;
     const unsigned lo = lds_ow;
     const i32x4 srd = o_srd;
     const int soff = decltype(b_c)::value * 128;
-    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %4 offen lds"
+    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds"
                  :: "s"(lo), "v"(voff), "s"(srd), "n"(DST), "s"(soff) : "memory", "m0", "scc");
+  };
+  // the same from a node-term table (descriptor `srd`), into the slot at byte `lo` of LDS (run-time, scalar)
+  auto g_dma = [&](unsigned voff, const i32x4& srd_in, unsigned lo, auto dst_c, auto b_c) {
+    constexpr int DST = decltype(dst_c)::value;
+    const i32x4 srd = srd_in;
+    const int soff = decltype(b_c)::value * 128;
+    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds"
+                 :: "s"(lo), "v"(voff), "s"(srd), "n"(DST), "s"(soff) : "memory", "m0", "scc");
+  };
+  // the tile's target / source atoms of this wave's 64 rows into the index slot of the tile's parity
+  auto idx_dma = [&](const Ctx& c, auto par_c) {
+    constexpr int DST = decltype(par_c)::value * 512;
+    const unsigned li_ = lds_iw, voff = (unsigned)c.row0 * 4u + lv_ix;
+    const i32x4 ts = t_srd, ss = s_srd;
+    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+                 :: "s"(li_), "v"(voff), "s"(ts), "n"(DST) : "memory", "m0", "scc");
+    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+                 :: "s"(li_), "v"(voff), "s"(ss), "n"(DST + 256) : "memory", "m0", "scc");
   };
   auto st1 = [&](float v, unsigned voff, const i32x4& srd, auto off_c) {
     constexpr int OFF = decltype(off_c)::value;
@@ -279,19 +336,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
   // b*32 + li (column half b first: one bias value and one pair of column sums live at a time)
   auto slice_loads = [&](auto sl_c, const Ctx& c) {
     constexpr int SL = decltype(sl_c)::value, b = SL >> 3, a = (SL >> 2) & 1, q = SL & 3;
-    p_static_for<0, 4>([&](auto j_c) {
-      constexpr int j = decltype(j_c)::value;
-      const unsigned rr = (unsigned)(a * 32 + 8 * q + j);
-      o_dma(lv_o + ((unsigned)c.row0 + rr) * ldo4, std::integral_constant<int, (SL & 3) * 1024 + j * 256>{},
-            std::integral_constant<int, b>{});
-    });
+    o_dma(lv_o + ((unsigned)c.row0 + (unsigned)(a * 32 + 8 * q)) * ldo4, std::integral_constant<int, (SL & 3) * 1024>{},
+          std::integral_constant<int, b>{});
   };
-  auto slice_operands = [&](auto sl_c, float (&o)[4]) {
+  // gather, operand K (0: by target, 1: by source) of slice SL of the tile whose indices sit in parity PAR: rows
+  // a*32 + 8q .. + 7 of the wave's 64 -> each lane reads the index of ITS row, one row-gathering DMA
+  auto gather_loads = [&](auto sl_c, auto par_c, auto k_c) {
+    constexpr int SL = decltype(sl_c)::value, PAR = decltype(par_c)::value, K = decltype(k_c)::value;
+    constexpr int b = SL >> 3, a = (SL >> 2) & 1, q = SL & 3;
+    const int ix = *reinterpret_cast<__attribute__((address_space(3))) int*>(
+        (unsigned long)(idx_base + (PAR * 512 + K * 256 + (a * 32 + 8 * q) * 4)));
+    const unsigned lo = lds_ow + slot_w;
+    const unsigned voff = __umul24((unsigned)ix, ldg4) + lv_g;
+    g_dma(voff, K ? gj_srd : gi_srd, lo, std::integral_constant<int, K * 1024>{}, std::integral_constant<int, b>{});
+  };
+  auto slice_operands = [&](auto sl_c, float (&o)[GATHER ? 8 : 4]) {
     constexpr int SL = decltype(sl_c)::value;
+    if constexpr (GATHER) {
+      // the slot filled two steps ago = the one after the slot being filled now
+      const unsigned rb = opr_base + (slot_w == 2 * SLOT_BYTES ? 0u : slot_w + SLOT_BYTES);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = p_lds_ld1(opr_base, (SL & 3) * 1024 + j * 256);
+      for (int j = 0; j < 8; ++j) o[j] = p_lds_ld1(rb, (j >> 2) * 1024 + (j & 3) * 128);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = p_lds_ld1(opr_base, (SL & 3) * 1024 + j * 128);
+    }
   };
-  auto slice_math = [&](auto sl_c, auto set_c, const Ctx& c, const float (&o)[4], float (&v)[4]) {
+  auto slice_math = [&](auto sl_c, auto set_c, const Ctx& c, const float (&o)[GATHER ? 8 : 4], float (&v)[4]) {
     constexpr int SL = decltype(sl_c)::value, SETP = decltype(set_c)::value, b = SL >> 3, a = (SL >> 2) & 1, q = SL & 3;
     if constexpr ((SL & 7) == 0) {
       bv = sbias[bias_idx + wn * S::WN + b * 32 + li];
@@ -304,6 +375,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float t = acc[SETP][a][b][4 * q + j] + bv;
+      if constexpr (GATHER) t += o[j] + o[4 + j];
       if constexpr (RESID) t += o[j];
       if constexpr (DACT) t *= (KIND & 256) ? fast_sigmoid(o[j]) : fast_dsilu(o[j]);
       v[j] = t;
@@ -397,18 +469,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
     constexpr bool SLICE = false, LOADS = false;
 #else
     constexpr bool SLICE = U < P_STEPS;               // this step carries slice U of the previous tile
-    // ... and the operand DMAs of slice (U + 3) % NS (the drain has no next tile)
-    constexpr bool LOADS = EL > 0 && ((U + 3) % NS) < P_STEPS && !(MODE == P_DRAIN && U + 3 >= P_STEPS);
+    // ... and the operand DMAs of slice (U + LA) % NS (the drain has no next tile)
+    constexpr bool LOADS = EL > 0 && ((U + LA) % NS) < P_STEPS && !(MODE == P_DRAIN && U + LA >= P_STEPS);
 #endif
-    constexpr int SL_LD = (U + 3) % NS;
+    constexpr int SL_LD = (U + LA) % NS;
+    using ParL = std::integral_constant<int, (U + LA < NS) ? (SET ^ 1) : SET>;     // gather: parity of that slice's tile
     const Ctx& cA = (U + AD < NS) ? cur : next;       // tile of K-step U + AD
     // tile of K-step U + 2 (the activation tile that gets its SiLU now; nothing real in the priming step)
     const Ctx& cA2 = MODE == P_PRIME ? prev : ((U + 2 < NS) ? cur : next);
-    const Ctx& cL = (U + 3 < NS) ? prev : cur;        // tile whose slice (U + 3) % NS gets its operands now
+    const Ctx& cL = (U + LA < NS) ? prev : cur;       // tile whose slice (U + LA) % NS gets its operands now
     using SetC = std::integral_constant<int, SET>;
     using PrevC = std::integral_constant<int, SET ^ 1>;
     using SlC = std::integral_constant<int, U % P_STEPS>;
-    float v[4], o[4] = {0.f, 0.f, 0.f, 0.f};
+    float v[4], o[GATHER ? 8 : 4] = {};
     f32x4 own;
 
     if constexpr (COMPUTE) {
@@ -422,14 +495,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
       mma4(SetC{}, std::integral_constant<bool, U == 0>{}, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-#if defined(CN_P_X) && (CN_P_X & 1)
-    if constexpr (MAIN && !COMPUTE) {
-#else
-    if constexpr (MAIN) {
-#endif
+    auto main_dmas = [&]() {
       b_issue(std::integral_constant<int, (U + 3) % NS>{}, std::integral_constant<int, (U + 3) & 3>{});
       a_dma(cA, std::integral_constant<int, (U + AD) % NS>{}, std::integral_constant<int, (U + AD) & (NA - 1)>{});
-    }
+      if constexpr (GATHER && (U % NS) == 0) idx_dma(cur, SetC{});
+    };
+    // gather: the operand DMAs of the step come BEFORE its tile DMAs (PCount, ELF), spread over the first MFMA groups
+    if constexpr (GATHER && LOADS) gather_loads(std::integral_constant<int, SL_LD % P_STEPS>{}, ParL{}, std::integral_constant<int, 0>{});
+#if defined(CN_P_X) && (CN_P_X & 1)
+    if constexpr (MAIN && !COMPUTE && !GATHER) main_dmas();
+#else
+    if constexpr (MAIN && !GATHER) main_dmas();
+#endif
     if constexpr (STATS && (U % NS) == 0) {
       if constexpr (MODE != P_PRIME) stats_flush(pend_row0);
       else stats_flush(tiles_m * BM);
@@ -443,11 +520,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if constexpr (LOADS) slice_loads(std::integral_constant<int, SL_LD % P_STEPS>{}, cL);
+    if constexpr (GATHER && LOADS) gather_loads(std::integral_constant<int, SL_LD % P_STEPS>{}, ParL{}, std::integral_constant<int, 1>{});
+    if constexpr (!GATHER && LOADS) slice_loads(std::integral_constant<int, SL_LD % P_STEPS>{}, cL);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (COMPUTE) {
       mma4(SetC{}, std::false_type{}, 0, 2);
       __builtin_amdgcn_sched_barrier(0);
+
       // (the SiLU of the activation tile sits behind the step's first MFMA groups: vector work in the first few hundred
       //  cycles after a barrier costs the younger wave of a SIMD its start -- MI355X_MICROARCH.md, two waves per SIMD, item 6)
       if constexpr (A_ACT) {
@@ -456,6 +535,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
         p_lds_st4(own_base, ((U + 2) & (NA - 1)) * P_A_BYTES, own);
       }
     }
+    if constexpr (GATHER && MAIN) main_dmas();
     if constexpr (COMPUTE && ACT_OUT) h_store(own, cA2, std::integral_constant<int, (U + 2) % NS>{});
     if constexpr (MODE == P_PRIME && ACT_OUT) h_store(f32x4{0.f, 0.f, 0.f, 0.f}, cA2, std::integral_constant<int, (U + 2) % NS>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -528,6 +608,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
       stall_b += t2 - t1;
 #endif
     }
+    if constexpr (GATHER) slot_w = slot_w == 2 * SLOT_BYTES ? 0u : slot_w + SLOT_BYTES;
   };
 
   // ---- prologue: the first K-steps of the first tile in ONE memory round trip, then the operations of "step -1" in order

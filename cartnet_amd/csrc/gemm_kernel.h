@@ -1090,6 +1090,11 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
         bool prepacked = fl.wide && a.splitk == 1 && m0 == 0 && a.nsegs == 1 && (double)a.M * a.lda * 4.0 < 4294967296.0;
         const int nptr = a.ngroups > 1 ? a.ngroups : a.nsegs;
         for (int i = 0; i < nptr; ++i) prepacked = prepacked && a.b_split[i] != nullptr;
+#ifdef CN_P_WHY
+        if (!prepacked && a.M >= 100000)
+          fprintf(stderr, "f32p NOIMG: M=%d N=%d K=%d groups=%d segs=%d wide=%d splitk=%d m0=%d img0=%d\n", a.M, a.N, a.K, a.ngroups,
+                  a.nsegs, (int)fl.wide, a.splitk, m0, a.b_split[0] != nullptr);
+#endif
         if (prepacked) {
           if (use_f32p(a)) launch_f32p(a, st);
           else if (A_ACT && a.a_act_out[0]) launch_f32nn_actout(a, fl, dim3(nm * tiles_n, ns, a.ngroups), st);

@@ -408,6 +408,7 @@ struct Att {
   int ldq;
   long long count;                // rows the bn_att statistics divide by
   int gparts, sparts;             // partial rows of the gate / segment kernels over S segments
+  int grows;                      // upper bound of the rows of term_i / term_j
 };
 
 int att_forward(const CartnetIcfModel& m, const CartnetIcfConv& P, const CartnetIcfBn& bn_att, const ConvW& cw, const Att& t,
@@ -422,7 +423,7 @@ int att_forward(const CartnetIcfModel& m, const CartnetIcfConv& P, const Cartnet
     fwd_operand(a, 0, cw, F_K1E, w.use_img); fwd_operand(a, 1, cw, F_M1E, w.use_img);
     a.C[0] = w.pr[l]; a.C[1] = w.pr[l] + C;
     a.gather_i[0] = t.term_i; a.gather_i[1] = t.term_i + C; a.gather_j[0] = t.term_j; a.gather_j[1] = t.term_j + C;
-    a.ldg = 2 * C; a.tgt = t.idx_i; a.src = t.idx_j;
+    a.ldg = 2 * C; a.tgt = t.idx_i; a.src = t.idx_j; a.gather_rows = t.grows;
     RUN(cartnet_gemm(&a, st));
   }
   {  // key' = silu(pr_k) W2k^T + b  -> keyb[:, :C];  msg = silu(pr_m) W2m^T + b -> gs[:, C:]
@@ -565,7 +566,7 @@ extern "C" int cartnet_icomformer_forward(const CartnetIcfModel* model, const Ca
       a.bias[0] = q.key0_b; a.bias[1] = q.msg0_b;
       RUN(cartnet_gemm(&a, st));
     }
-    Att t{E, N, w.rowptr, w.tgt32, w.src32, w.KPi[l], w.KPj[l], w.QKV[l], 3 * C, (long long)b.E, w.gp_n, w.sp_n};
+    Att t{E, N, w.rowptr, w.tgt32, w.src32, w.KPi[l], w.KPj[l], w.QKV[l], 3 * C, (long long)b.E, w.gp_n, w.sp_n, N};
     RUN(att_forward(m, q, m.att_bn_att[l], cw, t, l, e, w, training, st));
     {  // o = lin_concate(aggr) with the BatchNorm statistics over atoms
       CartnetGemmArgs a = gargs(prec, N, C, C, C, C, C);
@@ -614,7 +615,7 @@ extern "C" int cartnet_icomformer_forward(const CartnetIcfModel* model, const Ca
       a.A[0] = w.KY; a.A[1] = w.VY; a.B[0] = q.key0_w + C; a.B[1] = q.msg0_w + C; a.C[0] = w.KYb; a.C[1] = w.KYb + C;
       RUN(cartnet_gemm(&a, st));
     }
-    Att t{3 * E, E, w.ptr3, w.idx_edge, w.idx_gl, w.Ka, w.KYb, w.QKV[l], 3 * C, 3LL * b.E, w.gp_e, w.sp_e};
+    Att t{3 * E, E, w.ptr3, w.idx_edge, w.idx_gl, w.Ka, w.KYb, w.QKV[l], 3 * C, 3LL * b.E, w.gp_e, w.sp_e, E > 3 * Bg ? E : 3 * Bg};
     RUN(att_forward(m, q, m.edge_bn_att, cw, t, l, w.NA, w, training, st));
     RUN(cartnet_eltwise(3, q.concate_b, nullptr, w.bias3, 1, C, C, 0, C, 3.0f, st));
     {
@@ -889,7 +890,7 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     RUN(softplus_bwd(l, q, g, dy, N, x_in, g.concate_b));
     RUN(wg({w.d_o[l]}, C, {w.aggr[l]}, C, {g.concate_w}, C, N, C, C));
     RUN(dgemm(w.d_o[l], C, q.concate_w, C, w.use_img ? cw.B[B_CAT] : nullptr, w.daggr[l], C, N, C, C, nullptr, 0, st));
-    Att t{E, N, w.rowptr, w.tgt32, w.src32, w.KPi[l], w.KPj[l], w.QKV[l], 3 * C, (long long)b.E, w.gp_n, w.sp_n};
+    Att t{E, N, w.rowptr, w.tgt32, w.src32, w.KPi[l], w.KPj[l], w.QKV[l], 3 * C, (long long)b.E, w.gp_n, w.sp_n, N};
     RUN(att_backward(l, q, g, t, w.daggr[l], w.dQKV[l]));
     float* dpr = w.dpr[l];
     // lin_edge (folded into the row block): nothing on the chain of atom gradients reads de before the edge layer's
@@ -946,7 +947,7 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
     RUN(cartnet_eltwise(3, w.tmpb, nullptr, g.concate_b, 1, C, C, 0, C, 3.0f, st));     // the bias entered three times
     RUN(wg({w.d_o[l]}, C, {w.aggr[l]}, C, {g.concate_w}, C, b.E, C, C));
     RUN(dgemm(w.d_o[l], C, q.concate_w, C, w.use_img ? cw.B[B_CAT] : nullptr, w.daggr[l], C, b.E, C, C, nullptr, 0, st));
-    Att t{3 * E, E, w.ptr3, w.idx_edge, w.idx_gl, w.Ka, w.KYb, w.QKV[l], 3 * C, 3LL * b.E, w.gp_e, w.sp_e};
+    Att t{3 * E, E, w.ptr3, w.idx_edge, w.idx_gl, w.Ka, w.KYb, w.QKV[l], 3 * C, 3LL * b.E, w.gp_e, w.sp_e, E > 3 * Bg ? E : 3 * Bg};
     RUN(att_backward(l, q, g, t, w.daggr[l], w.dQKV[l]));
     float* dpr = w.dpr[l];
     // angle branch (lin_edge folded, no bias): only the RBF backward at the very end reads dNA

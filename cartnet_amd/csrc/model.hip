@@ -588,7 +588,7 @@ extern "C" int cartnet_model_forward(const CartnetModel* model, const CartnetBat
       a.B[0] = w.gate0T[l] + (size_t)2 * D * D; a.B[1] = w.aggr0T[l] + (size_t)2 * D * D;
       a.C[0] = w.pre[l]; a.C[1] = hcol(w.pre[l], D, half); a.c_half = half;
       a.gather_i[0] = w.Pn; a.gather_i[1] = w.Pn + D; a.gather_j[0] = w.Pn + 2 * D; a.gather_j[1] = w.Pn + 3 * D;
-      a.ldg = 4 * D; a.tgt = w.tgt32; a.src = w.src32;
+      a.ldg = 4 * D; a.tgt = w.tgt32; a.src = w.src32; a.gather_rows = N;
       if (w.i_pre[l]) { a.b_split[0] = w.i_pre[l]; a.b_split[1] = w.i_pre[l] + img_blk(m); }
       RUN(cartnet_gemm(&a, st));
     }

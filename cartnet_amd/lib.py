@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CARTNET_LIB (tools only): a diagnostic / A-B build of the same ABI next to the product library (tools/build_variant.sh)
 LIB_PATH = os.environ.get("CARTNET_LIB") or os.path.join(_HERE, "libcartnet_hip.so")
 MAX_GROUPS = 4
-ABI_VERSION = 11         # cartnet_abi_version() of the library this binding mirrors (include/cartnet_hip.h)
+ABI_VERSION = 12         # cartnet_abi_version() of the library this binding mirrors (include/cartnet_hip.h)
 
 _lib: Optional[C.CDLL] = None
 
@@ -57,6 +57,7 @@ class GemmArgs(C.Structure):
         ("gst_beta", C.c_void_p), ("gst_ld", C.c_int32),
         ("tile_policy", C.c_int32),
         ("dact_kind", C.c_int32),
+        ("gather_rows", C.c_int32),
     ]
 
 

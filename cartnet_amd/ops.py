@@ -201,6 +201,7 @@ def gemm(A: Sequence[Tensor] | Tensor, B: Sequence[Tensor] | Tensor, C_out: Sequ
                                                                   _ld(a) != _ld(b))):
                 raise ValueError("gemm: gather_i / gather_j must pair up with N columns and equal row stride")
         args.tgt, args.src = tgt.data_ptr(), src.data_ptr()
+        args.gather_rows = max(t.shape[0] for t in list(gi) + list(gj) if t is not None)
     per_group("resid", resid, (M, N), "resid", "ldr")
     args.dact_half = int(is_half(per_group("dact", dact, (M, N), "dact", "ldd"), "dact"))
     cp = per_group("cpre", cpre, (M, N), "cpre")

@@ -35,7 +35,7 @@ int cartnet_abi_version(void);
 /* sizeof of every struct below, in header order (CartnetGemmArgs, CartnetShard, CartnetCollated, CartnetGemmProfile,
  * CartnetGroups, CartnetLayerParams, CartnetLayerBuffers, CartnetParams, CartnetModel, CartnetBatch,
  * CartnetGateGemmArgs, CartnetIcfConv, CartnetIcfParams, CartnetIcfModel); returns the number of structs.  A binding checks its mirrors against these when it loads the
- * library, and cartnet_abi_version() against the version it was written for (11: CartnetGemmArgs.tile_policy = 3, the persistent activation x weight kernel; no layout change; 10: dact_kind closes CartnetGemmArgs, the *_sums / cartnet_att_gate_bwd_apply entry points; 9: gst_* in CartnetGemmArgs (8 also carried seg_*: per-target sums in an epilogue, measured and removed); 7: tile_policy in CartnetGemmArgs,
+ * library, and cartnet_abi_version() against the version it was written for (12: CartnetGemmArgs.gather_rows closes the struct -- the persistent kernel's node-term gather form; 11: CartnetGemmArgs.tile_policy = 3, the persistent activation x weight kernel; no layout change; 10: dact_kind closes CartnetGemmArgs, the *_sums / cartnet_att_gate_bwd_apply entry points; 9: gst_* in CartnetGemmArgs (8 also carried seg_*: per-target sums in an epilogue, measured and removed); 7: tile_policy in CartnetGemmArgs,
  * aux_stream in cartnet_model_forward, CartnetGateGemmArgs in the size table; cartnet_gemm_tile_policy() is gone). */
 int cartnet_abi_struct_sizes(size_t* out, int32_t capacity);
 
@@ -141,6 +141,10 @@ typedef struct CartnetGemmArgs {
                           yields d(softplus output) writes d(pre-activation) and, with colsum, the bias gradient -- no
                           element-wise pass, no column-sum pass); out_act then applies softplus (threshold 20) instead of
                           SiLU: with cpre the forward of such a branch in one launch.  Not with the bf16-storage flags. */
+  int32_t gather_rows; /* optional (ABI 12): an upper bound of the rows of the gather_i / gather_j tables (every tgt[m] and
+                          src[m] is below it); 0 = not stated.  The persistent kernel addresses the tables through 32-bit
+                          offsets and takes a gather launch only when it knows gather_rows * ldg * 4 < 2^32; every other
+                          kernel ignores the field. */
 } CartnetGemmArgs;
 
 int cartnet_gemm(const CartnetGemmArgs* args, void* stream);

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(cdll, name), f"{name} is declared in include/cartnet_hip.h but not exported"
     # the ctypes prototypes cover exactly the declared set
     assert sorted(lib.PROTOTYPES) == declared
-    assert lib.load().cartnet_abi_version() == 11 == lib.ABI_VERSION
+    assert lib.load().cartnet_abi_version() == 12 == lib.ABI_VERSION
 
 
 def test_ctypes_mirrors_have_the_c_struct_layouts():
@@ -46,7 +46,7 @@ def test_ctypes_mirrors_have_the_c_struct_layouts():
     assert lib.GemmArgs.gst_ld.offset == lib.GemmArgs.gst_g.offset + 40
     # ... and dact_kind (ABI 10) closes it: gst_ld, tile_policy, dact_kind + 4 bytes of tail padding
     assert lib.GemmArgs.dact_kind.offset == lib.GemmArgs.tile_policy.offset + 4
-    assert lib.GemmArgs.dact_kind.offset + 8 == ctypes.sizeof(lib.GemmArgs)
+    assert lib.GemmArgs.gather_rows.offset + 4 == ctypes.sizeof(lib.GemmArgs)
     assert lib.Model.grad_ready_user.offset + 8 == ctypes.sizeof(lib.Model)                          # last field
 
 

@@ -109,13 +109,28 @@ def _run(ops, pol, M, groups, N, form, seed=0):
             pad = tiles * 128 - M
             ref["cs_all"] = torch.stack([torch.cat([x, torch.zeros(pad, N, dtype=torch.float64, device=dev())])
                                          .view(tiles, 128, N).sum(1).reshape(-1) for x in v])
+    elif form == "gather":
+        # the layer's first product: + node terms of the edge's target and source atoms (tables of `atoms` rows, column
+        # blocks of one [atoms, 2 G N] matrix as in the model; every atom index occurs, also 0 and atoms - 1)
+        atoms = max(2, M // 14)
+        P = rnd(atoms, 2 * G * N, seed=seed + 40)
+        gen = torch.Generator().manual_seed(seed + 41)
+        tgt = torch.sort(torch.randint(0, atoms, (M,), generator=gen)).values.to(torch.int32).to(dev())
+        src = torch.randint(0, atoms, (M,), generator=gen).to(torch.int32).to(dev())
+        if M > 1:
+            tgt[0], tgt[-1], src[0], src[-1] = 0, atoms - 1, atoms - 1, 0
+        gi = [P[:, g * N:(g + 1) * N] for g in range(G)]
+        gj = [P[:, (G + g) * N:(G + g + 1) * N] for g in range(G)]
+        ops.gemm(Av, W, Cv, bias=bias, gather_i=gi, gather_j=gj, tgt=tgt, src=src, **kw)
+        ref["out"] = torch.cat([A64[g] @ W64[g] + bias[g].double() + gi[g].double()[tgt.long()] + gj[g].double()[src.long()]
+                                for g in range(G)], 1)
     else:
         raise AssertionError(form)
     torch.cuda.synchronize()
     return res, ref
 
 
-@pytest.mark.parametrize("form", ["plain", "bias", "act", "stats", "stats_actout", "dpre", "dpre_colsum"])
+@pytest.mark.parametrize("form", ["plain", "bias", "act", "stats", "stats_actout", "dpre", "dpre_colsum", "gather"])
 @pytest.mark.parametrize("M", SHAPES)
 def test_every_form_against_fp64_and_the_shipped_kernels(ops, form, M):
     new, ref = _run(ops, 3, M, 2, D, form)
@@ -124,7 +139,7 @@ def test_every_form_against_fp64_and_the_shipped_kernels(ops, form, M):
         assert not torch.isnan(new[k]).any(), f"{form} M={M}: {k} has elements the kernel never wrote"
         # column statistics are sums of up to 128 values: the bar is relative to the largest sum
         assert rel_err(new[k], ref[k]) < (TOL if k in ("out", "act") else 2e-5), (form, M, k)
-    bitwise = form in ("plain", "bias", "act", "stats", "stats_actout")
+    bitwise = form in ("plain", "bias", "act", "stats", "stats_actout", "gather")
     for k in ref:
         if bitwise:
             assert torch.equal(new[k], old[k]), f"{form} M={M}: {k} differs from the shipped kernel"
@@ -218,3 +233,46 @@ def test_forms_of_the_second_unit(ops, M):
     assert rel_err(res[3]["h3"], silu64(A64)) < TOL
     v4 = A64[:, :D] @ Wseg[0].double() + A64[:, D:] @ Wseg[1].double() + resid.double()
     assert rel_err(res[3]["c4"][:, :D], v4) < TOL
+
+
+@pytest.mark.parametrize("M", [300, 128 * 257, 89500])
+def test_forms_of_the_third_unit(ops, M):
+    """csrc/gemm_f32p3.hip (single-group products of the iComformer step): K = 512 from two folded segments without an
+    epilogue operand, fp32 column sums (a bias gradient), BatchNorm statistics without SiLU on A, and the K = 512 product
+    times sigmoid(pre) (softplus') with its bias gradient."""
+    A = rnd(M, 2 * D, seed=51)
+    W = rnd(D, D, seed=52, scale=0.06)
+    img = ops.pack_b([W])
+    Wseg = [rnd(D, D, seed=53 + g, scale=0.06) for g in range(2)]
+    img_fold = torch.cat(ops.pack_b(Wseg))
+    pre = rnd(M, D, seed=55)
+    tiles = ops.gemm_tiles_m(M)
+    Av = [A[:, :D], A[:, D:]]
+    res = {}
+    for pol in (3, 256):
+        o = {k: torch.full((M, D), float("nan"), device=dev()) for k in ("c1", "c2", "c3", "c4")}
+        s = {k: torch.full((tiles * D,), float("nan"), dtype=torch.float64, device=dev()) for k in ("s2", "s3", "q3", "s4")}
+        ops.gemm(Av, Wseg, o["c1"], b_kstrided=True, segments=True, b_split_folded=img_fold, tile_policy=pol)
+        ops.gemm(A[:, :D], W, o["c2"], b_kstrided=True, b_split=img, colsum=s["s2"], tile_policy=pol)
+        ops.gemm(A[:, :D], W, o["c3"], b_kstrided=True, b_split=img, colsum=s["s3"], colsq=s["q3"], tile_policy=pol)
+        ops.gemm(Av, Wseg, o["c4"], b_kstrided=True, segments=True, b_split_folded=img_fold, dact=pre, dact_kind=1,
+                 colsum=s["s4"], tile_policy=pol)
+        torch.cuda.synchronize()
+        res[pol] = {**o, **s}
+    for k in ("c1", "c2", "c3", "s3", "q3"):     # no transcendental in the epilogue: the shipped kernels' bits
+        assert torch.equal(res[3][k], res[256][k]), f"M={M}: {k} differs from the shipped kernel"
+    A64 = A.double()
+    pad = tiles * 128 - M
+
+    def tile_sums(v):
+        return torch.cat([v, torch.zeros(pad, D, dtype=torch.float64, device=dev())]).view(tiles, 128, D).sum(1).reshape(-1)
+
+    v1 = A64[:, :D] @ Wseg[0].double() + A64[:, D:] @ Wseg[1].double()
+    v2 = A64[:, :D] @ W.double()
+    v4 = v1 * torch.sigmoid(pre.double())
+    r = res[3]
+    assert not any(torch.isnan(t).any() for t in r.values())
+    assert rel_err(r["c1"], v1) < TOL and rel_err(r["c2"], v2) < TOL and rel_err(r["c3"], v2) < TOL and rel_err(r["c4"], v4) < TOL
+    assert rel_err(r["s2"], tile_sums(v2)) < 2e-5 and rel_err(r["s3"], tile_sums(v2)) < 2e-5
+    assert rel_err(r["q3"], tile_sums(v2 * v2)) < 2e-5 and rel_err(r["s4"], tile_sums(v4)) < 2e-5
+    assert rel_err(r["s2"], res[256]["s2"]) < 2e-6 and rel_err(r["c4"], res[256]["c4"]) < 2e-6

@@ -32,6 +32,10 @@ img_gs = ops.pack_b([W2gT, W2aT]); img_dpre = ops.pack_b([W2g, W2a])
 Wd = rnd(D, 2 * D, sc=0.05); img_dhe = ops.pack_b([Wd])
 We2T = rnd(2 * D, D, sc=0.05); img_e2 = ops.pack_b([We2T])
 img_fold = torch.cat(ops.pack_b([W2g, W2a]))
+NA = max(2, E // 14)               # atoms: ~14 edges each, targets sorted (CSR order) as in the model
+Pn = rnd(NA, 4 * D)
+tgt = torch.sort(torch.randint(0, NA, (E,), generator=g)).values.to(torch.int32).to(dev)
+src = (tgt.cpu() // 194 * 194 + torch.randint(0, 194, (E,), generator=g)).clamp(max=NA - 1).to(torch.int32).to(dev)   # same crystal
 tiles = ops.gemm_tiles_m(E)
 F = 2.0 * E * D * D * 2
 
@@ -73,10 +77,14 @@ def form(name, o, pol):
     elif name == "k512resid":       # two folded K-segments + residual (iComformer's d(rows) products; CartNet's dE without statistics)
         ops.gemm([pre[:, :D], pre[:, D:]], [W2g, W2a], o["out"][:, :D], b_kstrided=True, segments=True, resid=gs[:, :D],
                  b_split_folded=img_fold, tile_policy=pol)
+    elif name == "gather":          # the layer's first product: bias + node terms by target / source atom
+        ops.gemm([gs[:, :D], gs[:, D:]], [W2gT, W2aT], out, b_kstrided=True, b_split=img_gs, bias=[b2g, b2a],
+                 gather_i=[Pn[:, :D], Pn[:, D:2 * D]], gather_j=[Pn[:, 2 * D:3 * D], Pn[:, 3 * D:]], tgt=tgt, src=src,
+                 tile_policy=pol)
     else:
         raise SystemExit(f"unknown form {name}")
 
-forms = ["plain", "bias", "act", "stats", "stats_actout", "dpre", "dhe", "act_actout", "rbf352", "enc2", "k512resid"]
+forms = ["plain", "bias", "act", "stats", "stats_actout", "dpre", "dhe", "act_actout", "rbf352", "enc2", "k512resid", "gather"]
 for name in forms:
     if only and name not in only:
         continue
