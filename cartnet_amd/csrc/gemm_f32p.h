@@ -121,19 +121,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
   constexpr bool STATS = SUM1 || SUM2;
   // operand DMAs per slice: one per operand -- a slice is 8 consecutive rows x 128 B of the tile in every block of the
   // accumulator layout, i.e. ONE 16-byte-per-lane DMA (lane l: row l / 8, 16-byte piece l % 8) per operand
-  constexpr int EL = GATHER ? 2 : ((RESID || DACT) ? 1 : 0);
-  constexpr int LA = GATHER ? 2 : 3;                            // ... issued this many steps before the slice
+  // Two operands (the gather form's node terms; resid AND dact): a four-slot ring would not fit, so LA = 2, three slots whose
+  // index rotates at run time, and the operand DMAs of a step in front of its tile DMAs (PCount, ELF)
+  constexpr bool TWOOP = RESID && DACT;
+  constexpr bool ROT = GATHER || TWOOP;
+  constexpr int EL = ROT ? 2 : ((RESID || DACT) ? 1 : 0);
+  constexpr int LA = ROT ? 2 : 3;                               // ... issued this many steps before the slice
   constexpr int NSLOT = LA + 1;                                 // slots of the wave's operand ring (EL x 1 KB each)
   constexpr int SLOT_BYTES = EL * 1024;
   constexpr int ES = 4 + (CPRE ? 4 : 0);                        // stores per slice
   constexpr int NA = A_ACT ? 8 : 4;                             // stages of the activation ring
   constexpr int AD = A_ACT ? 4 : 3;                             // ... and how far ahead its DMA runs (the SiLU pass needs a step)
-  static_assert(NS == 16 || NS == 32, "K = 256 or 512");
-  static_assert(!(RESID && DACT), "one epilogue operand");
+  static_assert(NS == 16 || NS == 32 || NS == 48, "K = 256, 512 or 768");
   static_assert(!(A_ACT && EL > 0), "the eight activation stages and the operand ring do not fit together");
   static_assert(!ACT_OUT || A_ACT, "silu(A) is written where it is computed");
   static_assert(!GATHER || (!RESID && !DACT && !STATS && !CPRE && NS == 16), "the gather form: bias + node terms (+ out_act)");
-  using Cnt = PCount<EL, ES, ACT_OUT, STATS, NS, LA, GATHER, GATHER ? 2 : 0>;
+  static_assert(!TWOOP || !CPRE, "resid + dact: no kept pre-activation");
+  using Cnt = PCount<EL, ES, ACT_OUT, STATS, NS, LA, ROT, GATHER ? 2 : 0>;
   static_assert(Cnt::wait_count(0) <= 63 && Cnt::wait_count(1) <= 63, "vmcnt is a 6-bit counter");
   constexpr int LDS_BIAS = P_LDS_A + NA * P_A_BYTES;            // bias[g][n] of every group, staged once
   constexpr int LDS_RED = LDS_BIAS + P_BIAS_FLOATS * 4;         // double red[2][2][256]: column statistics of one tile
@@ -173,8 +177,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
   i32x4 c_srd = p_make_srd(p.C[g], cbytes);
 #endif
   i32x4 p_srd = p_make_srd(CPRE ? p.cpre[g] : nullptr, cbytes);
-  const int ldo = RESID ? p.ldr : p.ldd;                        // the epilogue operand (resid or dact)
+  const int ldo = RESID ? p.ldr : p.ldd;                        // the epilogue operand (resid or dact; with both: resid)
   i32x4 o_srd = p_make_srd(RESID ? p.resid[g] : (DACT ? p.dact[g] : nullptr), ((unsigned)(p.M - 1) * (unsigned)ldo + (unsigned)p.N) * 4u);
+  i32x4 d_srd = p_make_srd(TWOOP ? p.dact[g] : nullptr, ((unsigned)(p.M - 1) * (unsigned)p.ldd + (unsigned)p.N) * 4u);   // ... and dact
   i32x4 h_srd = p_make_srd(ACT_OUT ? p.a_act_out[g] : nullptr, ((unsigned)(p.M - 1) * (unsigned)p.lda + (unsigned)p.K) * 4u);
   // gather: the two node-term tables (gather_rows bounds both: use_f32p) and the edge -> atom index arrays; an index of a row
   // past M reads 0 and the index slots start as zeros, so every gathered row is one the caller vouches for (or row 0)
@@ -216,6 +221,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
   const unsigned lv_o = (unsigned)((wm * S::WM + (lane >> 3)) * ldo + col0 + wn * S::WN + (lane & 7) * 4) * 4u;   // operand DMAs: row l / 8, piece l % 8
   const int lane_row = wm * S::WM + 4 * lh;
   const unsigned ldc4 = (unsigned)p.ldc * 4u, ldo4 = (unsigned)ldo * 4u;
+  const unsigned lv_d = (unsigned)((wm * S::WM + (lane >> 3)) * p.ldd + col0 + wn * S::WN + (lane & 7) * 4) * 4u, ldd4 = (unsigned)p.ldd * 4u;
   const unsigned lv_g = (unsigned)(col0 + wn * S::WN + (lane & 7) * 4) * 4u, ldg4 = (unsigned)p.ldg * 4u;   // gather: this lane's piece of a row
   const unsigned lv_ix = (unsigned)(wm * S::WM + lane) * 4u;    // ... and its row of the wave's 64 in the index arrays
   const unsigned b_voff = lane * 16, b_voff2 = lane * 16 + 8192;
@@ -350,9 +356,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
     const unsigned voff = __umul24((unsigned)ix, ldg4) + lv_g;
     g_dma(voff, K ? gj_srd : gi_srd, lo, std::integral_constant<int, K * 1024>{}, std::integral_constant<int, b>{});
   };
-  auto slice_operands = [&](auto sl_c, float (&o)[GATHER ? 8 : 4]) {
+  // resid + dact: operand K (0: resid, 1: dact) of slice SL of tile c into the slot being filled
+  auto two_loads = [&](auto sl_c, const Ctx& c, auto k_c) {
+    constexpr int SL = decltype(sl_c)::value, K = decltype(k_c)::value, b = SL >> 3, a = (SL >> 2) & 1, q = SL & 3;
+    const unsigned rr = (unsigned)c.row0 + (unsigned)(a * 32 + 8 * q);
+    g_dma(K ? lv_d + rr * ldd4 : lv_o + rr * ldo4, K ? d_srd : o_srd, lds_ow + slot_w, std::integral_constant<int, K * 1024>{},
+          std::integral_constant<int, b>{});
+  };
+  auto slice_operands = [&](auto sl_c, float (&o)[ROT ? 8 : 4]) {
     constexpr int SL = decltype(sl_c)::value;
-    if constexpr (GATHER) {
+    if constexpr (ROT) {
       // the slot filled two steps ago = the one after the slot being filled now
       const unsigned rb = opr_base + (slot_w == 2 * SLOT_BYTES ? 0u : slot_w + SLOT_BYTES);
 #pragma unroll
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
       for (int j = 0; j < 4; ++j) o[j] = p_lds_ld1(opr_base, (SL & 3) * 1024 + j * 128);
     }
   };
-  auto slice_math = [&](auto sl_c, auto set_c, const Ctx& c, const float (&o)[GATHER ? 8 : 4], float (&v)[4]) {
+  auto slice_math = [&](auto sl_c, auto set_c, const Ctx& c, const float (&o)[ROT ? 8 : 4], float (&v)[4]) {
     constexpr int SL = decltype(sl_c)::value, SETP = decltype(set_c)::value, b = SL >> 3, a = (SL >> 2) & 1, q = SL & 3;
     if constexpr ((SL & 7) == 0) {
       bv = sbias[bias_idx + wn * S::WN + b * 32 + li];
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
       float t = acc[SETP][a][b][4 * q + j] + bv;
       if constexpr (GATHER) t += o[j] + o[4 + j];
       if constexpr (RESID) t += o[j];
-      if constexpr (DACT) t *= (KIND & 256) ? fast_sigmoid(o[j]) : fast_dsilu(o[j]);
+      if constexpr (DACT) t *= (KIND & 256) ? fast_sigmoid(o[TWOOP ? 4 + j : j]) : fast_dsilu(o[TWOOP ? 4 + j : j]);
       v[j] = t;
     }
     if constexpr (STATS) {
@@ -481,7 +494,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
     using SetC = std::integral_constant<int, SET>;
     using PrevC = std::integral_constant<int, SET ^ 1>;
     using SlC = std::integral_constant<int, U % P_STEPS>;
-    float v[4], o[GATHER ? 8 : 4] = {};
+    float v[4], o[ROT ? 8 : 4] = {};
     f32x4 own;
 
     if constexpr (COMPUTE) {
@@ -500,12 +513,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
       a_dma(cA, std::integral_constant<int, (U + AD) % NS>{}, std::integral_constant<int, (U + AD) & (NA - 1)>{});
       if constexpr (GATHER && (U % NS) == 0) idx_dma(cur, SetC{});
     };
-    // gather: the operand DMAs of the step come BEFORE its tile DMAs (PCount, ELF), spread over the first MFMA groups
+    // two operands: the operand DMAs of the step come BEFORE its tile DMAs (PCount, ELF), spread over the first MFMA groups
     if constexpr (GATHER && LOADS) gather_loads(std::integral_constant<int, SL_LD % P_STEPS>{}, ParL{}, std::integral_constant<int, 0>{});
+    if constexpr (TWOOP && LOADS) two_loads(std::integral_constant<int, SL_LD % P_STEPS>{}, cL, std::integral_constant<int, 0>{});
 #if defined(CN_P_X) && (CN_P_X & 1)
-    if constexpr (MAIN && !COMPUTE && !GATHER) main_dmas();
+    if constexpr (MAIN && !COMPUTE && !ROT) main_dmas();
 #else
-    if constexpr (MAIN && !GATHER) main_dmas();
+    if constexpr (MAIN && !ROT) main_dmas();
 #endif
     if constexpr (STATS && (U % NS) == 0) {
       if constexpr (MODE != P_PRIME) stats_flush(pend_row0);
@@ -521,7 +535,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
       }
     }
     if constexpr (GATHER && LOADS) gather_loads(std::integral_constant<int, SL_LD % P_STEPS>{}, ParL{}, std::integral_constant<int, 1>{});
-    if constexpr (!GATHER && LOADS) slice_loads(std::integral_constant<int, SL_LD % P_STEPS>{}, cL);
+    if constexpr (TWOOP && LOADS) two_loads(std::integral_constant<int, SL_LD % P_STEPS>{}, cL, std::integral_constant<int, 1>{});
+    if constexpr (!ROT && LOADS) slice_loads(std::integral_constant<int, SL_LD % P_STEPS>{}, cL);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (COMPUTE) {
       mma4(SetC{}, std::false_type{}, 0, 2);
@@ -535,7 +550,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
         p_lds_st4(own_base, ((U + 2) & (NA - 1)) * P_A_BYTES, own);
       }
     }
-    if constexpr (GATHER && MAIN) main_dmas();
+    if constexpr (ROT && MAIN) main_dmas();
     if constexpr (COMPUTE && ACT_OUT) h_store(own, cA2, std::integral_constant<int, (U + 2) % NS>{});
     if constexpr (MODE == P_PRIME && ACT_OUT) h_store(f32x4{0.f, 0.f, 0.f, 0.f}, cA2, std::integral_constant<int, (U + 2) % NS>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -608,7 +623,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
       stall_b += t2 - t1;
 #endif
     }
-    if constexpr (GATHER) slot_w = slot_w == 2 * SLOT_BYTES ? 0u : slot_w + SLOT_BYTES;
+    if constexpr (ROT) slot_w = slot_w == 2 * SLOT_BYTES ? 0u : slot_w + SLOT_BYTES;
   };
 
   // ---- prologue: the first K-steps of the first tile in ONE memory round trip, then the operations of "step -1" in order

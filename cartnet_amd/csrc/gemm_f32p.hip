@@ -27,7 +27,10 @@ void p_launch(const CartnetGemmArgs& a, int grid, hipStream_t st) {
   X(false, false, 0, 32)   /* K = 512 (two folded segments), plain */                               \
   X(false, false, 8, 16)   /* + column sums (a bias gradient) */                                    \
   X(false, false, 16, 16)  /* + BatchNorm statistics, no activation on A */                         \
-  X(false, false, 268, 32) /* K = 512: * sigmoid(pre) (softplus') + bias gradient */
+  X(false, false, 268, 32) /* K = 512: * sigmoid(pre) (softplus') + bias gradient */                \
+  X(false, false, 2, 48)   /* K = 768 (three folded segments) + residual */                        \
+  X(false, false, 14, 32)  /* K = 512 + residual, * silu'(pre), bias gradient: the encoder end of CartNet's backward */ \
+  X(false, false, 270, 32) /* ... the softplus family's (iComformer) */
 #define CN_P_EXTERN(AA, AO, KD, NSV) extern template void p_launch<AA, AO, KD, NSV>(const CartnetGemmArgs&, int, hipStream_t);
 #define CN_P_DEFINE(AA, AO, KD, NSV) template void p_launch<AA, AO, KD, NSV>(const CartnetGemmArgs&, int, hipStream_t);
 #if defined(CN_P_UNIT_B)
@@ -54,7 +57,9 @@ PLaunch p_find(bool a_act, bool act_out, int kind, int ns) {
   if (a_act == AA && act_out == AO && kind == KD && ns == NSV) return &p_launch<AA, AO, KD, NSV>;
   CN_P_FORMS_A(CN_P)
   CN_P_FORMS_B(CN_P)
+#ifndef CN_P_NO_C         /* A/B builds: the third unit's forms stay on the second-generation kernels */
   CN_P_FORMS_C(CN_P)
+#endif
 #undef CN_P
   return nullptr;
 }
@@ -74,8 +79,7 @@ bool use_f32p(const CartnetGemmArgs& a) {
   if (a.M >= 100000 && a.tile_policy != 128 && a.tile_policy != 256) {
     const int subs = (a.N / F32_BN) * a.ngroups;
     const bool form = p_find(a.a_act != 0, a.a_act_out[0] != nullptr, p_kind(a), a.K / BK) != nullptr;
-    const bool taken = (a.K == 256 || a.K == 512) && a.N % F32_BN == 0 && 32 % (subs ? subs : 1) == 0 && form &&
-                       !a.gst_g && !(a.resid[0] && a.dact[0]);
+    const bool taken = (a.K == 256 || a.K == 512 || a.K == 768) && a.N % F32_BN == 0 && 32 % (subs ? subs : 1) == 0 && form && !a.gst_g;
     fprintf(stderr, "f32p %s: M=%d N=%d K=%d groups=%d policy=%d a_act=%d act_out=%d kind=%d gather=%d gst=%d resid=%d dact=%d form=%d\n",
             taken ? "TAKEN" : "LEFT", a.M, a.N, a.K, a.ngroups, a.tile_policy, a.a_act, a.a_act_out[0] != nullptr, p_kind(a),
             a.gather_i[0] != nullptr, a.gst_g != nullptr, a.resid[0] != nullptr, a.dact[0] != nullptr, (int)form);
@@ -84,12 +88,12 @@ bool use_f32p(const CartnetGemmArgs& a) {
   if (a.tile_policy == 128 || a.tile_policy == 256) return false;
   if (a.tile_policy == 0 && CN_F32P_DEFAULT < 1) return false;
   if (a.tile_policy == 1 && CN_F32P_DEFAULT < 2) return false;
-  if (a.K != 256 && a.K != 512) return false;
+  if (a.K != 256 && a.K != 512 && a.K != 768) return false;
   if (a.N % F32_BN != 0 || a.ngroups * a.N > P_BIAS_FLOATS || a.M < 2) return false;
   if (32 % ((a.N / F32_BN) * a.ngroups) != 0) return false;   // a workgroup keeps one (group, column tile): 32 slots per XCD
   const long long tiles = (long long)((a.M + BM - 1) / BM) * (a.N / F32_BN) * a.ngroups;
   if (tiles < 1024 && a.tile_policy != 3) return false;      // fewer than 4 tiles per CU: the 2,768-workgroup kernels fill the chip as well
-  if (a.gst_g || (a.resid[0] && a.dact[0])) return false;
+  if (a.gst_g) return false;
 #ifdef CN_P_NO_GATHER     /* A/B builds: the gather launches stay on the second-generation kernels */
   if (a.gather_i[0]) return false;
 #endif

@@ -246,6 +246,10 @@ def test_forms_of_the_third_unit(ops, M):
     Wseg = [rnd(D, D, seed=53 + g, scale=0.06) for g in range(2)]
     img_fold = torch.cat(ops.pack_b(Wseg))
     pre = rnd(M, D, seed=55)
+    resid2 = rnd(M, D, seed=60)
+    A3 = rnd(M, 3 * D, seed=56)
+    Wseg3 = [rnd(D, D, seed=57 + g, scale=0.05) for g in range(3)]
+    img_fold3 = torch.cat(ops.pack_b(Wseg3))
     tiles = ops.gemm_tiles_m(M)
     Av = [A[:, :D], A[:, D:]]
     res = {}
@@ -259,7 +263,21 @@ def test_forms_of_the_third_unit(ops, M):
                  colsum=s["s4"], tile_policy=pol)
         torch.cuda.synchronize()
         res[pol] = {**o, **s}
-    for k in ("c1", "c2", "c3", "s3", "q3"):     # no transcendental in the epilogue: the shipped kernels' bits
+        # K = 768: three folded segments + residual
+        o["c5"] = torch.full((M, D), float("nan"), device=dev())
+        ops.gemm([A3[:, g * D:(g + 1) * D] for g in range(3)], Wseg3, o["c5"], b_kstrided=True, segments=True, resid=pre,
+                 b_split_folded=img_fold3, tile_policy=pol)
+        # K = 512 + residual, times the activation's derivative (both families), bias gradient: two epilogue operands
+        for name, kind in (("6", 0), ("7", 1)):
+            o["c" + name] = torch.full((M, D), float("nan"), device=dev())
+            o["s" + name] = torch.full((tiles * D,), float("nan"), dtype=torch.float64, device=dev())
+            ops.gemm(Av, Wseg, o["c" + name], b_kstrided=True, segments=True, b_split_folded=img_fold, resid=resid2, dact=pre,
+                     dact_kind=kind, colsum=o["s" + name], tile_policy=pol)
+        torch.cuda.synchronize()
+        res[pol].update({k: o[k] for k in ("c5", "c6", "s6", "c7", "s7")})
+    v5 = sum(A3.double()[:, g * D:(g + 1) * D] @ Wseg3[g].double() for g in range(3)) + pre.double()
+    assert rel_err(res[3]["c5"], v5) < TOL
+    for k in ("c1", "c2", "c3", "s3", "q3", "c5"):     # no transcendental in the epilogue: the shipped kernels' bits
         assert torch.equal(res[3][k], res[256][k]), f"M={M}: {k} differs from the shipped kernel"
     A64 = A.double()
     pad = tiles * 128 - M
@@ -276,3 +294,9 @@ def test_forms_of_the_third_unit(ops, M):
     assert rel_err(r["s2"], tile_sums(v2)) < 2e-5 and rel_err(r["s3"], tile_sums(v2)) < 2e-5
     assert rel_err(r["q3"], tile_sums(v2 * v2)) < 2e-5 and rel_err(r["s4"], tile_sums(v4)) < 2e-5
     assert rel_err(r["s2"], res[256]["s2"]) < 2e-6 and rel_err(r["c4"], res[256]["c4"]) < 2e-6
+    s_ = torch.sigmoid(pre.double())
+    v6 = (v1 + resid2.double()) * s_ * (1 + pre.double() * (1 - s_))
+    v7 = (v1 + resid2.double()) * s_
+    for k, v in (("6", v6), ("7", v7)):
+        assert rel_err(r["c" + k], v) < TOL and rel_err(r["s" + k], tile_sums(v)) < 2e-5
+        assert rel_err(r["c" + k], res[256]["c" + k]) < 2e-6 and rel_err(r["s" + k], res[256]["s" + k]) < 2e-6
