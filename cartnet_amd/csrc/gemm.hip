@@ -200,7 +200,7 @@ static bool f32_image_path(const CartnetGemmArgs& a) {
 static int choose_bn(const CartnetGemmArgs& a);
 
 // CartnetGemmArgs.gst_*: the launch reaches a kernel that carries the gate statistics epilogue -- precision 0:
-// cn_gemm_f32nn128_kernel<false, 1 / 2>; precision 1 (bf16x3): cn_gemm_x3nn16_kernel<false, 1 / 2>.  (The same predicates the
+// cn_gemm_f32p_kernel<false, false, 530, 32> (edge-sized launches) or cn_gemm_f32nn128_kernel<false, 1 / 2>; precision 1 (bf16x3): cn_gemm_x3nn16_kernel<false, 1 / 2>.  (The same predicates the
 // dispatch below and launch_variant apply, in their order; the two DMA-fed families take the same shapes.)
 static bool gate_stats_launch_ok(const CartnetGemmArgs& a) {
   if (!(a.gst_g && a.gst_mean_rstd && a.gst_gamma && a.gst_beta && a.gst_ld >= a.N && a.gst_ld % 4 == 0)) return false;
@@ -216,7 +216,8 @@ static bool gate_stats_launch_ok(const CartnetGemmArgs& a) {
 #ifdef CN_EXPERIMENTAL_Q
   if (a.precision == 0 && cn_gemm::use_f32nnq(f)) return false;     // (launch_variant asks the quad kernel first: no GST code there)
 #endif
-  return f.nsegs == 1 && (a.precision == 1 || cn_gemm::use_f32nn128(f));
+  // (launch_variant asks the persistent kernel first: it has the form -- gemm_f32p.h, KIND 530)
+  return f.nsegs == 1 && (a.precision == 1 || cn_gemm::use_f32p(f) || cn_gemm::use_f32nn128(f));
 }
 
 extern "C" int cartnet_gemm_gate_stats_ok(const CartnetGemmArgs* args) { return args && gate_stats_launch_ok(*args) ? 1 : 0; }

@@ -1,5 +1,5 @@
 // Third-generation fp32-MFMA kernel for activations x weights (CartnetGemmArgs.precision == 0 with a pre-packed weight
-// operand, K = 256 or 512): PERSISTENT, one 512-thread workgroup per CU, TWO accumulator sets.
+// operand, K = 256, 512 or 768): PERSISTENT, one 512-thread workgroup per CU, TWO accumulator sets.
 //
 // What the second generation (gemm_f32.h) loses at K = 256 is outside its main loop (profiles/r03_exp_phases.md: a lone
 // loop runs at 0.97 of the matrix pipe, the launch at 0.79-0.80): prologue, epilogue and hand-over of 2,768 short-lived
@@ -9,9 +9,10 @@
 //     (four) steps ahead -- so tile i+1's first K-steps are in flight while tile i finishes: no prologue per tile;
 //   * tile i's epilogue runs INSIDE tile i+1's MFMA chain, from the other accumulator set, one slice of 4 accumulator
 //     registers per K-step (16 slices = 16 K-steps), in the ACCUMULATOR layout: a register of a 32x32 block is two
-//     128-byte row segments, so every operand load and every store is a full-line dword access and nothing goes through an
-//     LDS transpose; rows past M are dropped by the buffer descriptor's range check (no predicates: the number of memory
-//     operations per step is a compile-time constant, which the counted waits below rely on);
+//     128-byte row segments, so every store is a full-line dword access; an epilogue operand (residual, pre-activation,
+//     gathered node terms) of a slice is 8 consecutive rows x 128 B = ONE 16-byte-per-lane DMA into a wave-private LDS ring,
+//     read back in the accumulator layout; rows past M are dropped by the buffer descriptor's range check (no predicates:
+//     the number of memory operations per step is a compile-time constant, which the counted waits below rely on);
 //   * fragments of k-group 0 of step u+1 are read under step u's MFMAs, so a wave leaves the barrier with its first 16
 //     MFMAs ready to issue.
 // Every vector-memory operation of the loop is inline asm and counted by hand: loads, stores and DMAs retire through ONE
@@ -109,21 +110,22 @@ static __device__ unsigned long long cn_p_dbg_wave[256 * 8 * 2];
 #endif
 
 // KIND: epilogue bits as in gemm_kernel.h (2 resid, 4 dact, 8 column sums, 16 column sums + squares (fp64), 32 cpre,
-// 64 out_act, 256 softplus family) + 1: node-term gather (v += gather_i[tgt[m]] + gather_j[src[m]]); at most one of
-// resid / dact / gather.  NS: K-steps per tile (16: K = 256; 32: K = 512 -- the
+// 64 out_act, 256 softplus family) + 1: node-term gather (v += gather_i[tgt[m]] + gather_j[src[m]]) + 512: the gate
+// statistics of CartNet's dE product (CartnetGemmArgs.gst_*: with 2 | 16 -- the residual may be missing, its descriptor then
+// reads zeros).  NS: K-steps per tile (16: K = 256; 32: K = 512 -- the
 // second 16 steps carry no slice).
 template <bool A_ACT, bool ACT_OUT, int KIND, int NS>
 __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const CartnetGemmArgs p, const int tiles_m) {
   using S = Shape<F32_BN>;
   constexpr bool RESID = (KIND & 2) != 0, DACT = (KIND & 4) != 0, SUM1 = (KIND & 8) != 0, SUM2 = (KIND & 16) != 0,
                  CPRE = (KIND & 32) != 0, OUTACT = (KIND & 64) != 0;
-  constexpr bool GATHER = (KIND & 1) != 0;
+  constexpr bool GATHER = (KIND & 1) != 0, GST = (KIND & 512) != 0;
   constexpr bool STATS = SUM1 || SUM2;
   // operand DMAs per slice: one per operand -- a slice is 8 consecutive rows x 128 B of the tile in every block of the
   // accumulator layout, i.e. ONE 16-byte-per-lane DMA (lane l: row l / 8, 16-byte piece l % 8) per operand
   // Two operands (the gather form's node terms; resid AND dact): a four-slot ring would not fit, so LA = 2, three slots whose
   // index rotates at run time, and the operand DMAs of a step in front of its tile DMAs (PCount, ELF)
-  constexpr bool TWOOP = RESID && DACT;
+  constexpr bool TWOOP = (RESID && DACT) || GST;
   constexpr bool ROT = GATHER || TWOOP;
   constexpr int EL = ROT ? 2 : ((RESID || DACT) ? 1 : 0);
   constexpr int LA = ROT ? 2 : 3;                               // ... issued this many steps before the slice
@@ -137,13 +139,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
   static_assert(!ACT_OUT || A_ACT, "silu(A) is written where it is computed");
   static_assert(!GATHER || (!RESID && !DACT && !STATS && !CPRE && NS == 16), "the gather form: bias + node terms (+ out_act)");
   static_assert(!TWOOP || !CPRE, "resid + dact: no kept pre-activation");
-  using Cnt = PCount<EL, ES, ACT_OUT, STATS, NS, LA, ROT, GATHER ? 2 : 0>;
+  static_assert(!GST || (RESID && SUM2 && !DACT && !CPRE && !OUTACT && !A_ACT && NS == 32), "the gate-statistics form: K = 512, resid, two sums");
+  using Cnt = PCount<EL, ES, ACT_OUT, STATS, NS, LA, ROT, GATHER ? 2 : (GST ? 1 : 0)>;
   static_assert(Cnt::wait_count(0) <= 63 && Cnt::wait_count(1) <= 63, "vmcnt is a 6-bit counter");
   constexpr int LDS_BIAS = P_LDS_A + NA * P_A_BYTES;            // bias[g][n] of every group, staged once
   constexpr int LDS_RED = LDS_BIAS + P_BIAS_FLOATS * 4;         // double red[2][2][256]: column statistics of one tile
   constexpr int LDS_OPR = LDS_RED + (STATS ? 2 * 2 * 256 * 8 : 0);   // per wave NSLOT slots x EL x 1 KB: epilogue operands in flight
   constexpr int LDS_IDX = LDS_OPR + 8 * NSLOT * SLOT_BYTES;    // gather: per wave [tile parity][tgt | src][64 rows]
-  constexpr int LDS_BYTES = LDS_IDX + (GATHER ? 8 * 1024 : 0);
+  // (the gate-statistics form keeps the envelope of the tile's rows there: per wave [tile parity][64 rows])
+  constexpr int LDS_BYTES = LDS_IDX + (GATHER ? 8 * 1024 : (GST ? 8 * 512 : 0));
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
@@ -179,7 +183,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
   i32x4 p_srd = p_make_srd(CPRE ? p.cpre[g] : nullptr, cbytes);
   const int ldo = RESID ? p.ldr : p.ldd;                        // the epilogue operand (resid or dact; with both: resid)
   i32x4 o_srd = p_make_srd(RESID ? p.resid[g] : (DACT ? p.dact[g] : nullptr), ((unsigned)(p.M - 1) * (unsigned)ldo + (unsigned)p.N) * 4u);
-  i32x4 d_srd = p_make_srd(TWOOP ? p.dact[g] : nullptr, ((unsigned)(p.M - 1) * (unsigned)p.ldd + (unsigned)p.N) * 4u);   // ... and dact
+  const int ld2 = GST ? p.gst_ld : p.ldd;                       // the second operand: dact, or the gate pre-activation
+  i32x4 d_srd = p_make_srd(TWOOP ? (GST ? p.gst_g : p.dact[g]) : nullptr, ((unsigned)(p.M - 1) * (unsigned)ld2 + (unsigned)p.N) * 4u);
+  i32x4 e_srd = p_make_srd(GST ? p.gst_env : nullptr, (unsigned)p.M * 4u);     // envelope: rows past M read 0 and drop out of the sums
   i32x4 h_srd = p_make_srd(ACT_OUT ? p.a_act_out[g] : nullptr, ((unsigned)(p.M - 1) * (unsigned)p.lda + (unsigned)p.K) * 4u);
   // gather: the two node-term tables (gather_rows bounds both: use_f32p) and the edge -> atom index arrays; an index of a row
   // past M reads 0 and the index slots start as zeros, so every gathered row is one the caller vouches for (or row 0)
@@ -221,14 +227,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
   const unsigned lv_o = (unsigned)((wm * S::WM + (lane >> 3)) * ldo + col0 + wn * S::WN + (lane & 7) * 4) * 4u;   // operand DMAs: row l / 8, piece l % 8
   const int lane_row = wm * S::WM + 4 * lh;
   const unsigned ldc4 = (unsigned)p.ldc * 4u, ldo4 = (unsigned)ldo * 4u;
-  const unsigned lv_d = (unsigned)((wm * S::WM + (lane >> 3)) * p.ldd + col0 + wn * S::WN + (lane & 7) * 4) * 4u, ldd4 = (unsigned)p.ldd * 4u;
+  const unsigned lv_d = (unsigned)((wm * S::WM + (lane >> 3)) * ld2 + col0 + wn * S::WN + (lane & 7) * 4) * 4u, ldd4 = (unsigned)ld2 * 4u;
   const unsigned lv_g = (unsigned)(col0 + wn * S::WN + (lane & 7) * 4) * 4u, ldg4 = (unsigned)p.ldg * 4u;   // gather: this lane's piece of a row
   const unsigned lv_ix = (unsigned)(wm * S::WM + lane) * 4u;    // ... and its row of the wave's 64 in the index arrays
   const unsigned b_voff = lane * 16, b_voff2 = lane * 16 + 8192;
   unsigned lds_bw = lds0 + P_LDS_B + wid * 1024;
   unsigned lds_aw = lds0 + P_LDS_A + wid * 1024;
   unsigned lds_ow = lds0 + LDS_OPR + wid * (NSLOT * SLOT_BYTES);
-  unsigned lds_iw = lds0 + LDS_IDX + wid * 1024;
+  unsigned lds_iw = lds0 + LDS_IDX + wid * (GST ? 512 : 1024);
+  unsigned env_base = lds0 + LDS_IDX + wid * 512 + lh * 16;      // gate statistics: the envelope of this lane's four rows of a slice
+  asm volatile("" : "+v"(env_base));
   const char* b_base_w = b_base + wid * 1024;
   // one base register per (region, k-group): the swizzle's XOR makes the two k-groups of a fragment differ by more than a constant
   unsigned fa0 = lds0 + P_LDS_A + f32_swz(wm * S::WM + li, 0 + lh), fa1 = lds0 + P_LDS_A + f32_swz(wm * S::WM + li, 2 + lh);
@@ -250,10 +258,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
     for (int i = tid; i < 8 * 256; i += NTHREADS) reinterpret_cast<int*>(lds + LDS_IDX)[i] = 0;
     __syncthreads();
   }
+  if constexpr (GST) {
+    // no bias in this form (use_f32p): its region holds, per column of the tile, rstd | -mean rstd | gamma | beta, the last
+    // two times -log2(e) (the gate's sigmoid through exp2) -- the second-generation kernel's constants (gemm_kernel.h)
+    __syncthreads();
+    for (int n = tid; n < F32_BN; n += NTHREADS) {
+      const float rs = p.gst_mean_rstd[p.N + col0 + n];
+      sbias[n] = rs;
+      sbias[256 + n] = -p.gst_mean_rstd[col0 + n] * rs;
+      sbias[512 + n] = p.gst_gamma[col0 + n] * -1.44269504088896f;
+      sbias[768 + n] = p.gst_beta[col0 + n] * -1.44269504088896f;
+    }
+    for (int i = tid; i < 8 * 128; i += NTHREADS) reinterpret_cast<float*>(lds + LDS_IDX)[i] = 0.f;
+  }
 
   f32x16 acc[2][2][2];            // [set][block row][block column]; a tile's first MFMAs start from 0: never initialised
   f32x4 af[2][2], bf[2][2];       // fragments [k-group][block]
   float bv = 0.f;
+  float g_rstd = 0.f, g_mean = 0.f, g_gam = 0.f, g_bet = 0.f, gs1 = 0.f, gs2 = 0.f;     // gate statistics: this lane's column
   int rows_in = 0;                // rows of the tile in its epilogue that exist, seen from this lane's first row
   double cs = 0.0, cq = 0.0;
   float csf = 0.f;
@@ -320,6 +342,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
     asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
                  :: "s"(li_), "v"(voff), "s"(ss), "n"(DST + 256) : "memory", "m0", "scc");
   };
+  // gate statistics: the envelope of the tile's rows (this wave's 64) into the slot of the tile's parity
+  auto env_dma = [&](const Ctx& c, auto par_c) {
+    constexpr int DST = decltype(par_c)::value * 256;
+    const unsigned li_ = lds_iw, voff = (unsigned)c.row0 * 4u + lv_ix;
+    const i32x4 es = e_srd;
+    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+                 :: "s"(li_), "v"(voff), "s"(es), "n"(DST) : "memory", "m0", "scc");
+  };
   auto st1 = [&](float v, unsigned voff, const i32x4& srd, auto off_c) {
     constexpr int OFF = decltype(off_c)::value;
     asm volatile("buffer_store_dword %0, %1, %2, 0 offen offset:%3" :: "v"(v), "v"(voff), "s"(srd), "n"(OFF) : "memory");
@@ -377,7 +407,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
   };
   auto slice_math = [&](auto sl_c, auto set_c, const Ctx& c, const float (&o)[ROT ? 8 : 4], float (&v)[4]) {
     constexpr int SL = decltype(sl_c)::value, SETP = decltype(set_c)::value, b = SL >> 3, a = (SL >> 2) & 1, q = SL & 3;
-    if constexpr ((SL & 7) == 0) {
+    if constexpr ((SL & 7) == 0 && GST) {
+      const int n = wn * S::WN + b * 32 + li;
+      g_rstd = sbias[n];
+      g_mean = sbias[256 + n];
+      g_gam = sbias[512 + n];
+      g_bet = sbias[768 + n];
+      gs1 = gs2 = 0.f;
+    }
+    if constexpr ((SL & 7) == 0 && !GST) {
       bv = sbias[bias_idx + wn * S::WN + b * 32 + li];
       if constexpr (STATS) {
         cs = cq = 0.0;
@@ -393,7 +431,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
       if constexpr (DACT) t *= (KIND & 256) ? fast_sigmoid(o[TWOOP ? 4 + j : j]) : fast_dsilu(o[TWOOP ? 4 + j : j]);
       v[j] = t;
     }
-    if constexpr (STATS) {
+    if constexpr (GST) {
+      // v = de_out of the layer below: its share of that layer's BatchNorm-backward sums, sum(v w) and sum(v w ghat), w = env
+      // sigma' with the gate recomputed from the kept pre-activation (the second-generation kernel's arithmetic, fp32 over
+      // the lane's 32 rows of a column half).  A row past M has envelope 0 (descriptor) and finite factors: it adds 0.
+      const f32x4 ev = p_lds_ld4(env_base, SETP * 256 + (a * 32 + 8 * q) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float ghat = o[4 + j] * g_rstd + g_mean;
+        const float t = __builtin_amdgcn_exp2f(fminf(ghat * g_gam + g_bet, 126.0f));
+        const float r = __builtin_amdgcn_rcpf(1.0f + t);
+        const float tv = (v[j] * ev[j]) * ((t * r) * r);
+        gs1 += tv;
+        gs2 += tv * ghat;
+      }
+    }
+    if constexpr (STATS && !GST) {
       // only the matrix's last row tile (and the tile "past the last row") has rows that do not exist: a scalar branch keeps
       // the 64 row predicates of a tile (64 SGPR pairs the compiler computed up front) out of the common path
       if (c.row0 + BM <= p.M) {
@@ -437,7 +490,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
   // column statistics of one 32-column half of the finished tile: lane halves, then into red[which][wm][column] (read at the
   // next tile's step 0, behind a barrier)
   auto stats_to_lds = [&](int b) {
-    double s = SUM2 ? cs : (double)csf, q2 = cq;
+    double s = GST ? (double)gs1 : (SUM2 ? cs : (double)csf), q2 = GST ? (double)gs2 : cq;
     s += __shfl_xor(s, 32);
     if constexpr (SUM2) q2 += __shfl_xor(q2, 32);
     if (lh == 0) {
@@ -512,6 +565,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cn_gemm_f32p_kernel(const Cartnet
       b_issue(std::integral_constant<int, (U + 3) % NS>{}, std::integral_constant<int, (U + 3) & 3>{});
       a_dma(cA, std::integral_constant<int, (U + AD) % NS>{}, std::integral_constant<int, (U + AD) & (NA - 1)>{});
       if constexpr (GATHER && (U % NS) == 0) idx_dma(cur, SetC{});
+      if constexpr (GST && (U % NS) == 0) env_dma(cur, SetC{});
     };
     // two operands: the operand DMAs of the step come BEFORE its tile DMAs (PCount, ELF), spread over the first MFMA groups
     if constexpr (GATHER && LOADS) gather_loads(std::integral_constant<int, SL_LD % P_STEPS>{}, ParL{}, std::integral_constant<int, 0>{});

@@ -30,7 +30,8 @@ void p_launch(const CartnetGemmArgs& a, int grid, hipStream_t st) {
   X(false, false, 268, 32) /* K = 512: * sigmoid(pre) (softplus') + bias gradient */                \
   X(false, false, 2, 48)   /* K = 768 (three folded segments) + residual */                        \
   X(false, false, 14, 32)  /* K = 512 + residual, * silu'(pre), bias gradient: the encoder end of CartNet's backward */ \
-  X(false, false, 270, 32) /* ... the softplus family's (iComformer) */
+  X(false, false, 270, 32) /* ... the softplus family's (iComformer) */                              \
+  X(false, false, 530, 32) /* CartNet's dE: K = 512 (+ residual), the gate statistics of the layer below (gst_*) */
 #define CN_P_EXTERN(AA, AO, KD, NSV) extern template void p_launch<AA, AO, KD, NSV>(const CartnetGemmArgs&, int, hipStream_t);
 #define CN_P_DEFINE(AA, AO, KD, NSV) template void p_launch<AA, AO, KD, NSV>(const CartnetGemmArgs&, int, hipStream_t);
 #if defined(CN_P_UNIT_B)
@@ -46,6 +47,7 @@ CN_P_FORMS_A(CN_P_DEFINE)
 #if !defined(CN_P_UNIT_B) && !defined(CN_P_UNIT_C)
 namespace {
 int p_kind(const CartnetGemmArgs& a) {
+  if (a.gst_g) return 2 | 16 | 512;     // (one form, with or without the residual: a missing one reads zeros)
   return (a.gather_i[0] ? 1 : 0) | (a.resid[0] ? 2 : 0) | (a.dact[0] ? 4 : 0) | (a.colsum[0] ? (a.colsq[0] ? 16 : 8) : 0) | (a.cpre[0] ? 32 : 0) |
          (a.out_act ? 64 : 0) | (a.dact_kind ? 256 : 0);
 }
@@ -79,7 +81,7 @@ bool use_f32p(const CartnetGemmArgs& a) {
   if (a.M >= 100000 && a.tile_policy != 128 && a.tile_policy != 256) {
     const int subs = (a.N / F32_BN) * a.ngroups;
     const bool form = p_find(a.a_act != 0, a.a_act_out[0] != nullptr, p_kind(a), a.K / BK) != nullptr;
-    const bool taken = (a.K == 256 || a.K == 512 || a.K == 768) && a.N % F32_BN == 0 && 32 % (subs ? subs : 1) == 0 && form && !a.gst_g;
+    const bool taken = (a.K == 256 || a.K == 512 || a.K == 768) && a.N % F32_BN == 0 && 32 % (subs ? subs : 1) == 0 && form;
     fprintf(stderr, "f32p %s: M=%d N=%d K=%d groups=%d policy=%d a_act=%d act_out=%d kind=%d gather=%d gst=%d resid=%d dact=%d form=%d\n",
             taken ? "TAKEN" : "LEFT", a.M, a.N, a.K, a.ngroups, a.tile_policy, a.a_act, a.a_act_out[0] != nullptr, p_kind(a),
             a.gather_i[0] != nullptr, a.gst_g != nullptr, a.resid[0] != nullptr, a.dact[0] != nullptr, (int)form);
@@ -93,7 +95,10 @@ bool use_f32p(const CartnetGemmArgs& a) {
   if (32 % ((a.N / F32_BN) * a.ngroups) != 0) return false;   // a workgroup keeps one (group, column tile): 32 slots per XCD
   const long long tiles = (long long)((a.M + BM - 1) / BM) * (a.N / F32_BN) * a.ngroups;
   if (tiles < 1024 && a.tile_policy != 3) return false;      // fewer than 4 tiles per CU: the 2,768-workgroup kernels fill the chip as well
-  if (a.gst_g) return false;
+  // the gate-statistics form: what cartnet_gemm admits for gst_* (one group, no bias / dact / cpre / out_act), with an envelope
+  if (a.gst_g && (!a.gst_env || a.ngroups != 1 || a.bias[0] || a.dact[0] || a.cpre[0] || a.out_act || a.a_act || !a.colsum[0] ||
+                  !a.colsq[0] || (double)((double)a.M + 384.0) * a.gst_ld * 4.0 >= 4294967296.0))
+    return false;
 #ifdef CN_P_NO_GATHER     /* A/B builds: the gather launches stay on the second-generation kernels */
   if (a.gather_i[0]) return false;
 #endif

@@ -128,7 +128,7 @@ typedef struct CartnetGemmArgs {
   int32_t gst_ld;
   int32_t tile_policy; /* which DMA-fed fp32 activation x weight kernel takes the launch (precision 0, b_split given).
                           0: the library's choice per launch -- the PERSISTENT kernel (one workgroup per CU walks its tiles,
-                          the epilogue of a tile inside the next tile's MFMA chain: csrc/gemm_f32p.h) for K = 256 / 512
+                          the epilogue of a tile inside the next tile's MFMA chain: csrc/gemm_f32p.h) for K = 256 / 512 / 768
                           launches of at least 4 tiles per CU whose epilogue it has a form for; otherwise 128 x 256 tiles
                           on two workgroups per CU, or 128 x 128 on three for the node-term gather epilogue, for
                           single-group N = 256 products and for launches with few tiles.  1: grouped N = 256 products

@@ -300,3 +300,43 @@ def test_forms_of_the_third_unit(ops, M):
     for k, v in (("6", v6), ("7", v7)):
         assert rel_err(r["c" + k], v) < TOL and rel_err(r["s" + k], tile_sums(v)) < 2e-5
         assert rel_err(r["c" + k], res[256]["c" + k]) < 2e-6 and rel_err(r["s" + k], res[256]["s" + k]) < 2e-6
+
+
+@pytest.mark.parametrize("M", [128 * 257 + 5, 89500])
+@pytest.mark.parametrize("with_resid", [True, False])
+def test_gate_statistics_form(ops, M, with_resid):
+    """CartNet's dE product with the gate statistics of the layer below in its epilogue (CartnetGemmArgs.gst_*; KIND 530 of
+    gemm_f32p.h: K = 512 from two folded segments, residual optional, envelope required): de_out bit for bit the
+    second-generation kernel's, the two column sums within 5e-6 of an fp64 evaluation (and of the other kernel's); a ragged last
+    row tile -- its missing rows have envelope 0 by the descriptor's range check -- and workgroups with 0 / 1 / 2 / 3 tiles."""
+    dpre = rnd(M, 2 * D, seed=71, scale=0.3)
+    W = rnd(2 * D, D, seed=72, scale=0.05)
+    resid = rnd(M, D, seed=73) if with_resid else None
+    gs = rnd(M, 2 * D, seed=74)
+    env = torch.rand(M, generator=torch.Generator().manual_seed(75)).to(dev())
+    g64 = gs[:, :D].double()
+    mean, rstd = g64.mean(0), torch.rsqrt(g64.var(0, unbiased=False) + 1e-5)
+    mean_rstd = torch.cat([mean, rstd]).float().contiguous()
+    gamma, beta = rnd(D, seed=76), rnd(D, seed=77)
+    img = ops.pack_b([W[:D], W[D:]])
+    folded = torch.cat([t.view(-1) for t in img]).contiguous()
+    tiles = ops.gemm_tiles_m(M)
+    got = {}
+    for pol in (3, 128):
+        o = torch.full((M, D), float("nan"), device=dev())
+        ca, cb = (torch.full((tiles * D,), float("nan"), device=dev(), dtype=torch.float64) for _ in range(2))
+        ops.gemm([dpre[:, :D], dpre[:, D:]], [W[:D], W[D:]], o, segments=True, b_kstrided=True, resid=resid, b_split=img,
+                 b_split_folded=folded, colsum=ca, colsq=cb, tile_policy=pol, gate_stats=(gs[:, :D], env, mean_rstd, gamma, beta))
+        torch.cuda.synchronize()
+        assert not torch.isnan(o).any() and not torch.isnan(ca).any() and not torch.isnan(cb).any()
+        got[pol] = (o, ca.view(tiles, D).sum(0), cb.view(tiles, D).sum(0))
+    assert torch.equal(got[3][0], got[128][0])
+    v = got[3][0].double()
+    ghat = (g64 - mean_rstd[:D].double()) * mean_rstd[D:].double()
+    z = torch.sigmoid(ghat * gamma.double() + beta.double())
+    w = env.double()[:, None] * z * (1 - z)
+    ref = dpre.double() @ W.double() + (resid.double() if with_resid else 0)
+    assert rel_err(got[3][0], ref) < TOL
+    for k, r in ((1, (v * w).sum(0)), (2, (v * w * ghat).sum(0))):
+        scale = (v * w).abs().sum(0).max() if k == 1 else (v * w * ghat).abs().sum(0).max()
+        assert (got[3][k] - r).abs().max() <= 5e-6 * scale and (got[3][k] - got[128][k]).abs().max() <= 5e-6 * scale

@@ -37,6 +37,8 @@ Pn = rnd(NA, 4 * D)
 tgt = torch.sort(torch.randint(0, NA, (E,), generator=g)).values.to(torch.int32).to(dev)
 src = (tgt.cpu() // 194 * 194 + torch.randint(0, 194, (E,), generator=g)).clamp(max=NA - 1).to(torch.int32).to(dev)   # same crystal
 tiles = ops.gemm_tiles_m(E)
+env = torch.rand(E, generator=g).to(dev)
+mean_rstd = torch.cat([gs[:, D:].mean(0), torch.rsqrt(gs[:, D:].var(0, unbiased=False) + 1e-5)]).contiguous()
 F = 2.0 * E * D * D * 2
 
 def outputs():
@@ -77,6 +79,10 @@ def form(name, o, pol):
     elif name == "k512resid":       # two folded K-segments + residual (iComformer's d(rows) products; CartNet's dE without statistics)
         ops.gemm([pre[:, :D], pre[:, D:]], [W2g, W2a], o["out"][:, :D], b_kstrided=True, segments=True, resid=gs[:, :D],
                  b_split_folded=img_fold, tile_policy=pol)
+    elif name == "de_gst":          # CartNet's dE: K = 512 + residual + the gate statistics of the layer below (shipped = the 128-wide kernel)
+        ops.gemm([pre[:, :D], pre[:, D:]], [W2g, W2a], o["out"][:, :D], b_kstrided=True, segments=True, resid=gs[:, :D],
+                 b_split=img_dpre, b_split_folded=img_fold, colsum=o["cs"], colsq=o["cq"],
+                 gate_stats=(gs[:, D:], env, mean_rstd, b2g, b2a), tile_policy=128 if pol == 256 else pol)
     elif name == "gather":          # the layer's first product: bias + node terms by target / source atom
         ops.gemm([gs[:, :D], gs[:, D:]], [W2gT, W2aT], out, b_kstrided=True, b_split=img_gs, bias=[b2g, b2a],
                  gather_i=[Pn[:, :D], Pn[:, D:2 * D]], gather_j=[Pn[:, 2 * D:3 * D], Pn[:, 3 * D:]], tgt=tgt, src=src,
@@ -84,7 +90,7 @@ def form(name, o, pol):
     else:
         raise SystemExit(f"unknown form {name}")
 
-forms = ["plain", "bias", "act", "stats", "stats_actout", "dpre", "dhe", "act_actout", "rbf352", "enc2", "k512resid", "gather"]
+forms = ["plain", "bias", "act", "stats", "stats_actout", "dpre", "dhe", "act_actout", "rbf352", "enc2", "k512resid", "gather", "de_gst"]
 for name in forms:
     if only and name not in only:
         continue
