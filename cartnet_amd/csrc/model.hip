@@ -966,6 +966,11 @@ extern "C" int cartnet_model_backward(const CartnetModel* model, const CartnetBa
       if (S.main_waits(seg_done) != 0) { cartnet_set_error("cartnet_model_backward: wait failed"); return 2; }
       RUN(main_dx());
     } else {
+      // (Round 6, with dpre and dE as persistent launches that own every CU: queueing the layer's weight gradients BEHIND dE
+      //  -- so that the two products run back to back and the weight gradients share the chip with the segment sums, dX, the
+      //  node update and the next gate kernels -- measured 13.29-13.32 against 13.14-13.21 ms for this order: dX, a 88 us
+      //  product on the critical chain, then waits 400 us for a CU slot beside a weight-gradient launch and the node kernels
+      //  run 3x slower beside one; profiles/HISTORY.md, "backward order")
       FORK();
       RUN(side_w2());
       RUN(main_dpre());
