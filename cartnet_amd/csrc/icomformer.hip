@@ -827,6 +827,8 @@ extern "C" int cartnet_icomformer_backward(const CartnetIcfModel* model, const C
       a.A[0] = dpr; a.A[1] = dpr + C; a.B[0] = w.Fk[l]; a.B[1] = w.Fm[l]; a.C[0] = d_rows; a.resid[0] = resid; a.ldr = C;
       if (w.use_img) a.b_split_folded = cw.B[B_E1];
       if (sp_pre) { a.dact[0] = sp_pre; a.ldd = C; a.dact_kind = 1; a.colsum[0] = w.cs_side; }
+      // (round 6: this side-stream launch is persistent and owns every CU for ~390 us while atom-sized kernels of the main
+      //  stream wait for a slot; forcing the tile kernels here (tile_policy = 256) measured 26.00 against 25.73-25.76 ms)
       RUN(cartnet_gemm(&a, sw));
       rows_ready[l] = S.mark_side();
       if (sp_pre) {
