@@ -311,12 +311,22 @@ __global__ __launch_bounds__(256) void cn_segment_sum_pair_kernel(const float* _
                                                                   const int* __restrict__ colptr,
                                                                   const int* __restrict__ perm, int N, int W,
                                                                   float* __restrict__ out_t, float* __restrict__ out_s,
-                                                                  int ldo, int ochunk) {
+                                                                  int ldo, int ochunk, int xcd_blocks) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int chunks = (W + 255) / 256;
   const long long items = 2LL * N * chunks;
-  for (long long it = (long long)blockIdx.x * NODES_PER_BLOCK + wid; it < items; it += (long long)gridDim.x * NODES_PER_BLOCK) {
+  // xcd_blocks > 0 (the grid is then a multiple of 8 * xcd_blocks and covers every item once): blocks b, b + 8, ... share an
+  // XCD, so XCD x takes the runs x, x + 8, ... of xcd_blocks consecutive blocks' worth of atoms (the host: one run of N / 8
+  // atoms per XCD) in atom order: the second reader of an edge row (once by its target, once by its source: both atoms of one
+  // crystal) then runs on the SAME XCD within ~140 atoms of the first and finds the row in that XCD's L2 instead of fetching
+  // it again
+  long long bfirst = blockIdx.x;
+  if (xcd_blocks > 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    bfirst = ((long long)(j / xcd_blocks) * 8 + xcd) * xcd_blocks + j % xcd_blocks;
+  }
+  for (long long it = bfirst * NODES_PER_BLOCK + wid; it < items; it += (long long)gridDim.x * NODES_PER_BLOCK) {
     const int per_node = 2 * chunks;
     const int t = (int)(it / per_node);
     const int sub = (int)(it % per_node);
@@ -706,13 +716,28 @@ static int segment_sum_pair_impl(bool half, const float* rows, int32_t ld, const
   CN_CHECK(rows && rowptr && colptr && perm && out_t && out_s, "cartnet_segment_sum_pair: null pointer");
   long long items = 2LL * N * ((W + 255) / 256);
   long long blocks = (items + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;
+  // One run of N / 8 consecutive atoms per XCD (kernel comment) when every block then has exactly one trip; else the plain
+  // dealing.  Alone on the chip, 64 crystals x 194 atoms (tools/experiments/exp_segpair_xcd.py): 682 -> 465 MB fetched,
+  // 102.6 -> 79.4 us per launch; runs of 128 / 256 / 512 atoms: 577 / 524 / 498 MB, 86.9 / 84.0 / 81.0 us.
+  // (CN_SEG_XCD_NODES: 0 = plain dealing, > 0 = runs of that many atoms; A/B builds)
+  int xcd_blocks = 0;
+#ifndef CN_SEG_XCD_NODES
+#define CN_SEG_XCD_NODES -1
+#endif
+  if (CN_SEG_XCD_NODES != 0) {
+    const long long per_node = 2LL * ((W + 255) / 256);
+    const long long nodes = CN_SEG_XCD_NODES > 0 ? (long long)CN_SEG_XCD_NODES : ((long long)N + 7) / 8;
+    const long long run = (nodes * per_node + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK;      // blocks per run
+    const long long padded = (blocks + 8 * run - 1) / (8 * run) * (8 * run);
+    if (padded <= 65536 && blocks >= 8 * run) { xcd_blocks = (int)run; blocks = padded; }
+  }
   if (blocks > 65536) blocks = 65536;
   if (half)
     hipLaunchKernelGGL(cn_segment_sum_pair_kernel<true>, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       rows, ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo, ochunk);
+                       rows, ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo, ochunk, xcd_blocks);
   else
     hipLaunchKernelGGL(cn_segment_sum_pair_kernel<false>, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       rows, ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo, ochunk);
+                       rows, ld, rowptr, colptr, perm, N, W, out_t, out_s, ldo, ochunk, xcd_blocks);
   CN_LAUNCH_CHECK("cartnet_segment_sum_pair");
   return 0;
 }
