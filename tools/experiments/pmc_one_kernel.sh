@@ -8,7 +8,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 PROG=$1; shift
 ARGS=()
-for a in "$@"; do case "$a" in tools/*) ARGS+=("$ROOT/$a");; *) ARGS+=("$a");; esac; done
+for a in "$@"; do case "$a" in tools/*|bench.py) ARGS+=("$ROOT/$a");; *) ARGS+=("$a");; esac; done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- "$PROG" "${ARGS[@]}" > "$OUT/fetch.log" 2>&1 &&
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- "$PROG" "${ARGS[@]}" > "$OUT/write.log" 2>&1
 python3 - "$OUT" <<'PY'
