@@ -213,7 +213,7 @@ namespace cn_gemm {
 //     s_waitcnt vmcnt(3)   this wave's three DMA pieces of step u have landed (step u+1's three stay in flight)
 //     s_barrier            everybody's have, and everybody is done reading stage (u+2) % 3 (used by step u-1)
 //     issue the DMA of step u+2 into that stage; read the fragments of step u; 32 MFMAs.
-// SiLU on the B operand is applied to the fragments (v_exp / v_rcp in the shadow of the 64-cycle MFMAs).
+// SiLU on the B operand: in place in LDS, one K-step before the tile is published (B_ACT below).
 // an LDS dword through a 32-bit address in ONE register + a constant the compiler folds into the instruction's offset field
 __device__ __forceinline__ float cn_lds_ld1(unsigned addr) {
   return *reinterpret_cast<__attribute__((address_space(3))) float*>((unsigned long)addr);
@@ -235,10 +235,14 @@ static __device__ unsigned long long cn_tn_dbg[1024 * 4];
 static __device__ unsigned long long cn_tn_dbg_wave[1024 * 8 * 2];
 #endif
 
-template <bool B_ACT>
+// B_ACT (NST = 5): SiLU on the B operand IN PLACE in LDS -- every thread activates the 32 bytes of a B tile that its own two
+// DMA pieces brought (no other wave's data: its own vmcnt is the only dependency), two K-steps after their issue and one
+// barrier before the tile is published; each element once (the fragment-side form of round 2 activated it in both waves
+// that read it: 15 % slower).  The fifth stage keeps two K-steps between a tile's issue and its activation.
+template <bool B_ACT, int NST = F32T_NSTAGE>
 __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const CartnetGemmArgs p, const GemmFlags fl) {
   using S = Shape<F32_BN>;
-  __shared__ __attribute__((aligned(16))) float smem[F32T_NSTAGE * F32T_STAGE / 4];
+  __shared__ __attribute__((aligned(16))) float smem[NST * F32T_STAGE / 4];
   char* lds = reinterpret_cast<char*>(smem);
 
   const int tid = threadIdx.x;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
   const size_t a_step = (size_t)BK * p.lda, b_step = (size_t)BK * p.ldb, b_half = (size_t)8 * p.ldb;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
   auto issue = [&](int v) {
-    const unsigned st = lds0 + (v % F32T_NSTAGE) * F32T_STAGE;
+    const unsigned st = lds0 + (v % NST) * F32T_STAGE;
     const float* sa = a_base + v * a_step;
     const float* sb = b_base + v * b_step;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
   // two 32-row (A) / 32-column (B) halves of a wave tile for one k
   float af[2][2][4], bf[2][2][4];      // [register set = k-group][tile][j]
   auto frags = [&](int u, int kg) {
-    const float* sA = reinterpret_cast<const float*>(lds + (u % F32T_NSTAGE) * F32T_STAGE);
+    const float* sA = reinterpret_cast<const float*>(lds + (u % NST) * F32T_STAGE);
     const float* sB = sA + F32T_A_BYTES / 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -300,8 +304,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
       for (int a = 0; a < 2; ++a) af[kg][a][j] = sA[k * BM + wm * S::WM + a * 32 + li];
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const float v = sB[k * F32_BN + wn * S::WN + b * 32 + li];
-        bf[kg][b][j] = B_ACT ? fast_silu(v) : v;
+        bf[kg][b][j] = sB[k * F32_BN + wn * S::WN + b * 32 + li];
       }
     }
   };
@@ -315,6 +318,19 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg][a][j], bf[kg][b][j], acc[a][b], 0, 0, 0);
   };
 
+  // B_ACT: this thread's own 2 x 16 bytes of B tile v (pieces wid and wid + 8 of its wave's DMAs), activated in place
+  auto silu_stage = [&](int stage) {
+    char* q = lds + stage * F32T_STAGE + F32T_A_BYTES + wid * 1024 + lane * 16;
+    f32x4 x0 = *reinterpret_cast<f32x4*>(q), x1 = *reinterpret_cast<f32x4*>(q + 8192);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      x0[c] = fast_silu(x0[c]);
+      x1[c] = fast_silu(x1[c]);
+    }
+    *reinterpret_cast<f32x4*>(q) = x0;
+    *reinterpret_cast<f32x4*>(q + 8192) = x1;
+  };
+
   // Software-pipelined around ONE barrier per K-step, placed between the two k-groups of a tile (round 4; the loop the
   // compiler made of the plain form kept four fragment registers and waited for LDS -- s_waitcnt lgkmcnt(0) -- in front
   // of every fourth MFMA: 0.78-0.80 of the matrix pipe isolated).  Iteration u (there is a tile u + 1) starts with
@@ -325,13 +341,22 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
   // land).  (3) 16 MFMAs of k-group 1 of tile u cover the latency of (2).  (4) k-group 1 of tile u + 1, covered by
   // (5) the 16 MFMAs of k-group 0 of tile u + 1.
   if (nsteps > 0) {
-    constexpr int PF = F32T_NSTAGE - 1;          // tiles in flight ahead of the one being multiplied
-    static_assert(F32T_NSTAGE >= 4 && F32T_NSTAGE <= 6, "four to six stages");
+    constexpr int PF = NST - 1;          // tiles in flight ahead of the one being multiplied
+    static_assert(NST >= 4 && NST <= 6, "four to six stages");
 #pragma unroll
     for (int v = 0; v < PF; ++v)
       if (v < nsteps) issue(v);
-    if (nsteps >= PF) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (PF - 1)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (B_ACT) {      // tiles 0 and 1 of this wave have landed: activate them (tile t >= 2: in iteration t - 2)
+      static_assert(!B_ACT || NST >= 5, "two K-steps between a tile's issue and its activation");
+      if (nsteps >= PF) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (PF - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      silu_stage(0);
+      if (nsteps > 1) silu_stage(1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      if (nsteps >= PF) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (PF - 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     frags(0, 0);
@@ -347,7 +372,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
     // DMA destination an immediate -- the rolled loop below recomputed 24 LDS addresses in vector instructions per K-step (on
     // an fp32 MFMA loop they are not free: 4,695 cycles per K-step measured, tools/exp_tn_stamps.py) and took five scalar
     // branches.  It keeps the head, the tail and K ranges too short for this one.
-    constexpr int NHI = (F32T_NSTAGE + 1) / 2;
+    constexpr int NHI = (NST + 1) / 2;
     unsigned fbA[2][NHI], fbB[2][NHI];   // [block][pair of stages]
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -400,25 +425,30 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
       st_w += st_t1 - st_t0;
       st_b += st_t2 - st_t1;
 #endif
-      frags_c(std::integral_constant<int, (Cc + 1) % F32T_NSTAGE>{}, std::integral_constant<int, 0>{});
+      frags_c(std::integral_constant<int, (Cc + 1) % NST>{}, std::integral_constant<int, 0>{});
       __builtin_amdgcn_sched_barrier(0);
-      issue_c(u + PF, std::integral_constant<int, (Cc + PF) % F32T_NSTAGE>{});
+      issue_c(u + PF, std::integral_constant<int, (Cc + PF) % NST>{});
       __builtin_amdgcn_sched_barrier(0);
       mma16(1);
       __builtin_amdgcn_sched_barrier(0);
-      frags_c(std::integral_constant<int, (Cc + 1) % F32T_NSTAGE>{}, std::integral_constant<int, 1>{});
+      if constexpr (B_ACT) {      // tiles u + 3 .. u + PF stay in flight: this wave's pieces of tile u + 2 have landed
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (PF - 2)) : "memory");
+        silu_stage((Cc + 2) % NST);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      frags_c(std::integral_constant<int, (Cc + 1) % NST>{}, std::integral_constant<int, 1>{});
       __builtin_amdgcn_sched_barrier(0);
       mma16(0);
     };
     int u = 0;
 #ifndef CN_TN_ROLLED
-    for (; u + 2 * F32T_NSTAGE - 1 <= nsteps; u += F32T_NSTAGE) {          // every (u + c) + PF < nsteps
+    for (; u + 2 * NST - 1 <= nsteps; u += NST) {          // every (u + c) + PF < nsteps
       iter_c(u, std::integral_constant<int, 0>{});
       iter_c(u + 1, std::integral_constant<int, 1>{});
       iter_c(u + 2, std::integral_constant<int, 2>{});
       iter_c(u + 3, std::integral_constant<int, 3>{});
-      if constexpr (F32T_NSTAGE > 4) iter_c(u + 4, std::integral_constant<int, 4>{});
-      if constexpr (F32T_NSTAGE > 5) iter_c(u + 5, std::integral_constant<int, 5>{});
+      if constexpr (NST > 4) iter_c(u + 4, std::integral_constant<int, 4>{});
+      if constexpr (NST > 5) iter_c(u + 5, std::integral_constant<int, 5>{});
     }
 #endif
     for (; u + 1 < nsteps; ++u) {
@@ -444,6 +474,14 @@ __global__ __launch_bounds__(NTHREADS, 4) void cn_gemm_f32tn_kernel(const Cartne
       __builtin_amdgcn_sched_barrier(0);
       mma16(1);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (B_ACT) {
+        if (u + 2 < nsteps) {
+          if (u + PF < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (PF - 2)) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          silu_stage((u + 2) % NST);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       frags(u + 1, 1);
       __builtin_amdgcn_sched_barrier(0);
       mma16(0);

@@ -9,10 +9,10 @@ void launch_f32nn(bool a_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim
 }
 
 void launch_f32tn(bool b_act, const CartnetGemmArgs& a, const GemmFlags& fl, dim3 grid, hipStream_t st) {
-  // (launch_variant sends SiLU-on-B weight gradients to the register-staged kernel at precision 0: b_act is false here;
-  //  the fragment-side SiLU form of this kernel measured 15 % slower in round 2 and is no longer instantiated)
-  (void)b_act;
-  hipLaunchKernelGGL((cn_gemm_f32tn_kernel<false>), grid, dim3(NTHREADS), 0, st, a, fl);
+  // SiLU on the B operand (dW = dY^T silu(X) without a kept silu(X)): the five-stage instance that activates its tiles in
+  // place in LDS (gemm_f32.h); the fragment-side form of round 2 measured 15 % slower and is gone
+  if (b_act) hipLaunchKernelGGL((cn_gemm_f32tn_kernel<true, 5>), grid, dim3(NTHREADS), 0, st, a, fl);
+  else hipLaunchKernelGGL((cn_gemm_f32tn_kernel<false>), grid, dim3(NTHREADS), 0, st, a, fl);
 }
 
 }  // namespace cn_gemm

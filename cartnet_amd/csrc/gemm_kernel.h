@@ -1116,8 +1116,8 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
   // over the whole K-steps; a K tail (< 16 rows) is one more slab from the checked fp32 kernel
   if constexpr (A_KS && B_KS && BN == 256 && !A_ACT) {
     // precision 0: the all-DMA fp32 kernel (gemm_f32.h); a ragged last row tile needs M % 4 == 0 (its lanes clamp)
-    // (SiLU on the B operand stays on the register-staged kernel at precision 0: applying it to the DMA-fed
-    //  fragments costs every wave 32 transcendental pairs per K-step in front of its MFMAs -- measured 15 % slower)
+    // (SiLU on the B operand: the five-stage instance that activates its DMA'd tiles in place in LDS, gemm_f32.h -- 10 %
+    //  slower than a plain operand; on the fragments it was 15 % and the register-staged kernel 2-3x)
     if (fl.x3 == 2 && any_half(a)) {
       // half-storage weight gradient: one kernel over all of K (it masks a ragged last K-step itself), S slabs
       if (a.M % 4 == 0 && fl.vecA && fl.vecB && a.nsegs == 1 && a.N % BN == 0 && a.M > 0 && a.K >= 1 &&
@@ -1128,7 +1128,11 @@ void launch_variant(const CartnetGemmArgs& a, GemmFlags fl, hipStream_t st) {
       }
       return;
     }
+#ifdef CN_TN_BACT_STAGED    /* A/B builds: SiLU-on-B weight gradients at precision 0 on the register-staged kernel */
     const bool tn_ok = a.M % 4 == 0 && (fl.x3 || !B_ACT);
+#else
+    const bool tn_ok = a.M % 4 == 0;
+#endif
     auto launch_tn = [&](dim3 grid) {
       if (fl.x3) launch_x3tn(B_ACT, a, fl, grid, st);
       else launch_f32tn(B_ACT, a, fl, grid, st);

@@ -157,12 +157,16 @@ Work carve(const CartnetModel& m, int N, long long E, int Bg, int M, bool need_b
     }
   }
   // fp32 training: the activated operands are kept (1 extra [E, 2D] matrix per layer + one for the encoder) so that the
-  // weight gradients dW2 = dY^T silu(pre) read a plain operand and run on the all-DMA kernel (step 15.26 vs 15.43 ms,
-  // same box, interleaved).  Not at precision 1 / 2: there the step got SLOWER (11.74 vs 11.56 ms) -- the bf16 step is
+  // weight gradients dW2 = dY^T silu(pre) read a plain operand (step 15.26 vs 15.43 ms, same box, interleaved, round 2).  Not at precision 1 / 2: there the step got SLOWER (11.74 vs 11.56 ms) -- the bf16 step is
   // power- and HBM-limited and 1.8 GB of extra writes cost more than the cheaper weight-gradient kernel returns.
   // (Re-measured at bf16x3 in round 3: 11.04-11.09 vs 10.87-10.96 ms, slower again.)
   if (need_bwd && m.gemm_precision == 0 && D % 256 == 0) {
+    // (Round 6: with SiLU applied in place to the weight-gradient kernel's DMA'd tile -- cn_gemm_f32tn_kernel<true, 5> --
+    //  dropping the layers' kept silu(pre) saves 1.45 GB of writes per step and costs 0.09 ms: the product 346 -> 380 us,
+    //  the second Linears 405 -> 378; 13.23-13.25 kept vs 13.32-13.35 ms dropped, same box.  Kept; -DCN_DROP_LAYER_ACT drops.)
+#ifndef CN_DROP_LAYER_ACT
     for (int l = 0; l < L; ++l) w.act[l] = c.take<float>(En * 2 * D);
+#endif
     w.he_act = c.take<float>(En * 2 * D);
   }
   if (need_bwd && gate_sums_fused(m, w.G, w.tiles_e, E)) {
